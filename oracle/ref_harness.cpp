@@ -1,0 +1,585 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Drives the *unmodified* reference (AidanShipperley/PPO-LibTorch) where it lies under
+// /root/reference, linked against the LibTorch that ships inside the torch wheel of this image.
+// It is built only by oracle/Makefile into oracle/_ref/ (git-ignored) and is used to
+//   (1) generate the golden vectors committed under tests/golden/   (mode "golden")
+//   (2) time the reference's own CPU ThreadPool path                 (mode "bench")
+// Nothing under ppo-libtorch_amd/ links, includes or executes this file.
+//
+// All members of the reference's algorithm classes are public (PPO/PPO_Discrete.h:24-108), so the
+// harness calls initEnvs/stepEnvs/computeActionLogic/calcAdvantage one by one and reads the m_*
+// buffers.  PPO_Discrete::train() is monolithic, so its minibatch loop (PPO_Discrete.cpp:567-644)
+// is re-driven here with the same LibTorch calls in the same RNG-consuming order; the harness then
+// CERTIFIES that re-drive by running the real train() on a twin instance and demanding
+// bit-identical final parameters ("certified_bitwise" entry in every scenario).
+//
+// Golden container ("PGLD1"): u32 count, then per entry {u32 name_len, name, u32 dtype, u32 ndim,
+// i64 dims[ndim], raw little-endian data}.  dtype: 0=f32 1=i64 2=i32 3=u8 4=f64.
+
+#include "PPO/PPO_Discrete.h"
+#include "PPO/PPO_MultiDiscrete.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <sstream>
+#include <unistd.h>
+
+namespace {
+
+struct Entry {
+    std::string name;
+    uint32_t dtype;
+    std::vector<int64_t> dims;
+    std::vector<char> bytes;
+};
+
+struct GoldWriter {
+    std::vector<Entry> entries;
+
+    void addRaw(const std::string& name, uint32_t dtype, std::vector<int64_t> dims, const void* p, size_t nbytes) {
+        Entry e;
+        e.name = name;
+        e.dtype = dtype;
+        e.dims = std::move(dims);
+        e.bytes.assign(static_cast<const char*>(p), static_cast<const char*>(p) + nbytes);
+        entries.push_back(std::move(e));
+    }
+    void add(const std::string& name, const torch::Tensor& tin) {
+        torch::Tensor t = tin.detach().cpu().contiguous();
+        uint32_t dt;
+        if (t.scalar_type() == torch::kFloat32) dt = 0;
+        else if (t.scalar_type() == torch::kInt64) dt = 1;
+        else if (t.scalar_type() == torch::kInt32) dt = 2;
+        else if (t.scalar_type() == torch::kBool) { t = t.to(torch::kUInt8); dt = 3; }
+        else if (t.scalar_type() == torch::kUInt8) dt = 3;
+        else if (t.scalar_type() == torch::kFloat64) dt = 4;
+        else throw std::runtime_error("GoldWriter: unsupported dtype for " + name);
+        addRaw(name, dt, t.sizes().vec(), t.data_ptr(), static_cast<size_t>(t.nbytes()));
+    }
+    void addF32(const std::string& name, const std::vector<float>& v, std::vector<int64_t> dims) {
+        addRaw(name, 0, std::move(dims), v.data(), v.size() * sizeof(float));
+    }
+    void addI64(const std::string& name, const std::vector<int64_t>& v, std::vector<int64_t> dims) {
+        addRaw(name, 1, std::move(dims), v.data(), v.size() * sizeof(int64_t));
+    }
+    void addF64(const std::string& name, const std::vector<double>& v, std::vector<int64_t> dims) {
+        addRaw(name, 4, std::move(dims), v.data(), v.size() * sizeof(double));
+    }
+    void save(const std::string& path) const {
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open " + path);
+        const char magic[8] = { 'P', 'G', 'L', 'D', '1', 0, 0, 0 };
+        f.write(magic, 8);
+        uint32_t n = static_cast<uint32_t>(entries.size());
+        f.write(reinterpret_cast<const char*>(&n), 4);
+        for (const Entry& e : entries) {
+            uint32_t nl = static_cast<uint32_t>(e.name.size());
+            f.write(reinterpret_cast<const char*>(&nl), 4);
+            f.write(e.name.data(), nl);
+            f.write(reinterpret_cast<const char*>(&e.dtype), 4);
+            uint32_t nd = static_cast<uint32_t>(e.dims.size());
+            f.write(reinterpret_cast<const char*>(&nd), 4);
+            f.write(reinterpret_cast<const char*>(e.dims.data()), nd * sizeof(int64_t));
+            f.write(e.bytes.data(), static_cast<std::streamsize>(e.bytes.size()));
+        }
+        std::cerr << "[ref_harness] wrote " << path << " (" << entries.size() << " entries)\n";
+    }
+};
+
+struct RunCfg {
+    int64_t obs_size = 4, action_size = 2, max_episode_steps = 500;
+    int64_t seed = 2, total_timesteps = 0;  // 0 => updates * batch
+    int64_t num_envs = 8, num_steps = 32, num_minibatches = 4, update_epochs = 10;
+    bool anneal_lr = true, use_gae = true, norm_adv = true, clip_vloss = true;
+    double learning_rate = 0.001, gamma = 0.98, gae_lambda = 0.95, clip_coef = 0.2, ent_coef = 0.0, vf_coef = 0.5,
+           max_grad_norm = 0.5;
+    int64_t updates = 1;
+};
+
+std::string makeScratchDir(const std::string& tag) {
+    std::string tmpl = "/tmp/ppo_ref_" + tag + "_XXXXXX";
+    std::vector<char> buf(tmpl.begin(), tmpl.end());
+    buf.push_back(0);
+    if (!mkdtemp(buf.data())) throw std::runtime_error("mkdtemp failed");
+    return std::string(buf.data());
+}
+
+// The reference reads ./PPOConfig.toml from the CWD (PPO_Discrete.cpp:108).
+void enterScratchWithConfig(const RunCfg& c, const std::string& tag) {
+    std::string dir = makeScratchDir(tag);
+    if (chdir(dir.c_str()) != 0) throw std::runtime_error("chdir failed");
+    std::ofstream f("PPOConfig.toml");
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    int64_t total = c.total_timesteps ? c.total_timesteps : c.updates * c.num_envs * c.num_steps;
+    f << std::setprecision(17);
+    f << "[environment]\nobs_size = " << c.obs_size << "\naction_size = " << c.action_size
+      << "\nmax_episode_steps = " << c.max_episode_steps << "\n\n";
+    f << "[general]\nseed = " << c.seed << "\ntotal_timesteps = " << total
+      << "\nuse_cuda = false\ntorch_deterministic = true\ncheckpoint_updates = 1000000\n\n";
+    f << "[ppo]\nlearning_rate = " << c.learning_rate << "\nnum_envs = " << c.num_envs << "\nnum_steps = " << c.num_steps
+      << "\nanneal_lr = " << b(c.anneal_lr) << "\nuse_gae = " << b(c.use_gae) << "\ngamma = " << c.gamma
+      << "\ngae_lambda = " << c.gae_lambda << "\nnum_minibatches = " << c.num_minibatches
+      << "\nupdate_epochs = " << c.update_epochs << "\nnorm_adv = " << b(c.norm_adv) << "\nclip_coef = " << c.clip_coef
+      << "\nclip_vloss = " << b(c.clip_vloss) << "\nent_coef = " << c.ent_coef << "\nvf_coef = " << c.vf_coef
+      << "\nmax_grad_norm = " << c.max_grad_norm << "\n";
+}
+
+torch::Tensor flatParams(const std::vector<torch::Tensor>& ps, bool grads = false) {
+    std::vector<torch::Tensor> parts;
+    for (const auto& p : ps) parts.push_back((grads ? p.grad() : p).detach().reshape(-1));
+    return torch::cat(parts).clone();
+}
+
+template <class Optim>
+std::array<torch::Tensor, 2> flatAdamState(Optim& opt, const std::vector<torch::Tensor>& ps) {
+    std::vector<torch::Tensor> m, v;
+    for (const auto& p : ps) {
+        auto& st = static_cast<torch::optim::AdamWParamState&>(*opt.state().at(p.unsafeGetTensorImpl()));
+        m.push_back(st.exp_avg().detach().reshape(-1));
+        v.push_back(st.exp_avg_sq().detach().reshape(-1));
+    }
+    return { torch::cat(m).clone(), torch::cat(v).clone() };
+}
+
+// Re-drive of one or more updates through the reference's public methods, recording everything.
+template <class Algo, bool Masked>
+void goldTrainScenario(const RunCfg& cfg, const std::string& tag, const std::string& outPath) {
+    GoldWriter g;
+    std::string home;
+    {
+        char cwd[4096];
+        home = getcwd(cwd, sizeof cwd);
+    }
+
+    // ---- instance A: manual re-drive -------------------------------------------------------
+    enterScratchWithConfig(cfg, tag + "_a");
+    auto algoPtr = std::make_unique<Algo>();
+    Algo& algo = *algoPtr;
+    const int64_t T = algo.m_num_steps, N = algo.m_num_envs, B = algo.m_batch_size, MB = algo.m_minibatch_size;
+    std::vector<torch::Tensor> params = algo.m_agent->parameters();
+    {
+        std::vector<int64_t> meta = { T, N, algo.m_obs_size, algo.m_action_size, algo.m_num_minibatches,
+                                      algo.m_update_epochs, algo.m_max_episode_steps, algo.m_seed, cfg.updates,
+                                      algo.m_anneal_lr, algo.m_use_gae, algo.m_norm_adv, algo.m_clip_vloss, Masked };
+        g.addI64("meta", meta, { static_cast<int64_t>(meta.size()) });
+        std::vector<float> hp = { algo.m_learning_rate, algo.m_gamma, algo.m_gae_lambda, algo.m_clip_coef,
+                                  algo.m_ent_coef, algo.m_vf_coef, algo.m_max_grad_norm };
+        g.addF32("hparams", hp, { static_cast<int64_t>(hp.size()) });
+        std::vector<int64_t> shapes;
+        for (const auto& p : params) { shapes.push_back(p.dim() > 0 ? p.size(0) : 1); shapes.push_back(p.dim() > 1 ? p.size(1) : 1); }
+        g.addI64("param_shapes", shapes, { static_cast<int64_t>(params.size()), 2 });
+    }
+    g.add("params_init", flatParams(params));
+
+    algo.m_threadPool->start();
+    torch::Tensor next_obs, next_done = torch::zeros({ N });
+    torch::Tensor next_mask;
+    if constexpr (Masked) {
+        next_mask = torch::ones({ N, 3 }, torch::kBool);
+        next_obs = algo.initEnvs(next_mask);
+    } else {
+        next_obs = algo.initEnvs();
+    }
+    g.add("init_obs", next_obs);
+
+    const int64_t num_updates = cfg.updates;
+    for (int64_t update = 1; update <= num_updates; update++) {
+        const std::string U = "u" + std::to_string(update) + "/";
+        if (algo.m_anneal_lr) {
+            double frac = 1.0 - (update - 1.0) / num_updates;
+            double lr_now = frac * algo.m_learning_rate;
+            static_cast<torch::optim::AdamWOptions&>(algo.m_optimizer->param_groups()[0].options()).lr() = lr_now;
+        }
+        g.addF64(U + "lr", { static_cast<torch::optim::AdamWOptions&>(algo.m_optimizer->param_groups()[0].options()).lr() }, { 1 });
+        g.add(U + "params_before", flatParams(params));
+
+        torch::Tensor reward, done;
+        std::vector<torch::Tensor> entropies;
+        for (int64_t step = 0; step < T; step++) {
+            algo.m_obs[step] = next_obs;
+            algo.m_dones[step] = next_done;
+            AgentOutput out;
+            if constexpr (Masked) {
+                algo.m_action_masks[step] = next_mask;
+                out = algo.computeActionLogic(next_obs, next_mask);
+            } else {
+                out = algo.computeActionLogic(next_obs);
+            }
+            entropies.push_back(out.entropy.detach().clone());
+            algo.m_values[step] = out.value.flatten();
+            if constexpr (Masked) algo.m_actions[step] = out.action;
+            else algo.m_actions[step] = out.action.unsqueeze(1);
+            algo.m_logprobs[step] = out.logprob;
+            std::tie(next_obs, reward, done) = algo.stepEnvs(out.action.cpu());
+            algo.m_rewards[step] = reward.view(-1);
+            next_done = done.squeeze();
+        }
+        g.add(U + "obs", algo.m_obs);
+        g.add(U + "actions", algo.m_actions);
+        g.add(U + "logprobs", algo.m_logprobs);
+        g.add(U + "rewards", algo.m_rewards);
+        g.add(U + "dones", algo.m_dones);
+        g.add(U + "values", algo.m_values);
+        g.add(U + "rollout_entropy", torch::stack(entropies));
+        if constexpr (Masked) g.add(U + "action_masks", algo.m_action_masks);
+        g.add(U + "next_obs", next_obs);
+        g.add(U + "next_done", next_done);  // int32 [N]
+        {
+            torch::NoGradGuard ng;
+            g.add(U + "next_value", algo.m_agent->getValue(next_obs).reshape({ 1, -1 }));
+        }
+        g.addF64(U + "ep_stats", { algo.m_episode_stats->avgLength(), static_cast<double>(algo.m_episode_stats->avgReward()),
+                                   static_cast<double>(algo.m_episode_stats->size()) }, { 3 });
+
+        // Both advantage modes on the same rollout (PPO_Discrete.cpp:283-329).
+        auto gae = algo.calcAdvantage(next_obs, next_done);
+        g.add(U + "gae_returns", gae[0]);
+        g.add(U + "gae_advantages", gae[1]);
+        torch::Tensor returns = gae[0], advantages = gae[1];
+        if (update == 1) {
+            // The n-step branch (use_gae = false, PPO_Discrete.cpp:309-329) assigns a [1,N] tensor into the [N] row
+            // returns[T-1] (next_return = next_value, :318,:324), which LibTorch rejects: record what the reference does.
+            algo.m_use_gae = false;
+            int64_t threw = 0;
+            try {
+                auto nstep = algo.calcAdvantage(next_obs, next_done);
+                g.add(U + "nstep_returns", nstep[0]);
+                g.add(U + "nstep_advantages", nstep[1]);
+            } catch (const std::exception& ex) {
+                threw = 1;
+                std::cerr << "[ref_harness] " << tag << ": reference n-step branch throws: "
+                          << std::string(ex.what()).substr(0, 90) << "\n";
+            }
+            algo.m_use_gae = true;
+            g.addI64(U + "nstep_branch_throws", { threw }, { 1 });
+        }
+
+        torch::Tensor b_obs = algo.m_obs.reshape({ B, algo.m_obs_size });
+        torch::Tensor b_logprobs = algo.m_logprobs.reshape(-1);
+        torch::Tensor b_actions = Masked ? algo.m_actions.reshape({ B, algo.m_action_size }) : algo.m_actions.reshape(-1);
+        torch::Tensor b_advantages = advantages.reshape(-1);
+        torch::Tensor b_returns = returns.reshape(-1);
+        torch::Tensor b_values = algo.m_values.reshape(-1);
+        torch::Tensor b_masks;
+        if constexpr (Masked) b_masks = algo.m_action_masks.reshape({ -1, algo.m_action_masks.sizes().back() });
+        std::vector<float>().swap(algo.m_clipfracs);
+
+        std::vector<torch::Tensor> perms;
+        std::vector<double> scal;  // per optimizer step: pg, v, ent, kl, clipfrac, loss, total_norm
+        int64_t k = 0;
+        const int64_t stepsPerUpdate = algo.m_update_epochs * ((B + MB - 1) / MB);
+        torch::Tensor pg_loss, v_loss, entropy_loss, loss, approx_kl;
+        for (int64_t epoch = 0; epoch < algo.m_update_epochs; epoch++) {
+            torch::Tensor b_inds = torch::randperm(B);
+            perms.push_back(b_inds.clone());
+            for (int64_t start = 0; start < B; start += MB) {
+                torch::Tensor mb = b_inds.index({ torch::indexing::Slice(start, start + MB) });
+                AgentOutput o;
+                if constexpr (Masked)
+                    o = algo.m_agent->getActionAndValueMasked(b_obs.index({ mb }), b_masks.index({ mb }),
+                                                              b_actions.to(torch::kLong).index({ mb }).t());
+                else
+                    o = algo.m_agent->getActionAndValueDiscrete(b_obs.index({ mb }), b_actions.to(torch::kLong).index({ mb }));
+                torch::Tensor logratio = o.logprob - b_logprobs.index({ mb });
+                torch::Tensor ratio = logratio.exp();
+                approx_kl = algo.getApproxKLAndClippedObj(ratio, logratio);
+                torch::Tensor adv = b_advantages.index({ mb });
+                if (algo.m_norm_adv) adv = (adv - adv.mean()) / (adv.std() + 1e-8f);
+                torch::Tensor l1 = -adv * ratio;
+                torch::Tensor l2 = -adv * torch::clamp(ratio, 1 - algo.m_clip_coef, 1 + algo.m_clip_coef);
+                pg_loss = torch::max(l1, l2).mean();
+                torch::Tensor nv = o.value.view(-1);
+                torch::Tensor ret = b_returns.index({ mb });
+                if (algo.m_clip_vloss) {
+                    torch::Tensor un = (nv - ret) * (nv - ret);
+                    torch::Tensor vold = b_values.index({ mb });
+                    torch::Tensor vc = vold + torch::clamp(nv - vold, -algo.m_clip_coef, algo.m_clip_coef);
+                    torch::Tensor cl = (vc - ret) * (vc - ret);
+                    v_loss = 0.5f * torch::max(un, cl).mean();
+                } else {
+                    v_loss = 0.5f * ((nv - ret) * (nv - ret)).mean();
+                }
+                entropy_loss = o.entropy.mean();
+                loss = pg_loss - algo.m_ent_coef * entropy_loss + v_loss * algo.m_vf_coef;
+                algo.m_optimizer->zero_grad();
+                loss.backward();
+                const bool dump = (update == 1) && (k == 0 || k == 1 || k == stepsPerUpdate - 1);
+                const std::string K = U + "k" + std::to_string(k) + "/";
+                if (dump) {
+                    g.add(K + "grads", flatParams(params, true));
+                    g.add(K + "newlogprob", o.logprob);
+                    g.add(K + "newvalue", nv);
+                    g.add(K + "entropy", o.entropy);
+                }
+                double total_norm = torch::nn::utils::clip_grad_norm_(params, algo.m_max_grad_norm);
+                algo.m_optimizer->step();
+                if (dump) {
+                    g.add(K + "params_after", flatParams(params));
+                    auto mv = flatAdamState(*algo.m_optimizer, params);
+                    g.add(K + "exp_avg", mv[0]);
+                    g.add(K + "exp_avg_sq", mv[1]);
+                }
+                scal.insert(scal.end(), { pg_loss.item<double>(), v_loss.item<double>(), entropy_loss.item<double>(),
+                                          approx_kl.item<double>(), static_cast<double>(algo.m_clipfracs.back()),
+                                          loss.item<double>(), total_norm });
+                k++;
+            }
+        }
+        g.add(U + "perms", torch::stack(perms));
+        g.addF64(U + "step_scalars", scal, { k, 7 });
+        torch::Tensor var_y = b_returns.var();
+        torch::Tensor ev = 1 - ((b_returns - b_values).var() / var_y);
+        g.addF64(U + "explained_var", { ev.item<double>() }, { 1 });
+        g.add(U + "params_after", flatParams(params));
+    }
+    algo.m_threadPool->stop();
+    torch::Tensor finalManual = flatParams(params);
+
+    // ---- instance B: the reference's own train() on the same config -------------------------
+    int64_t certified = -1;  // -1 = not applicable (MountainCar resets are unseedable, MountainCar.cpp:79-88)
+    if constexpr (!Masked) {
+        enterScratchWithConfig(cfg, tag + "_b");
+        Algo twin;
+        twin.train();
+        torch::Tensor finalReal = flatParams(twin.m_agent->parameters());
+        certified = torch::equal(finalReal, finalManual) ? 1 : 0;
+        std::cerr << "[ref_harness] " << tag << ": manual re-drive vs reference train(): "
+                  << (certified ? "BIT-IDENTICAL" : "MISMATCH") << " (max abs diff "
+                  << (finalReal - finalManual).abs().max().item<double>() << ")\n";
+        g.add("params_after_reference_train", finalReal);
+    }
+    g.addI64("certified_bitwise", { certified }, { 1 });
+    if (chdir(home.c_str()) != 0) throw std::runtime_error("chdir back failed");
+    g.save(outPath);
+    if (certified == 0) throw std::runtime_error("re-drive of train() is not bit-identical to the reference's train()");
+}
+
+void goldResetStream(const std::string& outPath) {
+    GoldWriter g;
+    for (int64_t seed : { 1, 2, 3, 12345 }) {
+        CartPole env(seed);
+        std::vector<float> v;
+        for (int k = 0; k < 64; k++) {
+            std::vector<float> s = env.reset();
+            v.insert(v.end(), s.begin(), s.end());
+        }
+        g.addF32("seed" + std::to_string(seed), v, { 64, 4 });
+    }
+    g.save(outPath);
+}
+
+float nudge(float v, int ulps) {
+    for (int i = 0; i < std::abs(ulps); i++) v = std::nextafter(v, ulps > 0 ? INFINITY : -INFINITY);
+    return v;
+}
+
+void goldCartPoleTransitions(const std::string& outPath) {
+    GoldWriter g;
+    const int64_t n = 8192;
+    std::mt19937_64 rng(20240611);
+    auto U = [&](float a, float b) { return std::uniform_real_distribution<float>(a, b)(rng); };
+    std::vector<float> s0(n * 4), s1(n * 4), rew(n);
+    std::vector<int64_t> act(n), term(n);
+    const float thr = static_cast<float>(12 * 2 * M_PI / 360);
+    for (int64_t i = 0; i < n; i++) {
+        float x, xd, th, thd;
+        int kind = static_cast<int>(i % 8);
+        if (kind < 4) { x = U(-2.6f, 2.6f); xd = U(-3.f, 3.f); th = U(-0.25f, 0.25f); thd = U(-3.5f, 3.5f); }
+        else if (kind < 6) { x = U(-0.05f, 0.05f); xd = U(-0.05f, 0.05f); th = U(-0.05f, 0.05f); thd = U(-0.05f, 0.05f); }
+        else if (kind == 6) {  // threshold edges: zero velocity keeps the position exactly
+            int u = static_cast<int>((i / 8) % 7) - 3;
+            bool onX = ((i / 56) % 2) == 0;
+            float sgn = ((i / 112) % 2) ? -1.f : 1.f;
+            x = onX ? sgn * nudge(2.4f, u) : U(-1.f, 1.f);
+            th = onX ? U(-0.1f, 0.1f) : sgn * nudge(thr, u);
+            xd = onX ? 0.f : U(-1.f, 1.f);
+            thd = onX ? U(-1.f, 1.f) : 0.f;
+        } else { x = U(-2.f, 2.f); xd = U(-2.f, 2.f); th = U(-3.0f, 3.0f); thd = U(-8.f, 8.f); }
+        int64_t a = static_cast<int64_t>(rng() % 3);  // 2 exercises "any non-zero action pushes right" (CartPole.cpp:54-57)
+        CartPole env(1);
+        env.state = { x, xd, th, thd };
+        env.terminated = false;
+        auto [ns, r, t, info] = env.step(a);
+        (void)info;
+        for (int j = 0; j < 4; j++) { s0[i * 4 + j] = (j == 0 ? x : j == 1 ? xd : j == 2 ? th : thd); s1[i * 4 + j] = ns[j]; }
+        rew[i] = r; act[i] = a; term[i] = t ? 1 : 0;
+    }
+    g.addF32("state", s0, { n, 4 });
+    g.addI64("action", act, { n });
+    g.addF32("next_state", s1, { n, 4 });
+    g.addF32("reward", rew, { n });
+    g.addI64("terminated", term, { n });
+    g.save(outPath);
+}
+
+void goldMountainCarTransitions(const std::string& outPath) {
+    GoldWriter g;
+    const int64_t n = 8192;
+    std::mt19937_64 rng(777);
+    auto U = [&](float a, float b) { return std::uniform_real_distribution<float>(a, b)(rng); };
+    std::vector<float> s0(n * 2), s1(n * 2), rew(n);
+    std::vector<int64_t> act(n), term(n);
+    for (int64_t i = 0; i < n; i++) {
+        float p = U(-1.2f, 0.6f), v = U(-0.07f, 0.07f);
+        int kind = static_cast<int>(i % 8);
+        if (kind == 5) { p = -1.2f; v = U(-0.07f, 0.0f); }               // left wall (MountainCar.cpp:40-42)
+        if (kind == 6) { p = U(0.45f, 0.6f); v = U(-0.01f, 0.07f); }     // goal edge (:44)
+        if (kind == 7) { p = U(-0.6f, -0.4f); v = 0.f; }                 // reset states
+        int64_t a = static_cast<int64_t>(rng() % 3);
+        MountainCar env;
+        env.state = { p, v };
+        auto [ns, r, t, info] = env.step(a);
+        (void)info;
+        s0[i * 2] = p; s0[i * 2 + 1] = v; s1[i * 2] = ns[0]; s1[i * 2 + 1] = ns[1];
+        rew[i] = r; act[i] = a; term[i] = t ? 1 : 0;
+    }
+    g.addF32("state", s0, { n, 2 });
+    g.addI64("action", act, { n });
+    g.addF32("next_state", s1, { n, 2 });
+    g.addF32("reward", rew, { n });
+    g.addI64("terminated", term, { n });
+    g.save(outPath);
+}
+
+void goldDistributions(const std::string& outPath) {
+    GoldWriter g;
+    torch::manual_seed(99);
+    auto dev = std::make_shared<torch::Device>(torch::kCPU);
+    for (int64_t A : { 1, 2, 3, 6 }) {
+        const std::string P = "cat" + std::to_string(A) + "/";
+        torch::Tensor logits = torch::randn({ 96, A }) * 2.0;
+        if (A >= 2) logits.index_put_({ 0 }, torch::full({ A }, 30.0f).index_put_({ 0 }, -30.0f));  // extreme row
+        Categorical c(logits, dev);
+        torch::Tensor value = torch::randint(A, { 96 });
+        g.add(P + "logits", logits);
+        g.add(P + "m_logits", c.m_logits);
+        g.add(P + "m_probs", c.m_probs);
+        g.add(P + "value", value);
+        g.add(P + "log_prob", c.log_prob(value));
+        g.add(P + "entropy", c.entropy());
+        g.add(P + "mode", c.mode());
+    }
+    for (int64_t A : { 2, 3, 6 }) {
+        const std::string P = "masked" + std::to_string(A) + "/";
+        torch::Tensor logits = torch::randn({ 96, A }) * 2.0;
+        torch::Tensor mask = torch::rand({ 96, A }) > 0.4;
+        torch::Tensor keep = torch::randint(A, { 96 });
+        mask.scatter_(1, keep.unsqueeze(1), torch::ones({ 96, 1 }, torch::kBool));  // >= 1 valid action
+        CategoricalMasked c(logits, mask, dev);
+        g.add(P + "logits", logits);
+        g.add(P + "mask", mask);
+        g.add(P + "m_logits", c.m_logits);
+        g.add(P + "m_probs", c.m_probs);
+        g.add(P + "value", keep);
+        g.add(P + "log_prob", c.log_prob(keep));
+        g.add(P + "entropy", c.entropy());
+        g.add(P + "mode", c.mode());
+    }
+    g.save(outPath);
+}
+
+// Multi-head masked agent: the split by m_actionSpace (Agent.cpp:140-141) with more than one head.
+void goldMultiHeadAgent(const std::string& outPath) {
+    GoldWriter g;
+    torch::manual_seed(5);
+    auto dev = std::make_shared<torch::Device>(torch::kCPU);
+    const int64_t O = 24, n = 64;
+    std::vector<int64_t> heads = { 3, 3, 3, 2 };
+    Agent agent(O, 11, dev);
+    agent.m_actionSpace = heads;
+    torch::Tensor x = torch::randn({ n, O });
+    torch::Tensor mask = torch::rand({ n, 11 }) > 0.35;
+    std::vector<torch::Tensor> acts;
+    int64_t off = 0;
+    for (int64_t h : heads) {
+        torch::Tensor a = torch::randint(h, { n });
+        mask.scatter_(1, (a + off).unsqueeze(1), torch::ones({ n, 1 }, torch::kBool));
+        acts.push_back(a);
+        off += h;
+    }
+    torch::Tensor action = torch::stack(acts);  // [H, n] as getActionAndValueMasked indexes action[i] (Agent.cpp:160-163)
+    AgentOutput o;
+    {
+        torch::NoGradGuard ng;
+        o = agent.getActionAndValueMasked(x, mask, action);
+    }
+    g.addI64("heads", heads, { 4 });
+    g.add("params", flatParams(agent.parameters()));
+    std::vector<int64_t> shapes;
+    for (const auto& p : agent.parameters()) { shapes.push_back(p.dim() > 0 ? p.size(0) : 1); shapes.push_back(p.dim() > 1 ? p.size(1) : 1); }
+    g.addI64("param_shapes", shapes, { static_cast<int64_t>(shapes.size() / 2), 2 });
+    g.add("x", x);
+    g.add("mask", mask);
+    g.add("action_hn", action);
+    g.add("action_out", o.action);
+    g.add("logprob", o.logprob);
+    g.add("entropy", o.entropy);
+    g.add("value", o.value);
+    g.save(outPath);
+}
+
+int benchReference(int64_t numEnvs, int64_t numSteps, int64_t updates) {
+    RunCfg c;
+    c.num_envs = numEnvs; c.num_steps = numSteps; c.updates = updates;
+    enterScratchWithConfig(c, "bench");
+    PPO_Discrete algo;
+    auto t0 = std::chrono::steady_clock::now();
+    algo.train();
+    auto t1 = std::chrono::steady_clock::now();
+    double sec = std::chrono::duration<double>(t1 - t0).count();
+    double steps = static_cast<double>(updates) * numEnvs * numSteps;
+    std::printf("REF_BENCH {\"num_envs\": %ld, \"num_steps\": %ld, \"updates\": %ld, \"seconds\": %.6f, "
+                "\"env_steps_per_sec\": %.3f, \"threads\": %u}\n",
+                (long)numEnvs, (long)numSteps, (long)updates, sec, steps / sec, std::thread::hardware_concurrency());
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    try {
+        std::string mode = argc > 1 ? argv[1] : "";
+        if (mode == "golden" && argc > 2) {
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            goldResetStream(out + "/cartpole_reset_stream.pgld");
+            goldCartPoleTransitions(out + "/cartpole_transitions.pgld");
+            goldMountainCarTransitions(out + "/mountaincar_transitions.pgld");
+            goldDistributions(out + "/distributions.pgld");
+            goldMultiHeadAgent(out + "/multihead_agent.pgld");
+            {
+                RunCfg c;  // shipped-TOML shape with action_size = 2; two updates cover the LR anneal
+                c.updates = 2;
+                goldTrainScenario<PPO_Discrete, false>(c, "t32n8", out + "/discrete_t32_n8_seed2.pgld");
+            }
+            {
+                RunCfg c;  // truncation at max_episode_steps inside a short rollout; no adv-norm / value clipping / anneal
+                c.seed = 3; c.num_envs = 16; c.num_steps = 64; c.max_episode_steps = 20; c.update_epochs = 2;
+                c.norm_adv = false; c.clip_vloss = false; c.anneal_lr = false; c.ent_coef = 0.01; c.gamma = 0.99;
+                goldTrainScenario<PPO_Discrete, false>(c, "t64n16", out + "/discrete_t64_n16_seed3_trunc.pgld");
+            }
+            {
+                RunCfg c;
+                c.seed = 1; c.num_envs = 64; c.num_steps = 128; c.update_epochs = 2; c.ent_coef = 0.01;
+                goldTrainScenario<PPO_Discrete, false>(c, "t128n64", out + "/discrete_t128_n64_seed1.pgld");
+            }
+            {
+                RunCfg c;  // PPO_MultiDiscrete + MountainCar (masked categorical, true entropy)
+                c.obs_size = 2; c.action_size = 3; c.max_episode_steps = 200; c.seed = 1; c.num_envs = 16; c.num_steps = 32;
+                c.update_epochs = 3; c.ent_coef = 0.01; c.gamma = 0.99;
+                goldTrainScenario<PPO_MultiDiscrete, true>(c, "mc", out + "/multidiscrete_mountaincar_t32_n16.pgld");
+            }
+            return 0;
+        }
+        if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));
+        std::cerr << "usage: ref_harness golden <outdir> | bench <num_envs> <num_steps> <updates>\n";
+        return 2;
+    } catch (const std::exception& ex) {
+        std::cerr << "[ref_harness] error: " << ex.what() << std::endl;
+        return 1;
+    }
+}

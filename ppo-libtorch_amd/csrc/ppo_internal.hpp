@@ -1,0 +1,365 @@
+// ppo-libtorch_amd/csrc/ppo_internal.hpp -- shared host/device definitions of libppo_hip.so (gfx950 only).
+//
+// Number model of the parity-critical paths (env step, reset mapping, GAE, AdamW element-wise): IEEE binary32 with
+// separately rounded operations.  The whole library is compiled with -ffp-contract=off; every fused multiply-add in
+// the MLP paths is an explicit __builtin_fmaf.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "ppo_hip.h"
+
+#define PPO_HIDDEN 64          // one hidden unit per lane of a 64-wide wavefront
+#define PPO_MAX_OBS 8
+#define PPO_MAX_ACT 32         // sum of head widths
+#define PPO_TILE 64            // samples per update tile
+#define PPO_LDS_STRIDE 68      // padded row stride (floats) of [unit][sample] LDS tiles: 16-B aligned, bank-spreading
+
+// ---------------------------------------------------------------------------------------------------------
+// Flat parameter layout = Agent::parameters() order (reference PPO/Agent.cpp:65-66): critic {W1,b1,W2,b2,W3,b3}, actor {..}
+// ---------------------------------------------------------------------------------------------------------
+struct NetLayout {
+    int obs, act, n_heads;
+    int head_dims[PPO_MAX_HEADS];
+    int w1[2], b1[2], w2[2], b2[2], w3[2], b3[2];  // offsets (floats) per net: 0 = critic, 1 = actor
+    int net_off[2], net_size[2];
+    int P;
+    int n_tensors;
+    int tensor_off[13];                             // 12 tensors + end
+};
+
+inline NetLayout make_layout(int obs, int n_heads, const int* head_dims) {
+    NetLayout L{};
+    L.obs = obs;
+    L.n_heads = n_heads;
+    L.act = 0;
+    for (int h = 0; h < n_heads; h++) { L.head_dims[h] = head_dims[h]; L.act += head_dims[h]; }
+    int o = 0, t = 0;
+    for (int net = 0; net < 2; net++) {
+        const int out = net == 0 ? 1 : L.act;
+        L.net_off[net] = o;
+        L.tensor_off[t++] = o; L.w1[net] = o; o += PPO_HIDDEN * obs;
+        L.tensor_off[t++] = o; L.b1[net] = o; o += PPO_HIDDEN;
+        L.tensor_off[t++] = o; L.w2[net] = o; o += PPO_HIDDEN * PPO_HIDDEN;
+        L.tensor_off[t++] = o; L.b2[net] = o; o += PPO_HIDDEN;
+        L.tensor_off[t++] = o; L.w3[net] = o; o += out * PPO_HIDDEN;
+        L.tensor_off[t++] = o; L.b3[net] = o; o += out;
+        L.net_size[net] = o - L.net_off[net];
+    }
+    L.tensor_off[t] = o;
+    L.n_tensors = t;
+    L.P = o;
+    return L;
+}
+
+// Hyper-parameters as the kernels consume them.
+struct LossParams {
+    float clip_coef, ent_coef, vf_coef;
+    int norm_adv, clip_vloss;
+    int dist_kind;
+};
+
+// Per-minibatch advantage statistics (sum, sum of squares over the GLOBAL minibatch) and the scalars derived from them.
+struct AdvStat { double s1, s2; };
+
+// Device-side record of one optimizer step's scalars (doubles so the host reads them as-is).
+struct StepStats {
+    double pg_loss, v_loss, entropy_loss, approx_kl, clipfrac, loss, total_norm, pad;
+};
+
+// Host-computed AdamW scalars of one step (LibTorch optim/adamw.cpp narrows its double scalars to float this way).
+struct AdamCoef { float decay, neg_step, sqrt_bc2, pad; };
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (build's own counter-based generator; mirrored bit-for-bit by oracle/ppo_oracle.c:orc_philox4x32)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// libstdc++ uniform_real_distribution<float>(a,b) on one 32-bit word (reference Environments/CartPole.cpp:96-100).
+__device__ __forceinline__ float canon_to_uniform(uint32_t u, float a, float b) {
+    float r = (float)u / 4294967296.0f;
+    if (r >= 1.0f) r = 0x1.fffffep-1f;
+    return r * (b - a) + a;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// glibc 2.35 sinf/cosf (x86-64 FMA ifunc variant), evaluated in binary64 with explicit fma -- what std::sin/std::cos
+// on float resolve to in the reference (Environments/CartPole.cpp:59-60, MountainCar.cpp:34).  Valid for |x| < 120;
+// the environments stay far inside.  Mirrors oracle/ppo_oracle.c:orc_sinf/orc_cosf, which is pinned exhaustively
+// against the host libm.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sc_poly(double x, double x2, int n, bool neg) {
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = __builtin_fma(x2, S3, S2);
+        const double x7 = x3 * x2;
+        const double s = __builtin_fma(x3, S1, x);
+        return (float)__builtin_fma(x7, s1, s);
+    } else {
+        const double sg = neg ? -1.0 : 1.0;
+        const double x4 = x2 * x2;
+        const double c2 = __builtin_fma(x2, sg * C4, sg * C3);
+        const double c1 = __builtin_fma(x2, sg * C1, sg * C0);
+        const double x6 = x4 * x2;
+        const double c = __builtin_fma(x4, sg * C2, c1);
+        return (float)__builtin_fma(x6, c2, c);
+    }
+}
+__device__ __forceinline__ uint32_t abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+__device__ __forceinline__ double sc_reduce_fast(double x, int& n) {
+    const double r = x * 0x1.45F306DC9C883p+23;
+    n = ((int32_t)r + 0x800000) >> 24;
+    return __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+}
+__device__ __forceinline__ float glibc_sinf(float y) {
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return y;
+        return sc_poly(x, x * x, 0, false);
+    }
+    int n;
+    x = sc_reduce_fast(x, n);
+    const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return sc_poly(x * s, x * x, n, (n & 2) != 0);
+}
+__device__ __forceinline__ float glibc_cosf(float y) {
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+        return sc_poly(x, x * x, 1, false);
+    }
+    int n;
+    x = sc_reduce_fast(x, n);
+    const int m = (n + 1) & 3;
+    const double s = (m == 1 || m == 2) ? -1.0 : 1.0;
+    return sc_poly(x * s, x * x, n ^ 1, ((n + 1) & 2) != 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Environment transitions
+// ---------------------------------------------------------------------------------------------------------
+// CartPole::step, reference Environments/CartPole.cpp:47-94 (constants :6-17).  st = {x, x_dot, theta, theta_dot}.
+__device__ __forceinline__ float cartpole_step(float* st, int action, int& terminated) {
+    const float gravity = 9.8f, mass_pole = 0.1f, total_mass = 0.1f + 1.0f, length = 0.5f;
+    const float polemass_length = 0.1f * 0.5f, force_mag = 10.0f, tau = 0.02f;
+    const float theta_thr = 0x1.acee9ep-3f; /* (float)(12*2*M_PI/360) = bits 0x3e567750, CartPole.cpp:16 */
+    const float x_thr = 2.4f;
+    float x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];
+    float force = force_mag;
+    if (action == 0) force = -force;
+    const float cos_theta = glibc_cosf(theta), sin_theta = glibc_sinf(theta);
+    const float temp = (force + polemass_length * theta_dot * theta_dot * sin_theta) / total_mass;
+    const float theta_acc = (gravity * sin_theta - cos_theta * temp) /
+                            (length * (4.0f / 3.0f - mass_pole * cos_theta * cos_theta / total_mass));
+    const float x_acc = temp - polemass_length * theta_acc * cos_theta / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * x_acc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * theta_acc;
+    st[0] = x; st[1] = x_dot; st[2] = theta; st[3] = theta_dot;
+    terminated = (x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr) ? 1 : 0;
+    return terminated ? -1.0f : 1.0f;
+}
+
+// MountainCar::step, reference Environments/MountainCar.cpp:29-57 (constants :5-13).  st = {position, velocity}.
+__device__ __forceinline__ float mountaincar_step(float* st, int action, int& terminated) {
+    const float min_position = -1.2f, max_position = 0.6f, max_speed = 0.07f, goal_position = 0.5f, goal_velocity = 0.0f;
+    const float force = 0.001f, gravity = 0.0025f;
+    float position = st[0], velocity = st[1];
+    velocity += ((float)action - 1.0f) * force + glibc_cosf(3.0f * position) * (-gravity);
+    velocity = velocity < -max_speed ? -max_speed : (velocity > max_speed ? max_speed : velocity);
+    position += velocity;
+    position = position < min_position ? min_position : (position > max_position ? max_position : position);
+    if (position == min_position && velocity < 0.0f) velocity = 0.0f;
+    terminated = (position >= goal_position && velocity >= goal_velocity) ? 1 : 0;
+    st[0] = position; st[1] = velocity;
+    return -1.0f;
+}
+
+template <int ENV>
+__device__ __forceinline__ float env_step(float* st, int action, int& terminated) {
+    if constexpr (ENV == PPO_ENV_CARTPOLE) return cartpole_step(st, action, terminated);
+    else return mountaincar_step(st, action, terminated);
+}
+
+// CartPole::reset (CartPole.cpp:34-45): the k-th reset of ANY env reads words 4k..4k+3 of the one stream all envs share
+// (every env is constructed with the same seed, PPO_Discrete.cpp:84-86).  MountainCar::reset (MountainCar.cpp:59-66,79-88)
+// draws from std::random_device in the reference; the build keys it: philox(seed; global env, reset#, 0, 1).x.
+template <int ENV>
+__device__ __forceinline__ void env_reset(float* st, const float* __restrict__ reset_table, int k, int64_t seed, int64_t env_global) {
+    if constexpr (ENV == PPO_ENV_CARTPOLE) {
+        const float4 r = reinterpret_cast<const float4*>(reset_table)[k];
+        st[0] = r.x; st[1] = r.y; st[2] = r.z; st[3] = r.w;
+    } else {
+        const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)env_global, (uint32_t)k, 0u, 1u);
+        st[0] = canon_to_uniform(w.x, -0.6f, -0.4f);
+        st[1] = 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Categorical / CategoricalMasked over one head of width A held in a small array (uniform across the wave or per-thread).
+// reference Distributions/Categorical.cpp:28-39,92-119; CategoricalMasked.cpp:31-46,107-144.
+//   z[a] in: raw logits; out: m_logits (log-probs).  p[a] out: m_probs.  returns entropy.
+// ---------------------------------------------------------------------------------------------------------
+template <int DIST>
+__device__ __forceinline__ float categorical_head(float* z, float* p, const uint8_t* mask, int A) {
+    float mx = -INFINITY;
+    for (int a = 0; a < A; a++) {
+        if (DIST == PPO_DIST_MASKED && mask && !mask[a]) z[a] = -1e8f;
+        mx = z[a] > mx ? z[a] : mx;
+    }
+    float se = 0.0f;
+    for (int a = 0; a < A; a++) { p[a] = expf(z[a] - mx); se += p[a]; }
+    const float lse = logf(se) + mx;
+    float ent = 0.0f;
+    for (int a = 0; a < A; a++) {
+        z[a] = z[a] - lse;
+        p[a] = p[a] / se;
+        if (DIST == PPO_DIST_CATEGORICAL) {
+            const float l = z[a] > 1.17549435e-38f ? z[a] : 1.17549435e-38f;  // torch::clamp(m_logits, FLT_MIN), Categorical.cpp:115
+            ent += l * p[a];
+        } else {
+            const float plp = z[a] * p[a];
+            ent += (mask == nullptr || mask[a]) ? plp : 0.0f;
+        }
+    }
+    return -ent;
+}
+
+// Inverse-CDF draw on m_probs with u in [0,1) (mirrors oracle/ppo_oracle.c:orc_act).
+__device__ __forceinline__ int sample_head(const float* p, int A, float u) {
+    int a = 0, last = 0;
+    float acc = 0.0f;
+    bool hit = false;
+    for (int k = 0; k < A; k++) {
+        if (p[k] > 0.0f) last = k;
+        acc += p[k];
+        if (!hit && u < acc) { a = k; hit = true; }
+    }
+    return hit ? a : last;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif  // __HIPCC__
+
+// ---------------------------------------------------------------------------------------------------------
+// Host-side launcher prototypes (each defined next to its kernels)
+// ---------------------------------------------------------------------------------------------------------
+struct RolloutArgs {
+    // network
+    const float* params;
+    NetLayout L;
+    int dist_kind;
+    // env
+    int env_kind;
+    int N, T;
+    int max_episode_steps;
+    int64_t seed, env_offset, step_base;  // step_base: global index of rollout step 0 (sampling stream position)
+    float* env_state;      // [O,N]
+    int32_t* ep_len;       // [N]
+    float* ep_rew;         // [N]
+    int32_t* reset_count;  // [N]
+    const float* reset_table;
+    int reset_cap;
+    int32_t* error_flag;
+    // rollout buffers
+    float* obs;            // [T,N,O]
+    int32_t* actions;      // [T,N,H]
+    float* logprobs;       // [T,N]
+    float* rewards;        // [T,N]
+    float* dones;          // [T,N]
+    float* values;         // [T,N]
+    uint8_t* masks;        // [T,N,A] or null
+    int32_t* fin_len;      // [T,N]
+    float* fin_rew;        // [T,N]
+    float* next_obs;       // [N,O]
+    int32_t* next_done;    // [N]
+    float* next_value;     // [N]
+    const int64_t* forced_actions;  // [T,N,H] or null
+};
+
+hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s);
+hipError_t launch_env_reset(int env_kind, int N, int64_t seed, int64_t env_offset, float* env_state, int32_t* ep_len, float* ep_rew,
+                            int32_t* reset_count, const float* reset_table, int reset_cap, float* next_obs, int32_t* next_done,
+                            int32_t* error_flag, hipStream_t s);
+hipError_t launch_env_step(int env_kind, int N, int H, int max_episode_steps, int64_t seed, int64_t env_offset, float* env_state,
+                           int32_t* ep_len, float* ep_rew, int32_t* reset_count, const float* reset_table, int reset_cap,
+                           const int64_t* action, float* obs, float* reward, int32_t* done, int32_t* error_flag, hipStream_t s);
+hipError_t launch_env_transition(int env_kind, const float* state_in, const int64_t* action, int64_t n, float* next_state,
+                                 float* reward, int32_t* terminated, hipStream_t s);
+hipError_t launch_aos_to_soa(const float* aos, float* soa, int N, int O, bool to_soa, hipStream_t s);
+
+hipError_t launch_policy_act(const float* params, const NetLayout& L, int dist_kind, const float* obs, const uint8_t* mask,
+                             const int64_t* forced_action, int64_t n, int64_t seed, int64_t env_offset, int64_t step_index,
+                             int64_t* action, float* logprob, float* entropy, float* value, bool value_only, hipStream_t s);
+hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n, int A,
+                              float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode, hipStream_t s);
+
+hipError_t launch_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
+                      const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
+                      hipStream_t s);
+hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
+                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s);
+
+struct UpdateArgs {
+    const float* params;
+    NetLayout L;
+    LossParams hp;
+    // flattened batch views [B,...]
+    const float* obs;
+    const int32_t* actions;  // [B,H]
+    const uint8_t* masks;    // [B,A] or null
+    const float* logprobs;
+    const float* advantages;
+    const float* returns;
+    const float* values;
+    const int32_t* idx;      // [M]
+    int M;                   // local minibatch rows
+    double inv_global_M;     // 1 / (rows of the global minibatch)
+    const AdvStat* adv_stat; // global sums for this minibatch (nullptr when !norm_adv)
+    double global_M;
+    float* slab;             // [n_blocks, P_net_max] partial gradients
+    double* stat_slab;       // [n_blocks, 8] partial loss sums
+    int n_blocks_per_net;
+};
+int update_blocks_per_net(int M);
+hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
+// grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
+hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
+                               double* sums_out, hipStream_t s);
+hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
+                             const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world,
+                             StepStats* stats_out, double* clipfrac_accum, hipStream_t s);
+hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
+                            hipStream_t s);
+hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s);
+hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s);
+hipError_t launch_orthogonal_init(float* params, const NetLayout& L, int64_t seed, hipStream_t s);

