@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec (rollout + GAE + update) of the MI355X-native PPO hot path, BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+
+A "step" is one pass of the hot path over one batch: one iteration of PPO_Discrete::train()'s loop (reference
+PPO/PPO_Discrete.cpp:511-659) = rollout of num_steps x num_envs env-steps, GAE scan, update_epochs x num_minibatches optimizer
+steps.  Workload at N = 1: BASELINE.json configs[1] (CartPole-v1, 4096 envs x 128 steps, 2x64 MLP, 4 minibatches x 10 epochs,
+hyper-parameters of the reference's CartPoleRecommendedSettings.toml with action_size = 2).  N > 1: every rank owns 4096 envs
+(weak scaling, configs[2] at N = 8) and ONE RCCL all-reduce of the flat gradient per optimizer step crosses xGMI.
+value = env-steps of all ranks / max-over-ranks wall time of the K timed steps; the reference prints the same quantity as `fps`
+(PPO_Discrete.cpp:650-652,718).  Everything is resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (fused gather+forward+loss+backward): algorithmic FLOPs per launch / its average launch
+                duration measured with HIP events on the kernel's own stream inside the timed region
+  gae_roofline  the GAE scan (the kernel BASELINE.json's HBM-roofline target names), algorithmic bytes / event time
+  cpu_baseline  the reference's own CPU ThreadPool path (oracle/_ref/ref_harness = the unmodified reference compiled against
+                LibTorch CPU) timed on this host, or the C port when that binary is absent -- a reported baseline
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_PEAK_TFLOPS = 157.3   # MI355X dense f32 (vector = f32-input MFMA) peak, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0     # HBM3E spec peak
+
+
+def flops_per_sample(obs, act):
+    """Algorithmic FLOPs of forward + backward of both MLPs for one sample (2 FLOP per MAC; backward = 2 x forward)."""
+    macs = 0
+    for out in (1, act):
+        macs += obs * 64 + 64 * 64 + 64 * out
+    return 3 * 2 * macs
+
+
+def cpu_baseline(num_envs, num_steps, obs, act):
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    cores = os.cpu_count() or 1
+    if os.path.exists(ref):
+        try:
+            updates = 2
+            out = subprocess.run([ref, "bench", str(num_envs), str(num_steps), str(updates)], capture_output=True, text=True, timeout=900).stdout
+            m = re.search(r"REF_BENCH (\{.*\})", out)
+            if m:
+                r = json.loads(m.group(1))
+                return {"value": r["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(r["threads"]), "kind": "reference",
+                        "sample": "%d full update iterations (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch "
+                                  "CPU, ThreadPool(hardware_concurrency), %d envs x %d steps" % (updates, num_envs, num_steps)}
+        except Exception as ex:  # fall through to the port
+            sys.stderr.write("reference harness failed: %r\n" % (ex,))
+    # C port (scalar, single thread): one rollout of a bounded env count + one minibatch of the update, scaled per env-step
+    import numpy as np
+    import oracle as O
+    n = 256
+    net = O.Net.make(obs, [act])
+    rng = np.random.default_rng(0)
+    params = (rng.standard_normal(O.param_count(net)) * 0.1).astype(np.float32)
+    env = O.VecEnv(O.ENV_CARTPOLE, n, 2, 500)
+    t0 = time.perf_counter()
+    x = env.init()
+    for t in range(num_steps):
+        a, lp, en, v = O.act(net, params, x, 2, t)
+        x, r, d = env.step(a[:, 0])
+    t_roll = time.perf_counter() - t0
+    B = n * num_steps
+    hp = O.HParams(gamma=0.98, gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, norm_adv=1, clip_vloss=1)
+    obs_b = rng.standard_normal((B, obs)).astype(np.float32)
+    z = rng.standard_normal(B).astype(np.float32)
+    t0 = time.perf_counter()
+    O.minibatch_grads(net, hp, params, obs_b, (rng.random(B) < 0.5).astype(np.float32), z * 0.1 - 0.7, z, z, z, np.arange(B))
+    t_upd = (time.perf_counter() - t0) * 10  # 10 epochs over the batch
+    return {"value": B / (t_roll + t_upd), "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "scalar C restatement, 1 thread: %d envs x %d steps rollout + 10 epochs of forward/backward over that batch" % (n, num_steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--num-steps", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs one process per GPU: launch with `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # plumbing only: barrier, id broadcast, max over ranks
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from __graft_entry__ import load_package
+    P = load_package()
+    obs, act = 4, 2
+    N, T = args.envs, args.num_steps
+    total_updates = args.steps + args.warmup
+    cfg = P.make_config(env_kind=P.ENV_CARTPOLE, dist_kind=P.DIST_CATEGORICAL, obs_size=obs, head_dims=(act,), num_envs=N, num_steps=T,
+                        num_minibatches=4, update_epochs=10, max_episode_steps=500, seed=2, total_timesteps=total_updates * N * T * world,
+                        env_offset=rank * N, global_num_envs=N * world, learning_rate=1e-3, gamma=0.98, gae_lambda=0.95, clip_coef=0.2,
+                        ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank)
+    ctx = P.Context(cfg)
+    if world > 1:
+        import torch
+        ident = [P.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        ctx.comm_init(ident[0], rank, world)
+    ctx.init_orthogonal(2)   # same seed on every rank: replicated weights
+    ctx.env_reset()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        ctx.train_iteration()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.train_iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = ctx.stats()
+
+    if rank == 0:
+        env_steps = args.steps * N * T * world
+        M = (N * T) // 4
+        fl = flops_per_sample(obs, act) * M
+        fb_ms = prof["fwd_bwd_ms"] / max(prof["fwd_bwd_launches"], 1)
+        gae_ms = prof["gae_ms"] / max(prof["gae_launches"], 1)
+        gae_bytes = 20 * N * T + 8 * N
+        out = {
+            "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (fixed-seed CartPole-v1, random-init 2x64 actor/critic)",
+            "config": {"workload": "CartPole-v1 PPO_Discrete, %d envs x %d steps per GPU, 2x64 MLP, 4 minibatches x 10 epochs (BASELINE.json configs[%d])"
+                                   % (N, T, 1 if world == 1 else 2), "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
+                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 RCCL grad all-reduce per optimizer step)" % world},
+            "roofline": {"kernel": "fwd_bwd_kernel (gather+forward+PPO loss+backward, fp32)", "bound": "mfma", "achieved": fl / (fb_ms * 1e-3) / 1e12,
+                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"]},
+            "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_bytes / (gae_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": gae_bytes,
+                             "avg_launch_ms": gae_ms, "launches": prof["gae_launches"]},
+            "phase_ms_per_step": {"rollout": prof["rollout_ms"] / args.steps, "gae": prof["gae_ms"] / args.steps, "fwd_bwd": prof["fwd_bwd_ms"] / args.steps,
+                                  "grad_reduce": prof["reduce_ms"] / args.steps, "clip_adamw": prof["optimizer_ms"] / args.steps},
+            "train_stats": {k: st[k] for k in ("loss", "ep_len_mean", "ep_rew_mean", "explained_variance", "global_step")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, T, obs, act)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,8 @@
 /* include/ppo_hip.h -- C-ABI of libppo_hip.so: the MI355X (gfx950) PPO rollout-buffer hot path.
  *
  * The reference (AidanShipperley/PPO-LibTorch) has no plugin/FFI boundary: its "API" is a set of C++ classes
- * whose methods exchange torch::Tensor (PPO/PPO_Discrete.h:24-108, PPO/Agent.h:22-54, Distributions/*.h,
- * Environments/*.h).  This header is the boundary a maintainer would bind instead of LibTorch for that path:
+ * whose methods exchange torch::Tensor (PPO/PPO_Discrete.h:24-108, PPO/Agent.h:22-54, the Distributions and
+ * Environments headers).  This header is the boundary a maintainer would bind instead of LibTorch for that path:
  * plain pointers and sizes, int32 status codes, no exceptions, no torch types.  Every entry point cites the
  * reference interface (file:line, relative to the reference root) it replaces.  The C++ classes with the
  * reference's names (ppo-libtorch_amd/host/) and the Python ctypes binding (ppo-libtorch_amd/binding.py) sit on
@@ -27,6 +27,7 @@ extern "C" {
 #endif
 
 #define PPO_MAX_HEADS 8
+#define PPO_API __attribute__((visibility("default")))
 #define PPO_ABI_VERSION 1
 
 typedef int32_t ppo_status;
@@ -108,45 +109,45 @@ enum {
 /* ---------------------------------------------------------------------------------------------------------
  * Lifecycle / plumbing
  * ------------------------------------------------------------------------------------------------------- */
-int32_t ppo_abi_version(void);
+PPO_API int32_t ppo_abi_version(void);
 /* PPO_Discrete::PPO_Discrete() (PPO_Discrete.cpp:4-100): allocates every device buffer once (rollout [T,N,*],
  * parameters, AdamW state, env SoA, reset-stream table); no allocation happens afterwards. */
-ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out);
-void ppo_ctx_destroy(ppo_ctx* ctx);
+PPO_API ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out);
+PPO_API void ppo_ctx_destroy(ppo_ctx* ctx);
 /* Error text of the last failing call on ctx (ctx == NULL: of the last failing ppo_ctx_create in this thread).
  * The C++ facade rethrows it as std::runtime_error like the reference's obs-size check does (:370-375). */
-const char* ppo_last_error(const ppo_ctx* ctx);
-ppo_status ppo_sync(ppo_ctx* ctx);              /* block until the context's stream is idle */
-void* ppo_stream(ppo_ctx* ctx);                 /* hipStream_t */
-ppo_status ppo_get_config(const ppo_ctx* ctx, ppo_config* out);
-ppo_status ppo_buffer(ppo_ctx* ctx, int32_t which, void** dev_ptr, size_t* bytes);
-ppo_status ppo_device_alloc(ppo_ctx* ctx, size_t bytes, void** dev_ptr);
-ppo_status ppo_device_free(ppo_ctx* ctx, void* dev_ptr);
-ppo_status ppo_memcpy_h2d(ppo_ctx* ctx, void* dst_dev, const void* src_h, size_t bytes); /* synchronous */
-ppo_status ppo_memcpy_d2h(ppo_ctx* ctx, void* dst_h, const void* src_dev, size_t bytes); /* synchronous */
+PPO_API const char* ppo_last_error(const ppo_ctx* ctx);
+PPO_API ppo_status ppo_sync(ppo_ctx* ctx);              /* block until the context's stream is idle */
+PPO_API void* ppo_stream(ppo_ctx* ctx);                 /* hipStream_t */
+PPO_API ppo_status ppo_get_config(const ppo_ctx* ctx, ppo_config* out);
+PPO_API ppo_status ppo_buffer(ppo_ctx* ctx, int32_t which, void** dev_ptr, size_t* bytes);
+PPO_API ppo_status ppo_device_alloc(ppo_ctx* ctx, size_t bytes, void** dev_ptr);
+PPO_API ppo_status ppo_device_free(ppo_ctx* ctx, void* dev_ptr);
+PPO_API ppo_status ppo_memcpy_h2d(ppo_ctx* ctx, void* dst_dev, const void* src_h, size_t bytes); /* synchronous */
+PPO_API ppo_status ppo_memcpy_d2h(ppo_ctx* ctx, void* dst_h, const void* src_dev, size_t bytes); /* synchronous */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Agent (PPO/Agent.h:22-54)
  * ------------------------------------------------------------------------------------------------------- */
-int64_t ppo_param_count(const ppo_ctx* ctx);
+PPO_API int64_t ppo_param_count(const ppo_ctx* ctx);
 /* 2*(n_hidden+1) tensors per net, critic first: rows {out,in} for weights and {out,1} for biases. */
-ppo_status ppo_param_shapes(const ppo_ctx* ctx, int64_t* shapes_h, int32_t* n_tensors);
+PPO_API ppo_status ppo_param_shapes(const ppo_ctx* ctx, int64_t* shapes_h, int32_t* n_tensors);
 /* Agent::ppoLayerInit (Agent.cpp:91-99): orthogonal_(W, gain) with gain sqrt(2) / 1.0 (critic head) / 0.01 (actor
  * head), bias 0.  Own Householder-QR of a Philox Gaussian (LibTorch's LAPACK+mt19937 draw is not reproducible). */
-ppo_status ppo_params_init_orthogonal(ppo_ctx* ctx, int64_t seed);
-ppo_status ppo_params_set_h(ppo_ctx* ctx, const float* params_h, int64_t count); /* also resets nothing else */
-ppo_status ppo_params_get_h(ppo_ctx* ctx, float* params_h, int64_t count);
-ppo_status ppo_optimizer_set_h(ppo_ctx* ctx, const float* exp_avg_h, const float* exp_avg_sq_h, int64_t count, int64_t step);
-ppo_status ppo_optimizer_get_h(ppo_ctx* ctx, float* exp_avg_h, float* exp_avg_sq_h, int64_t count, int64_t* step);
+PPO_API ppo_status ppo_params_init_orthogonal(ppo_ctx* ctx, int64_t seed);
+PPO_API ppo_status ppo_params_set_h(ppo_ctx* ctx, const float* params_h, int64_t count); /* also resets nothing else */
+PPO_API ppo_status ppo_params_get_h(ppo_ctx* ctx, float* params_h, int64_t count);
+PPO_API ppo_status ppo_optimizer_set_h(ppo_ctx* ctx, const float* exp_avg_h, const float* exp_avg_sq_h, int64_t count, int64_t step);
+PPO_API ppo_status ppo_optimizer_get_h(ppo_ctx* ctx, float* exp_avg_h, float* exp_avg_sq_h, int64_t count, int64_t* step);
 
 /* Agent::getValue (Agent.cpp:107-109): value[n] = Critic(obs[n,O]). */
-ppo_status ppo_get_value(ppo_ctx* ctx, const float* obs, int64_t n, float* value);
+PPO_API ppo_status ppo_get_value(ppo_ctx* ctx, const float* obs, int64_t n, float* value);
 /* Agent::getActionAndValueDiscrete (Agent.cpp:117-128) / getActionAndValueMasked (:137-170).
  *   obs [n,O]; mask u8 [n,A] or NULL; forced_action i64 [n,H] or NULL (NULL -> sample, Categorical.cpp:73-79, with the
  *   context's counter-based generator keyed by (seed, env_offset+row, step_index, head));
  *   outputs action i64 [n,H] (the transposed layout the reference returns, Agent.cpp:168), logprob/entropy/value f32 [n]
  *   (log-probs and entropies summed over heads, :165-168).  Any output may be NULL. */
-ppo_status ppo_policy_act(ppo_ctx* ctx, const float* obs, const uint8_t* mask, const int64_t* forced_action, int64_t n,
+PPO_API ppo_status ppo_policy_act(ppo_ctx* ctx, const float* obs, const uint8_t* mask, const int64_t* forced_action, int64_t n,
                           int64_t step_index, int64_t* action, float* logprob, float* entropy, float* value);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -155,7 +156,7 @@ ppo_status ppo_policy_act(ppo_ctx* ctx, const float* obs, const uint8_t* mask, c
 /* Constructor + log_prob + entropy + mode on logits [n,A]: m_logits = logits - logsumexp, m_probs = softmax
  * (Categorical.cpp:28-39; CategoricalMasked.cpp:31-46), log_prob = gather (:92-101), entropy (:112-119 / :127-144),
  * mode = argmax (:139-141).  value i64 [n] may be NULL; outputs may be NULL. */
-ppo_status ppo_categorical(int32_t dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n,
+PPO_API ppo_status ppo_categorical(int32_t dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n,
                            int32_t A, float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode,
                            void* stream);
 
@@ -165,21 +166,21 @@ ppo_status ppo_categorical(int32_t dist_kind, const float* logits, const uint8_t
 /* Stateless batched CartPole::step (CartPole.cpp:47-94) / MountainCar::step (MountainCar.cpp:29-57) on injected
  * states: state_in [n,O] (array-of-structs like the reference's std::vector<float> state), action i64 [n];
  * outputs next_state [n,O], reward f32 [n], terminated i32 [n]. */
-ppo_status ppo_env_transition(int32_t env_kind, const float* state_in, const int64_t* action, int64_t n, float* next_state,
+PPO_API ppo_status ppo_env_transition(int32_t env_kind, const float* state_in, const int64_t* action, int64_t n, float* next_state,
                               float* reward, int32_t* terminated, void* stream);
 /* First n_resets reset states [n_resets,4] of std::mt19937(seed) + uniform_real_distribution<float>(-0.05,0.05)
  * (CartPole.h:28-29, CartPole.cpp:3-4,34-45): host-side table builder used by the context. */
-ppo_status ppo_cartpole_reset_stream_h(int64_t seed, int64_t n_resets, float* out_h);
+PPO_API ppo_status ppo_cartpole_reset_stream_h(int64_t seed, int64_t n_resets, float* out_h);
 /* PPO_Discrete::initEnvs (PPO_Discrete.cpp:365-402): resets every env (env 0 twice, :368+:389), fills NEXT_OBS,
  * zeroes NEXT_DONE; checks obs_size against the env (:370-375 -> PPO_ERR_INVALID with the reference's message). */
-ppo_status ppo_env_reset(ppo_ctx* ctx);
+PPO_API ppo_status ppo_env_reset(ppo_ctx* ctx);
 /* PPO_Discrete::stepEnvs (PPO_Discrete.cpp:413-483): action i64 [N,H] (column 0 drives the env);
  * outputs obs [N,O] (first obs of the new episode where done), reward f32 [N], done i32 [N]. */
-ppo_status ppo_env_step(ppo_ctx* ctx, const int64_t* action, float* obs, float* reward, int32_t* done);
+PPO_API ppo_status ppo_env_step(ppo_ctx* ctx, const int64_t* action, float* obs, float* reward, int32_t* done);
 /* Inject / read env state for teacher-forced parity: state_h [N,O] AoS, ep_len i32, ep_rew f32, reset_count i32 (NULL = skip). */
-ppo_status ppo_env_set_state_h(ppo_ctx* ctx, const float* state_h, const int32_t* ep_len_h, const float* ep_rew_h,
+PPO_API ppo_status ppo_env_set_state_h(ppo_ctx* ctx, const float* state_h, const int32_t* ep_len_h, const float* ep_rew_h,
                                const int32_t* reset_count_h);
-ppo_status ppo_env_get_state_h(ppo_ctx* ctx, float* state_h, int32_t* ep_len_h, float* ep_rew_h, int32_t* reset_count_h);
+PPO_API ppo_status ppo_env_get_state_h(ppo_ctx* ctx, float* state_h, int32_t* ep_len_h, float* ep_rew_h, int32_t* reset_count_h);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Rollout and advantages
@@ -187,16 +188,16 @@ ppo_status ppo_env_get_state_h(ppo_ctx* ctx, float* state_h, int32_t* ep_len_h, 
 /* The rollout loop of PPO_Discrete::train (PPO_Discrete.cpp:524-548; PPO_MultiDiscrete.cpp:547-571) as ONE launch:
  * T x { store obs/done, policy forward + sample, store value/action/logprob, env step + auto-reset, store reward }.
  * forced_actions i64 [T,N,H] or NULL (teacher-forcing for parity).  Leaves NEXT_OBS / NEXT_DONE for the bootstrap. */
-ppo_status ppo_rollout(ppo_ctx* ctx, const int64_t* forced_actions);
+PPO_API ppo_status ppo_rollout(ppo_ctx* ctx, const int64_t* forced_actions);
 /* PPO_Discrete::calcAdvantage (PPO_Discrete.cpp:274-331) on the context's buffers: bootstrap NEXT_VALUE = Critic(NEXT_OBS)
  * (:280), then GAE (:283-306) or n-step returns (:309-329) by cfg.use_gae; fills ADVANTAGES and RETURNS. */
-ppo_status ppo_calc_advantage(ppo_ctx* ctx);
+PPO_API ppo_status ppo_calc_advantage(ppo_ctx* ctx);
 /* The same scan on caller buffers (all [T,N] time-major f32; next_value f32 [N]; next_done i32 [N]).  Exact mode:
  * the reference's association and evaluation order along t, no FMA contraction -> bit-identical advantages/returns. */
-ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
+PPO_API ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
                    const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages,
                    float* returns, void* stream);
-ppo_status ppo_nstep_returns(const float* rewards, const float* values, const float* dones, const float* next_value,
+PPO_API ppo_status ppo_nstep_returns(const float* rewards, const float* values, const float* dones, const float* next_value,
                              const int32_t* next_done, int64_t T, int64_t N, float gamma, float* advantages, float* returns,
                              void* stream);
 
@@ -205,30 +206,41 @@ ppo_status ppo_nstep_returns(const float* rewards, const float* values, const fl
  * ------------------------------------------------------------------------------------------------------- */
 /* torch::randperm replacement (:569): fills PERM[epoch] for every epoch of the coming update with a keyed
  * cycle-walking Feistel permutation of [0,B) (seed, update, epoch). */
-ppo_status ppo_generate_permutations(ppo_ctx* ctx);
+PPO_API ppo_status ppo_generate_permutations(ppo_ctx* ctx);
 /* One minibatch, forward + losses + backward (:576-638) on batch rows idx i32 [M] (device).  Leaves the UNCLIPPED
  * gradient of the global-minibatch loss in GRADS (local contribution when sharded) and the loss scalars in the stats. */
-ppo_status ppo_minibatch_forward_backward(ppo_ctx* ctx, const int32_t* idx, int64_t M);
+PPO_API ppo_status ppo_minibatch_forward_backward(ppo_ctx* ctx, const int32_t* idx, int64_t M);
 /* New in the build (no reference counterpart): sum GRADS over ranks with one RCCL all-reduce. No-op unsharded. */
-ppo_status ppo_allreduce_grads(ppo_ctx* ctx);
+PPO_API ppo_status ppo_allreduce_grads(ppo_ctx* ctx);
 /* clip_grad_norm_ (:640; LibTorch clip_grad.h:22-85) + AdamW::step (:641; eps 1e-5f, betas .9/.999, weight_decay 1e-2,
  * :76-78) as one fused launch. */
-ppo_status ppo_optimizer_step(ppo_ctx* ctx);
+PPO_API ppo_status ppo_optimizer_step(ppo_ctx* ctx);
 /* All epochs x minibatches of one update (:567-644) with the context's own permutations, then explained variance (:647-648). */
-ppo_status ppo_update(ppo_ctx* ctx);
+PPO_API ppo_status ppo_update(ppo_ctx* ctx);
 /* One iteration of the training loop (:511-659 minus printing/checkpoints): LR anneal, rollout, advantages, update. */
-ppo_status ppo_train_iteration(ppo_ctx* ctx);
+PPO_API ppo_status ppo_train_iteration(ppo_ctx* ctx);
 /* Synchronises and returns the scalars of the last update (printPPOResults' inputs, :700-774). */
-ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
+PPO_API ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
 /* LR anneal (:514-518) is applied by ppo_train_iteration; direct control for tests. */
-ppo_status ppo_set_learning_rate(ppo_ctx* ctx, double lr);
+PPO_API ppo_status ppo_set_learning_rate(ppo_ctx* ctx, double lr);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Measurement (new; the reference only has a wall clock around each update, PPO_Discrete.cpp:650-652)
+ * ------------------------------------------------------------------------------------------------------- */
+/* Per-kernel device time from HIP events recorded on the context's stream around the instrumented launches. */
+typedef struct ppo_profile {
+    int64_t fwd_bwd_launches, gae_launches, rollout_launches, optimizer_launches, reduce_launches;
+    double fwd_bwd_ms, gae_ms, rollout_ms, optimizer_ms, reduce_ms;   /* summed over the launches since enable/read */
+} ppo_profile;
+PPO_API ppo_status ppo_profile_enable(ppo_ctx* ctx, int32_t on);
+PPO_API ppo_status ppo_profile_read(ppo_ctx* ctx, ppo_profile* out);  /* synchronises; resets the accumulators */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Multi-GPU (new): one context per GPU/process, envs sharded, one gradient all-reduce per optimizer step
  * ------------------------------------------------------------------------------------------------------- */
 #define PPO_COMM_ID_BYTES 128
-ppo_status ppo_comm_unique_id(void* id_out_h /* PPO_COMM_ID_BYTES */);
-ppo_status ppo_comm_init(ppo_ctx* ctx, const void* id_h, int32_t rank, int32_t nranks);
+PPO_API ppo_status ppo_comm_unique_id(void* id_out_h /* PPO_COMM_ID_BYTES */);
+PPO_API ppo_status ppo_comm_init(ppo_ctx* ctx, const void* id_h, int32_t rank, int32_t nranks);
 
 #ifdef __cplusplus
 }

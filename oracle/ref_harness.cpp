@@ -486,7 +486,7 @@ void goldMultiHeadAgent(const std::string& outPath) {
     GoldWriter g;
     torch::manual_seed(5);
     auto dev = std::make_shared<torch::Device>(torch::kCPU);
-    const int64_t O = 24, n = 64;
+    const int64_t O = 4, n = 64;  // CartPole-sized observations so the context-level C-ABI can replay it
     std::vector<int64_t> heads = { 3, 3, 3, 2 };
     Agent agent(O, 11, dev);
     agent.m_actionSpace = heads;

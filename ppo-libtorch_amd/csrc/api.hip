@@ -1,0 +1,969 @@
+// ppo-libtorch_amd/csrc/api.hip -- the C-ABI of include/ppo_hip.h: context, buffers, launch sequencing, RCCL.
+//
+// Host language is C++ because the reference is C++; nothing here depends on LibTorch.  The context owns
+// every device buffer (allocated once in ppo_ctx_create) and one HIP stream; every entry point only enqueues work.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "ppo_internal.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL, bound lazily (single-GPU use never loads it).  One all-reduce per optimizer step.
+// ---------------------------------------------------------------------------------------------------------
+namespace rccl {
+typedef struct { char internal[128]; } UniqueId;
+typedef void* Comm;
+typedef int (*GetUniqueId_t)(UniqueId*);
+typedef int (*CommInitRank_t)(Comm*, int, UniqueId, int);
+typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+typedef int (*CommDestroy_t)(Comm);
+typedef const char* (*GetErrorString_t)(int);
+static GetUniqueId_t GetUniqueId;
+static CommInitRank_t CommInitRank;
+static AllReduce_t AllReduce;
+static CommDestroy_t CommDestroy;
+static GetErrorString_t GetErrorString;
+static const int kFloat32 = 7, kFloat64 = 8, kSum = 0;
+static bool load(std::string& err) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (AllReduce) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // reuse the copy a host process (e.g. PyTorch) already mapped
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    GetUniqueId = (GetUniqueId_t)dlsym(h, "ncclGetUniqueId");
+    CommInitRank = (CommInitRank_t)dlsym(h, "ncclCommInitRank");
+    AllReduce = (AllReduce_t)dlsym(h, "ncclAllReduce");
+    CommDestroy = (CommDestroy_t)dlsym(h, "ncclCommDestroy");
+    GetErrorString = (GetErrorString_t)dlsym(h, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { err = "librccl lacks nccl* symbols"; AllReduce = nullptr; return false; }
+    return true;
+}
+}  // namespace rccl
+
+struct ppo_ctx {
+    ppo_config cfg{};
+    NetLayout L{};
+    LossParams hp{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    int T = 0, N = 0, O = 0, H = 0, A = 0;
+    int64_t B = 0, MB = 0;
+    int n_mb = 0, steps_per_update = 0;
+    int world = 1, rank = 0;
+    rccl::Comm comm = nullptr;
+
+    std::vector<void*> allocs;
+    void* buf[PPO_BUF_COUNT_] = {};
+    size_t buf_bytes[PPO_BUF_COUNT_] = {};
+
+    float* reset_table = nullptr;
+    int reset_cap = 0;
+    int32_t* error_flag = nullptr;
+    float* slab = nullptr;
+    double* stat_slab = nullptr;
+    double* loss_sums = nullptr;
+    AdvStat* adv_stats = nullptr;       // [steps_per_update] + 1 scratch slot
+    AdamCoef* adam_coefs = nullptr;     // device [steps_per_update + 1]
+    AdamCoef* adam_coefs_h = nullptr;   // pinned mirror
+    StepStats* step_stats = nullptr;    // device [steps_per_update + 1]
+    double* clipfrac_accum = nullptr;   // {sum, count}
+    double* ev_sums = nullptr;          // [64][4]
+    int32_t* row_counts = nullptr;      // [T]
+    EpisodeRing* ring = nullptr;
+    float* scratch_obs = nullptr;       // [N,O] staging for AoS<->SoA conversions
+    int max_blocks_per_net = 0;
+
+    // host-side training state
+    double lr = 0.0;
+    int64_t opt_step = 0;
+    int64_t global_step = 0;
+    int64_t updates = 0;
+    int64_t num_updates_total = 0;
+    int64_t rollout_steps = 0;      // sampling-stream position (rollout steps taken so far)
+    int64_t act_calls = 0;
+    bool fin_pending = false;
+    bool have_ev = false;
+    int last_stat_slot = -1;
+    double last_global_M = 1.0;
+
+    // profiling: (start, stop) event pairs per instrumented launch
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+};
+
+enum { PROF_FWD_BWD = 0, PROF_GAE, PROF_ROLLOUT, PROF_OPT, PROF_REDUCE, PROF_KINDS_ };
+
+struct ProfScope {
+    ppo_ctx* c;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind;
+    static hipEvent_t get(ppo_ctx* c) {
+        if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    ProfScope(ppo_ctx* ctx, int k) : c(ctx), kind(k) {
+        if (!c->profiling) return;
+        a = get(c); b = get(c);
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->spans.push_back({ a, b, kind });
+    }
+};
+
+static thread_local std::string g_create_error;
+
+static ppo_status fail(ppo_ctx* ctx, ppo_status code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                                                   \
+    do {                                                                                                                    \
+        hipError_t e_ = (call);                                                                                             \
+        if (e_ != hipSuccess) return fail(ctx, PPO_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define NEED(ctx, cond, msg)                                        \
+    do {                                                            \
+        if (!(cond)) return fail(ctx, PPO_ERR_INVALID, "%s", msg);  \
+    } while (0)
+
+template <class Tp>
+static hipError_t dalloc(ppo_ctx* c, Tp** p, size_t count, bool zero = true) {
+    void* q = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(Tp), 16);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+    c->allocs.push_back(q);
+    if (zero) { e = hipMemset(q, 0, bytes); if (e != hipSuccess) return e; }
+    *p = static_cast<Tp*>(q);
+    return hipSuccess;
+}
+template <class Tp>
+static hipError_t dalloc_buf(ppo_ctx* c, int which, size_t count) {
+    Tp* p = nullptr;
+    hipError_t e = dalloc(c, &p, count);
+    c->buf[which] = p;
+    c->buf_bytes[which] = count * sizeof(Tp);
+    return e;
+}
+template <class Tp>
+static Tp* B_(ppo_ctx* c, int which) { return static_cast<Tp*>(c->buf[which]); }
+
+// ---------------------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx;
+    explicit Mt19937(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; i++) {
+                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+};
+}  // namespace
+
+// std::mt19937(seed) + std::uniform_real_distribution<float>(-0.05f, 0.05f): reference CartPole.h:28-29, CartPole.cpp:3-4,96-100.
+// libstdc++'s generate_canonical<float,24> consumes one 32-bit draw: float(u)/2^32, clamped below 1; then *(b-a)+a.
+extern "C" ppo_status ppo_cartpole_reset_stream_h(int64_t seed, int64_t n_resets, float* out_h) {
+    if (!out_h || n_resets < 0) return PPO_ERR_INVALID;
+    Mt19937 g((uint32_t)seed);
+    const float a = -0.05f, b = 0.05f;
+    for (int64_t i = 0; i < n_resets * 4; i++) {
+        float r = (float)g.next() / 4294967296.0f;
+        if (r >= 1.0f) r = std::nextafter(1.0f, 0.0f);
+        out_h[i] = r * (b - a) + a;
+    }
+    return PPO_OK;
+}
+
+static ppo_status ensure_reset_table(ppo_ctx* c, int64_t need) {
+    if (c->cfg.env_kind != PPO_ENV_CARTPOLE) return PPO_OK;
+    if (need <= c->reset_cap) return PPO_OK;
+    int64_t cap = std::max<int64_t>(c->reset_cap, 1024);
+    while (cap < need) cap *= 2;
+    NEED(c, cap < (1ll << 28), "reset table would exceed 2^28 entries");
+    std::vector<float> h((size_t)cap * 4);
+    ppo_cartpole_reset_stream_h(c->cfg.seed, cap, h.data());
+    float* d = nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), (size_t)cap * 4 * sizeof(float)));
+    HIPCHK(c, hipMemcpy(d, h.data(), (size_t)cap * 4 * sizeof(float), hipMemcpyHostToDevice));
+    if (c->reset_table) {
+        c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void*)c->reset_table), c->allocs.end());
+        hipFree(c->reset_table);
+    }
+    c->allocs.push_back(d);
+    c->reset_table = d;
+    c->reset_cap = (int)cap;
+    return PPO_OK;
+}
+
+static ppo_status check_device_flag(ppo_ctx* c) {
+    int32_t f = 0;
+    HIPCHK(c, hipMemcpyAsync(&f, c->error_flag, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (f & 1) return fail(c, PPO_ERR_STATE, "CartPole reset-stream table exhausted (capacity %d resets per env)", c->reset_cap);
+    return PPO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int32_t ppo_abi_version(void) { return PPO_ABI_VERSION; }
+
+extern "C" const char* ppo_last_error(const ppo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && rccl::CommDestroy) rccl::CommDestroy(c->comm);
+    for (auto& sp : c->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->adam_coefs_h) hipHostFree(c->adam_coefs_h);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, PPO_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(ppo_config)) return fail(nullptr, PPO_ERR_INVALID, "ppo_config.struct_size %d != %zu", cfg->struct_size, sizeof(ppo_config));
+    if (cfg->hidden != PPO_HIDDEN || cfg->n_hidden != 2)
+        return fail(nullptr, PPO_ERR_UNSUPPORTED, "only the reference architecture (2 hidden layers of 64, Agent.cpp:25-59) is built; got %d x %d", cfg->n_hidden, cfg->hidden);
+    if (cfg->env_kind != PPO_ENV_CARTPOLE && cfg->env_kind != PPO_ENV_MOUNTAINCAR) return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
+    if (cfg->dist_kind != PPO_DIST_CATEGORICAL && cfg->dist_kind != PPO_DIST_MASKED) return fail(nullptr, PPO_ERR_INVALID, "unknown dist_kind %d", cfg->dist_kind);
+    const int env_obs = cfg->env_kind == PPO_ENV_CARTPOLE ? 4 : 2;
+    if (cfg->obs_size != env_obs) {
+        // the reference's runtime check in initEnvs (PPO_Discrete.cpp:370-375), same wording
+        return fail(nullptr, PPO_ERR_INVALID,
+                    "The environment returned an observation of size %d, but your config defined the expected observation size to be %d.\n"
+                    "Have you properly defined your PPOConfig.toml file for your environment?", env_obs, cfg->obs_size);
+    }
+    if (cfg->n_heads < 1 || cfg->n_heads > PPO_MAX_HEADS) return fail(nullptr, PPO_ERR_INVALID, "n_heads must be in [1,%d]", PPO_MAX_HEADS);
+    int A = 0;
+    for (int h = 0; h < cfg->n_heads; h++) {
+        if (cfg->head_dims[h] < 1) return fail(nullptr, PPO_ERR_INVALID, "head_dims[%d] < 1", h);
+        A += cfg->head_dims[h];
+    }
+    if (A > PPO_MAX_ACT) return fail(nullptr, PPO_ERR_UNSUPPORTED, "sum(head_dims) = %d exceeds %d", A, PPO_MAX_ACT);
+    if (cfg->num_envs < 1 || cfg->num_steps < 1 || cfg->num_minibatches < 1 || cfg->update_epochs < 1)
+        return fail(nullptr, PPO_ERR_INVALID, "num_envs, num_steps, num_minibatches, update_epochs must be >= 1");
+    const int64_t B = (int64_t)cfg->num_envs * cfg->num_steps;
+    if (B / cfg->num_minibatches < 1) return fail(nullptr, PPO_ERR_INVALID, "minibatch_size = batch/num_minibatches is 0");
+    if (B >= (1ll << 31)) return fail(nullptr, PPO_ERR_UNSUPPORTED, "batch of %lld rows exceeds int32 indexing", (long long)B);
+
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, PPO_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
+    ppo_ctx* c = new ppo_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.global_num_envs <= 0) c->cfg.global_num_envs = cfg->num_envs;
+    c->L = make_layout(cfg->obs_size, cfg->n_heads, cfg->head_dims);
+    c->hp = LossParams{ cfg->clip_coef, cfg->ent_coef, cfg->vf_coef, cfg->norm_adv, cfg->clip_vloss, cfg->dist_kind };
+    c->T = cfg->num_steps; c->N = cfg->num_envs; c->O = cfg->obs_size; c->H = cfg->n_heads; c->A = A;
+    c->B = B;
+    c->MB = B / cfg->num_minibatches;                 // int division, PPO_Discrete.cpp:247
+    c->n_mb = (int)((B + c->MB - 1) / c->MB);          // a ragged tail is an extra short minibatch (:573-576)
+    c->steps_per_update = cfg->update_epochs * c->n_mb;
+    c->lr = (double)cfg->learning_rate;                // AdamWOptions(m_learning_rate): double(float lr), :76-78
+    const int64_t global_B = c->cfg.global_num_envs * (int64_t)cfg->num_steps;
+    c->num_updates_total = cfg->total_timesteps > 0 ? cfg->total_timesteps / global_B : 0;  // :496
+
+#define CK(call)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e2 = (call);                                                                          \
+        if (e2 != hipSuccess) {                                                                          \
+            fail(nullptr, PPO_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2));                    \
+            ppo_ctx_destroy(c);                                                                          \
+            return PPO_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t TN = (size_t)c->T * c->N, N = c->N, P = c->L.P;
+    CK(dalloc_buf<float>(c, PPO_BUF_OBS, TN * c->O));
+    CK(dalloc_buf<int32_t>(c, PPO_BUF_ACTIONS, TN * c->H));
+    CK(dalloc_buf<float>(c, PPO_BUF_LOGPROBS, TN));
+    CK(dalloc_buf<float>(c, PPO_BUF_REWARDS, TN));
+    CK(dalloc_buf<float>(c, PPO_BUF_DONES, TN));
+    CK(dalloc_buf<float>(c, PPO_BUF_VALUES, TN));
+    CK(dalloc_buf<uint8_t>(c, PPO_BUF_MASKS, TN * c->A));
+    CK(dalloc_buf<float>(c, PPO_BUF_ADVANTAGES, TN));
+    CK(dalloc_buf<float>(c, PPO_BUF_RETURNS, TN));
+    CK(dalloc_buf<float>(c, PPO_BUF_NEXT_OBS, N * c->O));
+    CK(dalloc_buf<int32_t>(c, PPO_BUF_NEXT_DONE, N));
+    CK(dalloc_buf<float>(c, PPO_BUF_NEXT_VALUE, N));
+    CK(dalloc_buf<float>(c, PPO_BUF_PARAMS, P));
+    CK(dalloc_buf<float>(c, PPO_BUF_GRADS, P + 8));   // + loss sums that ride through the all-reduce when sharded
+    c->buf_bytes[PPO_BUF_GRADS] = P * sizeof(float);
+    CK(dalloc_buf<float>(c, PPO_BUF_EXP_AVG, P));
+    CK(dalloc_buf<float>(c, PPO_BUF_EXP_AVG_SQ, P));
+    CK(dalloc_buf<float>(c, PPO_BUF_ENV_STATE, N * c->O));
+    CK(dalloc_buf<int32_t>(c, PPO_BUF_EP_LEN, N));
+    CK(dalloc_buf<float>(c, PPO_BUF_EP_REW, N));
+    CK(dalloc_buf<int32_t>(c, PPO_BUF_RESET_COUNT, N));
+    CK(dalloc_buf<int32_t>(c, PPO_BUF_PERM, (size_t)cfg->update_epochs * B));
+    CK(dalloc_buf<int32_t>(c, PPO_BUF_FIN_LEN, TN));
+    CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
+    CK(dalloc(c, &c->error_flag, 1));
+    c->max_blocks_per_net = update_blocks_per_net((int)std::min<int64_t>(B, INT32_MAX));
+    const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
+    CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));
+    CK(dalloc(c, &c->stat_slab, (size_t)2 * c->max_blocks_per_net * 8));
+    CK(dalloc(c, &c->loss_sums, 8));
+    CK(dalloc(c, &c->adv_stats, (size_t)c->steps_per_update + 1));
+    CK(dalloc(c, &c->adam_coefs, (size_t)c->steps_per_update + 1));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
+    CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
+    CK(dalloc(c, &c->clipfrac_accum, 2));
+    CK(dalloc(c, &c->ev_sums, 64 * 4));
+    CK(dalloc(c, &c->row_counts, (size_t)c->T));
+    CK(dalloc(c, &c->ring, 1));
+    CK(dalloc(c, &c->scratch_obs, N * c->O));
+#undef CK
+    // every env can reset at most once per step: steps per env over the whole run bounds the shared reset stream
+    const int64_t steps_per_env = cfg->total_timesteps > 0 ? cfg->total_timesteps / std::max<int64_t>(c->cfg.global_num_envs, 1) : 0;
+    ppo_status st = ensure_reset_table(c, std::max<int64_t>(steps_per_env + cfg->num_steps + 4, 4096));
+    if (st != PPO_OK) { g_create_error = c->err; ppo_ctx_destroy(c); return st; }
+    *out = c;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_sync(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PPO_OK;
+}
+extern "C" void* ppo_stream(ppo_ctx* c) { return c ? c->stream : nullptr; }
+extern "C" ppo_status ppo_get_config(const ppo_ctx* c, ppo_config* out) {
+    if (!c || !out) return PPO_ERR_INVALID;
+    *out = c->cfg;
+    return PPO_OK;
+}
+extern "C" ppo_status ppo_buffer(ppo_ctx* c, int32_t which, void** dev_ptr, size_t* bytes) {
+    NEED(c, c != nullptr, "null ctx");
+    NEED(c, which >= 0 && which < PPO_BUF_COUNT_, "unknown buffer id");
+    if (dev_ptr) *dev_ptr = c->buf[which];
+    if (bytes) *bytes = c->buf_bytes[which];
+    return PPO_OK;
+}
+extern "C" ppo_status ppo_device_alloc(ppo_ctx* c, size_t bytes, void** dev_ptr) {
+    NEED(c, c && dev_ptr, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMalloc(dev_ptr, std::max<size_t>(bytes, 16)));
+    return PPO_OK;
+}
+extern "C" ppo_status ppo_device_free(ppo_ctx* c, void* dev_ptr) {
+    NEED(c, c != nullptr, "null ctx");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(dev_ptr));
+    return PPO_OK;
+}
+extern "C" ppo_status ppo_memcpy_h2d(ppo_ctx* c, void* dst_dev, const void* src_h, size_t bytes) {
+    NEED(c, c != nullptr, "null ctx");
+    HIPCHK(c, hipMemcpyAsync(dst_dev, src_h, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PPO_OK;
+}
+extern "C" ppo_status ppo_memcpy_d2h(ppo_ctx* c, void* dst_h, const void* src_dev, size_t bytes) {
+    NEED(c, c != nullptr, "null ctx");
+    HIPCHK(c, hipMemcpyAsync(dst_h, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PPO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Agent
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int64_t ppo_param_count(const ppo_ctx* c) { return c ? c->L.P : -1; }
+
+extern "C" ppo_status ppo_param_shapes(const ppo_ctx* c, int64_t* shapes_h, int32_t* n_tensors) {
+    if (!c) return PPO_ERR_INVALID;
+    if (n_tensors) *n_tensors = c->L.n_tensors;
+    if (shapes_h) {
+        int k = 0;
+        for (int net = 0; net < 2; net++) {
+            const int out3 = net == 0 ? 1 : c->A;
+            const int64_t dims[6][2] = { { PPO_HIDDEN, c->O }, { PPO_HIDDEN, 1 }, { PPO_HIDDEN, PPO_HIDDEN }, { PPO_HIDDEN, 1 }, { out3, PPO_HIDDEN }, { out3, 1 } };
+            for (auto& d : dims) { shapes_h[k++] = d[0]; shapes_h[k++] = d[1]; }
+        }
+    }
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_params_set_h(ppo_ctx* c, const float* params_h, int64_t count) {
+    NEED(c, c && params_h, "null argument");
+    NEED(c, count == c->L.P, "parameter count mismatch");
+    return ppo_memcpy_h2d(c, c->buf[PPO_BUF_PARAMS], params_h, (size_t)count * sizeof(float));
+}
+extern "C" ppo_status ppo_params_get_h(ppo_ctx* c, float* params_h, int64_t count) {
+    NEED(c, c && params_h, "null argument");
+    NEED(c, count == c->L.P, "parameter count mismatch");
+    return ppo_memcpy_d2h(c, params_h, c->buf[PPO_BUF_PARAMS], (size_t)count * sizeof(float));
+}
+extern "C" ppo_status ppo_optimizer_set_h(ppo_ctx* c, const float* m_h, const float* v_h, int64_t count, int64_t step) {
+    NEED(c, c && m_h && v_h, "null argument");
+    NEED(c, count == c->L.P, "parameter count mismatch");
+    ppo_status s = ppo_memcpy_h2d(c, c->buf[PPO_BUF_EXP_AVG], m_h, (size_t)count * sizeof(float));
+    if (s != PPO_OK) return s;
+    s = ppo_memcpy_h2d(c, c->buf[PPO_BUF_EXP_AVG_SQ], v_h, (size_t)count * sizeof(float));
+    c->opt_step = step;
+    return s;
+}
+extern "C" ppo_status ppo_optimizer_get_h(ppo_ctx* c, float* m_h, float* v_h, int64_t count, int64_t* step) {
+    NEED(c, c != nullptr, "null ctx");
+    NEED(c, count == c->L.P, "parameter count mismatch");
+    ppo_status s = PPO_OK;
+    if (m_h) s = ppo_memcpy_d2h(c, m_h, c->buf[PPO_BUF_EXP_AVG], (size_t)count * sizeof(float));
+    if (s == PPO_OK && v_h) s = ppo_memcpy_d2h(c, v_h, c->buf[PPO_BUF_EXP_AVG_SQ], (size_t)count * sizeof(float));
+    if (step) *step = c->opt_step;
+    return s;
+}
+
+// Agent::ppoLayerInit (Agent.cpp:91-99): torch::nn::init::orthogonal_(W, gain) = gain * Q of a Gaussian matrix (QR with the
+// sign of diag(R) folded in), constant_(bias, 0).  LibTorch draws the Gaussian from its global mt19937 and calls LAPACK;
+// here: Box-Muller on Philox(seed; tensor, element) and Householder QR in binary64.  Distributionally equivalent, not bit-equal.
+static void orthogonal_fill(float* W, int rows, int cols, double gain, int64_t seed, int tensor_id) {
+    const bool transpose = rows < cols;
+    const int m = transpose ? cols : rows, n = transpose ? rows : cols;  // m >= n
+    std::vector<double> Aq((size_t)m * n);
+    auto philox_host = [&](uint32_t c0, uint32_t c1, uint32_t out[4]) {
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)((uint64_t)seed >> 32), c2 = (uint32_t)tensor_id, c3 = 3u;
+        for (int r = 0; r < 10; r++) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    };
+    for (size_t i = 0; i < Aq.size(); i += 2) {
+        uint32_t w[4];
+        philox_host((uint32_t)i, (uint32_t)(i >> 32), w);
+        const double u1 = ((double)w[0] + 1.0) / 4294967296.0, u2 = (double)w[1] / 4294967296.0;
+        const double r = std::sqrt(-2.0 * std::log(u1));
+        Aq[i] = r * std::cos(2.0 * M_PI * u2);
+        if (i + 1 < Aq.size()) Aq[i + 1] = r * std::sin(2.0 * M_PI * u2);
+    }
+    // Householder QR of Aq (m x n, row-major); accumulate Q (m x n) explicitly.
+    std::vector<double> R = Aq, Q((size_t)m * n, 0.0), v((size_t)m);
+    std::vector<std::vector<double>> vs;
+    for (int k = 0; k < n; k++) {
+        double norm = 0.0;
+        for (int i = k; i < m; i++) norm += R[(size_t)i * n + k] * R[(size_t)i * n + k];
+        norm = std::sqrt(norm);
+        std::fill(v.begin(), v.end(), 0.0);
+        const double alpha = R[(size_t)k * n + k] >= 0 ? -norm : norm;
+        for (int i = k; i < m; i++) v[i] = R[(size_t)i * n + k];
+        v[k] -= alpha;
+        double vn = 0.0;
+        for (int i = k; i < m; i++) vn += v[i] * v[i];
+        if (vn > 0) {
+            for (int j = k; j < n; j++) {
+                double dot = 0.0;
+                for (int i = k; i < m; i++) dot += v[i] * R[(size_t)i * n + j];
+                const double f = 2.0 * dot / vn;
+                for (int i = k; i < m; i++) R[(size_t)i * n + j] -= f * v[i];
+            }
+        }
+        vs.push_back(v);
+    }
+    for (int j = 0; j < n; j++) Q[(size_t)j * n + j] = 1.0;
+    for (int k = n - 1; k >= 0; k--) {
+        const std::vector<double>& vk = vs[k];
+        double vn = 0.0;
+        for (int i = k; i < m; i++) vn += vk[i] * vk[i];
+        if (vn <= 0) continue;
+        for (int j = 0; j < n; j++) {
+            double dot = 0.0;
+            for (int i = k; i < m; i++) dot += vk[i] * Q[(size_t)i * n + j];
+            const double f = 2.0 * dot / vn;
+            for (int i = k; i < m; i++) Q[(size_t)i * n + j] -= f * vk[i];
+        }
+    }
+    for (int j = 0; j < n; j++) {
+        const double sgn = R[(size_t)j * n + j] < 0 ? -1.0 : 1.0;  // q *= sign(diag(r))
+        for (int i = 0; i < m; i++) Q[(size_t)i * n + j] *= sgn;
+    }
+    for (int r = 0; r < rows; r++)
+        for (int cc = 0; cc < cols; cc++) W[(size_t)r * cols + cc] = (float)(gain * (transpose ? Q[(size_t)cc * n + r] : Q[(size_t)r * n + cc]));
+}
+
+extern "C" ppo_status ppo_params_init_orthogonal(ppo_ctx* c, int64_t seed) {
+    NEED(c, c != nullptr, "null ctx");
+    std::vector<float> p((size_t)c->L.P, 0.0f);
+    for (int net = 0; net < 2; net++) {
+        const int out3 = net == 0 ? 1 : c->A;
+        orthogonal_fill(p.data() + c->L.w1[net], PPO_HIDDEN, c->O, std::sqrt(2.0), seed, net * 3 + 0);
+        orthogonal_fill(p.data() + c->L.w2[net], PPO_HIDDEN, PPO_HIDDEN, std::sqrt(2.0), seed, net * 3 + 1);
+        orthogonal_fill(p.data() + c->L.w3[net], out3, PPO_HIDDEN, net == 0 ? 1.0 : 0.01, seed, net * 3 + 2);  // Agent.cpp:28,37
+    }
+    return ppo_params_set_h(c, p.data(), c->L.P);
+}
+
+extern "C" ppo_status ppo_get_value(ppo_ctx* c, const float* obs, int64_t n, float* value) {
+    NEED(c, c && obs && value, "null argument");
+    HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, obs, nullptr, nullptr, n, c->cfg.seed, c->cfg.env_offset, 0,
+                                nullptr, nullptr, nullptr, value, true, c->stream));
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_policy_act(ppo_ctx* c, const float* obs, const uint8_t* mask, const int64_t* forced_action, int64_t n,
+                                     int64_t step_index, int64_t* action, float* logprob, float* entropy, float* value) {
+    NEED(c, c && obs, "null argument");
+    NEED(c, forced_action || action, "sampling needs an action output");
+    HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, obs, mask, forced_action, n, c->cfg.seed, c->cfg.env_offset,
+                                step_index, action, logprob, entropy, value, false, c->stream));
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_categorical(int32_t dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n, int32_t A,
+                                      float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode, void* stream) {
+    if (!logits || n < 0) return PPO_ERR_INVALID;
+    return launch_categorical(dist_kind, logits, mask, value, n, A, m_logits, m_probs, log_prob, entropy, mode, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Environments
+// ---------------------------------------------------------------------------------------------------------
+extern "C" ppo_status ppo_env_transition(int32_t env_kind, const float* state_in, const int64_t* action, int64_t n, float* next_state,
+                                         float* reward, int32_t* terminated, void* stream) {
+    if (!state_in || !action || !next_state || !reward || !terminated || n < 0) return PPO_ERR_INVALID;
+    return launch_env_transition(env_kind, state_in, action, n, next_state, reward, terminated, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+}
+
+extern "C" ppo_status ppo_env_reset(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    HIPCHK(c, launch_env_reset(c->cfg.env_kind, c->N, c->cfg.seed, c->cfg.env_offset, B_<float>(c, PPO_BUF_ENV_STATE), B_<int32_t>(c, PPO_BUF_EP_LEN),
+                               B_<float>(c, PPO_BUF_EP_REW), B_<int32_t>(c, PPO_BUF_RESET_COUNT), c->reset_table, c->reset_cap,
+                               B_<float>(c, PPO_BUF_NEXT_OBS), B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->error_flag, c->stream));
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_env_step(ppo_ctx* c, const int64_t* action, float* obs, float* reward, int32_t* done) {
+    NEED(c, c && action && obs && reward && done, "null argument");
+    HIPCHK(c, launch_env_step(c->cfg.env_kind, c->N, c->H, c->cfg.max_episode_steps, c->cfg.seed, c->cfg.env_offset, B_<float>(c, PPO_BUF_ENV_STATE),
+                              B_<int32_t>(c, PPO_BUF_EP_LEN), B_<float>(c, PPO_BUF_EP_REW), B_<int32_t>(c, PPO_BUF_RESET_COUNT), c->reset_table,
+                              c->reset_cap, action, obs, reward, done, c->error_flag, c->stream));
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_env_set_state_h(ppo_ctx* c, const float* state_h, const int32_t* ep_len_h, const float* ep_rew_h, const int32_t* reset_count_h) {
+    NEED(c, c != nullptr, "null ctx");
+    if (state_h) {
+        ppo_status s = ppo_memcpy_h2d(c, c->scratch_obs, state_h, (size_t)c->N * c->O * sizeof(float));
+        if (s != PPO_OK) return s;
+        HIPCHK(c, launch_aos_to_soa(c->scratch_obs, B_<float>(c, PPO_BUF_ENV_STATE), c->N, c->O, true, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->buf[PPO_BUF_NEXT_OBS], c->scratch_obs, (size_t)c->N * c->O * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    ppo_status s = PPO_OK;
+    if (ep_len_h) s = ppo_memcpy_h2d(c, c->buf[PPO_BUF_EP_LEN], ep_len_h, (size_t)c->N * sizeof(int32_t));
+    if (s == PPO_OK && ep_rew_h) s = ppo_memcpy_h2d(c, c->buf[PPO_BUF_EP_REW], ep_rew_h, (size_t)c->N * sizeof(float));
+    if (s == PPO_OK && reset_count_h) s = ppo_memcpy_h2d(c, c->buf[PPO_BUF_RESET_COUNT], reset_count_h, (size_t)c->N * sizeof(int32_t));
+    if (s == PPO_OK) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return s;
+}
+
+extern "C" ppo_status ppo_env_get_state_h(ppo_ctx* c, float* state_h, int32_t* ep_len_h, float* ep_rew_h, int32_t* reset_count_h) {
+    NEED(c, c != nullptr, "null ctx");
+    ppo_status s = PPO_OK;
+    if (state_h) {
+        HIPCHK(c, launch_aos_to_soa(c->scratch_obs, B_<float>(c, PPO_BUF_ENV_STATE), c->N, c->O, false, c->stream));
+        s = ppo_memcpy_d2h(c, state_h, c->scratch_obs, (size_t)c->N * c->O * sizeof(float));
+    }
+    if (s == PPO_OK && ep_len_h) s = ppo_memcpy_d2h(c, ep_len_h, c->buf[PPO_BUF_EP_LEN], (size_t)c->N * sizeof(int32_t));
+    if (s == PPO_OK && ep_rew_h) s = ppo_memcpy_d2h(c, ep_rew_h, c->buf[PPO_BUF_EP_REW], (size_t)c->N * sizeof(float));
+    if (s == PPO_OK && reset_count_h) s = ppo_memcpy_d2h(c, reset_count_h, c->buf[PPO_BUF_RESET_COUNT], (size_t)c->N * sizeof(int32_t));
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Rollout and advantages
+// ---------------------------------------------------------------------------------------------------------
+static ppo_status consume_finished_episodes(ppo_ctx* c) {
+    if (!c->fin_pending) return PPO_OK;
+    HIPCHK(c, launch_episode_ring_update(B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), c->T, c->N, c->row_counts, c->ring, c->stream));
+    c->fin_pending = false;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
+    NEED(c, c != nullptr, "null ctx");
+    ppo_status s = consume_finished_episodes(c);
+    if (s != PPO_OK) return s;
+    // worst case one reset per env per step
+    s = ensure_reset_table(c, c->rollout_steps + c->T + 4);
+    if (s != PPO_OK) return s;
+    RolloutArgs a{};
+    a.params = B_<float>(c, PPO_BUF_PARAMS);
+    a.L = c->L;
+    a.dist_kind = c->cfg.dist_kind;
+    a.env_kind = c->cfg.env_kind;
+    a.N = c->N; a.T = c->T;
+    a.max_episode_steps = c->cfg.max_episode_steps;
+    a.seed = c->cfg.seed; a.env_offset = c->cfg.env_offset; a.step_base = c->rollout_steps;
+    a.env_state = B_<float>(c, PPO_BUF_ENV_STATE);
+    a.ep_len = B_<int32_t>(c, PPO_BUF_EP_LEN);
+    a.ep_rew = B_<float>(c, PPO_BUF_EP_REW);
+    a.reset_count = B_<int32_t>(c, PPO_BUF_RESET_COUNT);
+    a.reset_table = c->reset_table; a.reset_cap = c->reset_cap; a.error_flag = c->error_flag;
+    a.obs = B_<float>(c, PPO_BUF_OBS);
+    a.actions = B_<int32_t>(c, PPO_BUF_ACTIONS);
+    a.logprobs = B_<float>(c, PPO_BUF_LOGPROBS);
+    a.rewards = B_<float>(c, PPO_BUF_REWARDS);
+    a.dones = B_<float>(c, PPO_BUF_DONES);
+    a.values = B_<float>(c, PPO_BUF_VALUES);
+    a.masks = c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr;
+    a.fin_len = B_<int32_t>(c, PPO_BUF_FIN_LEN);
+    a.fin_rew = B_<float>(c, PPO_BUF_FIN_REW);
+    a.next_obs = B_<float>(c, PPO_BUF_NEXT_OBS);
+    a.next_done = B_<int32_t>(c, PPO_BUF_NEXT_DONE);
+    a.next_value = B_<float>(c, PPO_BUF_NEXT_VALUE);
+    a.forced_actions = forced_actions;
+    {
+        ProfScope ps(c, PROF_ROLLOUT);
+        HIPCHK(c, launch_rollout(a, c->stream));
+    }
+    c->rollout_steps += c->T;
+    c->global_step += (int64_t)c->T * c->cfg.global_num_envs;  // global_step += num_envs per step (:526)
+    c->fin_pending = true;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value, const int32_t* next_done,
+                              int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
+    if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;
+    return launch_gae(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, advantages, returns, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+}
+extern "C" ppo_status ppo_nstep_returns(const float* rewards, const float* values, const float* dones, const float* next_value,
+                                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* advantages, float* returns, void* stream) {
+    if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;
+    return launch_nstep(rewards, values, dones, next_value, next_done, T, N, gamma, advantages, returns, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+}
+
+// K4 on the context's buffers: GAE (PPO_Discrete.cpp:283-306) or n-step returns (:309-329) by cfg.use_gae.
+static ppo_status run_scan(ppo_ctx* c) {
+    ProfScope ps(c, PROF_GAE);
+    if (c->cfg.use_gae)
+        HIPCHK(c, launch_gae(B_<float>(c, PPO_BUF_REWARDS), B_<float>(c, PPO_BUF_VALUES), B_<float>(c, PPO_BUF_DONES), B_<float>(c, PPO_BUF_NEXT_VALUE),
+                             B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->T, c->N, c->cfg.gamma, c->cfg.gae_lambda, B_<float>(c, PPO_BUF_ADVANTAGES),
+                             B_<float>(c, PPO_BUF_RETURNS), c->stream));
+    else
+        HIPCHK(c, launch_nstep(B_<float>(c, PPO_BUF_REWARDS), B_<float>(c, PPO_BUF_VALUES), B_<float>(c, PPO_BUF_DONES), B_<float>(c, PPO_BUF_NEXT_VALUE),
+                               B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->T, c->N, c->cfg.gamma, B_<float>(c, PPO_BUF_ADVANTAGES),
+                               B_<float>(c, PPO_BUF_RETURNS), c->stream));
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_calc_advantage(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    // bootstrap value if not done: next_value = Critic(next_obs) (PPO_Discrete.cpp:280)
+    HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, B_<float>(c, PPO_BUF_NEXT_OBS), nullptr, nullptr, c->N, c->cfg.seed,
+                                c->cfg.env_offset, 0, nullptr, nullptr, nullptr, B_<float>(c, PPO_BUF_NEXT_VALUE), true, c->stream));
+    return run_scan(c);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Update
+// ---------------------------------------------------------------------------------------------------------
+extern "C" ppo_status ppo_generate_permutations(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    HIPCHK(c, launch_permutations(B_<int32_t>(c, PPO_BUF_PERM), c->B, c->cfg.update_epochs, c->cfg.seed, c->updates, c->rank, c->stream));
+    return PPO_OK;
+}
+
+// AdamW scalars exactly as LibTorch forms them on the host (optim/adamw.cpp): doubles narrowed to float at use.
+static AdamCoef adam_coef(double lr, int64_t t) {
+    const double beta1 = 0.9, beta2 = 0.999, wd = 1e-2;
+    const double bc1 = 1.0 - std::pow(beta1, (double)t), bc2 = 1.0 - std::pow(beta2, (double)t);
+    AdamCoef k;
+    k.decay = (float)(1.0 - lr * wd);
+    k.neg_step = (float)(-(lr / bc1));
+    k.sqrt_bc2 = (float)std::sqrt(bc2);
+    k.pad = 0.0f;
+    return k;
+}
+
+static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
+    if (c->world <= 1) return PPO_OK;
+    const int rc = rccl::AllReduce(buf, buf, count, f64 ? rccl::kFloat64 : rccl::kFloat32, rccl::kSum, c->comm, c->stream);
+    if (rc != 0) return fail(c, PPO_ERR_COMM, "ncclAllReduce failed: %s", rccl::GetErrorString ? rccl::GetErrorString(rc) : "?");
+    return PPO_OK;
+}
+
+static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
+    UpdateArgs a{};
+    a.params = B_<float>(c, PPO_BUF_PARAMS);
+    a.L = c->L;
+    a.hp = c->hp;
+    a.obs = B_<float>(c, PPO_BUF_OBS);
+    a.actions = B_<int32_t>(c, PPO_BUF_ACTIONS);
+    a.masks = c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr;
+    a.logprobs = B_<float>(c, PPO_BUF_LOGPROBS);
+    a.advantages = B_<float>(c, PPO_BUF_ADVANTAGES);
+    a.returns = B_<float>(c, PPO_BUF_RETURNS);
+    a.values = B_<float>(c, PPO_BUF_VALUES);
+    a.idx = idx;
+    a.M = (int)M;
+    a.global_M = (double)M * c->world;
+    a.inv_global_M = 1.0 / a.global_M;
+    c->last_global_M = a.global_M;
+    a.adv_stat = c->adv_stats + slot;
+    a.slab = c->slab;
+    a.stat_slab = c->stat_slab;
+    a.n_blocks_per_net = std::min(update_blocks_per_net((int)M), c->max_blocks_per_net);
+    {
+        ProfScope ps(c, PROF_FWD_BWD);
+        HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
+    }
+    {
+        ProfScope ps(c, PROF_REDUCE);
+        HIPCHK(c, launch_reduce_grads(c->slab, c->stat_slab, a.n_blocks_per_net, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, c->stream));
+    }
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* idx, int64_t M) {
+    NEED(c, c && idx, "null argument");
+    NEED(c, M >= 1 && M <= c->B, "minibatch size out of range");
+    const int slot = c->steps_per_update;  // scratch slot
+    if (c->cfg.norm_adv) {
+        HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), idx, M, M, 1, c->adv_stats + slot, c->stream));
+        ppo_status s = allreduce_sum(c, c->adv_stats + slot, 2, true);
+        if (s != PPO_OK) return s;
+    }
+    ppo_status s = fwd_bwd(c, idx, M, slot);
+    if (s != PPO_OK) return s;
+    // loss scalars and the norm of the unclipped gradient, without touching parameters
+    HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                                c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, (double)M * c->world, c->hp, 1, false,
+                                c->step_stats + slot, nullptr, c->stream));
+    c->last_stat_slot = slot;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_allreduce_grads(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    if (c->world <= 1) return PPO_OK;
+    HIPCHK(c, launch_append_sums(c->loss_sums, B_<float>(c, PPO_BUF_GRADS) + c->L.P, c->stream));
+    return allreduce_sum(c, c->buf[PPO_BUF_GRADS], (size_t)c->L.P + 8, false);
+}
+
+static ppo_status optimizer_step_slot(ppo_ctx* c, int slot, double global_M, bool coef_on_device) {
+    c->opt_step += 1;
+    if (!coef_on_device) {
+        c->adam_coefs_h[slot] = adam_coef(c->lr, c->opt_step);
+        HIPCHK(c, hipMemcpyAsync(c->adam_coefs + slot, c->adam_coefs_h + slot, sizeof(AdamCoef), hipMemcpyHostToDevice, c->stream));
+    }
+    {
+        ProfScope ps(c, PROF_OPT);
+        HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                                    c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, c->world, true,
+                                    c->step_stats + slot, c->clipfrac_accum, c->stream));
+    }
+    c->last_stat_slot = slot;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_optimizer_step(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    // stand-alone use: the slot's pinned coefficient must not be rewritten while a previous copy is in flight
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return optimizer_step_slot(c, c->steps_per_update, c->last_global_M, false);
+}
+
+extern "C" ppo_status ppo_set_learning_rate(ppo_ctx* c, double lr) {
+    NEED(c, c != nullptr, "null ctx");
+    c->lr = lr;
+    return PPO_OK;
+}
+
+// All epochs x minibatches of one update, PPO_Discrete.cpp:567-644, then explained variance (:647-648).
+extern "C" ppo_status ppo_update(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    const int E = c->cfg.update_epochs, nmb = c->n_mb;
+    ppo_status s = ppo_generate_permutations(c);
+    if (s != PPO_OK) return s;
+    const int32_t* perm = B_<int32_t>(c, PPO_BUF_PERM);
+    if (c->cfg.norm_adv) {
+        // the advantages and the permutations are fixed for the whole update: statistics of ALL minibatches in one launch
+        // (and, when sharded, one small all-reduce) instead of a reduction inside every optimizer step
+        HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), perm, c->B, c->MB, E * nmb, c->adv_stats, c->stream));
+        s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb, true);
+        if (s != PPO_OK) return s;
+    }
+    // AdamW scalars of every step of this update, one async copy (the pinned mirror is rewritten only after a sync)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < E * nmb; k++) c->adam_coefs_h[k] = adam_coef(c->lr, c->opt_step + 1 + k);
+    HIPCHK(c, hipMemcpyAsync(c->adam_coefs, c->adam_coefs_h, (size_t)E * nmb * sizeof(AdamCoef), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->clipfrac_accum, 0, 2 * sizeof(double), c->stream));  // m_clipfracs reset, :564
+    int k = 0;
+    for (int e = 0; e < E; e++) {
+        for (int mbi = 0; mbi < nmb; mbi++, k++) {
+            const int64_t start = (int64_t)mbi * c->MB;
+            const int64_t M = std::min<int64_t>(c->MB, c->B - start);
+            s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k);
+            if (s != PPO_OK) return s;
+            s = ppo_allreduce_grads(c);
+            if (s != PPO_OK) return s;
+            s = optimizer_step_slot(c, k, (double)M * c->world, true);
+            if (s != PPO_OK) return s;
+        }
+    }
+    HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
+    c->have_ev = true;
+    c->updates += 1;
+    return PPO_OK;
+}
+
+// One iteration of PPO_Discrete::train()'s loop (:511-659) without printing / checkpointing.
+extern "C" ppo_status ppo_train_iteration(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
+    if (c->cfg.anneal_lr && c->num_updates_total > 0) {
+        // frac = 1.0 - (update - 1.0) / num_updates; lr_now = frac * m_learning_rate  (:515-517), update is 1-based
+        const double frac = 1.0 - ((double)(c->updates + 1) - 1.0) / (double)c->num_updates_total;
+        c->lr = frac * c->cfg.learning_rate;
+    }
+    ppo_status s = ppo_rollout(c, nullptr);
+    if (s != PPO_OK) return s;
+    // NEXT_VALUE was produced by the rollout's epilogue with the same parameters: go straight to the scan
+    s = run_scan(c);
+    if (s != PPO_OK) return s;
+    return ppo_update(c);
+}
+
+extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
+    NEED(c, c && out, "null argument");
+    std::memset(out, 0, sizeof *out);
+    ppo_status s = consume_finished_episodes(c);
+    if (s != PPO_OK) return s;
+    s = check_device_flag(c);  // synchronises
+    if (s != PPO_OK) return s;
+    if (c->last_stat_slot >= 0) {
+        StepStats st;
+        HIPCHK(c, hipMemcpy(&st, c->step_stats + c->last_stat_slot, sizeof st, hipMemcpyDeviceToHost));
+        out->pg_loss = st.pg_loss; out->v_loss = st.v_loss; out->entropy_loss = st.entropy_loss; out->approx_kl = st.approx_kl;
+        out->loss = st.loss; out->clipfrac_last = st.clipfrac; out->total_norm = st.total_norm;
+    }
+    double cf[2] = { 0, 0 };
+    HIPCHK(c, hipMemcpy(cf, c->clipfrac_accum, sizeof cf, hipMemcpyDeviceToHost));
+    out->clipfrac_mean = cf[1] > 0 ? cf[0] / cf[1] : 0.0;
+    if (c->have_ev) {
+        double ev[64 * 4];
+        HIPCHK(c, hipMemcpy(ev, c->ev_sums, sizeof ev, hipMemcpyDeviceToHost));
+        double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
+        for (int b = 0; b < 64; b++) { sy += ev[b * 4]; sy2 += ev[b * 4 + 1]; sd += ev[b * 4 + 2]; sd2 += ev[b * 4 + 3]; }
+        const double n = (double)c->B;
+        const double var_y = (sy2 - sy * sy / n) / (n - 1.0), var_d = (sd2 - sd * sd / n) / (n - 1.0);
+        out->explained_variance = (double)(1.0f - (float)var_d / (float)var_y);  // :647-648 (float tensors)
+    }
+    EpisodeRing ring;
+    HIPCHK(c, hipMemcpy(&ring, c->ring, sizeof ring, hipMemcpyDeviceToHost));
+    if (ring.size > 0) {
+        double sl = 0, sr = 0;
+        for (int i = 0; i < ring.size; i++) { sl += ring.len[i]; sr += ring.rew[i]; }
+        out->ep_len_mean = sl / ring.size;                 // CircularBuffer::avgLength (Utils.h:76-78)
+        out->ep_rew_mean = (double)(float)(sr / ring.size); // avgReward returns float (Utils.h:72-74)
+    }
+    out->ep_count = ring.size;
+    out->learning_rate = c->lr;
+    out->global_step = c->global_step;
+    out->optimizer_steps = c->opt_step;
+    out->updates = c->updates;
+    return PPO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Measurement
+// ---------------------------------------------------------------------------------------------------------
+extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
+    NEED(c, c != nullptr, "null ctx");
+    c->profiling = on != 0;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_profile_read(ppo_ctx* c, ppo_profile* out) {
+    NEED(c, c && out, "null argument");
+    std::memset(out, 0, sizeof *out);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int64_t* cnt[PROF_KINDS_] = { &out->fwd_bwd_launches, &out->gae_launches, &out->rollout_launches, &out->optimizer_launches, &out->reduce_launches };
+    double* ms[PROF_KINDS_] = { &out->fwd_bwd_ms, &out->gae_ms, &out->rollout_ms, &out->optimizer_ms, &out->reduce_ms };
+    for (auto& sp : c->spans) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, sp.a, sp.b));
+        *cnt[sp.kind] += 1;
+        *ms[sp.kind] += (double)t;
+        c->event_pool.push_back(sp.a);
+        c->event_pool.push_back(sp.b);
+    }
+    c->spans.clear();
+    return PPO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-GPU
+// ---------------------------------------------------------------------------------------------------------
+extern "C" ppo_status ppo_comm_unique_id(void* id_out_h) {
+    if (!id_out_h) return PPO_ERR_INVALID;
+    std::string err;
+    if (!rccl::load(err)) { g_create_error = err; return PPO_ERR_COMM; }
+    rccl::UniqueId id;
+    std::memset(&id, 0, sizeof id);
+    const int rc = rccl::GetUniqueId(&id);
+    if (rc != 0) { g_create_error = "ncclGetUniqueId failed"; return PPO_ERR_COMM; }
+    static_assert(sizeof(rccl::UniqueId) == PPO_COMM_ID_BYTES, "unique id size");
+    std::memcpy(id_out_h, &id, sizeof id);
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, int32_t nranks) {
+    NEED(c, c && id_h, "null argument");
+    NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
+    if (nranks == 1) { c->world = 1; c->rank = 0; return PPO_OK; }
+    std::string err;
+    if (!rccl::load(err)) return fail(c, PPO_ERR_COMM, "%s", err.c_str());
+    rccl::UniqueId id;
+    std::memcpy(&id, id_h, sizeof id);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int rc = rccl::CommInitRank(&c->comm, nranks, id, rank);
+    if (rc != 0) return fail(c, PPO_ERR_COMM, "ncclCommInitRank failed: %s", rccl::GetErrorString ? rccl::GetErrorString(rc) : "?");
+    c->world = nranks;
+    c->rank = rank;
+    return PPO_OK;
+}

@@ -1,0 +1,200 @@
+// ppo-libtorch_amd/csrc/kernels_gae.hip -- K4: GAE advantage / return scan over time-major [T, N] buffers (gfx950).
+//
+// reference PPO_Discrete::calcAdvantage, PPO/PPO_Discrete.cpp:274-331:
+//     nnt_t   = 1 - dones[t+1]                (t == T-1: 1 - next_done)
+//     delta_t = (r_t + (gamma * v_{t+1}) * nnt_t) - v_t
+//     A_t     = delta_t + ((gamma*lambda) * nnt_t) * A_{t+1}
+//     R_t     = A_t + v_t
+//
+// EXACT mode (the only one shipped): bit-identical to the reference needs its evaluation order along t and separately
+// rounded mul/add (the library is built with -ffp-contract=off).  What is parallel without changing a single rounding:
+//   (i)  envs are independent                      -> a workgroup owns a strip of EPB env columns;
+//   (ii) delta_t and c_t = (gamma*lambda)*nnt_t are element-wise -> ALL 256 threads compute them while streaming
+//        r, v, dones with coalesced 16-byte loads into an LDS tile of TC time steps;
+//   (iii) only the 2-op recurrence A_t = delta_t + c_t * A_{t+1} is serial: EPB lanes of wave 0 walk the tile top-down
+//        out of LDS (one env per lane, carry in a register across tiles), writing A_t back in place;
+//   (iv) all threads then stream A_t and R_t = A_t + v_t to HBM with coalesced 16-byte stores.
+// A done flag cuts the chain (c_t = 0 => A_t = delta_t exactly): that is the "segmented" part; it needs no special
+// handling in the serial walk and costs nothing.
+// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done); the tile's
+// one-row halo (v_{t+1}, dones_{t+1} of the row above the tile) re-reads 1/TC of two arrays.
+#include "ppo_internal.hpp"
+
+namespace {
+
+constexpr int GAE_TC = 128;       // time steps per LDS tile
+constexpr int GAE_THREADS = 256;
+
+// MODE 0: GAE.  MODE 1: n-step returns (PPO_Discrete.cpp:309-329: ret_t = r_t + (gamma*nnt_t)*ret_{t+1}; adv = ret - v).
+template <int EPB, int MODE, bool VEC>
+__global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                           const float* __restrict__ dones, const float* __restrict__ next_value,
+                                                           const int32_t* __restrict__ next_done, int T, int N, float gamma,
+                                                           float gae_lambda, float* __restrict__ adv, float* __restrict__ ret) {
+    // sA: delta on input of the walk, advantage (or return) on output.  sC: chain coefficient.  sV: values incl. halo row.
+    __shared__ __attribute__((aligned(16))) float sA[GAE_TC * EPB];
+    __shared__ __attribute__((aligned(16))) float sC[GAE_TC * EPB];
+    __shared__ __attribute__((aligned(16))) float sV[(GAE_TC + 1) * EPB];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * EPB;
+    const float gl = gamma * gae_lambda;  // the C++ float product of PPO_Discrete.cpp:301
+
+    float carry = 0.0f;                                   // A_{t+1} (MODE 0) / ret_{t+1} (MODE 1) entering the tile
+    const bool walker = tid < EPB && (n0 + tid) < N;
+    if (MODE == 1 && walker) carry = next_value[n0 + tid];  // next_return = next_value at t = T-1 (:318)
+
+    for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {        // tile covers rows [t_lo, t_hi)
+        const int t_lo = t_hi > GAE_TC ? t_hi - GAE_TC : 0;
+        const int rows = t_hi - t_lo;
+
+        // ---- phase A: stream r, v, dones -> LDS; v gets one halo row (row `rows` of sV = v_{t_hi} or next_value) ----
+        if (VEC) {
+            constexpr int C4 = EPB / 4;                    // float4 columns per row
+            for (int e = tid; e < (rows + 1) * C4; e += GAE_THREADS) {
+                const int r = e / C4, c = (e % C4) * 4;
+                float4 v4;
+                if (r < rows) v4 = *reinterpret_cast<const float4*>(values + (size_t)(t_lo + r) * N + n0 + c);
+                else if (t_hi < T) v4 = *reinterpret_cast<const float4*>(values + (size_t)t_hi * N + n0 + c);
+                else v4 = *reinterpret_cast<const float4*>(next_value + n0 + c);
+                *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v4;
+            }
+            for (int e = tid; e < rows * C4; e += GAE_THREADS) {
+                const int r = e / C4, c = (e % C4) * 4;
+                const int t = t_lo + r;
+                const float4 rw = *reinterpret_cast<const float4*>(rewards + (size_t)t * N + n0 + c);
+                float4 nnt;
+                if (t + 1 < T) {
+                    const float4 d = *reinterpret_cast<const float4*>(dones + (size_t)(t + 1) * N + n0 + c);
+                    nnt = make_float4(1.0f - d.x, 1.0f - d.y, 1.0f - d.z, 1.0f - d.w);
+                } else {
+                    const int4 d = *reinterpret_cast<const int4*>(next_done + n0 + c);
+                    nnt = make_float4((float)(1 - d.x), (float)(1 - d.y), (float)(1 - d.z), (float)(1 - d.w));
+                }
+                *reinterpret_cast<float4*>(&sA[r * EPB + c]) = rw;   // reward for now; delta needs sV (next phase)
+                *reinterpret_cast<float4*>(&sC[r * EPB + c]) = nnt;
+            }
+        } else {
+            for (int e = tid; e < (rows + 1) * EPB; e += GAE_THREADS) {
+                const int r = e / EPB, c = e % EPB;
+                float v = 0.0f;
+                if (n0 + c < N) {
+                    if (r < rows) v = values[(size_t)(t_lo + r) * N + n0 + c];
+                    else if (t_hi < T) v = values[(size_t)t_hi * N + n0 + c];
+                    else v = next_value[n0 + c];
+                }
+                sV[r * EPB + c] = v;
+            }
+            for (int e = tid; e < rows * EPB; e += GAE_THREADS) {
+                const int r = e / EPB, c = e % EPB;
+                const int t = t_lo + r;
+                float rw = 0.0f, nnt = 0.0f;
+                if (n0 + c < N) {
+                    rw = rewards[(size_t)t * N + n0 + c];
+                    nnt = (t + 1 < T) ? 1.0f - dones[(size_t)(t + 1) * N + n0 + c] : (float)(1 - next_done[n0 + c]);
+                }
+                sA[r * EPB + c] = rw;
+                sC[r * EPB + c] = nnt;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase A': element-wise delta_t and c_t (every rounding as the reference's tensor expression) ----
+        for (int e = tid; e < rows * EPB; e += GAE_THREADS) {
+            const float nnt = sC[e];
+            if (MODE == 0) {
+                const float delta = (sA[e] + (gamma * sV[e + EPB]) * nnt) - sV[e];   // :300
+                sA[e] = delta;
+                sC[e] = gl * nnt;                                                    // :301 (gamma*lambda)*nnt
+            } else {
+                sC[e] = gamma * nnt;                                                 // :324 (gamma*nnt)
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: the serial 2-op chain, one env per lane of wave 0, top row first ----
+        if (walker) {
+            float last = carry;
+#pragma unroll 8
+            for (int r = rows - 1; r >= 0; r--) {
+                last = sA[r * EPB + tid] + sC[r * EPB + tid] * last;
+                sA[r * EPB + tid] = last;
+            }
+            carry = last;
+        }
+        __syncthreads();
+
+        // ---- phase C: stream out advantages and returns ----
+        if (VEC) {
+            constexpr int C4 = EPB / 4;
+            for (int e = tid; e < rows * C4; e += GAE_THREADS) {
+                const int r = e / C4, c = (e % C4) * 4;
+                const float4 a4 = *reinterpret_cast<const float4*>(&sA[r * EPB + c]);
+                const float4 v4 = *reinterpret_cast<const float4*>(&sV[r * EPB + c]);
+                float4 o_adv, o_ret;
+                if (MODE == 0) {
+                    o_adv = a4;
+                    o_ret = make_float4(a4.x + v4.x, a4.y + v4.y, a4.z + v4.z, a4.w + v4.w);   // :305
+                } else {
+                    o_ret = a4;
+                    o_adv = make_float4(a4.x - v4.x, a4.y - v4.y, a4.z - v4.z, a4.w - v4.w);   // :327
+                }
+                const size_t g = (size_t)(t_lo + r) * N + n0 + c;
+                *reinterpret_cast<float4*>(adv + g) = o_adv;
+                *reinterpret_cast<float4*>(ret + g) = o_ret;
+            }
+        } else {
+            for (int e = tid; e < rows * EPB; e += GAE_THREADS) {
+                const int r = e / EPB, c = e % EPB;
+                if (n0 + c >= N) continue;
+                const float a1 = sA[e], v1 = sV[e];
+                const size_t g = (size_t)(t_lo + r) * N + n0 + c;
+                if (MODE == 0) { adv[g] = a1; ret[g] = a1 + v1; }
+                else { ret[g] = a1; adv[g] = a1 - v1; }
+            }
+        }
+        __syncthreads();  // LDS tile is reused by the next (earlier) time tile
+    }
+}
+
+template <int MODE>
+hipError_t launch_scan(const float* rewards, const float* values, const float* dones, const float* next_value,
+                       const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
+                       hipStream_t s) {
+    if (T <= 0 || N <= 0) return hipSuccess;
+    if (T > INT32_MAX || N > INT32_MAX) return hipErrorInvalidValue;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec_ok = (N % 4 == 0) && al16(rewards) && al16(values) && al16(dones) && al16(next_value) && al16(next_done) &&
+                        al16(adv) && al16(ret);
+    // Strip width: wide strips coalesce better (EPB*4-byte rows), narrow strips give more workgroups.  Keep >= ~2 per CU.
+    int epb = 64;
+    if (N / 64 < 512) epb = 32;
+    if (N / 32 < 512) epb = 16;
+#define PPO_GAE_LAUNCH(EPB)                                                                                                   \
+    do {                                                                                                                      \
+        const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \
+        if (vec_ok && N % EPB == 0)                                                                                           \
+            hipLaunchKernelGGL((gae_kernel<EPB, MODE, true>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
+                               (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((gae_kernel<EPB, MODE, false>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
+                               (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
+    } while (0)
+    if (epb == 64) PPO_GAE_LAUNCH(64);
+    else if (epb == 32) PPO_GAE_LAUNCH(32);
+    else PPO_GAE_LAUNCH(16);
+#undef PPO_GAE_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
+                      const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
+                      hipStream_t s) {
+    return launch_scan<0>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, s);
+}
+
+hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
+                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s) {
+    return launch_scan<1>(rewards, values, dones, next_value, next_done, T, N, gamma, 1.0f, adv, ret, s);
+}

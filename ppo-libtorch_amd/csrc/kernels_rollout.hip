@@ -1,0 +1,509 @@
+// ppo-libtorch_amd/csrc/kernels_rollout.hip -- rollout-side kernels for gfx950 (wave64).
+//
+//   K1  batched env step + auto-reset (struct-of-arrays)      reference PPO_Discrete.cpp:413-483, CartPole.cpp, MountainCar.cpp
+//   K2  policy forward + categorical sample/log-prob/entropy  reference Agent.cpp:117-170, Categorical*.cpp
+//   K3  rollout stores                                        reference PPO_Discrete.cpp:529-546
+//   fused: the whole T-step rollout loop (PPO_Discrete.cpp:524-548) as ONE launch.
+//
+// Mapping: the reference's hidden width is 64 = one CDNA4 wavefront, so ONE WAVE OWNS ONE ENV (or one batch row) and
+// LANE j OWNS HIDDEN UNIT j of both the actor and the critic.  A lane keeps its rows of W1/W2 (2 x (O + 64) floats) in
+// VGPRs for the whole launch; a layer's activations are exchanged through a 512-byte LDS slab written once and
+// read back as wave-uniform (broadcast) 16-byte reads; head outputs are wave reductions (__shfl_xor).  Envs never
+// interact inside a rollout, so no grid-level synchronisation exists: the T-step loop runs inside the kernel.
+// Per step a wave touches HBM only for the stores of K3 (obs 4*O B, action, log-prob, value, reward, done).
+#include "ppo_internal.hpp"
+
+namespace {
+
+// Weights of both nets as seen by one lane (unit j = lane).
+template <int OBS>
+struct LaneNets {
+    float w1c[OBS], b1c, w2c[PPO_HIDDEN], b2c;  // critic rows j
+    float w1a[OBS], b1a, w2a[PPO_HIDDEN], b2a;  // actor rows j
+};
+
+template <int OBS>
+__device__ __forceinline__ void load_lane_nets(LaneNets<OBS>& n, const float* __restrict__ p, const NetLayout& L, int lane) {
+#pragma unroll
+    for (int k = 0; k < OBS; k++) {
+        n.w1c[k] = p[L.w1[0] + lane * OBS + k];
+        n.w1a[k] = p[L.w1[1] + lane * OBS + k];
+    }
+    n.b1c = p[L.b1[0] + lane];
+    n.b1a = p[L.b1[1] + lane];
+    const float4* wc = reinterpret_cast<const float4*>(p + L.w2[0] + lane * PPO_HIDDEN);
+    const float4* wa = reinterpret_cast<const float4*>(p + L.w2[1] + lane * PPO_HIDDEN);
+    const bool al = ((L.w2[0] | L.w2[1]) & 3) == 0;  // both W2 blocks 16-byte aligned inside the flat parameter vector
+#pragma unroll
+    for (int k = 0; k < PPO_HIDDEN / 4; k++) {
+        if (al) {
+            const float4 a = wc[k], b = wa[k];
+            n.w2c[4 * k] = a.x; n.w2c[4 * k + 1] = a.y; n.w2c[4 * k + 2] = a.z; n.w2c[4 * k + 3] = a.w;
+            n.w2a[4 * k] = b.x; n.w2a[4 * k + 1] = b.y; n.w2a[4 * k + 2] = b.z; n.w2a[4 * k + 3] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                n.w2c[4 * k + i] = p[L.w2[0] + lane * PPO_HIDDEN + 4 * k + i];
+                n.w2a[4 * k + i] = p[L.w2[1] + lane * PPO_HIDDEN + 4 * k + i];
+            }
+        }
+    }
+    n.b2c = p[L.b2[0] + lane];
+    n.b2a = p[L.b2[1] + lane];
+}
+
+// Both MLP trunks for one row: obs[] is wave-uniform.  Returns this lane's second-layer activations (h2c, h2a).
+// lds: 128 floats of this wave (critic h1 at [0,64), actor h1 at [64,128)).
+template <int OBS>
+__device__ __forceinline__ void trunk_forward(const LaneNets<OBS>& n, const float* obs, float* lds, int lane, float& h2c, float& h2a) {
+    float zc = n.b1c, za = n.b1a;
+#pragma unroll
+    for (int k = 0; k < OBS; k++) {
+        zc = __builtin_fmaf(obs[k], n.w1c[k], zc);
+        za = __builtin_fmaf(obs[k], n.w1a[k], za);
+    }
+    __syncthreads();  // previous readers of lds are done (single-wave workgroup: a wait, no s_barrier)
+    lds[lane] = tanhf(zc);
+    lds[PPO_HIDDEN + lane] = tanhf(za);
+    __syncthreads();
+    float ac = n.b2c, aa = n.b2a;
+    const float4* hc4 = reinterpret_cast<const float4*>(lds);
+    const float4* ha4 = reinterpret_cast<const float4*>(lds + PPO_HIDDEN);
+#pragma unroll
+    for (int k = 0; k < PPO_HIDDEN / 4; k++) {
+        const float4 c = hc4[k], a = ha4[k];  // wave-uniform addresses: LDS broadcast
+        ac = __builtin_fmaf(c.x, n.w2c[4 * k], ac); ac = __builtin_fmaf(c.y, n.w2c[4 * k + 1], ac);
+        ac = __builtin_fmaf(c.z, n.w2c[4 * k + 2], ac); ac = __builtin_fmaf(c.w, n.w2c[4 * k + 3], ac);
+        aa = __builtin_fmaf(a.x, n.w2a[4 * k], aa); aa = __builtin_fmaf(a.y, n.w2a[4 * k + 1], aa);
+        aa = __builtin_fmaf(a.z, n.w2a[4 * k + 2], aa); aa = __builtin_fmaf(a.w, n.w2a[4 * k + 3], aa);
+    }
+    h2c = tanhf(ac);
+    h2a = tanhf(aa);
+}
+
+// Heads: value = b3c + sum_j h2c[j] W3c[j];  logits[a] = b3a[a] + sum_j h2a[j] W3a[a][j]  (wave reductions).
+__device__ __forceinline__ float critic_head(const float* __restrict__ p, const NetLayout& L, float h2c, int lane) {
+    return wave_sum(h2c * p[L.w3[0] + lane]) + p[L.b3[0]];
+}
+__device__ __forceinline__ void actor_head(const float* __restrict__ p, const NetLayout& L, float h2a, int lane, float* logits) {
+    for (int a = 0; a < L.act; a++) logits[a] = wave_sum(h2a * p[L.w3[1] + a * PPO_HIDDEN + lane]) + p[L.b3[1] + a];
+}
+
+// Categorical over every head; action in/out.  Wave-uniform arithmetic (every lane computes the same values).
+template <int DIST>
+__device__ __forceinline__ void heads_eval(const NetLayout& L, float* logits, const uint8_t* mask, bool sample, int64_t seed,
+                                           int64_t row_global, int64_t step_index, int* act, float& logprob, float& entropy) {
+    float probs[PPO_MAX_ACT];
+    int off = 0;
+    logprob = 0.0f;
+    entropy = 0.0f;
+    for (int h = 0; h < L.n_heads; h++) {
+        const int A = L.head_dims[h];
+        const float e = categorical_head<DIST>(logits + off, probs + off, mask ? mask + off : nullptr, A);
+        if (sample) {
+            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global,
+                                          (uint32_t)step_index, (uint32_t)h, 0u);
+            act[h] = sample_head(probs + off, A, (float)(w.x >> 8) * 0x1p-24f);
+        }
+        const float lp = logits[off + act[h]];
+        if (h == 0) { logprob = lp; entropy = e; } else { logprob += lp; entropy += e; }  // stack(...).sum(0), Agent.cpp:165-168
+        off += A;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused rollout: grid = N workgroups of one wave.
+// ---------------------------------------------------------------------------------------------------------
+template <int ENV, int DIST, int OBS>
+__global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PPO_HIDDEN];
+    const int lane = threadIdx.x;
+    // Blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of envs so the partial-line stores
+    // of neighbouring envs meet in one L2 (speed only; any mapping is correct).
+    int env = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8, i = blockIdx.x / 8;
+        env = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    if (env >= a.N) return;
+    const NetLayout& L = a.L;
+    const int N = a.N, H = L.n_heads, A = L.act;
+    const int64_t env_global = a.env_offset + env;
+
+    LaneNets<OBS> nets;
+    load_lane_nets<OBS>(nets, a.params, L, lane);
+
+    float st[OBS];
+#pragma unroll
+    for (int k = 0; k < OBS; k++) st[k] = a.env_state[(size_t)k * N + env];
+    int ep_len = a.ep_len[env];
+    float ep_rew = a.ep_rew[env];
+    int resets = a.reset_count[env];
+    int done = a.next_done[env];
+
+    for (int t = 0; t < a.T; t++) {
+        const size_t tn = (size_t)t * N + env;
+        // m_obs[step] = next_obs; m_dones[step] = next_done   (PPO_Discrete.cpp:529-530)
+        if (lane < OBS) a.obs[tn * OBS + lane] = st[lane];
+        float h2c, h2a;
+        trunk_forward<OBS>(nets, st, lds, lane, h2c, h2a);
+        const float value = critic_head(a.params, L, h2c, lane);
+        float logits[PPO_MAX_ACT];
+        actor_head(a.params, L, h2a, lane, logits);
+        uint8_t mask[PPO_MAX_ACT];
+        const bool masked = (DIST == PPO_DIST_MASKED);
+        if (masked) {
+            for (int k = 0; k < A; k++) mask[k] = 1;  // MountainCar::getActionMask is all-ones (MountainCar.cpp:69-77)
+        }
+        int act[PPO_MAX_HEADS];
+        const bool forced = a.forced_actions != nullptr;
+        if (forced) {
+            for (int h = 0; h < H; h++) act[h] = (int)a.forced_actions[tn * H + h];
+        }
+        float logprob, entropy;
+        heads_eval<DIST>(L, logits, masked ? mask : nullptr, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy);
+
+        // env step + truncation + auto-reset (PPO_Discrete.cpp:440-458)
+        int term;
+        const float reward = env_step<ENV>(st, act[0], term);
+        ep_len += 1;        // CartPole.cpp:90-91
+        ep_rew += reward;
+        if (ep_len == a.max_episode_steps) term = 1;
+        int fin_len = 0;
+        float fin_rew = 0.0f;
+        if (term) {
+            fin_len = ep_len;
+            fin_rew = ep_rew;
+            int k = resets++;
+            if (ENV == PPO_ENV_CARTPOLE && k >= a.reset_cap) { k = a.reset_cap - 1; if (lane == 0) atomicOr(a.error_flag, 1); }
+            env_reset<ENV>(st, a.reset_table, k, a.seed, env_global);
+            ep_len = 0;
+            ep_rew = 0.0f;
+        }
+        if (lane == 0) {
+            a.dones[tn] = (float)done;
+            a.values[tn] = value;        // :536
+            a.logprobs[tn] = logprob;    // :538
+            a.rewards[tn] = reward;      // :544
+            a.fin_len[tn] = fin_len;     // :455-456
+            a.fin_rew[tn] = fin_rew;
+        }
+        if (lane < H) a.actions[tn * H + lane] = act[lane];  // :537
+        if (masked && lane < A) a.masks[tn * A + lane] = 1;   // PPO_MultiDiscrete.cpp:555
+        done = term;
+    }
+
+    // hand-over state and the bootstrap value Critic(next_obs) (PPO_Discrete.cpp:280)
+    {
+        float h2c, h2a;
+        trunk_forward<OBS>(nets, st, lds, lane, h2c, h2a);
+        const float nv = critic_head(a.params, L, h2c, lane);
+        if (lane == 0) {
+            a.next_value[env] = nv;
+            a.next_done[env] = done;
+            a.ep_len[env] = ep_len;
+            a.ep_rew[env] = ep_rew;
+            a.reset_count[env] = resets;
+        }
+        if (lane < OBS) {
+            a.next_obs[(size_t)env * OBS + lane] = st[lane];
+            a.env_state[(size_t)lane * N + env] = st[lane];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone policy evaluation (Agent::getActionAndValueDiscrete / Masked / getValue): one wave per row, grid-stride.
+// ---------------------------------------------------------------------------------------------------------
+template <int DIST, int OBS>
+__global__ __launch_bounds__(64) void policy_act_kernel(const float* __restrict__ params, NetLayout L, const float* __restrict__ obs,
+                                                        const uint8_t* __restrict__ mask, const int64_t* __restrict__ forced, int64_t n,
+                                                        int64_t seed, int64_t env_offset, int64_t step_index, int64_t* action,
+                                                        float* logprob, float* entropy, float* value, int value_only) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PPO_HIDDEN];
+    const int lane = threadIdx.x;
+    LaneNets<OBS> nets;
+    load_lane_nets<OBS>(nets, params, L, lane);
+    const int H = L.n_heads, A = L.act;
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        float x[OBS];
+#pragma unroll
+        for (int k = 0; k < OBS; k++) x[k] = obs[row * OBS + k];
+        float h2c, h2a;
+        trunk_forward<OBS>(nets, x, lds, lane, h2c, h2a);
+        const float v = critic_head(params, L, h2c, lane);
+        if (value && lane == 0) value[row] = v;
+        if (value_only) continue;
+        float logits[PPO_MAX_ACT];
+        actor_head(params, L, h2a, lane, logits);
+        uint8_t m[PPO_MAX_ACT];
+        const bool masked = (DIST == PPO_DIST_MASKED) && mask != nullptr;
+        if (masked) for (int k = 0; k < A; k++) m[k] = mask[row * A + k];
+        int act[PPO_MAX_HEADS];
+        if (forced) for (int h = 0; h < H; h++) act[h] = (int)forced[row * H + h];
+        float lp, en;
+        heads_eval<DIST>(L, logits, masked ? m : nullptr, forced == nullptr, seed, env_offset + row, step_index, act, lp, en);
+        if (lane == 0) {
+            if (logprob) logprob[row] = lp;
+            if (entropy) entropy[row] = en;
+        }
+        if (action && lane < H) action[row * H + lane] = act[lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone env kernels: one thread per env (struct-of-arrays state).
+// ---------------------------------------------------------------------------------------------------------
+template <int ENV, int OBS>
+__global__ void env_reset_kernel(int N, int64_t seed, int64_t env_offset, float* env_state, int32_t* ep_len, float* ep_rew,
+                                 int32_t* reset_count, const float* reset_table, int reset_cap, float* next_obs, int32_t* next_done,
+                                 int32_t* error_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    // initEnvs resets env 0 once for the obs-size probe and once more with everybody else (PPO_Discrete.cpp:368,389);
+    // the object is freshly constructed, so its reset counter starts at 0.
+    int k = (env_offset + i == 0) ? 1 : 0;
+    if (ENV == PPO_ENV_CARTPOLE && k >= reset_cap) { k = reset_cap - 1; atomicOr(error_flag, 1); }
+    float st[OBS];
+    env_reset<ENV>(st, reset_table, k, seed, env_offset + i);
+#pragma unroll
+    for (int j = 0; j < OBS; j++) {
+        env_state[(size_t)j * N + i] = st[j];
+        next_obs[(size_t)i * OBS + j] = st[j];
+    }
+    ep_len[i] = 0;
+    ep_rew[i] = 0.0f;
+    reset_count[i] = k + 1;
+    next_done[i] = 0;
+}
+
+template <int ENV, int OBS>
+__global__ void env_step_kernel(int N, int H, int max_episode_steps, int64_t seed, int64_t env_offset, float* env_state,
+                                int32_t* ep_len, float* ep_rew, int32_t* reset_count, const float* reset_table, int reset_cap,
+                                const int64_t* __restrict__ action, float* obs, float* reward, int32_t* done, int32_t* error_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float st[OBS];
+#pragma unroll
+    for (int j = 0; j < OBS; j++) st[j] = env_state[(size_t)j * N + i];
+    int term;
+    const float r = env_step<ENV>(st, (int)action[(size_t)i * H], term);
+    int len = ep_len[i] + 1;
+    float rew = ep_rew[i] + r;
+    if (len == max_episode_steps) term = 1;
+    if (term) {
+        int k = reset_count[i];
+        reset_count[i] = k + 1;
+        if (ENV == PPO_ENV_CARTPOLE && k >= reset_cap) { k = reset_cap - 1; atomicOr(error_flag, 1); }
+        env_reset<ENV>(st, reset_table, k, seed, env_offset + i);
+        len = 0;
+        rew = 0.0f;
+    }
+    ep_len[i] = len;
+    ep_rew[i] = rew;
+#pragma unroll
+    for (int j = 0; j < OBS; j++) {
+        env_state[(size_t)j * N + i] = st[j];
+        obs[(size_t)i * OBS + j] = st[j];
+    }
+    reward[i] = r;
+    done[i] = term;
+}
+
+template <int ENV, int OBS>
+__global__ void env_transition_kernel(const float* __restrict__ state_in, const int64_t* __restrict__ action, int64_t n,
+                                      float* next_state, float* reward, int32_t* terminated) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float st[OBS];
+#pragma unroll
+    for (int j = 0; j < OBS; j++) st[j] = state_in[i * OBS + j];
+    int term;
+    const float r = env_step<ENV>(st, (int)action[i], term);
+#pragma unroll
+    for (int j = 0; j < OBS; j++) next_state[i * OBS + j] = st[j];
+    reward[i] = r;
+    terminated[i] = term;
+}
+
+__global__ void aos_soa_kernel(const float* in, float* out, int N, int O, int to_soa) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * O) return;
+    const int n = i / O, o = i % O;
+    if (to_soa) out[(size_t)o * N + n] = in[i];
+    else out[i] = in[(size_t)o * N + n];
+}
+
+// Categorical API on caller logits: one thread per row.
+template <int DIST>
+__global__ void categorical_kernel(const float* __restrict__ logits, const uint8_t* __restrict__ mask, const int64_t* __restrict__ value,
+                                   int64_t n, int A, float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float z[PPO_MAX_ACT], p[PPO_MAX_ACT];
+    uint8_t m[PPO_MAX_ACT];
+    for (int a = 0; a < A; a++) { z[a] = logits[i * A + a]; m[a] = mask ? mask[i * A + a] : 1; }
+    const float e = categorical_head<DIST>(z, p, (DIST == PPO_DIST_MASKED && mask) ? m : nullptr, A);
+    int best = 0;
+    for (int a = 0; a < A; a++) {
+        if (m_logits) m_logits[i * A + a] = z[a];
+        if (m_probs) m_probs[i * A + a] = p[a];
+        if (p[a] > p[best]) best = a;
+    }
+    if (log_prob && value) log_prob[i] = z[value[i]];
+    if (entropy) entropy[i] = e;
+    if (mode) mode[i] = best;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Episode statistics: the reference appends finished episodes to CircularBuffer(100) in (step, env index) order
+// (PPO_Discrete.cpp:474-480).  Only the last 100 matter, so: count per step row in parallel, then ONE wave walks the
+// last rows (in order) that hold >= 100 finished episodes and pushes them with ballot-ordered slots.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void episode_count_kernel(const int32_t* __restrict__ fin_len, int N, int32_t* row_counts) {
+    __shared__ int red[4];
+    const int t = blockIdx.x;
+    int c = 0;
+    for (int n = threadIdx.x; n < N; n += 256) c += fin_len[(size_t)t * N + n] > 0 ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) row_counts[t] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restrict__ fin_len, const float* __restrict__ fin_rew, int T, int N,
+                                                          const int32_t* __restrict__ row_counts, EpisodeRing* ring) {
+    const int lane = threadIdx.x;
+    int64_t total = 0;
+    for (int t = 0; t < T; t++) total += row_counts[t];
+    int t_start = T, have = 0;
+    while (t_start > 0 && have < 100) { t_start--; have += row_counts[t_start]; }
+    int head = ring->head;
+    for (int t = t_start; t < T; t++) {
+        if (row_counts[t] == 0) continue;
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            const int n = n0 + lane;
+            const int len = n < N ? fin_len[(size_t)t * N + n] : 0;
+            const unsigned long long m = __ballot(len > 0);
+            if (len > 0) {
+                const int slot = (head + __popcll(m & ((1ull << lane) - 1ull))) % 100;
+                // when more than 100 episodes finish inside one 64-env group the later lane must win: serialise by rank
+                ring->len[slot] = len;
+                ring->rew[slot] = fin_rew[(size_t)t * N + n];
+            }
+            head = (head + __popcll(m)) % 100;
+        }
+    }
+    if (lane == 0) {
+        ring->head = head;
+        const int64_t sz = (int64_t)ring->size + total;
+        ring->size = (int32_t)(sz > 100 ? 100 : sz);
+        ring->total += total;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)a.N), block(64);
+    if (a.env_kind == PPO_ENV_CARTPOLE && a.L.obs == 4) {
+        if (a.dist_kind == PPO_DIST_CATEGORICAL) hipLaunchKernelGGL((rollout_kernel<PPO_ENV_CARTPOLE, PPO_DIST_CATEGORICAL, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollout_kernel<PPO_ENV_CARTPOLE, PPO_DIST_MASKED, 4>), grid, block, 0, s, a);
+    } else if (a.env_kind == PPO_ENV_MOUNTAINCAR && a.L.obs == 2) {
+        if (a.dist_kind == PPO_DIST_CATEGORICAL) hipLaunchKernelGGL((rollout_kernel<PPO_ENV_MOUNTAINCAR, PPO_DIST_CATEGORICAL, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rollout_kernel<PPO_ENV_MOUNTAINCAR, PPO_DIST_MASKED, 2>), grid, block, 0, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_env_reset(int env_kind, int N, int64_t seed, int64_t env_offset, float* env_state, int32_t* ep_len, float* ep_rew,
+                            int32_t* reset_count, const float* reset_table, int reset_cap, float* next_obs, int32_t* next_done,
+                            int32_t* error_flag, hipStream_t s) {
+    const dim3 block(256), grid((N + 255) / 256);
+    if (env_kind == PPO_ENV_CARTPOLE)
+        hipLaunchKernelGGL((env_reset_kernel<PPO_ENV_CARTPOLE, 4>), grid, block, 0, s, N, seed, env_offset, env_state, ep_len, ep_rew,
+                           reset_count, reset_table, reset_cap, next_obs, next_done, error_flag);
+    else
+        hipLaunchKernelGGL((env_reset_kernel<PPO_ENV_MOUNTAINCAR, 2>), grid, block, 0, s, N, seed, env_offset, env_state, ep_len, ep_rew,
+                           reset_count, reset_table, reset_cap, next_obs, next_done, error_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_step(int env_kind, int N, int H, int max_episode_steps, int64_t seed, int64_t env_offset, float* env_state,
+                           int32_t* ep_len, float* ep_rew, int32_t* reset_count, const float* reset_table, int reset_cap,
+                           const int64_t* action, float* obs, float* reward, int32_t* done, int32_t* error_flag, hipStream_t s) {
+    const dim3 block(256), grid((N + 255) / 256);
+    if (env_kind == PPO_ENV_CARTPOLE)
+        hipLaunchKernelGGL((env_step_kernel<PPO_ENV_CARTPOLE, 4>), grid, block, 0, s, N, H, max_episode_steps, seed, env_offset, env_state,
+                           ep_len, ep_rew, reset_count, reset_table, reset_cap, action, obs, reward, done, error_flag);
+    else
+        hipLaunchKernelGGL((env_step_kernel<PPO_ENV_MOUNTAINCAR, 2>), grid, block, 0, s, N, H, max_episode_steps, seed, env_offset, env_state,
+                           ep_len, ep_rew, reset_count, reset_table, reset_cap, action, obs, reward, done, error_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_transition(int env_kind, const float* state_in, const int64_t* action, int64_t n, float* next_state,
+                                 float* reward, int32_t* terminated, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 block(256), grid((unsigned)((n + 255) / 256));
+    if (env_kind == PPO_ENV_CARTPOLE)
+        hipLaunchKernelGGL((env_transition_kernel<PPO_ENV_CARTPOLE, 4>), grid, block, 0, s, state_in, action, n, next_state, reward, terminated);
+    else if (env_kind == PPO_ENV_MOUNTAINCAR)
+        hipLaunchKernelGGL((env_transition_kernel<PPO_ENV_MOUNTAINCAR, 2>), grid, block, 0, s, state_in, action, n, next_state, reward, terminated);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_aos_to_soa(const float* aos, float* soa, int N, int O, bool to_soa, hipStream_t s) {
+    const int n = N * O;
+    if (to_soa) hipLaunchKernelGGL(aos_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, s, aos, soa, N, O, 1);
+    else hipLaunchKernelGGL(aos_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, s, soa, const_cast<float*>(aos), N, O, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_act(const float* params, const NetLayout& L, int dist_kind, const float* obs, const uint8_t* mask,
+                             const int64_t* forced_action, int64_t n, int64_t seed, int64_t env_offset, int64_t step_index,
+                             int64_t* action, float* logprob, float* entropy, float* value, bool value_only, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n < 16384 ? n : 16384);
+    const int vo = value_only ? 1 : 0;
+#define PPO_LAUNCH_ACT(DIST, OBS)                                                                                              \
+    hipLaunchKernelGGL((policy_act_kernel<DIST, OBS>), dim3(grid), dim3(64), 0, s, params, L, obs, mask, forced_action, n, seed, \
+                       env_offset, step_index, action, logprob, entropy, value, vo)
+    if (L.obs == 4) {
+        if (dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ACT(PPO_DIST_CATEGORICAL, 4); else PPO_LAUNCH_ACT(PPO_DIST_MASKED, 4);
+    } else if (L.obs == 2) {
+        if (dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ACT(PPO_DIST_CATEGORICAL, 2); else PPO_LAUNCH_ACT(PPO_DIST_MASKED, 2);
+    } else if (L.obs == 8) {
+        if (dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ACT(PPO_DIST_CATEGORICAL, 8); else PPO_LAUNCH_ACT(PPO_DIST_MASKED, 8);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef PPO_LAUNCH_ACT
+    return hipGetLastError();
+}
+
+hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n, int A,
+                              float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (A < 1 || A > PPO_MAX_ACT) return hipErrorInvalidValue;
+    const dim3 block(128), grid((unsigned)((n + 127) / 128));
+    if (dist_kind == PPO_DIST_CATEGORICAL)
+        hipLaunchKernelGGL((categorical_kernel<PPO_DIST_CATEGORICAL>), grid, block, 0, s, logits, mask, value, n, A, m_logits, m_probs, log_prob, entropy, mode);
+    else
+        hipLaunchKernelGGL((categorical_kernel<PPO_DIST_MASKED>), grid, block, 0, s, logits, mask, value, n, A, m_logits, m_probs, log_prob, entropy, mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, EpisodeRing* ring,
+                                      hipStream_t s) {
+    hipLaunchKernelGGL(episode_count_kernel, dim3((unsigned)T), dim3(256), 0, s, fin_len, N, row_counts);
+    hipLaunchKernelGGL(episode_push_kernel, dim3(1), dim3(64), 0, s, fin_len, fin_rew, T, N, row_counts, ring);
+    return hipGetLastError();
+}

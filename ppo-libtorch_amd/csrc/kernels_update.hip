@@ -1,0 +1,681 @@
+// ppo-libtorch_amd/csrc/kernels_update.hip -- update-side kernels for gfx950 (wave64).
+//
+//   K5  minibatch gather by permutation index        reference PPO_Discrete.cpp:569-582 (b_*.index({mb_inds}))
+//   K6  teacher-forced forward (new log-prob, value) reference Agent.cpp:117-170
+//   K7  PPO loss + statistics                        reference PPO_Discrete.cpp:585-631, :343-356
+//   K8  backward through both MLPs                   reference PPO_Discrete.cpp:638 (autograd)
+//   K9  global-norm clip  + K10 AdamW                reference PPO_Discrete.cpp:640-641 (LibTorch clip_grad.h:22-85, optim/adamw.cpp)
+//   K11 explained variance                           reference PPO_Discrete.cpp:647-648
+//   plus: minibatch advantage statistics (:591-594), permutation generator (torch::randperm, :569).
+//
+// K5-K8 are ONE kernel.  Actor and critic are independent networks whose only coupling is the scalar sum of their
+// losses (Agent.cpp:25-59, PPO_Discrete.cpp:631), so blockIdx.y selects the net and a workgroup streams 64-sample tiles
+// of its net end to end: gather -> layer 1 -> layer 2 -> head -> loss -> d head -> d layer 2 -> d layer 1, with the
+// activations of the tile resident in LDS as [unit][sample] images (row stride 68 floats: 16-byte aligned rows that
+// spread over the banks) and the 64x64 weight block resident in LDS in both orientations for the whole launch.
+// The three 64x64 contractions per tile are register-tiled 4x4 per thread (16 FMAs per two 16-byte LDS reads).
+// Weight gradients accumulate in registers across all tiles of the workgroup and are written ONCE as a partial slab;
+// a second kernel adds the slabs in a fixed order (bit-reproducible, no float atomics).
+#include "ppo_internal.hpp"
+
+namespace {
+
+constexpr int UPD_THREADS = 256;
+constexpr int S = PPO_LDS_STRIDE;  // 68
+constexpr int TILE = PPO_TILE;     // 64
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+struct SmemLayout {
+    int w2t, w2, w1, b1, b2, w3, b3, x, h1, h2, dout, total;  // offsets in floats
+};
+__host__ __device__ inline SmemLayout smem_layout(int obs, int aout) {
+    SmemLayout m;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.w2t = take(64 * 64);
+    m.w2 = take(64 * 64);
+    m.w1 = take(64 * obs);
+    m.b1 = take(64);
+    m.b2 = take(64);
+    m.w3 = take(aout * 64);
+    m.b3 = take(aout);
+    m.x = take(obs * S);
+    m.h1 = take(64 * S);
+    m.h2 = take(64 * S);
+    m.dout = take(aout * S);
+    m.total = o;
+    return m;
+}
+
+template <int NET, int DIST, int OBS>
+__device__ __forceinline__ void fwd_bwd_body(const UpdateArgs& a, float* smem) {
+    const NetLayout& L = a.L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ts = tid >> 4, tu = tid & 15;
+    const int AOUT = NET == 0 ? 1 : L.act;
+    const SmemLayout m = smem_layout(OBS, AOUT);
+    float* sW2T = smem + m.w2t;
+    float* sW2 = smem + m.w2;
+    float* sW1 = smem + m.w1;
+    float* sB1 = smem + m.b1;
+    float* sB2 = smem + m.b2;
+    float* sW3 = smem + m.w3;
+    float* sB3 = smem + m.b3;
+    float* sX = smem + m.x;
+    float* sH1 = smem + m.h1;
+    float* sH2 = smem + m.h2;
+    float* sD = smem + m.dout;
+    const float* __restrict__ P = a.params;
+
+    // ---- weights of this net -> LDS (once per launch) ----
+    for (int e = tid; e < 64 * 64; e += UPD_THREADS) {
+        const float w = P[L.w2[NET] + e];  // [u][k]
+        sW2[e] = w;
+        sW2T[(e & 63) * 64 + (e >> 6)] = w;
+    }
+    for (int e = tid; e < 64 * OBS; e += UPD_THREADS) sW1[e] = P[L.w1[NET] + e];
+    for (int e = tid; e < AOUT * 64; e += UPD_THREADS) sW3[e] = P[L.w3[NET] + e];
+    if (tid < 64) { sB1[tid] = P[L.b1[NET] + tid]; sB2[tid] = P[L.b2[NET] + tid]; }
+    if (tid < AOUT) sB3[tid] = P[L.b3[NET] + tid];
+
+    // ---- per-thread gradient accumulators (whole launch) ----
+    float gW2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) gW2[i][j] = 0.0f;
+    constexpr int W3R = (PPO_MAX_ACT * 64) / UPD_THREADS;  // 8
+    float gW3[W3R];
+#pragma unroll
+    for (int r = 0; r < W3R; r++) gW3[r] = 0.0f;
+    constexpr int W1R = (OBS * 64 + UPD_THREADS - 1) / UPD_THREADS;
+    float gW1[W1R];
+#pragma unroll
+    for (int r = 0; r < W1R; r++) gW1[r] = 0.0f;
+    float gb1 = 0.0f, gb2 = 0.0f, gb3 = 0.0f;
+
+    // loss partial sums (wave 0 lanes)
+    double st0 = 0.0, st1 = 0.0, st2 = 0.0, st3 = 0.0;  // NET1: pg, entropy, kl, clip count ; NET0: v
+
+    const float clip = a.hp.clip_coef;
+    const float lo = 1 - clip, hi = 1 + clip;  // int - float -> float (PPO_Discrete.cpp:598)
+    const float invM = (float)a.inv_global_M;
+    float mean_f = 0.0f, std_f = 0.0f;
+    if (NET == 1 && a.hp.norm_adv) {
+        // (adv - mean) / (std + 1e-8) over the minibatch, std Bessel-corrected (PPO_Discrete.cpp:591-594)
+        const double mean = a.adv_stat->s1 / a.global_M;
+        const double var = (a.adv_stat->s2 - a.adv_stat->s1 * mean) / (a.global_M - 1.0);
+        mean_f = (float)mean;
+        std_f = (float)sqrt(var > 0.0 ? var : 0.0);
+    }
+    __syncthreads();
+
+    const int n_tiles = (a.M + TILE - 1) / TILE;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // ---------------- gather (K5): wave 0, lane = sample ----------------
+        bool valid = false;
+        int row = 0;
+        float s_oldlp = 0.0f, s_adv = 0.0f, s_ret = 0.0f, s_oldv = 0.0f;
+        int s_act[PPO_MAX_HEADS];
+        uint32_t s_mask = 0xffffffffu;
+        if (tid < TILE) {
+            const int j = tile * TILE + tid;
+            valid = j < a.M;
+            row = valid ? a.idx[j] : 0;
+#pragma unroll
+            for (int o = 0; o < OBS; o++) sX[o * S + tid] = valid ? a.obs[(size_t)row * OBS + o] : 0.0f;
+            if (NET == 1) {
+                s_oldlp = a.logprobs[row];
+                s_adv = a.advantages[row];
+                for (int h = 0; h < L.n_heads; h++) s_act[h] = a.actions[(size_t)row * L.n_heads + h];
+                if (DIST == PPO_DIST_MASKED && a.masks) {
+                    s_mask = 0u;
+                    for (int k = 0; k < L.act; k++) s_mask |= (a.masks[(size_t)row * L.act + k] ? 1u : 0u) << k;
+                }
+            } else {
+                s_ret = a.returns[row];
+                s_oldv = a.values[row];
+            }
+        }
+        __syncthreads();
+
+        // ---------------- layer 1 forward: h1[u][s] = tanh(b1[u] + sum_o x[o][s] W1[u][o]) ----------------
+        {
+            float xs[OBS][4];
+#pragma unroll
+            for (int o = 0; o < OBS; o++) {
+                const float4 v = ld4(&sX[o * S + ts * 4]);
+                xs[o][0] = v.x; xs[o][1] = v.y; xs[o][2] = v.z; xs[o][3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = tu * 4 + j;
+                float z[4] = { sB1[u], sB1[u], sB1[u], sB1[u] };
+#pragma unroll
+                for (int o = 0; o < OBS; o++) {
+                    const float w = sW1[u * OBS + o];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) z[i] = __builtin_fmaf(xs[o][i], w, z[i]);
+                }
+                st4(&sH1[u * S + ts * 4], make_float4(tanhf(z[0]), tanhf(z[1]), tanhf(z[2]), tanhf(z[3])));
+            }
+        }
+        __syncthreads();
+
+        // ---------------- layer 2 forward: h2[u][s] = tanh(b2[u] + sum_k h1[k][s] W2[u][k]) ----------------
+        {
+            float acc[4][4];  // [sample i][unit j]
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float b = sB2[tu * 4 + j];
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i][j] = b;
+            }
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) {
+                const float4 h = ld4(&sH1[k * S + ts * 4]);
+                const float4 w = ld4(&sW2T[k * 64 + tu * 4]);
+                const float hv[4] = { h.x, h.y, h.z, h.w }, wv[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_fmaf(hv[i], wv[j], acc[i][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                st4(&sH2[(tu * 4 + j) * S + ts * 4], make_float4(tanhf(acc[0][j]), tanhf(acc[1][j]), tanhf(acc[2][j]), tanhf(acc[3][j])));
+        }
+        __syncthreads();
+
+        // ---------------- head + loss + d(head output) (K6, K7): wave 0, lane = sample ----------------
+        if (tid < TILE) {
+            if (NET == 0) {
+                float v = sB3[0];
+#pragma unroll 8
+                for (int u = 0; u < 64; u++) v = __builtin_fmaf(sH2[u * S + tid], sW3[u], v);
+                // value loss, PPO_Discrete.cpp:603-625
+                const float R = s_ret, vold = s_oldv;
+                const float un = (v - R) * (v - R);
+                float g_v;
+                float lossv;
+                if (a.hp.clip_vloss) {
+                    const float dv = v - vold;
+                    const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+                    const float vc = vold + dvc;
+                    const float cl = (vc - R) * (vc - R);
+                    lossv = un > cl ? un : cl;
+                    const bool vin = (dv >= -clip && dv <= clip);
+                    const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+                    const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);  // torch::max splits ties
+                    g_v = a.hp.vf_coef * 0.5f * invM * d;
+                } else {
+                    lossv = un;
+                    g_v = a.hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+                }
+                if (valid) st0 += (double)lossv;
+                sD[tid] = valid ? g_v : 0.0f;
+            } else {
+                float z[PPO_MAX_ACT], p[PPO_MAX_ACT], headH[PPO_MAX_HEADS];
+                for (int k = 0; k < L.act; k++) {
+                    float acc = sB3[k];
+#pragma unroll 8
+                    for (int u = 0; u < 64; u++) acc = __builtin_fmaf(sH2[u * S + tid], sW3[k * 64 + u], acc);
+                    z[k] = acc;
+                }
+                uint8_t mk[PPO_MAX_ACT];
+                for (int k = 0; k < L.act; k++) mk[k] = (uint8_t)((s_mask >> k) & 1u);
+                const bool use_mask = (DIST == PPO_DIST_MASKED) && a.masks != nullptr;
+                float nlp = 0.0f, ent = 0.0f;
+                int off = 0;
+                for (int h = 0; h < L.n_heads; h++) {
+                    const int Ah = L.head_dims[h];
+                    headH[h] = categorical_head<DIST>(z + off, p + off, use_mask ? mk + off : nullptr, Ah);
+                    const float l1 = z[off + s_act[h]];
+                    if (h == 0) { nlp = l1; ent = headH[h]; } else { nlp += l1; ent += headH[h]; }
+                    off += Ah;
+                }
+                // PPO_Discrete.cpp:585-599
+                const float logratio = nlp - s_oldlp;
+                const float ratio = expf(logratio);
+                float adv = s_adv;
+                if (a.hp.norm_adv) adv = (adv - mean_f) / (std_f + 1e-8f);
+                const float rc = ratio < lo ? lo : (ratio > hi ? hi : ratio);
+                const float l1 = -adv * ratio, l2 = -adv * rc;
+                const bool inside = (ratio >= lo && ratio <= hi);
+                float d_ratio;
+                if (l1 > l2) d_ratio = -adv;
+                else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+                else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);
+                const float g_nlp = invM * d_ratio * ratio;
+                const float g_ent = -a.hp.ent_coef * invM;
+                if (valid) {
+                    st0 += (double)(l1 > l2 ? l1 : l2);
+                    st1 += (double)ent;
+                    st2 += (double)((ratio - 1.0f) - logratio);         // :352
+                    st3 += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;     // :348
+                }
+                off = 0;
+                for (int h = 0; h < L.n_heads; h++) {
+                    const int Ah = L.head_dims[h];
+                    for (int k = 0; k < Ah; k++) {
+                        const bool ok = !use_mask || mk[off + k];
+                        const float pk = p[off + k];
+                        float d = g_nlp * ((k == s_act[h] ? 1.0f : 0.0f) - pk);
+                        // CategoricalMasked entropy is the true entropy: dH/dz_k = -p_k (log p_k + H).  The plain Categorical's
+                        // clamp turns entropy into -FLT_MIN*sum(p): gradient is a denormal times ent_coef/M, i.e. zero.
+                        if (DIST == PPO_DIST_MASKED) d += g_ent * (-pk * (z[off + k] + headH[h]));
+                        sD[(off + k) * S + tid] = (valid && ok) ? d : 0.0f;
+                    }
+                    off += Ah;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- dW3, db3 (reads h2 before it is overwritten) ----------------
+#pragma unroll
+        for (int r = 0; r < W3R; r++) {
+            const int q = tid + r * UPD_THREADS;
+            if (q < AOUT * 64) {
+                const int aa = q >> 6, u = q & 63;
+                float acc = 0.0f;
+#pragma unroll
+                for (int s4 = 0; s4 < TILE; s4 += 4) {
+                    const float4 d = ld4(&sD[aa * S + s4]);
+                    const float4 h = ld4(&sH2[u * S + s4]);
+                    acc = __builtin_fmaf(d.x, h.x, acc); acc = __builtin_fmaf(d.y, h.y, acc);
+                    acc = __builtin_fmaf(d.z, h.z, acc); acc = __builtin_fmaf(d.w, h.w, acc);
+                }
+                gW3[r] += acc;
+            }
+        }
+        if (tid < AOUT) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int s4 = 0; s4 < TILE; s4 += 4) { const float4 d = ld4(&sD[tid * S + s4]); acc += (d.x + d.y) + (d.z + d.w); }
+            gb3 += acc;
+        }
+        __syncthreads();
+
+        // ---------------- dz2[u][s] = (sum_a dOut[a][s] W3[a][u]) * (1 - h2^2), in place of h2 ----------------
+        {
+            float dh[4][4];  // [unit j][sample i]
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) dh[j][i] = 0.0f;
+            for (int aa = 0; aa < AOUT; aa++) {
+                const float4 d = ld4(&sD[aa * S + ts * 4]);
+                const float dv[4] = { d.x, d.y, d.z, d.w };
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float w = sW3[aa * 64 + tu * 4 + j];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) dh[j][i] = __builtin_fmaf(dv[i], w, dh[j][i]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float* ph = &sH2[(tu * 4 + j) * S + ts * 4];
+                const float4 h = ld4(ph);
+                st4(ph, make_float4(dh[j][0] * (1.0f - h.x * h.x), dh[j][1] * (1.0f - h.y * h.y), dh[j][2] * (1.0f - h.z * h.z),
+                                    dh[j][3] * (1.0f - h.w * h.w)));
+            }
+        }
+        __syncthreads();
+
+        // ---------------- dW2[u][k] += sum_s dz2[u][s] h1[k][s]   (u = tu + 16 j, k = ts + 16 i) ; db2 ----------------
+#pragma unroll 4
+        for (int s4 = 0; s4 < TILE; s4 += 4) {
+            float4 dz[4], hh[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) dz[j] = ld4(&sH2[(tu + 16 * j) * S + s4]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) hh[i] = ld4(&sH1[(ts + 16 * i) * S + s4]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float acc = gW2[j][i];
+                    acc = __builtin_fmaf(dz[j].x, hh[i].x, acc); acc = __builtin_fmaf(dz[j].y, hh[i].y, acc);
+                    acc = __builtin_fmaf(dz[j].z, hh[i].z, acc); acc = __builtin_fmaf(dz[j].w, hh[i].w, acc);
+                    gW2[j][i] = acc;
+                }
+        }
+        if (tid < 64) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int s4 = 0; s4 < TILE; s4 += 4) { const float4 d = ld4(&sH2[tid * S + s4]); acc += (d.x + d.y) + (d.z + d.w); }
+            gb2 += acc;
+        }
+
+        // ---------------- dh1[k][s] = sum_u dz2[u][s] W2[u][k]  (registers; h1 is still being read by dW2) ----------------
+        float dh1[4][4];  // [unit k_j][sample i]
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) dh1[j][i] = 0.0f;
+#pragma unroll 8
+        for (int u = 0; u < 64; u++) {
+            const float4 d = ld4(&sH2[u * S + ts * 4]);
+            const float4 w = ld4(&sW2[u * 64 + tu * 4]);
+            const float dv[4] = { d.x, d.y, d.z, d.w }, wv[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) dh1[j][i] = __builtin_fmaf(dv[i], wv[j], dh1[j][i]);
+        }
+        __syncthreads();
+        // dz1 = dh1 * (1 - h1^2), in place of h1
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float* ph = &sH1[(tu * 4 + j) * S + ts * 4];
+            const float4 h = ld4(ph);
+            st4(ph, make_float4(dh1[j][0] * (1.0f - h.x * h.x), dh1[j][1] * (1.0f - h.y * h.y), dh1[j][2] * (1.0f - h.z * h.z),
+                                dh1[j][3] * (1.0f - h.w * h.w)));
+        }
+        __syncthreads();
+
+        // ---------------- dW1[u][o] += sum_s dz1[u][s] x[o][s] ; db1 ----------------
+#pragma unroll
+        for (int r = 0; r < W1R; r++) {
+            const int q = tid + r * UPD_THREADS;
+            if (q < OBS * 64) {
+                const int u = q & 63, o = q >> 6;
+                float acc = 0.0f;
+#pragma unroll
+                for (int s4 = 0; s4 < TILE; s4 += 4) {
+                    const float4 d = ld4(&sH1[u * S + s4]);
+                    const float4 x = ld4(&sX[o * S + s4]);
+                    acc = __builtin_fmaf(d.x, x.x, acc); acc = __builtin_fmaf(d.y, x.y, acc);
+                    acc = __builtin_fmaf(d.z, x.z, acc); acc = __builtin_fmaf(d.w, x.w, acc);
+                }
+                gW1[r] += acc;
+            }
+        }
+        if (tid < 64) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int s4 = 0; s4 < TILE; s4 += 4) { const float4 d = ld4(&sH1[tid * S + s4]); acc += (d.x + d.y) + (d.z + d.w); }
+            gb1 += acc;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- write this workgroup's partial gradient slab (net-local flat layout) ----------------
+    const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
+    float* slab = a.slab + ((size_t)NET * a.n_blocks_per_net + blockIdx.x) * Pmax;
+    const int base = L.net_off[NET];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) slab[L.w2[NET] - base + (tu + 16 * j) * 64 + (ts + 16 * i)] = gW2[j][i];
+#pragma unroll
+    for (int r = 0; r < W3R; r++) {
+        const int q = tid + r * UPD_THREADS;
+        if (q < AOUT * 64) slab[L.w3[NET] - base + q] = gW3[r];
+    }
+#pragma unroll
+    for (int r = 0; r < W1R; r++) {
+        const int q = tid + r * UPD_THREADS;
+        if (q < OBS * 64) slab[L.w1[NET] - base + (q & 63) * OBS + (q >> 6)] = gW1[r];
+    }
+    if (tid < 64) { slab[L.b1[NET] - base + tid] = gb1; slab[L.b2[NET] - base + tid] = gb2; }
+    if (tid < AOUT) slab[L.b3[NET] - base + tid] = gb3;
+    if (tid < 64) {
+        st0 = wave_sum_d(st0); st1 = wave_sum_d(st1); st2 = wave_sum_d(st2); st3 = wave_sum_d(st3);
+        if (lane == 0) {
+            double* o = a.stat_slab + ((size_t)NET * a.n_blocks_per_net + blockIdx.x) * 8;
+            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+        }
+    }
+}
+
+template <int DIST, int OBS>
+__global__ __launch_bounds__(UPD_THREADS, 2) void fwd_bwd_kernel(UpdateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.y == 0) fwd_bwd_body<0, DIST, OBS>(a, smem);
+    else fwd_bwd_body<1, DIST, OBS>(a, smem);
+}
+
+// grads[p] = sum_b slab[net(p)][b][p - net_off]  (fixed order: four contiguous quarters, each summed in order, then combined).
+__global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb,
+                                                           NetLayout L, float* __restrict__ grads, double* __restrict__ sums_out) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
+    double acc = 0.0;
+    if (p < L.P) {
+        const int net = p >= L.net_off[1] ? 1 : 0;
+        const float* col = slab + (size_t)net * nb * Pmax + (p - L.net_off[net]);
+        const int b0 = (nb * w) / 4, b1 = (nb * (w + 1)) / 4;
+        for (int b = b0; b < b1; b++) acc += (double)col[(size_t)b * Pmax];
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && p < L.P) grads[p] = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor blocks), [4]=value loss (critic blocks)
+        const int k = threadIdx.x;
+        double s = 0.0;
+        if (k < 4) for (int b = 0; b < nb; b++) s += stat_slab[((size_t)nb + b) * 8 + k];
+        else if (k == 4) for (int b = 0; b < nb; b++) s += stat_slab[(size_t)b * 8 + 0];
+        sums_out[k] = s;
+    }
+}
+
+// K9 + K10: global-norm clip and AdamW in one single-workgroup launch (P is a few thousand floats).
+__global__ __launch_bounds__(1024) void clip_adamw_kernel(float* __restrict__ params, float* __restrict__ grads, float* __restrict__ exp_avg,
+                                                          float* __restrict__ exp_avg_sq, NetLayout L, float max_norm,
+                                                          const AdamCoef* __restrict__ coef_p, const double* __restrict__ loss_sums,
+                                                          double global_M, LossParams hp, int world, int do_step,
+                                                          StepStats* stats_out, double* clipfrac_accum) {
+    __shared__ double red[16][12];
+    __shared__ float s_coef;
+    __shared__ float s_total;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // per-tensor L2 norms (clip_grad.h:58-66)
+    for (int t = 0; t < L.n_tensors; t++) {
+        double acc = 0.0;
+        for (int p = L.tensor_off[t] + tid; p < L.tensor_off[t + 1]; p += 1024) { const double g = grads[p]; acc += g * g; }
+        acc = wave_sum_d(acc);
+        if (lane == 0) red[w][t] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < L.n_tensors; t++) {
+            double s = 0.0;
+            for (int k = 0; k < 16; k++) s += red[k][t];
+            const float nrm = (float)sqrt(s);
+            tot += (double)nrm * nrm;
+        }
+        const float total = (float)sqrt(tot);
+        float c = max_norm / (total + 1e-6f);   // clip_grad.h:76-78
+        if (c > 1.0f) c = 1.0f;
+        s_coef = c;
+        s_total = total;
+    }
+    __syncthreads();
+    const float c = s_coef;
+    const AdamCoef k = *coef_p;
+    const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
+    for (int p = tid; do_step && p < L.P; p += 1024) {
+        const float g = grads[p] * c;              // grads scaled in place (clip_grad.h:79-81)
+        grads[p] = g;
+        const float pi = params[p] * k.decay;      // p.mul_(1 - lr*wd)
+        const float mi = __builtin_fmaf(g, omb1, exp_avg[p] * b1);          // exp_avg.mul_(b1).add_(g, 1-b1)   (ATen fmadd)
+        const float vi = __builtin_fmaf(omb2 * g, g, exp_avg_sq[p] * b2);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
+        params[p] = pi + (k.neg_step * mi) / denom;                        // addcdiv_(exp_avg, denom, -step_size)
+        exp_avg[p] = mi;
+        exp_avg_sq[p] = vi;
+    }
+    if (tid == 0) {
+        // scalars as the reference forms them (PPO_Discrete.cpp:599,619,628,631,349,352), means over the global minibatch
+        double s_pg, s_ent, s_kl, s_clip, s_v;
+        if (world > 1) {  // sums travelled (as floats) behind the gradient through the all-reduce
+            s_pg = grads[L.P + 0]; s_ent = grads[L.P + 1]; s_kl = grads[L.P + 2]; s_clip = grads[L.P + 3]; s_v = grads[L.P + 4];
+        } else {
+            s_pg = loss_sums[0]; s_ent = loss_sums[1]; s_kl = loss_sums[2]; s_clip = loss_sums[3]; s_v = loss_sums[4];
+        }
+        const float pg = (float)(s_pg / global_M);
+        const float vl = 0.5f * (float)(s_v / global_M);
+        const float el = (float)(s_ent / global_M);
+        StepStats o;
+        o.pg_loss = pg;
+        o.v_loss = vl;
+        o.entropy_loss = el;
+        o.approx_kl = (float)(s_kl / global_M);
+        o.clipfrac = (float)s_clip / (float)global_M;
+        o.loss = (pg - hp.ent_coef * el) + vl * hp.vf_coef;
+        o.total_norm = s_total;
+        o.pad = 0.0;
+        *stats_out = o;
+        if (clipfrac_accum && do_step) { clipfrac_accum[0] += o.clipfrac; clipfrac_accum[1] += 1.0; }  // m_clipfracs (:349), mean at :755
+    }
+}
+
+// when sharded: float copies of the loss sums ride behind the gradient so ONE all-reduce carries both
+__global__ void append_sums_kernel(const double* sums, float* grads_tail) {
+    if (threadIdx.x < 8) grads_tail[threadIdx.x] = (float)sums[threadIdx.x];
+}
+
+// Sum and sum of squares of the advantages of every minibatch of the coming update (one workgroup each).
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict__ adv, const int32_t* __restrict__ perm, int64_t B,
+                                                         int64_t MB, int n_mb_per_epoch, AdvStat* out) {
+    __shared__ double r1[16], r2[16];
+    const int mb = blockIdx.x;
+    const int e = mb / n_mb_per_epoch, m = mb % n_mb_per_epoch;
+    const int64_t start = (int64_t)m * MB;
+    const int64_t end = start + MB < B ? start + MB : B;
+    const int32_t* idx = perm + (size_t)e * B;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t j = start + threadIdx.x; j < end; j += 1024) { const double x = adv[idx[j]]; s1 += x; s2 += x * x; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < 16; k++) { a1 += r1[k]; a2 += r2[k]; }
+        out[mb].s1 = a1;
+        out[mb].s2 = a2;
+    }
+}
+
+// Keyed bijection of [0, 2^bits) (xor / odd multiply / xorshift are each invertible mod 2^bits), cycle-walked into [0, B).
+__device__ __forceinline__ uint32_t mix_bits(uint32_t x, uint32_t mask, int bits, uint4 k) {
+    const int sh = bits > 1 ? bits / 2 : 1;
+    x ^= k.x & mask; x = (x * 0x9E3779B1u) & mask; x ^= x >> sh;
+    x ^= k.y & mask; x = (x * 0x85EBCA77u) & mask; x ^= x >> sh;
+    x ^= k.z & mask; x = (x * 0xC2B2AE3Du) & mask; x ^= x >> sh;
+    x ^= k.w & mask; x = (x * 0x27D4EB2Fu) & mask; x ^= x >> sh;
+    return x;
+}
+__global__ void permutation_kernel(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.y;
+    if (i >= B || e >= E) return;
+    int bits = 1;
+    while ((1ll << bits) < B) bits++;
+    const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    const uint4 k = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)update_index, (uint32_t)e, (uint32_t)rank_salt, 2u);
+    uint32_t x = (uint32_t)i;
+    do { x = mix_bits(x, mask, bits, k); } while (x >= (uint64_t)B);
+    perm[(size_t)e * B + i] = (int32_t)x;
+}
+
+// K11 partial sums: per block {sum y, sum y^2, sum d, sum d^2} with y = returns, d = returns - values (float subtraction).
+__global__ __launch_bounds__(256) void explained_variance_kernel(const float* __restrict__ returns, const float* __restrict__ values,
+                                                                  int64_t B, double* out) {
+    __shared__ double red[4][4];
+    double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const double y = returns[i], d = (double)(returns[i] - values[i]);
+        sy += y; sy2 += y * y; sd += d; sd2 += d * d;
+    }
+    sy = wave_sum_d(sy); sy2 = wave_sum_d(sy2); sd = wave_sum_d(sd); sd2 = wave_sum_d(sd2);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = sy; red[w][1] = sy2; red[w][2] = sd; red[w][3] = sd2; }
+    __syncthreads();
+    if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+int update_blocks_per_net(int M) {
+    const int tiles = (M + PPO_TILE - 1) / PPO_TILE;
+    return tiles < 256 ? (tiles > 0 ? tiles : 1) : 256;  // one (actor, critic) workgroup pair per CU
+}
+
+hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipErrorInvalidValue;
+    const int aout = a.L.act > 1 ? a.L.act : 1;
+    const size_t shmem = (size_t)smem_layout(a.L.obs, aout).total * sizeof(float);
+    const dim3 grid((unsigned)a.n_blocks_per_net, 2), block(UPD_THREADS);
+#define PPO_LAUNCH_UPD(DIST, OBS)                                                                                     \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_kernel<DIST, OBS>),             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+            if (e != hipSuccess) return e;                                                                            \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((fwd_bwd_kernel<DIST, OBS>), grid, block, shmem, s, a);                                    \
+    } while (0)
+    if (a.L.obs == 4) {
+        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_UPD(PPO_DIST_CATEGORICAL, 4); else PPO_LAUNCH_UPD(PPO_DIST_MASKED, 4);
+    } else if (a.L.obs == 2) {
+        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_UPD(PPO_DIST_CATEGORICAL, 2); else PPO_LAUNCH_UPD(PPO_DIST_MASKED, 2);
+    } else if (a.L.obs == 8) {
+        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_UPD(PPO_DIST_CATEGORICAL, 8); else PPO_LAUNCH_UPD(PPO_DIST_MASKED, 8);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef PPO_LAUNCH_UPD
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
+                               double* sums_out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64), dim3(256), 0, s, slab, stat_slab, n_blocks_per_net, L, grads, sums_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
+                             const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
+                             StepStats* stats_out, double* clipfrac_accum, hipStream_t s) {
+    hipLaunchKernelGGL(clip_adamw_kernel, dim3(1), dim3(1024), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, coef, loss_sums,
+                       global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t s) {
+    hipLaunchKernelGGL(append_sums_kernel, dim3(1), dim3(64), 0, s, sums, grads_tail);
+    return hipGetLastError();
+}
+
+hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
+                            hipStream_t s) {
+    const int per_epoch = (int)((B + MB - 1) / MB);
+    hipLaunchKernelGGL(adv_stats_kernel, dim3(n_mb_total), dim3(1024), 0, s, advantages, perm, B, MB, per_epoch, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s) {
+    hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)E), dim3(256), 0, s, perm, B, E, seed, update_index, rank_salt);
+    return hipGetLastError();
+}
+
+hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s) {
+    hipLaunchKernelGGL(explained_variance_kernel, dim3(64), dim3(256), 0, s, returns, values, B, sums4);
+    return hipGetLastError();
+}

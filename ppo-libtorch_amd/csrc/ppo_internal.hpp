@@ -160,7 +160,7 @@ __device__ __forceinline__ float glibc_cosf(float y) {
 __device__ __forceinline__ float cartpole_step(float* st, int action, int& terminated) {
     const float gravity = 9.8f, mass_pole = 0.1f, total_mass = 0.1f + 1.0f, length = 0.5f;
     const float polemass_length = 0.1f * 0.5f, force_mag = 10.0f, tau = 0.02f;
-    const float theta_thr = 0x1.acee9ep-3f; /* (float)(12*2*M_PI/360) = bits 0x3e567750, CartPole.cpp:16 */
+    const float theta_thr = 0x1.aceeap-3f; /* (float)(12*2*M_PI/360) = bits 0x3e567750, CartPole.cpp:16 */
     const float x_thr = 2.4f;
     float x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];
     float force = force_mag;
@@ -356,8 +356,19 @@ hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s);
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
-                             const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world,
+                             const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
                              StepStats* stats_out, double* clipfrac_accum, hipStream_t s);
+hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t s);
+
+// Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
+struct EpisodeRing {
+    float rew[100];
+    int32_t len[100];
+    int32_t size, head;
+    int64_t total;
+};
+hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, EpisodeRing* ring,
+                                      hipStream_t s);
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s);
 hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s);

