@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -73,7 +74,9 @@ struct ppo_ctx {
     double* loss_sums = nullptr;
     AdvStat* adv_stats = nullptr;       // [steps_per_update] + 1 scratch slot
     AdamCoef* adam_coefs = nullptr;     // device [steps_per_update + 1]
-    AdamCoef* adam_coefs_h = nullptr;   // pinned mirror
+    AdamCoef* adam_coefs_h = nullptr;   // pinned mirror, two halves used alternately
+    hipEvent_t coef_copied[2] = { nullptr, nullptr };  // H2D copy of each half has completed
+    int coef_half = 0;
     StepStats* step_stats = nullptr;    // device [steps_per_update + 1]
     double* clipfrac_accum = nullptr;   // {sum, count}
     double* ev_sums = nullptr;          // [64][4]
@@ -81,6 +84,7 @@ struct ppo_ctx {
     EpisodeRing* ring = nullptr;
     float* scratch_obs = nullptr;       // [N,O] staging for AoS<->SoA conversions
     int max_blocks_per_net = 0;
+    bool use_mfma = true;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
 
     // host-side training state
     double lr = 0.0;
@@ -257,6 +261,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (void* p : c->allocs) hipFree(p);
     if (c->adam_coefs_h) hipHostFree(c->adam_coefs_h);
+    for (hipEvent_t e : c->coef_copied) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -341,14 +346,20 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc_buf<int32_t>(c, PPO_BUF_FIN_LEN, TN));
     CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
     CK(dalloc(c, &c->error_flag, 1));
-    c->max_blocks_per_net = update_blocks_per_net((int)std::min<int64_t>(B, INT32_MAX));
+    {
+        const char* k = getenv("PPO_UPDATE_KERNEL");
+        c->use_mfma = (A <= 4) && !(k && std::strcmp(k, "valu") == 0);
+    }
+    c->max_blocks_per_net = std::max(update_blocks_per_net((int)std::min<int64_t>(B, INT32_MAX)), update_blocks_per_net_mfma((int)std::min<int64_t>(B, INT32_MAX)));
     const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
     CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));
     CK(dalloc(c, &c->stat_slab, (size_t)2 * c->max_blocks_per_net * 8));
     CK(dalloc(c, &c->loss_sums, 8));
     CK(dalloc(c, &c->adv_stats, (size_t)c->steps_per_update + 1));
     CK(dalloc(c, &c->adam_coefs, (size_t)c->steps_per_update + 1));
-    CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), 2 * ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
+    CK(hipEventCreateWithFlags(&c->coef_copied[0], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->coef_copied[1], hipEventDisableTiming));
     CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
     CK(dalloc(c, &c->clipfrac_accum, 2));
     CK(dalloc(c, &c->ev_sums, 64 * 4));
@@ -746,10 +757,11 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
     a.adv_stat = c->adv_stats + slot;
     a.slab = c->slab;
     a.stat_slab = c->stat_slab;
-    a.n_blocks_per_net = std::min(update_blocks_per_net((int)M), c->max_blocks_per_net);
+    a.n_blocks_per_net = std::min(c->use_mfma ? update_blocks_per_net_mfma((int)M) : update_blocks_per_net((int)M), c->max_blocks_per_net);
     {
         ProfScope ps(c, PROF_FWD_BWD);
-        HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
+        if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
+        else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
     {
         ProfScope ps(c, PROF_REDUCE);
@@ -827,10 +839,17 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb, true);
         if (s != PPO_OK) return s;
     }
-    // AdamW scalars of every step of this update, one async copy (the pinned mirror is rewritten only after a sync)
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < E * nmb; k++) c->adam_coefs_h[k] = adam_coef(c->lr, c->opt_step + 1 + k);
-    HIPCHK(c, hipMemcpyAsync(c->adam_coefs, c->adam_coefs_h, (size_t)E * nmb * sizeof(AdamCoef), hipMemcpyHostToDevice, c->stream));
+    // AdamW scalars of every step of this update, one async copy.  The pinned mirror has two halves used alternately; a half is
+    // rewritten only once its previous copy has completed (normally long ago: no stall, and no stream-wide synchronisation).
+    {
+        const int half = c->coef_half;
+        c->coef_half ^= 1;
+        AdamCoef* h = c->adam_coefs_h + (size_t)half * (c->steps_per_update + 1);
+        HIPCHK(c, hipEventSynchronize(c->coef_copied[half]));
+        for (int k = 0; k < E * nmb; k++) h[k] = adam_coef(c->lr, c->opt_step + 1 + k);
+        HIPCHK(c, hipMemcpyAsync(c->adam_coefs, h, (size_t)E * nmb * sizeof(AdamCoef), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->coef_copied[half], c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->clipfrac_accum, 0, 2 * sizeof(double), c->stream));  // m_clipfracs reset, :564
     int k = 0;
     for (int e = 0; e < E; e++) {

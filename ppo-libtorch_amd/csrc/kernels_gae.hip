@@ -10,20 +10,21 @@
 // rounded mul/add (the library is built with -ffp-contract=off).  What is parallel without changing a single rounding:
 //   (i)  envs are independent                      -> a workgroup owns a strip of EPB env columns;
 //   (ii) delta_t and c_t = (gamma*lambda)*nnt_t are element-wise -> ALL 256 threads compute them while streaming
-//        r, v, dones with coalesced 16-byte loads into an LDS tile of TC time steps;
+//        r, v, dones with coalesced 16-byte loads, and park them in an LDS tile of TC time steps;
 //   (iii) only the 2-op recurrence A_t = delta_t + c_t * A_{t+1} is serial: EPB lanes of wave 0 walk the tile top-down
 //        out of LDS (one env per lane, carry in a register across tiles), writing A_t back in place;
 //   (iv) all threads then stream A_t and R_t = A_t + v_t to HBM with coalesced 16-byte stores.
 // A done flag cuts the chain (c_t = 0 => A_t = delta_t exactly): that is the "segmented" part; it needs no special
 // handling in the serial walk and costs nothing.
-// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done); the tile's
-// one-row halo (v_{t+1}, dones_{t+1} of the row above the tile) re-reads 1/TC of two arrays.
+// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done).  v_{t+1} is read
+// a second time by the thread that forms delta_t, but that row is being loaded as v_t by a neighbour: an L1/L2 hit.
 #include "ppo_internal.hpp"
 
 namespace {
 
 constexpr int GAE_TC = 128;       // time steps per LDS tile
 constexpr int GAE_THREADS = 256;
+constexpr int GAE_WALK = 16;      // rows the serial walk pulls into registers at a time
 
 // MODE 0: GAE.  MODE 1: n-step returns (PPO_Discrete.cpp:309-329: ret_t = r_t + (gamma*nnt_t)*ret_{t+1}; adv = ret - v).
 template <int EPB, int MODE, bool VEC>
@@ -31,10 +32,10 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
                                                            const float* __restrict__ dones, const float* __restrict__ next_value,
                                                            const int32_t* __restrict__ next_done, int T, int N, float gamma,
                                                            float gae_lambda, float* __restrict__ adv, float* __restrict__ ret) {
-    // sA: delta on input of the walk, advantage (or return) on output.  sC: chain coefficient.  sV: values incl. halo row.
+    // sA: delta_t (MODE 0) / r_t (MODE 1) on input of the walk, A_t / ret_t on output.  sC: chain coefficient.  sV: v_t.
     __shared__ __attribute__((aligned(16))) float sA[GAE_TC * EPB];
     __shared__ __attribute__((aligned(16))) float sC[GAE_TC * EPB];
-    __shared__ __attribute__((aligned(16))) float sV[(GAE_TC + 1) * EPB];
+    __shared__ __attribute__((aligned(16))) float sV[GAE_TC * EPB];
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * EPB;
     const float gl = gamma * gae_lambda;  // the C++ float product of PPO_Discrete.cpp:301
@@ -47,77 +48,87 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         const int t_lo = t_hi > GAE_TC ? t_hi - GAE_TC : 0;
         const int rows = t_hi - t_lo;
 
-        // ---- phase A: stream r, v, dones -> LDS; v gets one halo row (row `rows` of sV = v_{t_hi} or next_value) ----
+        // ---- phase A: stream r_t, v_t, v_{t+1}, dones_{t+1}; delta_t and c_t are element-wise (every rounding as the
+        //      reference's tensor expression) and go straight to LDS.  v_{t+1} is the row a neighbouring thread loads as v_t:
+        //      it is served by L1/L2, not HBM. ----
         if (VEC) {
             constexpr int C4 = EPB / 4;                    // float4 columns per row
-            for (int e = tid; e < (rows + 1) * C4; e += GAE_THREADS) {
-                const int r = e / C4, c = (e % C4) * 4;
-                float4 v4;
-                if (r < rows) v4 = *reinterpret_cast<const float4*>(values + (size_t)(t_lo + r) * N + n0 + c);
-                else if (t_hi < T) v4 = *reinterpret_cast<const float4*>(values + (size_t)t_hi * N + n0 + c);
-                else v4 = *reinterpret_cast<const float4*>(next_value + n0 + c);
-                *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v4;
-            }
             for (int e = tid; e < rows * C4; e += GAE_THREADS) {
                 const int r = e / C4, c = (e % C4) * 4;
                 const int t = t_lo + r;
-                const float4 rw = *reinterpret_cast<const float4*>(rewards + (size_t)t * N + n0 + c);
-                float4 nnt;
+                const size_t g = (size_t)t * N + n0 + c;
+                const float4 rw = *reinterpret_cast<const float4*>(rewards + g);
+                const float4 v = *reinterpret_cast<const float4*>(values + g);
+                float4 nv, nnt;
                 if (t + 1 < T) {
-                    const float4 d = *reinterpret_cast<const float4*>(dones + (size_t)(t + 1) * N + n0 + c);
+                    nv = *reinterpret_cast<const float4*>(values + g + N);
+                    const float4 d = *reinterpret_cast<const float4*>(dones + g + N);
                     nnt = make_float4(1.0f - d.x, 1.0f - d.y, 1.0f - d.z, 1.0f - d.w);
                 } else {
+                    nv = *reinterpret_cast<const float4*>(next_value + n0 + c);
                     const int4 d = *reinterpret_cast<const int4*>(next_done + n0 + c);
                     nnt = make_float4((float)(1 - d.x), (float)(1 - d.y), (float)(1 - d.z), (float)(1 - d.w));
                 }
-                *reinterpret_cast<float4*>(&sA[r * EPB + c]) = rw;   // reward for now; delta needs sV (next phase)
-                *reinterpret_cast<float4*>(&sC[r * EPB + c]) = nnt;
+                float4 a4, c4;
+                if (MODE == 0) {
+                    a4 = make_float4((rw.x + (gamma * nv.x) * nnt.x) - v.x, (rw.y + (gamma * nv.y) * nnt.y) - v.y,   // :300
+                                     (rw.z + (gamma * nv.z) * nnt.z) - v.z, (rw.w + (gamma * nv.w) * nnt.w) - v.w);
+                    c4 = make_float4(gl * nnt.x, gl * nnt.y, gl * nnt.z, gl * nnt.w);                                 // :301
+                } else {
+                    a4 = rw;
+                    c4 = make_float4(gamma * nnt.x, gamma * nnt.y, gamma * nnt.z, gamma * nnt.w);                     // :324
+                }
+                *reinterpret_cast<float4*>(&sA[r * EPB + c]) = a4;
+                *reinterpret_cast<float4*>(&sC[r * EPB + c]) = c4;
+                *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
             }
         } else {
-            for (int e = tid; e < (rows + 1) * EPB; e += GAE_THREADS) {
-                const int r = e / EPB, c = e % EPB;
-                float v = 0.0f;
-                if (n0 + c < N) {
-                    if (r < rows) v = values[(size_t)(t_lo + r) * N + n0 + c];
-                    else if (t_hi < T) v = values[(size_t)t_hi * N + n0 + c];
-                    else v = next_value[n0 + c];
-                }
-                sV[r * EPB + c] = v;
-            }
             for (int e = tid; e < rows * EPB; e += GAE_THREADS) {
                 const int r = e / EPB, c = e % EPB;
                 const int t = t_lo + r;
-                float rw = 0.0f, nnt = 0.0f;
+                float a1 = 0.0f, c1 = 0.0f, v = 0.0f;
                 if (n0 + c < N) {
-                    rw = rewards[(size_t)t * N + n0 + c];
-                    nnt = (t + 1 < T) ? 1.0f - dones[(size_t)(t + 1) * N + n0 + c] : (float)(1 - next_done[n0 + c]);
+                    const size_t g = (size_t)t * N + n0 + c;
+                    const float rw = rewards[g];
+                    v = values[g];
+                    const float nv = (t + 1 < T) ? values[g + N] : next_value[n0 + c];
+                    const float nnt = (t + 1 < T) ? 1.0f - dones[g + N] : (float)(1 - next_done[n0 + c]);
+                    if (MODE == 0) { a1 = (rw + (gamma * nv) * nnt) - v; c1 = gl * nnt; }
+                    else { a1 = rw; c1 = gamma * nnt; }
                 }
-                sA[r * EPB + c] = rw;
-                sC[r * EPB + c] = nnt;
+                sA[e] = a1;
+                sC[e] = c1;
+                sV[e] = v;
             }
         }
         __syncthreads();
 
-        // ---- phase A': element-wise delta_t and c_t (every rounding as the reference's tensor expression) ----
-        for (int e = tid; e < rows * EPB; e += GAE_THREADS) {
-            const float nnt = sC[e];
-            if (MODE == 0) {
-                const float delta = (sA[e] + (gamma * sV[e + EPB]) * nnt) - sV[e];   // :300
-                sA[e] = delta;
-                sC[e] = gl * nnt;                                                    // :301 (gamma*lambda)*nnt
-            } else {
-                sC[e] = gamma * nnt;                                                 // :324 (gamma*nnt)
-            }
-        }
-        __syncthreads();
-
-        // ---- phase B: the serial 2-op chain, one env per lane of wave 0, top row first ----
+        // ---- phase B: the serial 2-op chain A_t = delta_t + c_t * A_{t+1}, one env per lane of wave 0, top row first.
+        //      GAE_WALK rows are pulled into registers at a time so the LDS reads are in flight together and only the
+        //      mul/add chain itself is serial. ----
         if (walker) {
             float last = carry;
-#pragma unroll 8
-            for (int r = rows - 1; r >= 0; r--) {
-                last = sA[r * EPB + tid] + sC[r * EPB + tid] * last;
-                sA[r * EPB + tid] = last;
+            int r = rows;
+            while (r > 0) {
+                const int k = r >= GAE_WALK ? GAE_WALK : r;
+                float d[GAE_WALK], cc[GAE_WALK];
+#pragma unroll
+                for (int i = 0; i < GAE_WALK; i++) {
+                    const int rr = r - 1 - i;
+                    d[i] = i < k ? sA[rr * EPB + tid] : 0.0f;
+                    cc[i] = i < k ? sC[rr * EPB + tid] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < GAE_WALK; i++) {
+                    if (i < k) {
+                        last = d[i] + cc[i] * last;
+                        d[i] = last;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < GAE_WALK; i++)
+                    if (i < k) sA[(r - 1 - i) * EPB + tid] = d[i];
+                r -= k;
             }
             carry = last;
         }
@@ -166,9 +177,8 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     const bool vec_ok = (N % 4 == 0) && al16(rewards) && al16(values) && al16(dones) && al16(next_value) && al16(next_done) &&
                         al16(adv) && al16(ret);
     // Strip width: wide strips coalesce better (EPB*4-byte rows), narrow strips give more workgroups.  Keep >= ~2 per CU.
-    int epb = 64;
-    if (N / 64 < 512) epb = 32;
-    if (N / 32 < 512) epb = 16;
+    int epb = 32;                    // 48 KB of LDS per workgroup: three workgroups per CU overlap load / walk / store phases
+    if (N / 32 < 512) epb = 16;      // small N: more, narrower strips so every CU gets a workgroup
 #define PPO_GAE_LAUNCH(EPB)                                                                                                   \
     do {                                                                                                                      \
         const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \
@@ -179,8 +189,7 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
             hipLaunchKernelGGL((gae_kernel<EPB, MODE, false>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
                                (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
     } while (0)
-    if (epb == 64) PPO_GAE_LAUNCH(64);
-    else if (epb == 32) PPO_GAE_LAUNCH(32);
+    if (epb == 32) PPO_GAE_LAUNCH(32);
     else PPO_GAE_LAUNCH(16);
 #undef PPO_GAE_LAUNCH
     return hipGetLastError();

@@ -15,108 +15,124 @@
 
 namespace {
 
-// Weights of both nets as seen by one lane (unit j = lane).
+// Rows j = lane of one net's W1 / W2 (and the matching biases) as seen by one lane.
 template <int OBS>
-struct LaneNets {
-    float w1c[OBS], b1c, w2c[PPO_HIDDEN], b2c;  // critic rows j
-    float w1a[OBS], b1a, w2a[PPO_HIDDEN], b2a;  // actor rows j
+struct LaneNet {
+    float w1[OBS], b1, w2[PPO_HIDDEN], b2;
 };
 
 template <int OBS>
-__device__ __forceinline__ void load_lane_nets(LaneNets<OBS>& n, const float* __restrict__ p, const NetLayout& L, int lane) {
+__device__ __forceinline__ void load_lane_net(LaneNet<OBS>& n, const float* __restrict__ p, const NetLayout& L, int net, int lane) {
 #pragma unroll
-    for (int k = 0; k < OBS; k++) {
-        n.w1c[k] = p[L.w1[0] + lane * OBS + k];
-        n.w1a[k] = p[L.w1[1] + lane * OBS + k];
-    }
-    n.b1c = p[L.b1[0] + lane];
-    n.b1a = p[L.b1[1] + lane];
-    const float4* wc = reinterpret_cast<const float4*>(p + L.w2[0] + lane * PPO_HIDDEN);
-    const float4* wa = reinterpret_cast<const float4*>(p + L.w2[1] + lane * PPO_HIDDEN);
-    const bool al = ((L.w2[0] | L.w2[1]) & 3) == 0;  // both W2 blocks 16-byte aligned inside the flat parameter vector
+    for (int k = 0; k < OBS; k++) n.w1[k] = p[L.w1[net] + lane * OBS + k];
+    n.b1 = p[L.b1[net] + lane];
 #pragma unroll
-    for (int k = 0; k < PPO_HIDDEN / 4; k++) {
-        if (al) {
-            const float4 a = wc[k], b = wa[k];
-            n.w2c[4 * k] = a.x; n.w2c[4 * k + 1] = a.y; n.w2c[4 * k + 2] = a.z; n.w2c[4 * k + 3] = a.w;
-            n.w2a[4 * k] = b.x; n.w2a[4 * k + 1] = b.y; n.w2a[4 * k + 2] = b.z; n.w2a[4 * k + 3] = b.w;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                n.w2c[4 * k + i] = p[L.w2[0] + lane * PPO_HIDDEN + 4 * k + i];
-                n.w2a[4 * k + i] = p[L.w2[1] + lane * PPO_HIDDEN + 4 * k + i];
-            }
-        }
-    }
-    n.b2c = p[L.b2[0] + lane];
-    n.b2a = p[L.b2[1] + lane];
+    for (int k = 0; k < PPO_HIDDEN; k++) n.w2[k] = p[L.w2[net] + lane * PPO_HIDDEN + k];
+    n.b2 = p[L.b2[net] + lane];
 }
 
-// Both MLP trunks for one row: obs[] is wave-uniform.  Returns this lane's second-layer activations (h2c, h2a).
-// lds: 128 floats of this wave (critic h1 at [0,64), actor h1 at [64,128)).
+// One MLP trunk for one row: obs[] is wave-uniform.  Returns this lane's second-layer activation.  lds: 64 floats of this wave.
 template <int OBS>
-__device__ __forceinline__ void trunk_forward(const LaneNets<OBS>& n, const float* obs, float* lds, int lane, float& h2c, float& h2a) {
-    float zc = n.b1c, za = n.b1a;
+__device__ __forceinline__ float trunk_forward(const LaneNet<OBS>& n, const float* obs, float* lds, int lane) {
+    float z = n.b1;
 #pragma unroll
-    for (int k = 0; k < OBS; k++) {
-        zc = __builtin_fmaf(obs[k], n.w1c[k], zc);
-        za = __builtin_fmaf(obs[k], n.w1a[k], za);
-    }
+    for (int k = 0; k < OBS; k++) z = __builtin_fmaf(obs[k], n.w1[k], z);
     __syncthreads();  // previous readers of lds are done (single-wave workgroup: a wait, no s_barrier)
-    lds[lane] = tanhf(zc);
-    lds[PPO_HIDDEN + lane] = tanhf(za);
+    lds[lane] = tanhf(z);
     __syncthreads();
-    float ac = n.b2c, aa = n.b2a;
-    const float4* hc4 = reinterpret_cast<const float4*>(lds);
-    const float4* ha4 = reinterpret_cast<const float4*>(lds + PPO_HIDDEN);
+    float acc = n.b2;
+    const float4* h4 = reinterpret_cast<const float4*>(lds);
 #pragma unroll
     for (int k = 0; k < PPO_HIDDEN / 4; k++) {
-        const float4 c = hc4[k], a = ha4[k];  // wave-uniform addresses: LDS broadcast
-        ac = __builtin_fmaf(c.x, n.w2c[4 * k], ac); ac = __builtin_fmaf(c.y, n.w2c[4 * k + 1], ac);
-        ac = __builtin_fmaf(c.z, n.w2c[4 * k + 2], ac); ac = __builtin_fmaf(c.w, n.w2c[4 * k + 3], ac);
-        aa = __builtin_fmaf(a.x, n.w2a[4 * k], aa); aa = __builtin_fmaf(a.y, n.w2a[4 * k + 1], aa);
-        aa = __builtin_fmaf(a.z, n.w2a[4 * k + 2], aa); aa = __builtin_fmaf(a.w, n.w2a[4 * k + 3], aa);
+        const float4 h = h4[k];  // wave-uniform address: LDS broadcast
+        acc = __builtin_fmaf(h.x, n.w2[4 * k], acc); acc = __builtin_fmaf(h.y, n.w2[4 * k + 1], acc);
+        acc = __builtin_fmaf(h.z, n.w2[4 * k + 2], acc); acc = __builtin_fmaf(h.w, n.w2[4 * k + 3], acc);
     }
-    h2c = tanhf(ac);
-    h2a = tanhf(aa);
+    return tanhf(acc);
 }
 
 // Heads: value = b3c + sum_j h2c[j] W3c[j];  logits[a] = b3a[a] + sum_j h2a[j] W3a[a][j]  (wave reductions).
 __device__ __forceinline__ float critic_head(const float* __restrict__ p, const NetLayout& L, float h2c, int lane) {
     return wave_sum(h2c * p[L.w3[0] + lane]) + p[L.b3[0]];
 }
-__device__ __forceinline__ void actor_head(const float* __restrict__ p, const NetLayout& L, float h2a, int lane, float* logits) {
-    for (int a = 0; a < L.act; a++) logits[a] = wave_sum(h2a * p[L.w3[1] + a * PPO_HIDDEN + lane]) + p[L.b3[1] + a];
-}
 
-// Categorical over every head; action in/out.  Wave-uniform arithmetic (every lane computes the same values).
-template <int DIST>
-__device__ __forceinline__ void heads_eval(const NetLayout& L, float* logits, const uint8_t* mask, bool sample, int64_t seed,
-                                           int64_t row_global, int64_t step_index, int* act, float& logprob, float& entropy) {
-    float probs[PPO_MAX_ACT];
-    int off = 0;
+// Actor head + Categorical over every head.  Two code shapes with identical arithmetic per element:
+//   AMAX == 4  : sum(head_dims) <= 4 (CartPole 2, MountainCar 3): everything statically indexed -> registers;
+//   AMAX == 32 : generic (runtime-indexed small arrays, compiler places them in scratch).
+// Wave-uniform arithmetic (every lane computes the same values).  act[] in (forced) / out (sampled).
+template <int DIST, int AMAX>
+__device__ __forceinline__ void actor_heads(const float* __restrict__ p, const NetLayout& L, float h2a, int lane, const uint8_t* mask_row,
+                                            bool all_valid, bool sample, int64_t seed, int64_t row_global, int64_t step_index, int* act,
+                                            float& logprob, float& entropy) {
+    const int A = L.act;
+    float z[AMAX], pr[AMAX];
+    bool ok[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+        z[a] = 0.0f; pr[a] = 0.0f; ok[a] = true;
+        if (a < A) {
+            z[a] = wave_sum(h2a * p[L.w3[1] + a * PPO_HIDDEN + lane]) + p[L.b3[1] + a];
+            if (DIST == PPO_DIST_MASKED && !all_valid && mask_row) ok[a] = mask_row[a] != 0;
+            if (DIST == PPO_DIST_MASKED && !ok[a]) z[a] = -1e8f;   // torch::where(mask, logits, -1e8f), CategoricalMasked.cpp:34-35
+        }
+    }
     logprob = 0.0f;
     entropy = 0.0f;
+    int off = 0;
     for (int h = 0; h < L.n_heads; h++) {
-        const int A = L.head_dims[h];
-        const float e = categorical_head<DIST>(logits + off, probs + off, mask ? mask + off : nullptr, A);
-        if (sample) {
-            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global,
-                                          (uint32_t)step_index, (uint32_t)h, 0u);
-            act[h] = sample_head(probs + off, A, (float)(w.x >> 8) * 0x1p-24f);
+        const int Ah = L.head_dims[h];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) mx = z[a] > mx ? z[a] : mx;
+        float se = 0.0f;
+#pragma unroll
+        for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) { pr[a] = expf(z[a] - mx); se += pr[a]; }
+        const float lse = logf(se) + mx;
+        float ent = 0.0f;
+#pragma unroll
+        for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) {
+            z[a] = z[a] - lse;          // m_logits
+            pr[a] = pr[a] / se;         // m_probs
+            if (DIST == PPO_DIST_CATEGORICAL) {
+                const float l = z[a] > 1.17549435e-38f ? z[a] : 1.17549435e-38f;  // clamp(m_logits, FLT_MIN), Categorical.cpp:115
+                ent += l * pr[a];
+            } else {
+                const float plp = z[a] * pr[a];
+                ent += ok[a] ? plp : 0.0f;                                         // where(mask, p_log_p, 0), CategoricalMasked.cpp:141
+            }
         }
-        const float lp = logits[off + act[h]];
-        if (h == 0) { logprob = lp; entropy = e; } else { logprob += lp; entropy += e; }  // stack(...).sum(0), Agent.cpp:165-168
-        off += A;
+        ent = -ent;
+        if (sample) {
+            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)step_index,
+                                          (uint32_t)h, 0u);
+            const float u = (float)(w.x >> 8) * 0x1p-24f;
+            int pick = 0, last = 0;
+            float acc = 0.0f;
+            bool hit = false;
+#pragma unroll
+            for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) {
+                if (pr[a] > 0.0f) last = a - off;
+                acc += pr[a];
+                if (!hit && u < acc) { pick = a - off; hit = true; }
+            }
+            act[h] = hit ? pick : last;
+        }
+        float lp = 0.0f;
+#pragma unroll
+        for (int a = 0; a < AMAX; a++) if (a == off + act[h]) lp = z[a];
+        if (h == 0) { logprob = lp; entropy = ent; } else { logprob += lp; entropy += ent; }  // stack(...).sum(0), Agent.cpp:165-168
+        off += Ah;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fused rollout: grid = N workgroups of one wave.
+// Fused rollout: grid = N workgroups of one wave.  Only the ACTOR sits on the env loop's dependency chain
+// (obs -> logits -> action -> physics -> next obs); the critic's values are a pure function of the stored observations
+// and are produced afterwards by values_kernel over all T*N + N rows at once (same per-row arithmetic).
 // ---------------------------------------------------------------------------------------------------------
-template <int ENV, int DIST, int OBS>
-__global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * PPO_HIDDEN];
+template <int ENV, int DIST, int OBS, int AMAX>
+__global__ __launch_bounds__(64, (AMAX <= 4 ? 4 : 1)) void rollout_kernel(RolloutArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[PPO_HIDDEN];
     const int lane = threadIdx.x;
     // Blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of envs so the partial-line stores
     // of neighbouring envs meet in one L2 (speed only; any mapping is correct).
@@ -130,8 +146,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
     const int N = a.N, H = L.n_heads, A = L.act;
     const int64_t env_global = a.env_offset + env;
 
-    LaneNets<OBS> nets;
-    load_lane_nets<OBS>(nets, a.params, L, lane);
+    LaneNet<OBS> actor;
+    load_lane_net<OBS>(actor, a.params, L, 1, lane);
 
     float st[OBS];
 #pragma unroll
@@ -145,23 +161,15 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         const size_t tn = (size_t)t * N + env;
         // m_obs[step] = next_obs; m_dones[step] = next_done   (PPO_Discrete.cpp:529-530)
         if (lane < OBS) a.obs[tn * OBS + lane] = st[lane];
-        float h2c, h2a;
-        trunk_forward<OBS>(nets, st, lds, lane, h2c, h2a);
-        const float value = critic_head(a.params, L, h2c, lane);
-        float logits[PPO_MAX_ACT];
-        actor_head(a.params, L, h2a, lane, logits);
-        uint8_t mask[PPO_MAX_ACT];
-        const bool masked = (DIST == PPO_DIST_MASKED);
-        if (masked) {
-            for (int k = 0; k < A; k++) mask[k] = 1;  // MountainCar::getActionMask is all-ones (MountainCar.cpp:69-77)
-        }
+        const float h2a = trunk_forward<OBS>(actor, st, lds, lane);
         int act[PPO_MAX_HEADS];
         const bool forced = a.forced_actions != nullptr;
         if (forced) {
             for (int h = 0; h < H; h++) act[h] = (int)a.forced_actions[tn * H + h];
         }
         float logprob, entropy;
-        heads_eval<DIST>(L, logits, masked ? mask : nullptr, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy);
+        // MountainCar::getActionMask is all-ones (MountainCar.cpp:69-77): every action valid
+        actor_heads<DIST, AMAX>(a.params, L, h2a, lane, nullptr, true, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy);
 
         // env step + truncation + auto-reset (PPO_Discrete.cpp:440-458)
         int term;
@@ -182,67 +190,76 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutArgs a) {
         }
         if (lane == 0) {
             a.dones[tn] = (float)done;
-            a.values[tn] = value;        // :536
             a.logprobs[tn] = logprob;    // :538
             a.rewards[tn] = reward;      // :544
             a.fin_len[tn] = fin_len;     // :455-456
             a.fin_rew[tn] = fin_rew;
         }
-        if (lane < H) a.actions[tn * H + lane] = act[lane];  // :537
-        if (masked && lane < A) a.masks[tn * A + lane] = 1;   // PPO_MultiDiscrete.cpp:555
+        if (lane < H) a.actions[tn * H + lane] = act[lane];                          // :537
+        if (DIST == PPO_DIST_MASKED && a.masks && lane < A) a.masks[tn * A + lane] = 1;  // PPO_MultiDiscrete.cpp:555
         done = term;
     }
 
-    // hand-over state and the bootstrap value Critic(next_obs) (PPO_Discrete.cpp:280)
-    {
-        float h2c, h2a;
-        trunk_forward<OBS>(nets, st, lds, lane, h2c, h2a);
-        const float nv = critic_head(a.params, L, h2c, lane);
-        if (lane == 0) {
-            a.next_value[env] = nv;
-            a.next_done[env] = done;
-            a.ep_len[env] = ep_len;
-            a.ep_rew[env] = ep_rew;
-            a.reset_count[env] = resets;
-        }
-        if (lane < OBS) {
-            a.next_obs[(size_t)env * OBS + lane] = st[lane];
-            a.env_state[(size_t)lane * N + env] = st[lane];
-        }
+    // hand-over state
+    if (lane == 0) {
+        a.next_done[env] = done;
+        a.ep_len[env] = ep_len;
+        a.ep_rew[env] = ep_rew;
+        a.reset_count[env] = resets;
+    }
+    if (lane < OBS) {
+        a.next_obs[(size_t)env * OBS + lane] = st[lane];
+        a.env_state[(size_t)lane * N + env] = st[lane];
+    }
+}
+
+// Critic over rows [0, n0) of obs0 and rows [0, n1) of obs1 (m_values[step] = Critic(obs[step]), PPO_Discrete.cpp:534-536, and the
+// bootstrap next_value = Critic(next_obs), :280): one wave per row, grid-stride, critic rows resident in registers.
+template <int OBS>
+__global__ __launch_bounds__(64) void values_kernel(const float* __restrict__ params, NetLayout L, const float* __restrict__ obs0, int64_t n0,
+                                                    float* __restrict__ out0, const float* __restrict__ obs1, int64_t n1, float* __restrict__ out1) {
+    __shared__ __attribute__((aligned(16))) float lds[PPO_HIDDEN];
+    const int lane = threadIdx.x;
+    LaneNet<OBS> critic;
+    load_lane_net<OBS>(critic, params, L, 0, lane);
+    for (int64_t row = blockIdx.x; row < n0 + n1; row += gridDim.x) {
+        const float* src = row < n0 ? obs0 + row * OBS : obs1 + (row - n0) * OBS;
+        float x[OBS];
+#pragma unroll
+        for (int k = 0; k < OBS; k++) x[k] = src[k];
+        const float v = critic_head(params, L, trunk_forward<OBS>(critic, x, lds, lane), lane);
+        if (lane == 0) { if (row < n0) out0[row] = v; else out1[row - n0] = v; }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Stand-alone policy evaluation (Agent::getActionAndValueDiscrete / Masked / getValue): one wave per row, grid-stride.
+// Stand-alone policy evaluation (Agent::getActionAndValueDiscrete / Masked): one wave per row, grid-stride.
 // ---------------------------------------------------------------------------------------------------------
-template <int DIST, int OBS>
+template <int DIST, int OBS, int AMAX>
 __global__ __launch_bounds__(64) void policy_act_kernel(const float* __restrict__ params, NetLayout L, const float* __restrict__ obs,
                                                         const uint8_t* __restrict__ mask, const int64_t* __restrict__ forced, int64_t n,
                                                         int64_t seed, int64_t env_offset, int64_t step_index, int64_t* action,
-                                                        float* logprob, float* entropy, float* value, int value_only) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * PPO_HIDDEN];
+                                                        float* logprob, float* entropy, float* value) {
+    __shared__ __attribute__((aligned(16))) float lds[PPO_HIDDEN];
     const int lane = threadIdx.x;
-    LaneNets<OBS> nets;
-    load_lane_nets<OBS>(nets, params, L, lane);
+    LaneNet<OBS> actor, critic;
+    load_lane_net<OBS>(actor, params, L, 1, lane);
+    load_lane_net<OBS>(critic, params, L, 0, lane);
     const int H = L.n_heads, A = L.act;
     for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
         float x[OBS];
 #pragma unroll
         for (int k = 0; k < OBS; k++) x[k] = obs[row * OBS + k];
-        float h2c, h2a;
-        trunk_forward<OBS>(nets, x, lds, lane, h2c, h2a);
-        const float v = critic_head(params, L, h2c, lane);
-        if (value && lane == 0) value[row] = v;
-        if (value_only) continue;
-        float logits[PPO_MAX_ACT];
-        actor_head(params, L, h2a, lane, logits);
-        uint8_t m[PPO_MAX_ACT];
-        const bool masked = (DIST == PPO_DIST_MASKED) && mask != nullptr;
-        if (masked) for (int k = 0; k < A; k++) m[k] = mask[row * A + k];
+        if (value) {
+            const float v = critic_head(params, L, trunk_forward<OBS>(critic, x, lds, lane), lane);
+            if (lane == 0) value[row] = v;
+        }
+        const float h2a = trunk_forward<OBS>(actor, x, lds, lane);
         int act[PPO_MAX_HEADS];
         if (forced) for (int h = 0; h < H; h++) act[h] = (int)forced[row * H + h];
         float lp, en;
-        heads_eval<DIST>(L, logits, masked ? m : nullptr, forced == nullptr, seed, env_offset + row, step_index, act, lp, en);
+        actor_heads<DIST, AMAX>(params, L, h2a, lane, mask ? mask + row * A : nullptr, mask == nullptr, forced == nullptr, seed,
+                                env_offset + row, step_index, act, lp, en);
         if (lane == 0) {
             if (logprob) logprob[row] = lp;
             if (entropy) entropy[row] = en;
@@ -409,15 +426,36 @@ __global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restr
 // ---------------------------------------------------------------------------------------------------------
 hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.N), block(64);
+#define PPO_LAUNCH_ROLLOUT(ENV, DIST, OBS)                                                                       \
+    do {                                                                                                         \
+        if (a.L.act <= 4) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4>), grid, block, 0, s, a);         \
+        else hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, PPO_MAX_ACT>), grid, block, 0, s, a);            \
+    } while (0)
     if (a.env_kind == PPO_ENV_CARTPOLE && a.L.obs == 4) {
-        if (a.dist_kind == PPO_DIST_CATEGORICAL) hipLaunchKernelGGL((rollout_kernel<PPO_ENV_CARTPOLE, PPO_DIST_CATEGORICAL, 4>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollout_kernel<PPO_ENV_CARTPOLE, PPO_DIST_MASKED, 4>), grid, block, 0, s, a);
+        if (a.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ROLLOUT(PPO_ENV_CARTPOLE, PPO_DIST_CATEGORICAL, 4);
+        else PPO_LAUNCH_ROLLOUT(PPO_ENV_CARTPOLE, PPO_DIST_MASKED, 4);
     } else if (a.env_kind == PPO_ENV_MOUNTAINCAR && a.L.obs == 2) {
-        if (a.dist_kind == PPO_DIST_CATEGORICAL) hipLaunchKernelGGL((rollout_kernel<PPO_ENV_MOUNTAINCAR, PPO_DIST_CATEGORICAL, 2>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rollout_kernel<PPO_ENV_MOUNTAINCAR, PPO_DIST_MASKED, 2>), grid, block, 0, s, a);
+        if (a.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ROLLOUT(PPO_ENV_MOUNTAINCAR, PPO_DIST_CATEGORICAL, 2);
+        else PPO_LAUNCH_ROLLOUT(PPO_ENV_MOUNTAINCAR, PPO_DIST_MASKED, 2);
     } else {
         return hipErrorInvalidValue;
     }
+#undef PPO_LAUNCH_ROLLOUT
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // m_values and the bootstrap value in one batched launch
+    return launch_values(a.params, a.L, a.obs, (int64_t)a.T * a.N, a.values, a.next_obs, a.N, a.next_value, s);
+}
+
+hipError_t launch_values(const float* params, const NetLayout& L, const float* obs0, int64_t n0, float* out0, const float* obs1, int64_t n1,
+                         float* out1, hipStream_t s) {
+    const int64_t n = n0 + n1;
+    if (n <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(n < 8192 ? n : 8192);
+    if (L.obs == 4) hipLaunchKernelGGL((values_kernel<4>), dim3(grid), dim3(64), 0, s, params, L, obs0, n0, out0, obs1, n1, out1);
+    else if (L.obs == 2) hipLaunchKernelGGL((values_kernel<2>), dim3(grid), dim3(64), 0, s, params, L, obs0, n0, out0, obs1, n1, out1);
+    else if (L.obs == 8) hipLaunchKernelGGL((values_kernel<8>), dim3(grid), dim3(64), 0, s, params, L, obs0, n0, out0, obs1, n1, out1);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -471,11 +509,17 @@ hipError_t launch_policy_act(const float* params, const NetLayout& L, int dist_k
                              const int64_t* forced_action, int64_t n, int64_t seed, int64_t env_offset, int64_t step_index,
                              int64_t* action, float* logprob, float* entropy, float* value, bool value_only, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)(n < 16384 ? n : 16384);
-    const int vo = value_only ? 1 : 0;
-#define PPO_LAUNCH_ACT(DIST, OBS)                                                                                              \
-    hipLaunchKernelGGL((policy_act_kernel<DIST, OBS>), dim3(grid), dim3(64), 0, s, params, L, obs, mask, forced_action, n, seed, \
-                       env_offset, step_index, action, logprob, entropy, value, vo)
+    if (value_only) return launch_values(params, L, obs, n, value, nullptr, 0, nullptr, s);
+    const unsigned grid = (unsigned)(n < 8192 ? n : 8192);
+#define PPO_LAUNCH_ACT(DIST, OBS)                                                                                                     \
+    do {                                                                                                                              \
+        if (L.act <= 4)                                                                                                               \
+            hipLaunchKernelGGL((policy_act_kernel<DIST, OBS, 4>), dim3(grid), dim3(64), 0, s, params, L, obs, mask, forced_action, n, seed, \
+                               env_offset, step_index, action, logprob, entropy, value);                                              \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((policy_act_kernel<DIST, OBS, PPO_MAX_ACT>), dim3(grid), dim3(64), 0, s, params, L, obs, mask, forced_action, n, \
+                               seed, env_offset, step_index, action, logprob, entropy, value);                                        \
+    } while (0)
     if (L.obs == 4) {
         if (dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ACT(PPO_DIST_CATEGORICAL, 4); else PPO_LAUNCH_ACT(PPO_DIST_MASKED, 4);
     } else if (L.obs == 2) {

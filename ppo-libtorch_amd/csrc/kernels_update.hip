@@ -441,30 +441,56 @@ __global__ __launch_bounds__(UPD_THREADS, 2) void fwd_bwd_kernel(UpdateArgs a) {
     else fwd_bwd_body<1, DIST, OBS>(a, smem);
 }
 
-// grads[p] = sum_b slab[net(p)][b][p - net_off]  (fixed order: four contiguous quarters, each summed in order, then combined).
-__global__ __launch_bounds__(256) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb,
-                                                           NetLayout L, float* __restrict__ grads, double* __restrict__ sums_out) {
-    __shared__ double part[4][64];
+// grads[p] = sum_b slab[net(p)][b][p - net_off] in a fixed order (16 contiguous groups of slabs, each summed in order by one
+// wave with its loads in flight together, then the 16 partials added in order): bit-reproducible, no float atomics.
+// The last block adds the per-workgroup loss sums the same way.
+__global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb,
+                                                            NetLayout L, float* __restrict__ grads, double* __restrict__ sums_out) {
+    __shared__ double part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
-    const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
-    double acc = 0.0;
-    if (p < L.P) {
-        const int net = p >= L.net_off[1] ? 1 : 0;
-        const float* col = slab + (size_t)net * nb * Pmax + (p - L.net_off[net]);
-        const int b0 = (nb * w) / 4, b1 = (nb * (w + 1)) / 4;
-        for (int b = b0; b < b1; b++) acc += (double)col[(size_t)b * Pmax];
-    }
-    part[w][lane] = acc;
-    __syncthreads();
-    if (w == 0 && p < L.P) grads[p] = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
-    if (blockIdx.x == 0 && threadIdx.x < 8) {
-        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor blocks), [4]=value loss (critic blocks)
-        const int k = threadIdx.x;
-        double s = 0.0;
-        if (k < 4) for (int b = 0; b < nb; b++) s += stat_slab[((size_t)nb + b) * 8 + k];
-        else if (k == 4) for (int b = 0; b < nb; b++) s += stat_slab[(size_t)b * 8 + 0];
-        sums_out[k] = s;
+    if (blockIdx.x + 1 < gridDim.x) {
+        const int p = blockIdx.x * 64 + lane;
+        const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
+        double acc = 0.0;
+        if (p < L.P) {
+            const int net = p >= L.net_off[1] ? 1 : 0;
+            const float* col = slab + (size_t)net * nb * Pmax + (p - L.net_off[net]);
+            const int b0 = (nb * w) / 16, b1 = (nb * (w + 1)) / 16;
+            int b = b0;
+            for (; b + 8 <= b1; b += 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = col[(size_t)(b + i) * Pmax];
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc += (double)v[i];
+            }
+            for (; b < b1; b++) acc += (double)col[(size_t)b * Pmax];
+        }
+        part[w][lane] = acc;
+        __syncthreads();
+        if (w == 0 && p < L.P) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += part[k][lane];
+            grads[p] = (float)s;
+        }
+    } else {
+        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor workgroups), [4]=value loss (critic workgroups)
+        for (int k = 0; k < 5; k++) {
+            const int net = k < 4 ? 1 : 0, col = k < 4 ? k : 0;
+            double v = 0.0;
+            for (int b = threadIdx.x; b < nb; b += 1024) v += stat_slab[((size_t)net * nb + b) * 8 + col];
+            v = wave_sum_d(v);
+            __syncthreads();
+            if (lane == 0) part[0][w] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s = 0.0;
+                for (int i = 0; i < 16; i++) s += part[0][i];
+                sums_out[k] = s;
+            }
+        }
+        if (threadIdx.x >= 5 && threadIdx.x < 8) sums_out[threadIdx.x] = 0.0;
     }
 }
 
@@ -646,7 +672,7 @@ hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s) {
 
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64), dim3(256), 0, s, slab, stat_slab, n_blocks_per_net, L, grads, sums_out);
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64 + 1), dim3(1024), 0, s, slab, stat_slab, n_blocks_per_net, L, grads, sums_out);
     return hipGetLastError();
 }
 

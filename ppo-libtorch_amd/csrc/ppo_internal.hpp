@@ -307,6 +307,8 @@ struct RolloutArgs {
 };
 
 hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s);
+hipError_t launch_values(const float* params, const NetLayout& L, const float* obs0, int64_t n0, float* out0, const float* obs1, int64_t n1,
+                         float* out1, hipStream_t s);
 hipError_t launch_env_reset(int env_kind, int N, int64_t seed, int64_t env_offset, float* env_state, int32_t* ep_len, float* ep_rew,
                             int32_t* reset_count, const float* reset_table, int reset_cap, float* next_obs, int32_t* next_done,
                             int32_t* error_flag, hipStream_t s);
@@ -352,6 +354,9 @@ struct UpdateArgs {
 };
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
+// MFMA (v_mfma_f32_32x32x2_f32) version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}
+int update_blocks_per_net_mfma(int M);
+hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
 // grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s);

@@ -414,6 +414,27 @@ def test_update_equals_stepwise_path_and_permutations_are_permutations(P):
     ctx2.close()
 
 
+def test_mfma_and_valu_update_kernels_agree(P, monkeypatch):
+    """The matrix-core kernel (default) and the VALU kernel implement the same minibatch step: identical loss scalars to 1e-6
+    and gradients to 1e-5 relative on a 131 072-row minibatch drawn from a real rollout (BASELINE configs[1] shape)."""
+    cfg = dict(num_envs=4096, num_steps=128, num_minibatches=4, update_epochs=1, seed=3, total_timesteps=4096 * 128 * 2)
+    grads, stats = [], []
+    for kernel in ("mfma", "valu"):
+        monkeypatch.setenv("PPO_UPDATE_KERNEL", kernel)
+        ctx = P.Context(P.make_config(**cfg))
+        ctx.init_orthogonal(5)
+        ctx.env_reset()
+        ctx.rollout()
+        ctx.calc_advantage()
+        perm = ctx.generate_permutations()
+        grads.append(ctx.minibatch_forward_backward(perm[0, :131072]))
+        stats.append(ctx.stats())
+        ctx.close()
+    for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss", "total_norm"):
+        assert abs(stats[0][key] - stats[1][key]) <= 1e-6 * max(1.0, abs(stats[1][key])), (key, stats[0][key], stats[1][key])
+    assert np.abs(grads[0] - grads[1]).max() <= 1e-5 * np.abs(grads[1]).max()
+
+
 def test_ragged_minibatches(P):
     """batch % num_minibatches != 0: minibatch_size is the integer quotient and a short extra minibatch follows
     (reference PPO_Discrete.cpp:247,573-576)."""
@@ -488,7 +509,9 @@ def test_mountaincar_masked_iteration(P):
     for _ in range(4):
         ctx.train_iteration()
     st = ctx.stats()
-    assert np.isfinite(st["loss"]) and abs(st["entropy_loss"] - np.log(3)) < 0.05   # true entropy on the masked path
+    # true entropy on the masked path (CategoricalMasked.cpp:127-144): starts at ln 3 and stays a real entropy, never the
+    # -FLT_MIN of the plain Categorical's clamp bug
+    assert np.isfinite(st["loss"]) and 0.3 < st["entropy_loss"] <= np.log(3) + 1e-4
     assert np.all(ctx.read("MASKS") == 1)
     assert np.all(ctx.read("REWARDS") == -1.0)
     ctx.close()
