@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel + GAE")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,7 +133,7 @@ def main():
 
     for _ in range(args.warmup):
         ctx.train_iteration()
-    ctx.profile_enable(True)
+    ctx.profile_enable(args.profile)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -140,7 +141,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
-    ctx.profile_enable(False)
+    ctx.profile_enable(0)
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
@@ -152,8 +153,8 @@ def main():
         env_steps = args.steps * N * T * world
         M = (N * T) // 4
         fl = flops_per_sample(obs, act) * M
-        fb_ms = prof["fwd_bwd_ms"] / max(prof["fwd_bwd_launches"], 1)
-        gae_ms = prof["gae_ms"] / max(prof["gae_launches"], 1)
+        fb_ms = prof["fwd_bwd_ms"] / max(prof["fwd_bwd_launches"], 1) or float("nan")
+        gae_ms = prof["gae_ms"] / max(prof["gae_launches"], 1) or float("nan")
         gae_bytes = 20 * N * T + 8 * N
         out = {
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,

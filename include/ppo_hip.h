@@ -231,7 +231,10 @@ PPO_API ppo_status ppo_set_learning_rate(ppo_ctx* ctx, double lr);
 typedef struct ppo_profile {
     int64_t fwd_bwd_launches, gae_launches, rollout_launches, optimizer_launches, reduce_launches;
     double fwd_bwd_ms, gae_ms, rollout_ms, optimizer_ms, reduce_ms;   /* summed over the launches since enable/read */
+    double phase_cycles[24];  /* mode 3: [critic, actor][12 phases] shader cycles of one wave of the dominant kernel */
 } ppo_profile;
+/* on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fused forward/backward) and the GAE scan,
+ * 3 = in-kernel phase stamps of the dominant kernel (diagnostic kernel variant; read shares, not run time) */
 PPO_API ppo_status ppo_profile_enable(ppo_ctx* ctx, int32_t on);
 PPO_API ppo_status ppo_profile_read(ppo_ctx* ctx, ppo_profile* out);  /* synchronises; resets the accumulators */
 

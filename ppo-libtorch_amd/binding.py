@@ -65,10 +65,12 @@ class Stats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("fwd_bwd_launches", C.c_int64), ("gae_launches", C.c_int64), ("rollout_launches", C.c_int64),
                 ("optimizer_launches", C.c_int64), ("reduce_launches", C.c_int64), ("fwd_bwd_ms", C.c_double), ("gae_ms", C.c_double),
-                ("rollout_ms", C.c_double), ("optimizer_ms", C.c_double), ("reduce_ms", C.c_double)]
+                ("rollout_ms", C.c_double), ("optimizer_ms", C.c_double), ("reduce_ms", C.c_double), ("phase_cycles", C.c_double * 24)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "phase_cycles"}
+        d["phase_cycles"] = list(self.phase_cycles)
+        return d
 
 
 def make_config(env_kind=ENV_CARTPOLE, dist_kind=DIST_CATEGORICAL, obs_size=4, head_dims=(2,), num_envs=8, num_steps=32,
@@ -326,8 +328,9 @@ class Context:
         _check(lib().ppo_read_stats(self.h, C.byref(s)), self.h)
         return s.as_dict()
 
-    def profile_enable(self, on=True):
-        _check(lib().ppo_profile_enable(self.h, C.c_int32(1 if on else 0)), self.h)
+    def profile_enable(self, on=1):
+        """0 = off, 1 = every instrumented launch, 2 = only the dominant kernel and the GAE scan."""
+        _check(lib().ppo_profile_enable(self.h, C.c_int32(int(on))), self.h)
 
     def profile_read(self):
         p = Profile()

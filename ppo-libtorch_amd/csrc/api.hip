@@ -79,12 +79,18 @@ struct ppo_ctx {
     int coef_half = 0;
     StepStats* step_stats = nullptr;    // device [steps_per_update + 1]
     double* clipfrac_accum = nullptr;   // {sum, count}
+    double* norm2 = nullptr;            // [12] per-tensor squared gradient norms of the current step
     double* ev_sums = nullptr;          // [64][4]
     int32_t* row_counts = nullptr;      // [T]
+    uint64_t* group_bits = nullptr;     // [T, ceil(N/64)] ballots of finished episodes
     EpisodeRing* ring = nullptr;
     float* scratch_obs = nullptr;       // [N,O] staging for AoS<->SoA conversions
     int max_blocks_per_net = 0;
-    bool use_mfma = true;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
+    bool use_mfma = true;
+    double actor_share = 0.5;       // share of the fwd/bwd workgroups given to the actor (measured: with 4 tiles per wave an uneven
+                                    // split only moves the integer tile count of the slower side up; kept as a tuning knob)
+    unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
+    bool stamping = false;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
 
     // host-side training state
     double lr = 0.0;
@@ -100,7 +106,7 @@ struct ppo_ctx {
     double last_global_M = 1.0;
 
     // profiling: (start, stop) event pairs per instrumented launch
-    bool profiling = false;
+    uint32_t profiling = 0;         // bit k set: time launches of kind k
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
@@ -119,7 +125,7 @@ struct ProfScope {
         return e;
     }
     ProfScope(ppo_ctx* ctx, int k) : c(ctx), kind(k) {
-        if (!c->profiling) return;
+        if (!(c->profiling & (1u << kind))) return;
         a = get(c); b = get(c);
         if (a) (void)hipEventRecord(a, c->stream);
     }
@@ -349,23 +355,29 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     {
         const char* k = getenv("PPO_UPDATE_KERNEL");
         c->use_mfma = (A <= 4) && !(k && std::strcmp(k, "valu") == 0);
+        const char* sh = getenv("PPO_ACTOR_SHARE");
+        if (sh) c->actor_share = atof(sh);
+
     }
-    c->max_blocks_per_net = std::max(update_blocks_per_net((int)std::min<int64_t>(B, INT32_MAX)), update_blocks_per_net_mfma((int)std::min<int64_t>(B, INT32_MAX)));
+    c->max_blocks_per_net = 512;
     const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
     CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));
     CK(dalloc(c, &c->stat_slab, (size_t)2 * c->max_blocks_per_net * 8));
     CK(dalloc(c, &c->loss_sums, 8));
-    CK(dalloc(c, &c->adv_stats, (size_t)c->steps_per_update + 1));
+    CK(dalloc(c, &c->adv_stats, ((size_t)c->steps_per_update + 1) * PPO_ADV_PARTS));
     CK(dalloc(c, &c->adam_coefs, (size_t)c->steps_per_update + 1));
     CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), 2 * ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
     CK(hipEventCreateWithFlags(&c->coef_copied[0], hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->coef_copied[1], hipEventDisableTiming));
     CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
     CK(dalloc(c, &c->clipfrac_accum, 2));
+    CK(dalloc(c, &c->norm2, 16));
     CK(dalloc(c, &c->ev_sums, 64 * 4));
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
+    CK(dalloc(c, &c->group_bits, (size_t)c->T * ((N + 63) / 64)));
     CK(dalloc(c, &c->ring, 1));
     CK(dalloc(c, &c->scratch_obs, N * c->O));
+    CK(dalloc(c, &c->stamps, 24));
 #undef CK
     // every env can reset at most once per step: steps per env over the whole run bounds the shared reset stream
     const int64_t steps_per_env = cfg->total_timesteps > 0 ? cfg->total_timesteps / std::max<int64_t>(c->cfg.global_num_envs, 1) : 0;
@@ -628,7 +640,7 @@ extern "C" ppo_status ppo_env_get_state_h(ppo_ctx* c, float* state_h, int32_t* e
 // ---------------------------------------------------------------------------------------------------------
 static ppo_status consume_finished_episodes(ppo_ctx* c) {
     if (!c->fin_pending) return PPO_OK;
-    HIPCHK(c, launch_episode_ring_update(B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), c->T, c->N, c->row_counts, c->ring, c->stream));
+    HIPCHK(c, launch_episode_ring_update(B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), c->T, c->N, c->row_counts, c->group_bits, c->ring, c->stream));
     c->fin_pending = false;
     return PPO_OK;
 }
@@ -754,10 +766,12 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
     a.global_M = (double)M * c->world;
     a.inv_global_M = 1.0 / a.global_M;
     c->last_global_M = a.global_M;
-    a.adv_stat = c->adv_stats + slot;
+    a.adv_stat = c->adv_stats + (size_t)slot * PPO_ADV_PARTS;
     a.slab = c->slab;
     a.stat_slab = c->stat_slab;
-    a.n_blocks_per_net = std::min(c->use_mfma ? update_blocks_per_net_mfma((int)M) : update_blocks_per_net((int)M), c->max_blocks_per_net);
+    a.stamps = c->stamping ? c->stamps : nullptr;
+    if (c->use_mfma) update_blocks_mfma((int)M, c->actor_share, a.n_blocks);
+    else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
         ProfScope ps(c, PROF_FWD_BWD);
         if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
@@ -765,7 +779,7 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
     }
     {
         ProfScope ps(c, PROF_REDUCE);
-        HIPCHK(c, launch_reduce_grads(c->slab, c->stat_slab, a.n_blocks_per_net, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, c->stream));
+        HIPCHK(c, launch_reduce_grads(c->slab, c->stat_slab, a.n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, c->stream));
     }
     return PPO_OK;
 }
@@ -775,8 +789,8 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
     NEED(c, M >= 1 && M <= c->B, "minibatch size out of range");
     const int slot = c->steps_per_update;  // scratch slot
     if (c->cfg.norm_adv) {
-        HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), idx, M, M, 1, c->adv_stats + slot, c->stream));
-        ppo_status s = allreduce_sum(c, c->adv_stats + slot, 2, true);
+        HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), idx, M, M, 1, c->adv_stats + (size_t)slot * PPO_ADV_PARTS, c->stream));
+        ppo_status s = allreduce_sum(c, c->adv_stats + (size_t)slot * PPO_ADV_PARTS, 2 * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
     }
     ppo_status s = fwd_bwd(c, idx, M, slot);
@@ -784,7 +798,7 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
     // loss scalars and the norm of the unclipped gradient, without touching parameters
     HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
                                 c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, (double)M * c->world, c->hp, 1, false,
-                                c->step_stats + slot, nullptr, c->stream));
+                                c->step_stats + slot, nullptr, c->norm2, c->stream));
     c->last_stat_slot = slot;
     return PPO_OK;
 }
@@ -806,7 +820,7 @@ static ppo_status optimizer_step_slot(ppo_ctx* c, int slot, double global_M, boo
         ProfScope ps(c, PROF_OPT);
         HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
                                     c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, c->world, true,
-                                    c->step_stats + slot, c->clipfrac_accum, c->stream));
+                                    c->step_stats + slot, c->clipfrac_accum, c->norm2, c->stream));
     }
     c->last_stat_slot = slot;
     return PPO_OK;
@@ -836,7 +850,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         // the advantages and the permutations are fixed for the whole update: statistics of ALL minibatches in one launch
         // (and, when sharded, one small all-reduce) instead of a reduction inside every optimizer step
         HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), perm, c->B, c->MB, E * nmb, c->adv_stats, c->stream));
-        s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb, true);
+        s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
     }
     // AdamW scalars of every step of this update, one async copy.  The pinned mirror has two halves used alternately; a half is
@@ -932,7 +946,11 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
     NEED(c, c != nullptr, "null ctx");
-    c->profiling = on != 0;
+    // on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fwd/bwd) and the GAE scan,
+    //     3 = in-kernel phase stamps of the dominant kernel (diagnostic variant: read its SHARES, never its run time)
+    c->profiling = (on == 0 || on == 3) ? 0u : (on == 2 ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE)) : 0xffffffffu);
+    c->stamping = on == 3;
+    if (c->stamping) HIPCHK(c, hipMemsetAsync(c->stamps, 0, 24 * sizeof(unsigned long long), c->stream));
     return PPO_OK;
 }
 
@@ -951,6 +969,9 @@ extern "C" ppo_status ppo_profile_read(ppo_ctx* c, ppo_profile* out) {
         c->event_pool.push_back(sp.b);
     }
     c->spans.clear();
+    unsigned long long st[24];
+    HIPCHK(c, hipMemcpy(st, c->stamps, sizeof st, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 24; i++) out->phase_cycles[i] = (double)st[i];
     return PPO_OK;
 }
 

@@ -53,34 +53,48 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         //      it is served by L1/L2, not HBM. ----
         if (VEC) {
             constexpr int C4 = EPB / 4;                    // float4 columns per row
-            for (int e = tid; e < rows * C4; e += GAE_THREADS) {
+            constexpr int ITERS = GAE_TC * C4 / GAE_THREADS;
+            // every load of the tile is issued before the first use: one memory round trip per tile, not one per row group
+            float4 rw[ITERS], vv[ITERS], nvv[ITERS], dd[ITERS];
+#pragma unroll
+            for (int i = 0; i < ITERS; i++) {
+                const int e = tid + i * GAE_THREADS;
                 const int r = e / C4, c = (e % C4) * 4;
                 const int t = t_lo + r;
-                const size_t g = (size_t)t * N + n0 + c;
-                const float4 rw = *reinterpret_cast<const float4*>(rewards + g);
-                const float4 v = *reinterpret_cast<const float4*>(values + g);
-                float4 nv, nnt;
-                if (t + 1 < T) {
-                    nv = *reinterpret_cast<const float4*>(values + g + N);
-                    const float4 d = *reinterpret_cast<const float4*>(dones + g + N);
-                    nnt = make_float4(1.0f - d.x, 1.0f - d.y, 1.0f - d.z, 1.0f - d.w);
-                } else {
-                    nv = *reinterpret_cast<const float4*>(next_value + n0 + c);
-                    const int4 d = *reinterpret_cast<const int4*>(next_done + n0 + c);
-                    nnt = make_float4((float)(1 - d.x), (float)(1 - d.y), (float)(1 - d.z), (float)(1 - d.w));
+                if (r < rows) {
+                    const size_t g = (size_t)t * N + n0 + c;
+                    rw[i] = *reinterpret_cast<const float4*>(rewards + g);
+                    vv[i] = *reinterpret_cast<const float4*>(values + g);
+                    if (t + 1 < T) {
+                        nvv[i] = *reinterpret_cast<const float4*>(values + g + N);
+                        dd[i] = *reinterpret_cast<const float4*>(dones + g + N);
+                    } else {
+                        nvv[i] = *reinterpret_cast<const float4*>(next_value + n0 + c);
+                        const int4 d = *reinterpret_cast<const int4*>(next_done + n0 + c);
+                        dd[i] = make_float4((float)d.x, (float)d.y, (float)d.z, (float)d.w);   // 0/1: exact, 1 - d below is the same value
+                    }
                 }
-                float4 a4, c4;
-                if (MODE == 0) {
-                    a4 = make_float4((rw.x + (gamma * nv.x) * nnt.x) - v.x, (rw.y + (gamma * nv.y) * nnt.y) - v.y,   // :300
-                                     (rw.z + (gamma * nv.z) * nnt.z) - v.z, (rw.w + (gamma * nv.w) * nnt.w) - v.w);
-                    c4 = make_float4(gl * nnt.x, gl * nnt.y, gl * nnt.z, gl * nnt.w);                                 // :301
-                } else {
-                    a4 = rw;
-                    c4 = make_float4(gamma * nnt.x, gamma * nnt.y, gamma * nnt.z, gamma * nnt.w);                     // :324
+            }
+#pragma unroll
+            for (int i = 0; i < ITERS; i++) {
+                const int e = tid + i * GAE_THREADS;
+                const int r = e / C4, c = (e % C4) * 4;
+                if (r < rows) {
+                    const float4 nnt = make_float4(1.0f - dd[i].x, 1.0f - dd[i].y, 1.0f - dd[i].z, 1.0f - dd[i].w);
+                    const float4 nv = nvv[i], v = vv[i];
+                    float4 a4, c4;
+                    if (MODE == 0) {
+                        a4 = make_float4((rw[i].x + (gamma * nv.x) * nnt.x) - v.x, (rw[i].y + (gamma * nv.y) * nnt.y) - v.y,   // :300
+                                         (rw[i].z + (gamma * nv.z) * nnt.z) - v.z, (rw[i].w + (gamma * nv.w) * nnt.w) - v.w);
+                        c4 = make_float4(gl * nnt.x, gl * nnt.y, gl * nnt.z, gl * nnt.w);                                     // :301
+                    } else {
+                        a4 = rw[i];
+                        c4 = make_float4(gamma * nnt.x, gamma * nnt.y, gamma * nnt.z, gamma * nnt.w);                         // :324
+                    }
+                    *reinterpret_cast<float4*>(&sA[r * EPB + c]) = a4;
+                    *reinterpret_cast<float4*>(&sC[r * EPB + c]) = c4;
+                    *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
                 }
-                *reinterpret_cast<float4*>(&sA[r * EPB + c]) = a4;
-                *reinterpret_cast<float4*>(&sC[r * EPB + c]) = c4;
-                *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
             }
         } else {
             for (int e = tid; e < rows * EPB; e += GAE_THREADS) {

@@ -377,38 +377,52 @@ __global__ void categorical_kernel(const float* __restrict__ logits, const uint8
 // (PPO_Discrete.cpp:474-480).  Only the last 100 matter, so: count per step row in parallel, then ONE wave walks the
 // last rows (in order) that hold >= 100 finished episodes and pushes them with ballot-ordered slots.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void episode_count_kernel(const int32_t* __restrict__ fin_len, int N, int32_t* row_counts) {
+__global__ __launch_bounds__(256) void episode_count_kernel(const int32_t* __restrict__ fin_len, int N, int32_t* row_counts, uint64_t* group_bits) {
+    // row_counts[t] = finished episodes in step row t; group_bits[t][g] = ballot of the 64 envs of group g
     __shared__ int red[4];
     const int t = blockIdx.x;
+    const int G = (N + 63) / 64;
     int c = 0;
-    for (int n = threadIdx.x; n < N; n += 256) c += fin_len[(size_t)t * N + n] > 0 ? 1 : 0;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    for (int g = threadIdx.x >> 6; g < G; g += 4) {
+        const int n = g * 64 + (threadIdx.x & 63);
+        const bool f = n < N && fin_len[(size_t)t * N + n] > 0;
+        const unsigned long long m = __ballot(f);
+        if ((threadIdx.x & 63) == 0) { group_bits[(size_t)t * G + g] = m; c += __popcll(m); }
+    }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) row_counts[t] = red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restrict__ fin_len, const float* __restrict__ fin_rew, int T, int N,
-                                                          const int32_t* __restrict__ row_counts, EpisodeRing* ring) {
+                                                          const int32_t* __restrict__ row_counts, const uint64_t* __restrict__ group_bits,
+                                                          EpisodeRing* ring) {
     const int lane = threadIdx.x;
+    const int G = (N + 63) / 64;
     int64_t total = 0;
-    for (int t = 0; t < T; t++) total += row_counts[t];
+    for (int t = lane; t < T; t += 64) total += row_counts[t];
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
     int t_start = T, have = 0;
     while (t_start > 0 && have < 100) { t_start--; have += row_counts[t_start]; }
     int head = ring->head;
     for (int t = t_start; t < T; t++) {
         if (row_counts[t] == 0) continue;
-        for (int n0 = 0; n0 < N; n0 += 64) {
-            const int n = n0 + lane;
-            const int len = n < N ? fin_len[(size_t)t * N + n] : 0;
-            const unsigned long long m = __ballot(len > 0);
-            if (len > 0) {
-                const int slot = (head + __popcll(m & ((1ull << lane) - 1ull))) % 100;
-                // when more than 100 episodes finish inside one 64-env group the later lane must win: serialise by rank
-                ring->len[slot] = len;
-                ring->rew[slot] = fin_rew[(size_t)t * N + n];
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            const int g = g0 + lane;
+            const unsigned long long bits = g < G ? group_bits[(size_t)t * G + g] : 0ull;
+            unsigned long long nz = __ballot(bits != 0ull);      // groups of this stripe that hold a finished episode
+            while (nz) {
+                const int src = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                const unsigned long long m = __shfl(bits, src, 64);
+                const int n = (g0 + src) * 64 + lane;
+                if ((m >> lane) & 1ull) {
+                    const int slot = (head + __popcll(m & ((1ull << lane) - 1ull))) % 100;
+                    ring->len[slot] = fin_len[(size_t)t * N + n];
+                    ring->rew[slot] = fin_rew[(size_t)t * N + n];
+                }
+                head = (head + __popcll(m)) % 100;
             }
-            head = (head + __popcll(m)) % 100;
         }
     }
     if (lane == 0) {
@@ -545,9 +559,9 @@ hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t*
     return hipGetLastError();
 }
 
-hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, EpisodeRing* ring,
-                                      hipStream_t s) {
-    hipLaunchKernelGGL(episode_count_kernel, dim3((unsigned)T), dim3(256), 0, s, fin_len, N, row_counts);
-    hipLaunchKernelGGL(episode_push_kernel, dim3(1), dim3(64), 0, s, fin_len, fin_rew, T, N, row_counts, ring);
+hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, uint64_t* group_bits,
+                                      EpisodeRing* ring, hipStream_t s) {
+    hipLaunchKernelGGL(episode_count_kernel, dim3((unsigned)T), dim3(256), 0, s, fin_len, N, row_counts, group_bits);
+    hipLaunchKernelGGL(episode_push_kernel, dim3(1), dim3(64), 0, s, fin_len, fin_rew, T, N, row_counts, group_bits, ring);
     return hipGetLastError();
 }

@@ -106,8 +106,10 @@ __device__ __forceinline__ void fwd_bwd_body(const UpdateArgs& a, float* smem) {
     float mean_f = 0.0f, std_f = 0.0f;
     if (NET == 1 && a.hp.norm_adv) {
         // (adv - mean) / (std + 1e-8) over the minibatch, std Bessel-corrected (PPO_Discrete.cpp:591-594)
-        const double mean = a.adv_stat->s1 / a.global_M;
-        const double var = (a.adv_stat->s2 - a.adv_stat->s1 * mean) / (a.global_M - 1.0);
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += a.adv_stat[i].s1; t2 += a.adv_stat[i].s2; }
+        const double mean = t1 / a.global_M;
+        const double var = (t2 - t1 * mean) / (a.global_M - 1.0);
         mean_f = (float)mean;
         std_f = (float)sqrt(var > 0.0 ? var : 0.0);
     }
@@ -407,7 +409,7 @@ __device__ __forceinline__ void fwd_bwd_body(const UpdateArgs& a, float* smem) {
 
     // ---------------- write this workgroup's partial gradient slab (net-local flat layout) ----------------
     const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
-    float* slab = a.slab + ((size_t)NET * a.n_blocks_per_net + blockIdx.x) * Pmax;
+    float* slab = a.slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blockIdx.x) * Pmax;
     const int base = L.net_off[NET];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -428,7 +430,7 @@ __device__ __forceinline__ void fwd_bwd_body(const UpdateArgs& a, float* smem) {
     if (tid < 64) {
         st0 = wave_sum_d(st0); st1 = wave_sum_d(st1); st2 = wave_sum_d(st2); st3 = wave_sum_d(st3);
         if (lane == 0) {
-            double* o = a.stat_slab + ((size_t)NET * a.n_blocks_per_net + blockIdx.x) * 8;
+            double* o = a.stat_slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blockIdx.x) * 8;
             o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
         }
     }
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(UPD_THREADS, 2) void fwd_bwd_kernel(UpdateArgs a) {
 // grads[p] = sum_b slab[net(p)][b][p - net_off] in a fixed order (16 contiguous groups of slabs, each summed in order by one
 // wave with its loads in flight together, then the 16 partials added in order): bit-reproducible, no float atomics.
 // The last block adds the per-workgroup loss sums the same way.
-__global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb,
+__global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb0, int nb1,
                                                             NetLayout L, float* __restrict__ grads, double* __restrict__ sums_out) {
     __shared__ double part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -454,7 +456,8 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
         double acc = 0.0;
         if (p < L.P) {
             const int net = p >= L.net_off[1] ? 1 : 0;
-            const float* col = slab + (size_t)net * nb * Pmax + (p - L.net_off[net]);
+            const int nb = net ? nb1 : nb0;
+            const float* col = slab + (size_t)(net ? nb0 : 0) * Pmax + (p - L.net_off[net]);
             const int b0 = (nb * w) / 16, b1 = (nb * (w + 1)) / 16;
             int b = b0;
             for (; b + 8 <= b1; b += 8) {
@@ -478,8 +481,9 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
         // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor workgroups), [4]=value loss (critic workgroups)
         for (int k = 0; k < 5; k++) {
             const int net = k < 4 ? 1 : 0, col = k < 4 ? k : 0;
+            const int nb = net ? nb1 : nb0;
             double v = 0.0;
-            for (int b = threadIdx.x; b < nb; b += 1024) v += stat_slab[((size_t)net * nb + b) * 8 + col];
+            for (int b = threadIdx.x; b < nb; b += 1024) v += stat_slab[((size_t)(net ? nb0 : 0) + b) * 8 + col];
             v = wave_sum_d(v);
             __syncthreads();
             if (lane == 0) part[0][w] = v;
@@ -494,75 +498,85 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
     }
 }
 
-// K9 + K10: global-norm clip and AdamW in one single-workgroup launch (P is a few thousand floats).
-__global__ __launch_bounds__(1024) void clip_adamw_kernel(float* __restrict__ params, float* __restrict__ grads, float* __restrict__ exp_avg,
-                                                          float* __restrict__ exp_avg_sq, NetLayout L, float max_norm,
-                                                          const AdamCoef* __restrict__ coef_p, const double* __restrict__ loss_sums,
-                                                          double global_M, LossParams hp, int world, int do_step,
-                                                          StepStats* stats_out, double* clipfrac_accum) {
-    __shared__ double red[16][12];
-    __shared__ float s_coef;
-    __shared__ float s_total;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // per-tensor L2 norms (clip_grad.h:58-66)
-    for (int t = 0; t < L.n_tensors; t++) {
-        double acc = 0.0;
-        for (int p = L.tensor_off[t] + tid; p < L.tensor_off[t + 1]; p += 1024) { const double g = grads[p]; acc += g * g; }
-        acc = wave_sum_d(acc);
-        if (lane == 0) red[w][t] = acc;
+// K9: per-tensor squared L2 norms of the gradient (clip_grad.h:58-66), one workgroup per tensor, every load in flight at once.
+constexpr int NORM_THREADS = 256;
+__global__ __launch_bounds__(NORM_THREADS) void grad_norm_kernel(const float* __restrict__ grads, NetLayout L, double* __restrict__ norm2) {
+    __shared__ double red[NORM_THREADS / 64];
+    const int t = blockIdx.x;
+    const int a0 = L.tensor_off[t], a1 = L.tensor_off[t + 1];
+    double acc = 0.0;
+    for (int p0 = a0 + threadIdx.x; p0 < a1; p0 += 16 * NORM_THREADS) {
+        float g[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int p = p0 + i * NORM_THREADS; g[i] = p < a1 ? grads[p] : 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc += (double)g[i] * (double)g[i];
     }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (tid == 0) {
-        double tot = 0.0;
-        for (int t = 0; t < L.n_tensors; t++) {
-            double s = 0.0;
-            for (int k = 0; k < 16; k++) s += red[k][t];
-            const float nrm = (float)sqrt(s);
-            tot += (double)nrm * nrm;
-        }
-        const float total = (float)sqrt(tot);
-        float c = max_norm / (total + 1e-6f);   // clip_grad.h:76-78
-        if (c > 1.0f) c = 1.0f;
-        s_coef = c;
-        s_total = total;
-    }
-    __syncthreads();
-    const float c = s_coef;
+    if (threadIdx.x == 0) norm2[t] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// K9 (clip coefficient) + K10 (AdamW), element-parallel.  GRADS is left holding the UNCLIPPED gradient (the reference scales
+// .grad in place, clip_grad.h:79-81, but nothing reads it before zero_grad); the clip coefficient is applied on the fly.
+constexpr int ADAM_THREADS = 256;
+__global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ exp_avg,
+                                                                  float* __restrict__ exp_avg_sq, NetLayout L, float max_norm,
+                                                                  const double* __restrict__ norm2, const AdamCoef* __restrict__ coef_p,
+                                                                  const double* __restrict__ loss_sums, double global_M, LossParams hp,
+                                                                  int world, int do_step, StepStats* stats_out, double* clipfrac_accum) {
+    const int tid = threadIdx.x;
+    // this thread's element, the norms and the statistics scalars are all requested before anything is consumed
+    const int pu = blockIdx.x * ADAM_THREADS + tid;
+    const bool upd = do_step && pu < L.P;
+    float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
+    if (upd) { u_g = grads[pu]; u_p = params[pu]; u_m = exp_avg[pu]; u_v = exp_avg_sq[pu]; }
+    double n2[12];
+#pragma unroll
+    for (int t = 0; t < 12; t++) n2[t] = t < L.n_tensors ? norm2[t] : 0.0;
     const AdamCoef k = *coef_p;
-    const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
-    for (int p = tid; do_step && p < L.P; p += 1024) {
-        const float g = grads[p] * c;              // grads scaled in place (clip_grad.h:79-81)
-        grads[p] = g;
-        const float pi = params[p] * k.decay;      // p.mul_(1 - lr*wd)
-        const float mi = __builtin_fmaf(g, omb1, exp_avg[p] * b1);          // exp_avg.mul_(b1).add_(g, 1-b1)   (ATen fmadd)
-        const float vi = __builtin_fmaf(omb2 * g, g, exp_avg_sq[p] * b2);   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-        const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
-        params[p] = pi + (k.neg_step * mi) / denom;                        // addcdiv_(exp_avg, denom, -step_size)
-        exp_avg[p] = mi;
-        exp_avg_sq[p] = vi;
+    double ls[5] = { 0, 0, 0, 0, 0 }, cf0 = 0.0, cf1 = 0.0;
+    const bool stat_thread = tid == 0 && blockIdx.x == 0;
+    if (stat_thread) {
+        if (world > 1) { for (int i = 0; i < 5; i++) ls[i] = grads[L.P + i]; }   // sums travelled (as floats) behind the gradient
+        else { for (int i = 0; i < 5; i++) ls[i] = loss_sums[i]; }
+        if (clipfrac_accum && do_step) { cf0 = clipfrac_accum[0]; cf1 = clipfrac_accum[1]; }
     }
-    if (tid == 0) {
+    // total_norm = || (||g_1||, ..., ||g_12||) ||_2 with float per-tensor norms (clip_grad.h:58-70); every thread forms the same bits
+    double tot = 0.0;
+#pragma unroll
+    for (int t = 0; t < 12; t++) { const float nrm = (float)sqrt(n2[t]); tot += (double)nrm * nrm; }
+    const float total = (float)sqrt(tot);
+    float c = max_norm / (total + 1e-6f);   // clip_grad.h:76-78
+    if (c > 1.0f) c = 1.0f;
+    const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
+    if (upd) {
+        const float g = u_g * c;                   // param.grad().mul_(clip_coef_clamped), clip_grad.h:79-81
+        const float pi = u_p * k.decay;            // p.mul_(1 - lr*wd)
+        const float mi = __builtin_fmaf(g, omb1, u_m * b1);          // exp_avg.mul_(b1).add_(g, 1-b1)   (ATen fmadd)
+        const float vi = __builtin_fmaf(omb2 * g, g, u_v * b2);      // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+        const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
+        params[pu] = pi + (k.neg_step * mi) / denom;                 // addcdiv_(exp_avg, denom, -step_size)
+        exp_avg[pu] = mi;
+        exp_avg_sq[pu] = vi;
+    }
+    if (stat_thread) {
         // scalars as the reference forms them (PPO_Discrete.cpp:599,619,628,631,349,352), means over the global minibatch
-        double s_pg, s_ent, s_kl, s_clip, s_v;
-        if (world > 1) {  // sums travelled (as floats) behind the gradient through the all-reduce
-            s_pg = grads[L.P + 0]; s_ent = grads[L.P + 1]; s_kl = grads[L.P + 2]; s_clip = grads[L.P + 3]; s_v = grads[L.P + 4];
-        } else {
-            s_pg = loss_sums[0]; s_ent = loss_sums[1]; s_kl = loss_sums[2]; s_clip = loss_sums[3]; s_v = loss_sums[4];
-        }
-        const float pg = (float)(s_pg / global_M);
-        const float vl = 0.5f * (float)(s_v / global_M);
-        const float el = (float)(s_ent / global_M);
+        const float pg = (float)(ls[0] / global_M);
+        const float vl = 0.5f * (float)(ls[4] / global_M);
+        const float el = (float)(ls[1] / global_M);
         StepStats o;
         o.pg_loss = pg;
         o.v_loss = vl;
         o.entropy_loss = el;
-        o.approx_kl = (float)(s_kl / global_M);
-        o.clipfrac = (float)s_clip / (float)global_M;
+        o.approx_kl = (float)(ls[2] / global_M);
+        o.clipfrac = (float)ls[3] / (float)global_M;
         o.loss = (pg - hp.ent_coef * el) + vl * hp.vf_coef;
-        o.total_norm = s_total;
+        o.total_norm = total;
         o.pad = 0.0;
         *stats_out = o;
-        if (clipfrac_accum && do_step) { clipfrac_accum[0] += o.clipfrac; clipfrac_accum[1] += 1.0; }  // m_clipfracs (:349), mean at :755
+        if (clipfrac_accum && do_step) { clipfrac_accum[0] = cf0 + o.clipfrac; clipfrac_accum[1] = cf1 + 1.0; }  // m_clipfracs (:349), mean at :755
     }
 }
 
@@ -571,25 +585,34 @@ __global__ void append_sums_kernel(const double* sums, float* grads_tail) {
     if (threadIdx.x < 8) grads_tail[threadIdx.x] = (float)sums[threadIdx.x];
 }
 
-// Sum and sum of squares of the advantages of every minibatch of the coming update (one workgroup each).
-__global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict__ adv, const int32_t* __restrict__ perm, int64_t B,
-                                                         int64_t MB, int n_mb_per_epoch, AdvStat* out) {
-    __shared__ double r1[16], r2[16];
-    const int mb = blockIdx.x;
+// Sum and sum of squares of the advantages of every minibatch of the coming update: PPO_ADV_PARTS workgroups per minibatch,
+// each over a contiguous slice, eight gathered loads in flight per thread.
+__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int32_t* __restrict__ perm, int64_t B,
+                                                        int64_t MB, int n_mb_per_epoch, AdvStat* out) {
+    __shared__ double r1[4], r2[4];
+    const int mb = blockIdx.x, part = blockIdx.y;
     const int e = mb / n_mb_per_epoch, m = mb % n_mb_per_epoch;
     const int64_t start = (int64_t)m * MB;
     const int64_t end = start + MB < B ? start + MB : B;
+    const int64_t len = end - start;
+    const int64_t p0 = start + (len * part) / PPO_ADV_PARTS, p1 = start + (len * (part + 1)) / PPO_ADV_PARTS;
     const int32_t* idx = perm + (size_t)e * B;
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t j = start + threadIdx.x; j < end; j += 1024) { const double x = adv[idx[j]]; s1 += x; s2 += x * x; }
+    int64_t j = p0 + threadIdx.x;
+    for (; j + 7 * 256 < p1; j += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = adv[idx[j + i * 256]];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const double x = v[i]; s1 += x; s2 += x * x; }
+    }
+    for (; j < p1; j += 256) { const double x = adv[idx[j]]; s1 += x; s2 += x * x; }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a1 = 0.0, a2 = 0.0;
-        for (int k = 0; k < 16; k++) { a1 += r1[k]; a2 += r2[k]; }
-        out[mb].s1 = a1;
-        out[mb].s2 = a2;
+        out[mb * PPO_ADV_PARTS + part].s1 = ((r1[0] + r1[1]) + r1[2]) + r1[3];
+        out[mb * PPO_ADV_PARTS + part].s2 = ((r2[0] + r2[1]) + r2[2]) + r2[3];
     }
 }
 
@@ -645,7 +668,7 @@ hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipErrorInvalidValue;
     const int aout = a.L.act > 1 ? a.L.act : 1;
     const size_t shmem = (size_t)smem_layout(a.L.obs, aout).total * sizeof(float);
-    const dim3 grid((unsigned)a.n_blocks_per_net, 2), block(UPD_THREADS);
+    const dim3 grid((unsigned)a.n_blocks[0], 2), block(UPD_THREADS);  // the VALU kernel uses equal shares
 #define PPO_LAUNCH_UPD(DIST, OBS)                                                                                     \
     do {                                                                                                              \
         static bool attr_set = false;                                                                                 \
@@ -670,17 +693,19 @@ hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
+hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64 + 1), dim3(1024), 0, s, slab, stat_slab, n_blocks_per_net, L, grads, sums_out);
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64 + 1), dim3(1024), 0, s, slab, stat_slab, n_blocks[0], n_blocks[1], L, grads, sums_out);
     return hipGetLastError();
 }
 
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
-                             StepStats* stats_out, double* clipfrac_accum, hipStream_t s) {
-    hipLaunchKernelGGL(clip_adamw_kernel, dim3(1), dim3(1024), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, coef, loss_sums,
-                       global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum);
+                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s) {
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(L.n_tensors), dim3(NORM_THREADS), 0, s, grads, L, norm2_scratch);
+    const int blocks = do_step ? (L.P + ADAM_THREADS - 1) / ADAM_THREADS : 1;
+    hipLaunchKernelGGL(clip_adamw_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, norm2_scratch,
+                       coef, loss_sums, global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum);
     return hipGetLastError();
 }
 
@@ -692,7 +717,7 @@ hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s) {
     const int per_epoch = (int)((B + MB - 1) / MB);
-    hipLaunchKernelGGL(adv_stats_kernel, dim3(n_mb_total), dim3(1024), 0, s, advantages, perm, B, MB, per_epoch, out);
+    hipLaunchKernelGGL(adv_stats_kernel, dim3(n_mb_total, PPO_ADV_PARTS), dim3(256), 0, s, advantages, perm, B, MB, per_epoch, out);
     return hipGetLastError();
 }
 

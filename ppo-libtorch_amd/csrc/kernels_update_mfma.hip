@@ -28,6 +28,10 @@ constexpr int LS = 68;              // padded LDS row stride (floats)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// exp / log on the hardware exp2 / log2 units (v_exp_f32, v_log_f32; ~1 ULP of the base-2 result): the loss only needs them to
+// ~1e-6 relative (north_star: losses within 1e-5), and the correctly rounded library versions cost ~10x the instructions.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -100.0f) * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ int umap(int r, int hi, int t) { return (r & 3) + 8 * (r >> 2) + 4 * hi + 32 * t; }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -69,8 +73,25 @@ __device__ __forceinline__ void store_dlayout(float* img, const float* v, int s,
             st4(&img[s * LS + 8 * q + 4 * hi + 32 * t], make_float4(v[16 * t + 4 * q], v[16 * t + 4 * q + 1], v[16 * t + 4 * q + 2], v[16 * t + 4 * q + 3]));
 }
 
-template <int NET, int DIST, int OBS, int AMAX>
-__device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
+// In-kernel phase stamps (diagnostic variant only, STAMP = true): cycles per phase of wave 0 of workgroup 0 of each net,
+// summed over its tiles, written to a debug buffer no other code reads.
+#define MF_STAMP(i)                                                                            \
+    do {                                                                                       \
+        if constexpr (STAMP) {                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            ph[i] += now_ - t_prev;                                                            \
+            t_prev = now_;                                                                     \
+        }                                                                                      \
+    } while (0)
+
+template <int NET, int DIST, int OBS, int AMAX, bool STAMP>
+__device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
+    unsigned long long ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long t_prev = 0;
+    if constexpr (STAMP) t_prev = __builtin_amdgcn_s_memtime();
     const NetLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, hi = lane >> 5;
@@ -90,11 +111,18 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
     const float* __restrict__ P = a.params;
 
     // ---- weights of this net -> LDS (once per launch) ----
-    for (int e = tid; e < 64 * 64; e += MF_THREADS) {
-        const float w = P[L.w2[NET] + e];
-        const int n = e >> 6, k = e & 63;
-        sW2[n * LS + k] = w;
-        sW2T[k * LS + n] = w;
+    {
+        // 4096 weights, 16 per thread, every global load issued before the first LDS store
+        float wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = P[L.w2[NET] + tid + i * MF_THREADS];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + i * MF_THREADS;
+            const int n = e >> 6, k = e & 63;
+            sW2[n * LS + k] = wv[i];
+            sW2T[k * LS + n] = wv[i];
+        }
     }
     for (int e = tid; e < 64 * OBS; e += MF_THREADS) sW1[e] = P[L.w1[NET] + e];
     for (int e = tid; e < AOUT * 64; e += MF_THREADS) sW3[e] = P[L.w3[NET] + e];
@@ -118,51 +146,118 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
 #pragma unroll
     for (int k = 0; k < AMAX; k++) gb3[k] = 0.0f;
     double st0 = 0.0, st1 = 0.0, st2 = 0.0, st3 = 0.0;
+    // layer-1 A operands: W1[u = s + 32 t][o = 2 st + hi] (zero beyond OBS); K = OBS is contracted in ceil(OBS/2) MFMA steps
+    constexpr int L1S = (OBS + 1) / 2;
+    float w1op[2][L1S];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int stp = 0; stp < L1S; stp++) {
+            const int o = 2 * stp + hi;
+            w1op[t][stp] = o < OBS ? P[L.w1[NET] + (s + 32 * t) * OBS + o] : 0.0f;
+        }
 
     const float clip = a.hp.clip_coef;
     const float lo = 1 - clip, hi_c = 1 + clip;
     const float invM = (float)a.inv_global_M;
     float mean_f = 0.0f, std_f = 0.0f;
     if (NET == 1 && a.hp.norm_adv) {
-        const double mean = a.adv_stat->s1 / a.global_M;
-        const double var = (a.adv_stat->s2 - a.adv_stat->s1 * mean) / (a.global_M - 1.0);
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += a.adv_stat[i].s1; t2 += a.adv_stat[i].s2; }
+        const double mean = t1 / a.global_M;
+        const double var = (t2 - t1 * mean) / (a.global_M - 1.0);
         mean_f = (float)mean;
         std_f = (float)sqrt(var > 0.0 ? var : 0.0);
     }
+    const float inv_std = 1.0f / (std_f + 1e-8f);
     __syncthreads();
+    MF_STAMP(0);   // prologue: weights -> LDS
 
     const int n_tiles = (a.M + MT - 1) / MT;
-    for (int tile = blockIdx.x * MF_WAVES + wave; tile < n_tiles; tile += gridDim.x * MF_WAVES) {
+    const int tile_step = nblk * MF_WAVES;
+    // gather of the first tile; every later tile's batch row is fetched one tile ahead (its two dependent HBM round trips
+    // hide behind the current tile's MFMAs)
+    int tile = blk * MF_WAVES + wave;
+    // software pipeline of the gather: batch-row indices are fetched TWO tiles ahead and the observation row ONE tile ahead, so
+    // neither of the two dependent HBM round trips is ever waited for inside a tile
+    auto fetch_row = [&](int tl) -> int {
+        const int j = tl * MT + s;
+        return (tl < n_tiles && j < a.M) ? a.idx[j] : -1;
+    };
+    int row_n = fetch_row(tile);
+    int row_nn = fetch_row(tile + tile_step);
+    float x_n[OBS];
+#pragma unroll
+    for (int o = 0; o < OBS; o++) x_n[o] = row_n >= 0 ? a.obs[(size_t)row_n * OBS + o] : 0.0f;
+    for (; tile < n_tiles; tile += tile_step) {
         // ---------------- gather (K5): lanes (s, 0) and (s, 1) read the same batch row ----------------
-        const int j = tile * MT + s;
-        const bool valid = j < a.M;
-        const int row = valid ? a.idx[j] : 0;
+        const bool valid = row_n >= 0;
+        const int row = valid ? row_n : 0;
         float x[OBS];
 #pragma unroll
-        for (int o = 0; o < OBS; o++) x[o] = valid ? a.obs[(size_t)row * OBS + o] : 0.0f;
+        for (int o = 0; o < OBS; o++) x[o] = x_n[o];
+        // per-sample scalars of this tile: issued now, consumed at the loss
+        float s_oldlp = 0.0f, s_adv = 0.0f, s_ret = 0.0f, s_oldv = 0.0f;
+        int act_s[AMAX];
+        uint32_t s_maskbits = 0xffffffffu;
+#pragma unroll
+        for (int h = 0; h < AMAX; h++) act_s[h] = 0;
+        if (NET == 1) {
+            s_oldlp = a.logprobs[row];
+            s_adv = a.advantages[row];
+#pragma unroll
+            for (int h = 0; h < AMAX; h++) if (h < L.n_heads) act_s[h] = a.actions[(size_t)row * L.n_heads + h];
+            if (DIST == PPO_DIST_MASKED && a.masks) {
+                s_maskbits = 0u;
+#pragma unroll
+                for (int k = 0; k < AMAX; k++) if (k < L.act) s_maskbits |= (a.masks[(size_t)row * L.act + k] ? 1u : 0u) << k;
+            }
+        } else {
+            s_ret = a.returns[row];
+            s_oldv = a.values[row];
+        }
+        {   // next tile's observation row (its index arrived a tile ago); the index after that
+            row_n = row_nn;
+#pragma unroll
+            for (int o = 0; o < OBS; o++) x_n[o] = row_n >= 0 ? a.obs[(size_t)row_n * OBS + o] : 0.0f;
+            row_nn = fetch_row(tile + 2 * tile_step);
+        }
         if (hi == 0) {
 #pragma unroll
             for (int o = 0; o < OBS; o++) sX[o * MT + s] = x[o];
         }
 
-        // ---------------- layer 1 (VALU): this lane's 32 units ----------------
+        MF_STAMP(1);   // gather hand-over + prefetch issue
+        // ---------------- layer 1 (MFMA, K = OBS): z1^T[u][s] = b1[u] + sum_o W1[u][o] x[s][o], D layout ----------------
         float h1[32];
 #pragma unroll
-        for (int e = 0; e < 32; e++) {
-            const int u = umap(e & 15, hi, e >> 4);
-            float z = sB1[u];
+        for (int t = 0; t < 2; t++) {
+            f32x16 acc;
 #pragma unroll
-            for (int o = 0; o < OBS; o++) z = __builtin_fmaf(x[o], sW1[u * OBS + o], z);
-            h1[e] = tanhf(z);
+            for (int q = 0; q < 4; q++) {
+                const float4 b = ld4(&sB1[8 * q + 4 * hi + 32 * t]);
+                acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+            }
+#pragma unroll
+            for (int stp = 0; stp < L1S; stp++) {
+                const float xb = (2 * stp + 1 < OBS) ? (hi ? x[2 * stp + 1] : x[2 * stp]) : (hi ? 0.0f : x[2 * stp]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1op[t][stp], xb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_fast(acc[r]);
         }
 
+        MF_STAMP(2);   // layer 1 + tanh
         // ---------------- layer 2 forward (MFMA): z2^T[n][s] = b2[n] + sum_k W2[n][k] h1[s][k] ----------------
         float h2[32];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = sB2[umap(r, hi, t)];
+            for (int q = 0; q < 4; q++) {
+                const float4 b = ld4(&sB2[8 * q + 4 * hi + 32 * t]);
+                acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+            }
 #pragma unroll
             for (int tk = 0; tk < 2; tk++)
 #pragma unroll
@@ -174,9 +269,10 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[16 * tk + 4 * q + 3], acc, 0, 0, 0);
                 }
 #pragma unroll
-            for (int r = 0; r < 16; r++) h2[16 * t + r] = tanhf(acc[r]);
+            for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_fast(acc[r]);
         }
 
+        MF_STAMP(3);   // layer 2 MFMA + tanh
         // ---------------- head + loss (K6, K7): both half-lanes of a sample compute the same scalars ----------------
         float dOut[AMAX];
 #pragma unroll
@@ -184,10 +280,14 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
         if (NET == 0) {
             float part = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 32; e++) part = __builtin_fmaf(h2[e], sW3[umap(e & 15, hi, e >> 4)], part);
+            for (int g = 0; g < 8; g++) {   // g = 4 t + q: units 8q + 4hi + 32t .. +3
+                const float4 w = ld4(&sW3[8 * (g & 3) + 4 * hi + 32 * (g >> 2)]);
+                part = __builtin_fmaf(h2[4 * g], w.x, part); part = __builtin_fmaf(h2[4 * g + 1], w.y, part);
+                part = __builtin_fmaf(h2[4 * g + 2], w.z, part); part = __builtin_fmaf(h2[4 * g + 3], w.w, part);
+            }
             const float other = __shfl_xor(part, 32, 64);
             const float v = ((hi == 0 ? part : other) + (hi == 0 ? other : part)) + sB3[0];  // same association in both halves
-            const float R = a.returns[row], vold = a.values[row];
+            const float R = s_ret, vold = s_oldv;
             const float un = (v - R) * (v - R);
             float g_v, lossv;
             if (a.hp.clip_vloss) {   // PPO_Discrete.cpp:603-620
@@ -216,18 +316,21 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
                 if (k < A) {
                     float part = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < 32; e++) part = __builtin_fmaf(h2[e], sW3[k * 64 + umap(e & 15, hi, e >> 4)], part);
+                    for (int g = 0; g < 8; g++) {
+                        const float4 w = ld4(&sW3[k * 64 + 8 * (g & 3) + 4 * hi + 32 * (g >> 2)]);
+                        part = __builtin_fmaf(h2[4 * g], w.x, part); part = __builtin_fmaf(h2[4 * g + 1], w.y, part);
+                        part = __builtin_fmaf(h2[4 * g + 2], w.z, part); part = __builtin_fmaf(h2[4 * g + 3], w.w, part);
+                    }
                     const float other = __shfl_xor(part, 32, 64);
                     z[k] = ((hi == 0 ? part : other) + (hi == 0 ? other : part)) + sB3[k];
-                    if (DIST == PPO_DIST_MASKED && a.masks) ok[k] = a.masks[(size_t)row * A + k] != 0;
+                    if (DIST == PPO_DIST_MASKED && a.masks) ok[k] = ((s_maskbits >> k) & 1u) != 0u;
                     if (DIST == PPO_DIST_MASKED && !ok[k]) z[k] = -1e8f;
                 }
             }
             float nlp = 0.0f, ent = 0.0f;
             float headH[AMAX];
-            int act_s[AMAX];
 #pragma unroll
-            for (int h = 0; h < AMAX; h++) { headH[h] = 0.0f; act_s[h] = (h < L.n_heads) ? a.actions[(size_t)row * L.n_heads + h] : 0; }
+            for (int h = 0; h < AMAX; h++) headH[h] = 0.0f;
             int off = 0;
 #pragma unroll
             for (int h = 0; h < AMAX; h++) {
@@ -239,13 +342,14 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
                 for (int k = 0; k < AMAX; k++) if (k >= off && k < off + Ah) mx = z[k] > mx ? z[k] : mx;
                 float se = 0.0f;
 #pragma unroll
-                for (int k = 0; k < AMAX; k++) if (k >= off && k < off + Ah) { pr[k] = expf(z[k] - mx); se += pr[k]; }
-                const float lse = logf(se) + mx;
+                for (int k = 0; k < AMAX; k++) if (k >= off && k < off + Ah) { pr[k] = fast_exp(z[k] - mx); se += pr[k]; }
+                const float lse = fast_log(se) + mx;
+                const float rse = __builtin_amdgcn_rcpf(se);
                 float e1 = 0.0f, lp = 0.0f;
 #pragma unroll
                 for (int k = 0; k < AMAX; k++) if (k >= off && k < off + Ah) {
                     z[k] = z[k] - lse;
-                    pr[k] = pr[k] / se;
+                    pr[k] = pr[k] * rse;
                     if (DIST == PPO_DIST_CATEGORICAL) {
                         const float l = z[k] > 1.17549435e-38f ? z[k] : 1.17549435e-38f;
                         e1 += l * pr[k];
@@ -258,10 +362,10 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
                 if (h == 0) { nlp = lp; ent = headH[h]; } else { nlp += lp; ent += headH[h]; }
                 off += Ah;
             }
-            const float logratio = nlp - a.logprobs[row];   // :585
-            const float ratio = expf(logratio);             // :586
-            float adv = a.advantages[row];
-            if (a.hp.norm_adv) adv = (adv - mean_f) / (std_f + 1e-8f);   // :593
+            const float logratio = nlp - s_oldlp;           // :585
+            const float ratio = fast_exp(logratio);         // :586
+            float adv = s_adv;
+            if (a.hp.norm_adv) adv = (adv - mean_f) * inv_std;           // :593 (reciprocal hoisted: (a - mean) / (std + 1e-8))
             const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
             const float l1 = -adv * ratio, l2 = -adv * rc;  // :597-598
             const bool inside = (ratio >= lo && ratio <= hi_c);
@@ -293,6 +397,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
             }
         }
 
+        MF_STAMP(4);   // head + loss
         // ---------------- h2 -> image; dOut -> [a][s]; then dW3[a][u = lane], db3 ----------------
         store_dlayout(img, h2, s, hi);
         if (hi == 0) {
@@ -304,23 +409,41 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
         for (int k = 0; k < AMAX; k++) {
             if (k < AOUT) {
                 float acc = 0.0f;
-#pragma unroll 8
-                for (int ss = 0; ss < MT; ss++) acc = __builtin_fmaf(sDo[k * MT + ss], img[ss * LS + lane], acc);
+#pragma unroll
+                for (int c0 = 0; c0 < MT; c0 += 16) {   // 16 image rows + 4 x 16-byte dOut reads in flight together
+                    float hv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) hv[i] = img[(c0 + i) * LS + lane];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        const float4 d = ld4(&sDo[k * MT + c0 + i]);
+                        acc = __builtin_fmaf(d.x, hv[i], acc); acc = __builtin_fmaf(d.y, hv[i + 1], acc);
+                        acc = __builtin_fmaf(d.z, hv[i + 2], acc); acc = __builtin_fmaf(d.w, hv[i + 3], acc);
+                    }
+                }
                 gW3[k] += acc;
                 gb3[k] += hi == 0 ? dOut[k] : 0.0f;   // summed over lanes at the end
             }
         }
 
+        MF_STAMP(5);   // h2 image + dW3
         // ---------------- dz2 = (sum_a dOut[a] W3[a][u]) (1 - h2^2), D layout ----------------
         float dz2[32];
 #pragma unroll
-        for (int e = 0; e < 32; e++) {
-            const int u = umap(e & 15, hi, e >> 4);
-            float d = 0.0f;
+        for (int e = 0; e < 32; e++) dz2[e] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < AMAX; k++) if (k < AOUT) d = __builtin_fmaf(dOut[k], sW3[k * 64 + u], d);
-            dz2[e] = d * (1.0f - h2[e] * h2[e]);
+        for (int k = 0; k < AMAX; k++) {
+            if (k < AOUT) {
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const float4 w = ld4(&sW3[k * 64 + 8 * (g & 3) + 4 * hi + 32 * (g >> 2)]);
+                    dz2[4 * g] = __builtin_fmaf(dOut[k], w.x, dz2[4 * g]); dz2[4 * g + 1] = __builtin_fmaf(dOut[k], w.y, dz2[4 * g + 1]);
+                    dz2[4 * g + 2] = __builtin_fmaf(dOut[k], w.z, dz2[4 * g + 2]); dz2[4 * g + 3] = __builtin_fmaf(dOut[k], w.w, dz2[4 * g + 3]);
+                }
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 32; e++) dz2[e] = dz2[e] * (1.0f - h2[e] * h2[e]);
         wave_lds_fence();  // dW3 reads of the image are done
         store_dlayout(img, dz2, s, hi);
         wave_lds_fence();
@@ -343,6 +466,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
         wave_lds_fence();
         store_dlayout(img, h1, s, hi);
         wave_lds_fence();
+        MF_STAMP(6);   // dz2, images, opA, db2
         // ---------------- dW2[n][k] += sum_s dz2[s][n] h1[s][k] (MFMA, contraction over samples) ----------------
 #pragma unroll
         for (int stp = 0; stp < 16; stp++) {
@@ -354,6 +478,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
             gW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[1][stp], b1, gW2[1][1], 0, 0, 0);
         }
 
+        MF_STAMP(7);   // dW2 MFMA
         // ---------------- dh1^T[k][s] = sum_n W2[n][k] dz2[s][n] (MFMA), dz1 = dh1 (1 - h1^2) ----------------
         float dz1[32];
 #pragma unroll
@@ -371,9 +496,18 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, dz2[16 * tn + 4 * q + 2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, dz2[16 * tn + 4 * q + 3], acc, 0, 0, 0);
                 }
+            // h1 comes back from its [sample][unit] image (still intact: dW2 only read it), so its 32 registers are free
+            // during the dW2 / d(hidden) MFMA phases
 #pragma unroll
-            for (int r = 0; r < 16; r++) dz1[16 * t + r] = acc[r] * (1.0f - h1[16 * t + r] * h1[16 * t + r]);
+            for (int q = 0; q < 4; q++) {
+                const float4 hb = ld4(&img[s * LS + 8 * q + 4 * hi + 32 * t]);
+                dz1[16 * t + 4 * q + 0] = acc[4 * q + 0] * (1.0f - hb.x * hb.x);
+                dz1[16 * t + 4 * q + 1] = acc[4 * q + 1] * (1.0f - hb.y * hb.y);
+                dz1[16 * t + 4 * q + 2] = acc[4 * q + 2] * (1.0f - hb.z * hb.z);
+                dz1[16 * t + 4 * q + 3] = acc[4 * q + 3] * (1.0f - hb.w * hb.w);
+            }
         }
+        MF_STAMP(8);   // dh1 MFMA + dz1
         wave_lds_fence();  // dW2's reads of the h1 image are done
         store_dlayout(img, dz1, s, hi);
         wave_lds_fence();
@@ -382,97 +516,125 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem) {
             float accw[OBS], accb = 0.0f;
 #pragma unroll
             for (int o = 0; o < OBS; o++) accw[o] = 0.0f;
-#pragma unroll 8
-            for (int ss = 0; ss < MT; ss++) {
-                const float d = img[ss * LS + lane];
-                accb += d;
 #pragma unroll
-                for (int o = 0; o < OBS; o++) accw[o] = __builtin_fmaf(d, sX[o * MT + ss], accw[o]);
+            for (int c0 = 0; c0 < MT; c0 += 16) {
+                float dv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) dv[i] = img[(c0 + i) * LS + lane];
+#pragma unroll
+                for (int i = 0; i < 16; i++) accb += dv[i];
+#pragma unroll
+                for (int o = 0; o < OBS; o++)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        const float4 xv = ld4(&sX[o * MT + c0 + i]);
+                        accw[o] = __builtin_fmaf(dv[i], xv.x, accw[o]); accw[o] = __builtin_fmaf(dv[i + 1], xv.y, accw[o]);
+                        accw[o] = __builtin_fmaf(dv[i + 2], xv.z, accw[o]); accw[o] = __builtin_fmaf(dv[i + 3], xv.w, accw[o]);
+                    }
             }
             gb1 += accb;
 #pragma unroll
             for (int o = 0; o < OBS; o++) gW1[o] += accw[o];
         }
         wave_lds_fence();  // image and sX are rewritten by the next tile
+        MF_STAMP(9);   // dz1 image + dW1
     }
 
-    // ---------------- add the four waves in a fixed order into one slab ----------------
-    __syncthreads();
-    float* red = smem;  // weights are dead: reuse the front of LDS as a [net_size] accumulator
+    // ---------------- the four waves park their accumulators in private LDS regions (plain stores), then every thread adds the
+    //                  four regions in a fixed order into the workgroup's slab ----------------
+    __syncthreads();   // weights and images are dead: the whole dynamic LDS block is reused
     const int base = L.net_off[NET];
     const int nsz = L.net_size[NET];
-    for (int e = tid; e < nsz; e += MF_THREADS) red[e] = 0.0f;
-    __syncthreads();
-#pragma unroll 1
-    for (int w = 0; w < MF_WAVES; w++) {
-        if (wave == w) {
+    const int rstride = (nsz + 3) & ~3;
+    float* red = smem + wave * rstride;
 #pragma unroll
-            for (int tn = 0; tn < 2; tn++)
+    for (int tn = 0; tn < 2; tn++)
 #pragma unroll
-                for (int tk = 0; tk < 2; tk++)
+        for (int tk = 0; tk < 2; tk++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        red[L.w2[NET] - base + umap(r, hi, tn) * 64 + s + 32 * tk] += gW2[tn][tk][r];
+            for (int r = 0; r < 16; r++) red[L.w2[NET] - base + umap(r, hi, tn) * 64 + s + 32 * tk] = gW2[tn][tk][r];
 #pragma unroll
-            for (int k = 0; k < AMAX; k++) if (k < AOUT) red[L.w3[NET] - base + k * 64 + lane] += gW3[k];
+    for (int k = 0; k < AMAX; k++) if (k < AOUT) red[L.w3[NET] - base + k * 64 + lane] = gW3[k];
 #pragma unroll
-            for (int o = 0; o < OBS; o++) red[L.w1[NET] - base + lane * OBS + o] += gW1[o];
-            red[L.b1[NET] - base + lane] += gb1;
-            if (hi == 0) { red[L.b2[NET] - base + s] += gb2[0]; red[L.b2[NET] - base + s + 32] += gb2[1]; }
+    for (int o = 0; o < OBS; o++) red[L.w1[NET] - base + lane * OBS + o] = gW1[o];
+    red[L.b1[NET] - base + lane] = gb1;
+    if (hi == 0) { red[L.b2[NET] - base + s] = gb2[0]; red[L.b2[NET] - base + s + 32] = gb2[1]; }
 #pragma unroll
-            for (int k = 0; k < AMAX; k++) if (k < AOUT) {
-                const float t = wave_sum(gb3[k]);
-                if (lane == 0) red[L.b3[NET] - base + k] += t;
-            }
-        }
-        __syncthreads();
+    for (int k = 0; k < AMAX; k++) if (k < AOUT) {
+        const float t = wave_sum(gb3[k]);
+        if (lane == 0) red[L.b3[NET] - base + k] = t;
     }
+    __syncthreads();
     const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
-    float* slab = a.slab + ((size_t)NET * a.n_blocks_per_net + blockIdx.x) * Pmax;
-    for (int e = tid; e < nsz; e += MF_THREADS) slab[e] = red[e];
+    float* slab = a.slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * Pmax;
+    for (int e = tid; e < nsz; e += MF_THREADS)
+        slab[e] = ((smem[e] + smem[rstride + e]) + smem[2 * rstride + e]) + smem[3 * rstride + e];
     // loss sums
     st0 = wave_sum_d(st0); st1 = wave_sum_d(st1); st2 = wave_sum_d(st2); st3 = wave_sum_d(st3);
     __syncthreads();
-    double* dred = reinterpret_cast<double*>(smem + ((nsz + 3) & ~3) + 4);
+    double* dred = reinterpret_cast<double*>(smem + 4 * rstride + 4);
     if (lane == 0) { dred[wave * 4 + 0] = st0; dred[wave * 4 + 1] = st1; dred[wave * 4 + 2] = st2; dred[wave * 4 + 3] = st3; }
     __syncthreads();
     if (tid < 4) {
-        double* o = a.stat_slab + ((size_t)NET * a.n_blocks_per_net + blockIdx.x) * 8;
+        double* o = a.stat_slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * 8;
         o[tid] = ((dred[0 + tid] + dred[4 + tid]) + dred[8 + tid]) + dred[12 + tid];
+    }
+    MF_STAMP(10);  // epilogue
+    if constexpr (STAMP) {
+        if (blk == 0 && tid == 0 && a.stamps) {
+            for (int i = 0; i < 12; i++) a.stamps[NET * 12 + i] += ph[i];
+        }
     }
 }
 
-template <int DIST, int OBS, int AMAX>
+template <int DIST, int OBS, int AMAX, bool STAMP>
 __global__ __launch_bounds__(MF_THREADS, 2) void fwd_bwd_mfma_kernel(UpdateArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (blockIdx.y == 0) mf_body<0, DIST, OBS, 1>(a, smem);
-    else mf_body<1, DIST, OBS, AMAX>(a, smem);
+    // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor (the actor's loss makes its tiles dearer, so it
+    // gets the larger share of the workgroups)
+    const int b = blockIdx.x;
+    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, STAMP>(a, smem, b, a.n_blocks[0]);
+    else mf_body<1, DIST, OBS, AMAX, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
 
 }  // namespace
 
-int update_blocks_per_net_mfma(int M) {
+void update_blocks_mfma(int M, double actor_share, int n_blocks[2]) {
     const int tiles = (M + MT - 1) / MT;
-    const int blocks = (tiles + MF_WAVES - 1) / MF_WAVES;
-    return blocks < 256 ? (blocks > 0 ? blocks : 1) : 256;  // one (actor, critic) workgroup pair per CU
+    const int per_net = (tiles + MF_WAVES - 1) / MF_WAVES;       // workgroups that still get a tile per wave
+    if (per_net <= 256) { n_blocks[0] = n_blocks[1] = per_net > 0 ? per_net : 1; return; }
+    // 512 workgroups (two per CU) split by the relative cost of an actor tile and a critic tile
+    int na = (int)(512.0 * actor_share + 0.5);
+    na = na < 64 ? 64 : (na > 448 ? 448 : na);
+    n_blocks[1] = na;
+    n_blocks[0] = 512 - na;
 }
 
 hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipErrorInvalidValue;
     if (a.L.act > 4) return hipErrorNotSupported;  // wider heads run on the VALU kernel
     const int aout = a.L.act > 1 ? a.L.act : 1;
-    const size_t shmem = (size_t)mf_smem(a.L.obs, aout).total * sizeof(float);
-    const dim3 grid((unsigned)a.n_blocks_per_net, 2), block(MF_THREADS);
+    size_t shmem = (size_t)mf_smem(a.L.obs, aout).total * sizeof(float);
+    {   // the epilogue parks four per-wave gradient images (+ 16 doubles of loss sums) in the same block
+        const int nmax = a.L.net_size[0] > a.L.net_size[1] ? a.L.net_size[0] : a.L.net_size[1];
+        const size_t need = ((size_t)4 * ((nmax + 3) & ~3) + 4 + 40) * sizeof(float);
+        if (need > shmem) shmem = need;
+    }
+    const dim3 grid((unsigned)(a.n_blocks[0] + a.n_blocks[1])), block(MF_THREADS);
 #define PPO_LAUNCH_MF(DIST, OBS)                                                                                       \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, 4>),      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, 4, false>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+            if (e == hipSuccess)                                                                                       \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, 4, true>),       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, 4>), grid, block, shmem, s, a);                             \
+        if (a.stamps) hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, 4, true>), grid, block, shmem, s, a);         \
+        else hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, 4, false>), grid, block, shmem, s, a);                 \
     } while (0)
     if (a.L.obs == 4) {
         if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 4); else PPO_LAUNCH_MF(PPO_DIST_MASKED, 4);

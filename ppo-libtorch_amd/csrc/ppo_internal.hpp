@@ -65,6 +65,7 @@ struct LossParams {
 
 // Per-minibatch advantage statistics (sum, sum of squares over the GLOBAL minibatch) and the scalars derived from them.
 struct AdvStat { double s1, s2; };
+#define PPO_ADV_PARTS 8   // partial sums per minibatch (one workgroup each), added in order by the consumer
 
 // Device-side record of one optimizer step's scalars (doubles so the host reads them as-is).
 struct StepStats {
@@ -258,6 +259,20 @@ __device__ __forceinline__ int sample_head(const float* p, int A, float u) {
     return hit ? a : last;
 }
 
+// tanh for the update kernels: branch-free, ~3 ULP.  |x| >= 0.12: (1 - t) / (1 + t) with t = exp(-2|x|) on the hardware
+// exp2 / rcp (v_exp_f32, v_rcp_f32); below that the odd Taylor polynomial to x^7 (truncation < 2e-9 relative at 0.12) avoids the
+// cancellation in 1 - t.  The clamp keeps the exp2 argument inside the range where v_exp_f32 needs no denormal pre-scaling.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float ax = fminf(fabsf(x), 20.0f);
+    const float t = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);   // exp(-2|x|)
+    const float big = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    const float x2 = x * x;
+    const float poly = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, -17.0f / 315.0f, 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    const float small = x * poly;
+    const float bigs = __builtin_copysignf(big, x);
+    return ax < 0.12f ? small : bigs;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -350,19 +365,20 @@ struct UpdateArgs {
     double global_M;
     float* slab;             // [n_blocks, P_net_max] partial gradients
     double* stat_slab;       // [n_blocks, 8] partial loss sums
-    int n_blocks_per_net;
+    int n_blocks[2];         // workgroups of the critic / of the actor; slab row = (net ? n_blocks[0] : 0) + workgroup
+    unsigned long long* stamps;  // diagnostic build only: [2 nets][12 phases] cycle sums of wave 0 / workgroup 0
 };
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
 // MFMA (v_mfma_f32_32x32x2_f32) version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}
-int update_blocks_per_net_mfma(int M);
+void update_blocks_mfma(int M, double actor_share, int n_blocks[2]);
 hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
 // grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
-hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, int n_blocks_per_net, const NetLayout& L, float* grads,
+hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s);
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
-                             StepStats* stats_out, double* clipfrac_accum, hipStream_t s);
+                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s);
 hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t s);
 
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
@@ -372,8 +388,8 @@ struct EpisodeRing {
     int32_t size, head;
     int64_t total;
 };
-hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, EpisodeRing* ring,
-                                      hipStream_t s);
+hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, uint64_t* group_bits,
+                                      EpisodeRing* ring, hipStream_t s);
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s);
 hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s);
