@@ -101,27 +101,20 @@ def main():
             sys.exit("--gpus %d needs one process per GPU: launch with `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # plumbing only: barrier, id broadcast, max over ranks
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
     from __graft_entry__ import load_package
     P = load_package()
+    dist = None
+    if world > 1:
+        dist, rank, world = P.dist.init_process_group("gloo")  # plumbing only: rendezvous, id broadcast, barrier, max over ranks
     obs, act = 4, 2
     N, T = args.envs, args.num_steps
     total_updates = args.steps + args.warmup
-    cfg = P.make_config(env_kind=P.ENV_CARTPOLE, dist_kind=P.DIST_CATEGORICAL, obs_size=obs, head_dims=(act,), num_envs=N, num_steps=T,
-                        num_minibatches=4, update_epochs=10, max_episode_steps=500, seed=2, total_timesteps=total_updates * N * T * world,
-                        env_offset=rank * N, global_num_envs=N * world, learning_rate=1e-3, gamma=0.98, gae_lambda=0.95, clip_coef=0.2,
-                        ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank)
+    cfg = P.dist.shard_config(P.make_config, rank, world, N * world, env_kind=P.ENV_CARTPOLE, dist_kind=P.DIST_CATEGORICAL, obs_size=obs,
+                              head_dims=(act,), num_steps=T, num_minibatches=4, update_epochs=10, max_episode_steps=500, seed=2,
+                              total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98, gae_lambda=0.95, clip_coef=0.2,
+                              ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank)
     ctx = P.Context(cfg)
-    if world > 1:
-        import torch
-        ident = [P.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        ctx.comm_init(ident[0], rank, world)
+    P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id)
     ctx.init_orthogonal(2)   # same seed on every rank: replicated weights
     ctx.env_reset()
 
@@ -143,10 +136,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(0)
     if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = P.dist.max_over_ranks(dist, dt)
     st = ctx.stats()
 
     if rank == 0:

@@ -244,6 +244,9 @@ PPO_API ppo_status ppo_profile_read(ppo_ctx* ctx, ppo_profile* out);  /* synchro
 #define PPO_COMM_ID_BYTES 128
 PPO_API ppo_status ppo_comm_unique_id(void* id_out_h /* PPO_COMM_ID_BYTES */);
 PPO_API ppo_status ppo_comm_init(ppo_ctx* ctx, const void* id_h, int32_t rank, int32_t nranks);
+/* Same contract without RCCL for contexts that live in ONE process (one host thread per context; up to 8): the ranks of
+ * `group_id` rendezvous inside each all-reduce and the last to arrive sums every rank's buffer in rank order on its stream. */
+PPO_API ppo_status ppo_comm_init_local(ppo_ctx* ctx, int64_t group_id, int32_t rank, int32_t nranks);
 
 #ifdef __cplusplus
 }

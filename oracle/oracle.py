@@ -280,6 +280,23 @@ def minibatch_grads(net, hp, params, b_obs, b_actions, b_logprobs, b_advantages,
     return grads, dict(zip(STAT_NAMES, list(stats)))
 
 
+def minibatch_grads_shard(net, hp, params, b_obs, b_actions, b_logprobs, b_advantages, b_returns, b_values, idx, global_M, adv_sums=None,
+                          b_mask=None):
+    """One shard of a data-parallel minibatch step: returns (grads scaled by 1/global_M, stats share, local advantage sums)."""
+    b_obs = _f32(b_obs).reshape(-1, net.obs_size)
+    b_actions = _f32(b_actions)
+    act_cols = 1 if b_actions.ndim == 1 else b_actions.shape[1]
+    idx = _i64(idx).ravel()
+    grads = np.empty(param_count(net), np.float32)
+    stats = (C.c_double * 6)()
+    local = (C.c_double * 2)()
+    sums = None if adv_sums is None else (C.c_double * 2)(float(adv_sums[0]), float(adv_sums[1]))
+    lib().orc_minibatch_grads_shard(C.byref(net), C.byref(hp), _p(_f32(params)), _p(b_obs), _p(b_actions), C.c_int32(act_cols),
+                                    _p(_u8(b_mask)), _p(_f32(b_logprobs)), _p(_f32(b_advantages)), _p(_f32(b_returns)),
+                                    _p(_f32(b_values)), _p(idx), C.c_int64(idx.size), sums, C.c_int64(global_M), _p(grads), stats, local)
+    return grads, dict(zip(STAT_NAMES, list(stats))), (local[0], local[1])
+
+
 def clip_grad_norm(net, grads, max_norm):
     g = _f32(grads).copy()
     total = lib().orc_clip_grad_norm(C.byref(net), _p(g), C.c_float(max_norm))

@@ -534,10 +534,27 @@ static void mlp_backward1(const orc_net* c, int net, const float* p, const float
     }
 }
 
+/* Data-parallel building block (no reference counterpart): the same minibatch step on ONE shard of a global
+ * minibatch.  adv_sums = {sum, sum of squares} of the advantages over the GLOBAL minibatch (NULL: use this shard's own),
+ * global_M = rows of the global minibatch.  Gradients and loss sums come out scaled by 1/global_M, so that a plain sum over
+ * shards equals the single-process result on the concatenated minibatch.  stats[] then holds this shard's share of each mean. */
+void orc_minibatch_grads_shard(const orc_net* c, const orc_hparams* hp, const float* params, const float* b_obs, const float* b_actions,
+                               int32_t act_cols, const uint8_t* b_mask, const float* b_logprobs, const float* b_advantages,
+                               const float* b_returns, const float* b_values, const int64_t* idx, int64_t M, const double* adv_sums,
+                               int64_t global_M, float* grads, double stats[6], double local_adv_sums[2]);
+
 void orc_minibatch_grads(const orc_net* c, const orc_hparams* hp, const float* params, const float* b_obs, const float* b_actions,
                          int32_t act_cols, const uint8_t* b_mask, const float* b_logprobs, const float* b_advantages,
                          const float* b_returns, const float* b_values, const int64_t* idx, int64_t M, float* grads,
                          double stats[6]) {
+    orc_minibatch_grads_shard(c, hp, params, b_obs, b_actions, act_cols, b_mask, b_logprobs, b_advantages, b_returns, b_values, idx, M,
+                              NULL, M, grads, stats, NULL);
+}
+
+void orc_minibatch_grads_shard(const orc_net* c, const orc_hparams* hp, const float* params, const float* b_obs, const float* b_actions,
+                               int32_t act_cols, const uint8_t* b_mask, const float* b_logprobs, const float* b_advantages,
+                               const float* b_returns, const float* b_values, const int64_t* idx, int64_t M, const double* adv_sums,
+                               int64_t global_M, float* grads, double stats[6], double local_adv_sums[2]) {
     const int A = act_total(c);
     const int64_t P = orc_param_count(c);
     const int64_t Pc = net_size(c, 0);
@@ -549,19 +566,31 @@ void orc_minibatch_grads(const orc_net* c, const orc_hparams* hp, const float* p
 
     /* advantage normalisation statistics over the minibatch, PPO_Discrete.cpp:591-594 (std is Bessel-corrected) */
     float mean_f = 0.0f, std_f = 0.0f;
+    {
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t j = 0; j < M; j++) { double a = b_advantages[idx[j]]; s1 += a; s2 += a * a; }
+        if (local_adv_sums) { local_adv_sums[0] = s1; local_adv_sums[1] = s2; }
+    }
     if (hp->norm_adv) {
-        double s = 0.0;
-        for (int64_t j = 0; j < M; j++) s += b_advantages[idx[j]];
-        double mean = s / (double)M;
-        double ss = 0.0;
-        for (int64_t j = 0; j < M; j++) { double d = b_advantages[idx[j]] - mean; ss += d * d; }
-        mean_f = (float)mean;
-        std_f = (float)sqrt(ss / (double)(M - 1));
+        if (adv_sums) {  /* global statistics supplied by the caller (summed over shards) */
+            double mean = adv_sums[0] / (double)global_M;
+            double var = (adv_sums[1] - adv_sums[0] * mean) / (double)(global_M - 1);
+            mean_f = (float)mean;
+            std_f = (float)sqrt(var > 0.0 ? var : 0.0);
+        } else {
+            double s = 0.0;
+            for (int64_t j = 0; j < M; j++) s += b_advantages[idx[j]];
+            double mean = s / (double)M;
+            double ss = 0.0;
+            for (int64_t j = 0; j < M; j++) { double d = b_advantages[idx[j]] - mean; ss += d * d; }
+            mean_f = (float)mean;
+            std_f = (float)sqrt(ss / (double)(M - 1));
+        }
     }
 
     double s_pg = 0, s_v = 0, s_ent = 0, s_kl = 0;
     int64_t n_clip = 0;
-    const float invM = 1.0f / (float)M;
+    const float invM = 1.0f / (float)global_M;
     float* actsA = (float*)malloc((size_t)c->n_hidden * c->hidden * sizeof(float));
     float* actsC = (float*)malloc((size_t)c->n_hidden * c->hidden * sizeof(float));
     for (int64_t j = 0; j < M; j++) {
@@ -645,12 +674,12 @@ void orc_minibatch_grads(const orc_net* c, const orc_hparams* hp, const float* p
     free(actsA); free(actsC);
     for (int64_t k = 0; k < P; k++) grads[k] = (float)g[k];
     free(g);
-    float pg = (float)(s_pg / (double)M);
-    float vl = 0.5f * (float)(s_v / (double)M);
-    float el = (float)(s_ent / (double)M);
+    float pg = (float)(s_pg / (double)global_M);
+    float vl = 0.5f * (float)(s_v / (double)global_M);
+    float el = (float)(s_ent / (double)global_M);
     stats[0] = pg; stats[1] = vl; stats[2] = el;
-    stats[3] = (float)(s_kl / (double)M);
-    stats[4] = (float)n_clip / (float)M; /* PPO_Discrete.cpp:349 */
+    stats[3] = (float)(s_kl / (double)global_M);
+    stats[4] = (float)n_clip / (float)global_M; /* PPO_Discrete.cpp:349 */
     stats[5] = (pg - hp->ent_coef * el) + vl * hp->vf_coef; /* :631 */
 }
 

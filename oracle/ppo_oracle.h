@@ -107,6 +107,11 @@ void orc_minibatch_grads(const orc_net*, const orc_hparams*, const float* params
                          int32_t act_cols, const uint8_t* b_mask, const float* b_logprobs, const float* b_advantages,
                          const float* b_returns, const float* b_values, const int64_t* idx, int64_t M, float* grads,
                          double stats[6]);
+/* One shard of a data-parallel minibatch step (see ppo_oracle.c): global advantage sums in, 1/global_M-scaled gradients out. */
+void orc_minibatch_grads_shard(const orc_net*, const orc_hparams*, const float* params, const float* b_obs, const float* b_actions,
+                               int32_t act_cols, const uint8_t* b_mask, const float* b_logprobs, const float* b_advantages,
+                               const float* b_returns, const float* b_values, const int64_t* idx, int64_t M, const double* adv_sums,
+                               int64_t global_M, float* grads, double stats[6], double local_adv_sums[2]);
 /* torch::nn::utils::clip_grad_norm_ (LibTorch clip_grad.h:22-85, called at PPO_Discrete.cpp:640). Returns total_norm. */
 double orc_clip_grad_norm(const orc_net*, float* grads, float max_norm);
 /* torch::optim::AdamW::step (PPO_Discrete.cpp:76-78,641; eps 1e-5f, betas .9/.999, weight_decay 1e-2). step_t is 1-based. */

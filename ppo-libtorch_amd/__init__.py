@@ -9,5 +9,5 @@ Layout
 The directory name carries a hyphen (repo convention), so it is imported through `__graft_entry__.load_package()`
 under the module name `ppo_libtorch_amd`.
 """
-from . import binding  # noqa: F401
+from . import binding, dist  # noqa: F401
 from .binding import *  # noqa: F401,F403

@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "ppo_rollout", "ppo_calc_advantage", "ppo_gae", "ppo_nstep_returns", "ppo_generate_permutations",
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",
     "ppo_read_stats", "ppo_set_learning_rate", "ppo_profile_enable", "ppo_profile_read", "ppo_comm_unique_id", "ppo_comm_init",
+    "ppo_comm_init_local",
 ]
 
 
@@ -340,6 +341,13 @@ class Context:
     def comm_init(self, unique_id, rank, nranks):
         buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         _check(lib().ppo_comm_init(self.h, buf, C.c_int32(rank), C.c_int32(nranks)), self.h)
+
+
+def _comm_init_local(self, group_id, rank, nranks):
+    _check(lib().ppo_comm_init_local(self.h, C.c_int64(group_id), C.c_int32(rank), C.c_int32(nranks)), self.h)
+
+
+Context.comm_init_local = _comm_init_local
 
 
 def comm_unique_id():

@@ -9,6 +9,9 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -50,6 +53,26 @@ static bool load(std::string& err) {
 }
 }  // namespace rccl
 
+// ---------------------------------------------------------------------------------------------------------
+// In-process communicator: several contexts of ONE process (one host thread each) on one or more GPUs.  Same semantics as
+// the RCCL path -- every rank calls the all-reduce, the sum is formed in rank order (deterministic) -- without any RCCL:
+// the last rank to arrive runs one kernel on its own stream that reads every rank's buffer and writes the sum back to all.
+// ---------------------------------------------------------------------------------------------------------
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, joined = 0;
+    uint64_t generation = 0;
+    void* bufs[8] = {};
+    hipEvent_t ready[8] = {};
+    hipEvent_t done[2] = { nullptr, nullptr };
+};
+static std::map<int64_t, std::shared_ptr<LocalGroup>> g_local_groups;
+static std::mutex g_local_groups_mu;
+struct PtrPack { void* p[8]; };
+hipError_t launch_local_allreduce(const PtrPack& pk, int n, size_t count, bool f64, hipStream_t s);
+
 struct ppo_ctx {
     ppo_config cfg{};
     NetLayout L{};
@@ -61,6 +84,8 @@ struct ppo_ctx {
     int n_mb = 0, steps_per_update = 0;
     int world = 1, rank = 0;
     rccl::Comm comm = nullptr;
+    std::shared_ptr<LocalGroup> lgroup;   // in-process communicator (exclusive with comm)
+    hipEvent_t lg_ready = nullptr;
 
     std::vector<void*> allocs;
     void* buf[PPO_BUF_COUNT_] = {};
@@ -263,6 +288,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && rccl::CommDestroy) rccl::CommDestroy(c->comm);
+    if (c->lg_ready) hipEventDestroy(c->lg_ready);
     for (auto& sp : c->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     for (void* p : c->allocs) hipFree(p);
@@ -744,6 +770,31 @@ static AdamCoef adam_coef(double lr, int64_t t) {
 
 static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
     if (c->world <= 1) return PPO_OK;
+    if (c->lgroup) {
+        LocalGroup* g = c->lgroup.get();
+        HIPCHK(c, hipEventRecord(c->lg_ready, c->stream));
+        uint64_t my_gen;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->bufs[c->rank] = buf;
+            g->ready[c->rank] = c->lg_ready;
+            my_gen = g->generation;
+            if (++g->arrived == g->n) {
+                for (int r = 0; r < g->n; r++) HIPCHK(c, hipStreamWaitEvent(c->stream, g->ready[r], 0));
+                PtrPack pk{};
+                for (int r = 0; r < g->n; r++) pk.p[r] = g->bufs[r];
+                HIPCHK(c, launch_local_allreduce(pk, g->n, count, f64, c->stream));
+                HIPCHK(c, hipEventRecord(g->done[my_gen & 1], c->stream));
+                g->arrived = 0;
+                g->generation++;
+                g->cv.notify_all();
+            } else {
+                g->cv.wait(lk, [&] { return g->generation != my_gen; });
+            }
+        }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, g->done[my_gen & 1], 0));
+        return PPO_OK;
+    }
     const int rc = rccl::AllReduce(buf, buf, count, f64 ? rccl::kFloat64 : rccl::kFloat32, rccl::kSum, c->comm, c->stream);
     if (rc != 0) return fail(c, PPO_ERR_COMM, "ncclAllReduce failed: %s", rccl::GetErrorString ? rccl::GetErrorString(rc) : "?");
     return PPO_OK;
@@ -1003,6 +1054,36 @@ extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, 
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int rc = rccl::CommInitRank(&c->comm, nranks, id, rank);
     if (rc != 0) return fail(c, PPO_ERR_COMM, "ncclCommInitRank failed: %s", rccl::GetErrorString ? rccl::GetErrorString(rc) : "?");
+    c->world = nranks;
+    c->rank = rank;
+    return PPO_OK;
+}
+
+// Joins the in-process group `group_id` as rank `rank` of `nranks` (all members live in this process, one host thread each).
+extern "C" ppo_status ppo_comm_init_local(ppo_ctx* c, int64_t group_id, int32_t rank, int32_t nranks) {
+    NEED(c, c != nullptr, "null ctx");
+    NEED(c, nranks >= 1 && nranks <= 8 && rank >= 0 && rank < nranks, "bad rank / nranks (in-process groups hold at most 8 contexts)");
+    NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
+    NEED(c, c->comm == nullptr && !c->lgroup, "context already has a communicator");
+    if (nranks == 1) { c->world = 1; c->rank = 0; return PPO_OK; }
+    std::shared_ptr<LocalGroup> g;
+    {
+        std::lock_guard<std::mutex> lk(g_local_groups_mu);
+        auto it = g_local_groups.find(group_id);
+        if (it == g_local_groups.end()) {
+            g = std::make_shared<LocalGroup>();
+            g->n = nranks;
+            HIPCHK(c, hipEventCreateWithFlags(&g->done[0], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&g->done[1], hipEventDisableTiming));
+            g_local_groups[group_id] = g;
+        } else {
+            g = it->second;
+        }
+        NEED(c, g->n == nranks, "group was created with a different size");
+        if (++g->joined == g->n) g_local_groups.erase(group_id);  // complete: the id may be reused by a later group
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&c->lg_ready, hipEventDisableTiming));
+    c->lgroup = g;
     c->world = nranks;
     c->rank = rank;
     return PPO_OK;

@@ -638,6 +638,17 @@ __global__ void permutation_kernel(int32_t* perm, int64_t B, int E, int64_t seed
     perm[(size_t)e * B + i] = (int32_t)x;
 }
 
+// In-process all-reduce: out[i] = bufs[0][i] + bufs[1][i] + ... (rank order), written back to every rank's buffer.
+struct PtrPack8 { void* p[8]; };
+template <class Tp>
+__global__ void local_allreduce_kernel(PtrPack8 pk, int n, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Tp acc = static_cast<const Tp*>(pk.p[0])[i];
+    for (int r = 1; r < n; r++) acc += static_cast<const Tp*>(pk.p[r])[i];
+    for (int r = 0; r < n; r++) static_cast<Tp*>(pk.p[r])[i] = acc;
+}
+
 // K11 partial sums: per block {sum y, sum y^2, sum d, sum d^2} with y = returns, d = returns - values (float subtraction).
 __global__ __launch_bounds__(256) void explained_variance_kernel(const float* __restrict__ returns, const float* __restrict__ values,
                                                                   int64_t B, double* out) {
@@ -728,5 +739,15 @@ hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, in
 
 hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s) {
     hipLaunchKernelGGL(explained_variance_kernel, dim3(64), dim3(256), 0, s, returns, values, B, sums4);
+    return hipGetLastError();
+}
+
+struct PtrPack { void* p[8]; };
+hipError_t launch_local_allreduce(const PtrPack& pk, int n, size_t count, bool f64, hipStream_t s) {
+    PtrPack8 q;
+    for (int i = 0; i < 8; i++) q.p[i] = pk.p[i];
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (f64) hipLaunchKernelGGL(local_allreduce_kernel<double>, grid, block, 0, s, q, n, count);
+    else hipLaunchKernelGGL(local_allreduce_kernel<float>, grid, block, 0, s, q, n, count);
     return hipGetLastError();
 }

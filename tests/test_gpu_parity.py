@@ -522,3 +522,102 @@ def test_errors_are_reported_like_the_reference(P):
         P.Context(P.make_config(obs_size=2))
     with pytest.raises(P.binding.PPOError, match="only the reference architecture"):
         P.Context(P.make_config(hidden=256, n_hidden=4))
+
+
+# ------------------------------------------------------------------------------------------- data parallel
+def test_sharded_rollout_equals_columns_of_the_global_rollout(P):
+    """Env sharding: RNG streams, the shared reset stream and the 'env 0 is reset twice' quirk are tied to GLOBAL env indices,
+    so shard r of a 2-way split reproduces columns [r*N/2, (r+1)*N/2) of the single-context rollout bit for bit."""
+    T, N = 64, 128
+    base = dict(num_steps=T, num_minibatches=4, update_epochs=1, seed=9, max_episode_steps=40, total_timesteps=T * N * 2)
+    whole = P.Context(P.make_config(num_envs=N, **base))
+    whole.init_orthogonal(4)
+    params = whole.get_params()
+    params[-130:] *= 25.0
+    whole.set_params(params)
+    whole.env_reset()
+    whole.rollout()
+    for r in range(2):
+        sh = P.Context(P.dist.shard_config(P.make_config, r, 2, N, **base))
+        sh.set_params(params)
+        sh.env_reset()
+        sh.rollout()
+        sl = slice(r * N // 2, (r + 1) * N // 2)
+        for name, shape in (("OBS", (T, N, 4)), ("ACTIONS", (T, N)), ("LOGPROBS", (T, N)), ("REWARDS", (T, N)), ("DONES", (T, N)), ("VALUES", (T, N))):
+            full = whole.read(name, shape)
+            part = sh.read(name, (T, N // 2) + shape[2:])
+            assert np.array_equal(full[:, sl].view(np.uint32) if full.dtype == np.float32 else full[:, sl], part.view(np.uint32) if part.dtype == np.float32 else part), (r, name)
+        assert np.array_equal(bits(whole.read("NEXT_OBS", (N, 4))[sl]), bits(sh.read("NEXT_OBS", (N // 2, 4))))
+        sh.close()
+    whole.close()
+
+
+def test_two_rank_update_equals_single_context(P):
+    """Two contexts (one host thread each) joined by the in-process communicator run the same protocol as the RCCL path:
+    advantage sums of the global minibatch, then ONE all-reduce of the 1/M_global-scaled gradient per optimizer step.
+    Losses, gradient and parameters equal the single-context step on the concatenated minibatch."""
+    import threading
+    g, meta = load("discrete_t128_n64_seed1")
+    T, N, U = meta["T"], meta["N"], "u1/"
+    rng = np.random.default_rng(3)
+    steps = []
+    for _ in range(3):
+        t_rows = rng.choice(T, 32, replace=False)
+        steps.append(np.array([t * N + e for t in t_rows for e in range(N)], np.int32))
+    # single context
+    one = make_ctx(P, meta)
+    _load_batch(one, g, U, meta)
+    one.set_params(g[U + "params_before"])
+    one.set_learning_rate(1e-3)
+    ref = []
+    for rows in steps:
+        grads = one.minibatch_forward_backward(rows)
+        st = one.stats()
+        one.optimizer_step()
+        ref.append((grads, st, one.get_params()))
+    one.close()
+    # two ranks
+    out = [None, None]
+    errors = []
+
+    def run(rank):
+        try:
+            n, off = P.dist.shard_envs(N, rank, 2)
+            ctx = make_ctx(P, meta, num_envs=n, env_offset=off, global_num_envs=N)
+            ctx.comm_init_local(1234, rank, 2)
+            sl = slice(off, off + n)
+            ctx.write("OBS", np.ascontiguousarray(g[U + "obs"][:, sl]))
+            ctx.write("ACTIONS", np.ascontiguousarray(g[U + "actions"].reshape(T, N, 1)[:, sl].astype(np.int32)))
+            for name, key in (("LOGPROBS", "logprobs"), ("VALUES", "values"), ("ADVANTAGES", "gae_advantages"), ("RETURNS", "gae_returns")):
+                ctx.write(name, np.ascontiguousarray(g[U + key][:, sl]))
+            ctx.set_params(g[U + "params_before"])
+            ctx.set_learning_rate(1e-3)
+            res = []
+            for rows in steps:
+                local = np.array(P.dist.local_rows_of_global_rows(rows, T, N, rank, 2), np.int32)
+                d = ctx.dev(local, np.int32)
+                P.binding._check(P.binding.lib().ppo_minibatch_forward_backward(ctx.h, d.ptr, __import__("ctypes").c_int64(local.size)), ctx.h)
+                P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
+                grads = ctx.read("GRADS")
+                ctx.optimizer_step()
+                res.append((grads, ctx.stats(), ctx.get_params()))
+            out[rank] = res
+            ctx.close()
+        except Exception as ex:  # surface failures of the worker threads
+            errors.append(ex)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(o is not None for o in out)
+    for k, (grads, st, params) in enumerate(ref):
+        for r in range(2):
+            g2, st2, p2 = out[r][k]
+            assert np.abs(g2 - grads).max() <= 2e-6 * max(1.0, np.abs(grads).max()), (k, r)
+            for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss", "total_norm"):
+                assert abs(st2[key] - st[key]) <= 2e-6 * max(1.0, abs(st[key])), (k, r, key, st2[key], st[key])
+            assert np.abs(p2 - params).max() <= 2e-6, (k, r)
+        assert np.array_equal(bits(out[0][k][2]), bits(out[1][k][2]))   # replicas stay bit-identical
