@@ -160,6 +160,11 @@ PPO_API ppo_status ppo_categorical(int32_t dist_kind, const float* logits, const
                            int32_t A, float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode,
                            void* stream);
 
+/* Categorical::sample / CategoricalMasked::sample (Categorical.cpp:73-79: multinomial(probs, 1, replacement = true)) on given
+ * m_probs [n,A]: inverse-CDF draw with the counter-based generator keyed by (seed; row_offset + row, step_index, head). */
+PPO_API ppo_status ppo_categorical_sample(const float* m_probs, int64_t n, int32_t A, int64_t seed, int64_t row_offset, int64_t step_index,
+                                  int32_t head, int64_t* sample, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Environments (Environments/CartPole.h, MountainCar.h) and their vectorised driver
  * ------------------------------------------------------------------------------------------------------- */

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "ppo_abi_version", "ppo_ctx_create", "ppo_ctx_destroy", "ppo_last_error", "ppo_sync", "ppo_stream", "ppo_get_config",
     "ppo_buffer", "ppo_device_alloc", "ppo_device_free", "ppo_memcpy_h2d", "ppo_memcpy_d2h", "ppo_param_count",
     "ppo_param_shapes", "ppo_params_init_orthogonal", "ppo_params_set_h", "ppo_params_get_h", "ppo_optimizer_set_h",
-    "ppo_optimizer_get_h", "ppo_get_value", "ppo_policy_act", "ppo_categorical", "ppo_env_transition",
+    "ppo_optimizer_get_h", "ppo_get_value", "ppo_policy_act", "ppo_categorical", "ppo_categorical_sample", "ppo_env_transition",
     "ppo_cartpole_reset_stream_h", "ppo_env_reset", "ppo_env_step", "ppo_env_set_state_h", "ppo_env_get_state_h",
     "ppo_rollout", "ppo_calc_advantage", "ppo_gae", "ppo_nstep_returns", "ppo_generate_permutations",
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",

@@ -607,6 +607,12 @@ extern "C" ppo_status ppo_categorical(int32_t dist_kind, const float* logits, co
     return launch_categorical(dist_kind, logits, mask, value, n, A, m_logits, m_probs, log_prob, entropy, mode, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
 }
 
+extern "C" ppo_status ppo_categorical_sample(const float* m_probs, int64_t n, int32_t A, int64_t seed, int64_t row_offset, int64_t step_index,
+                                             int32_t head, int64_t* sample, void* stream) {
+    if (!m_probs || !sample || n < 0) return PPO_ERR_INVALID;
+    return launch_categorical_sample(m_probs, n, A, seed, row_offset, step_index, head, sample, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Environments
 // ---------------------------------------------------------------------------------------------------------

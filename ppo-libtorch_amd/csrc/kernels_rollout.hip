@@ -433,6 +433,16 @@ __global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restr
     }
 }
 
+__global__ void categorical_sample_kernel(const float* __restrict__ probs, int64_t n, int A, int64_t seed, int64_t row_offset,
+                                          int64_t step_index, int head, int64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p[PPO_MAX_ACT];
+    for (int a = 0; a < A; a++) p[a] = probs[i * A + a];
+    const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(row_offset + i), (uint32_t)step_index, (uint32_t)head, 0u);
+    out[i] = sample_head(p, A, (float)(w.x >> 8) * 0x1p-24f);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -563,5 +573,13 @@ hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_r
                                       EpisodeRing* ring, hipStream_t s) {
     hipLaunchKernelGGL(episode_count_kernel, dim3((unsigned)T), dim3(256), 0, s, fin_len, N, row_counts, group_bits);
     hipLaunchKernelGGL(episode_push_kernel, dim3(1), dim3(64), 0, s, fin_len, fin_rew, T, N, row_counts, group_bits, ring);
+    return hipGetLastError();
+}
+
+hipError_t launch_categorical_sample(const float* probs, int64_t n, int A, int64_t seed, int64_t row_offset, int64_t step_index, int head,
+                                     int64_t* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (A < 1 || A > PPO_MAX_ACT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(categorical_sample_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, probs, n, A, seed, row_offset, step_index, head, out);
     return hipGetLastError();
 }

@@ -340,6 +340,9 @@ hipError_t launch_policy_act(const float* params, const NetLayout& L, int dist_k
 hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n, int A,
                               float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode, hipStream_t s);
 
+hipError_t launch_categorical_sample(const float* probs, int64_t n, int A, int64_t seed, int64_t row_offset, int64_t step_index, int head,
+                                     int64_t* out, hipStream_t s);
+
 hipError_t launch_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
                       const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
                       hipStream_t s);
