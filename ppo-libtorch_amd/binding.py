@@ -379,6 +379,12 @@ def gae(ctx, rewards, values, dones, next_value, next_done, gamma, gae_lambda, n
     return out
 
 
+def gae_launch(ctx, d_rewards, d_values, d_dones, d_next_value, d_next_done, T, N, gamma, gae_lambda, d_adv, d_ret):
+    """Enqueues the scan on device arrays that already live in HBM (no copies, no synchronisation)."""
+    _check(lib().ppo_gae(d_rewards.ptr, d_values.ptr, d_dones.ptr, d_next_value.ptr, d_next_done.ptr, C.c_int64(T), C.c_int64(N), C.c_float(gamma),
+                         C.c_float(gae_lambda), d_adv.ptr, d_ret.ptr, C.c_void_p(ctx.stream())), ctx.h)
+
+
 def env_transition(ctx, env_kind, state, action):
     state = np.ascontiguousarray(state, np.float32)
     n, O = state.shape

@@ -18,6 +18,8 @@
 // handling in the serial walk and costs nothing.
 // Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done).  v_{t+1} is read
 // a second time by the thread that forms delta_t, but that row is being loaded as v_t by a neighbour: an L1/L2 hit.
+#include <cstdlib>
+
 #include "ppo_internal.hpp"
 
 namespace {
@@ -123,26 +125,27 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         if (walker) {
             float last = carry;
             int r = rows;
-            while (r > 0) {
-                const int k = r >= GAE_WALK ? GAE_WALK : r;
+            // full chunks: unconditional code (16 + 16 LDS reads in flight, then the 16-step mul/add chain, then 16 writes);
+            // a per-element guard here costs more than the chain itself (12 us -> 4.9 us at 4096 x 128)
+            while (r >= GAE_WALK) {
                 float d[GAE_WALK], cc[GAE_WALK];
 #pragma unroll
                 for (int i = 0; i < GAE_WALK; i++) {
-                    const int rr = r - 1 - i;
-                    d[i] = i < k ? sA[rr * EPB + tid] : 0.0f;
-                    cc[i] = i < k ? sC[rr * EPB + tid] : 0.0f;
+                    d[i] = sA[(r - 1 - i) * EPB + tid];
+                    cc[i] = sC[(r - 1 - i) * EPB + tid];
                 }
 #pragma unroll
                 for (int i = 0; i < GAE_WALK; i++) {
-                    if (i < k) {
-                        last = d[i] + cc[i] * last;
-                        d[i] = last;
-                    }
+                    last = d[i] + cc[i] * last;
+                    d[i] = last;
                 }
 #pragma unroll
-                for (int i = 0; i < GAE_WALK; i++)
-                    if (i < k) sA[(r - 1 - i) * EPB + tid] = d[i];
-                r -= k;
+                for (int i = 0; i < GAE_WALK; i++) sA[(r - 1 - i) * EPB + tid] = d[i];
+                r -= GAE_WALK;
+            }
+            for (; r > 0; r--) {   // ragged tail (T not a multiple of 16)
+                last = sA[(r - 1) * EPB + tid] + sC[(r - 1) * EPB + tid] * last;
+                sA[(r - 1) * EPB + tid] = last;
             }
             carry = last;
         }
@@ -191,8 +194,10 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     const bool vec_ok = (N % 4 == 0) && al16(rewards) && al16(values) && al16(dones) && al16(next_value) && al16(next_done) &&
                         al16(adv) && al16(ret);
     // Strip width: wide strips coalesce better (EPB*4-byte rows), narrow strips give more workgroups.  Keep >= ~2 per CU.
-    int epb = 32;                    // 48 KB of LDS per workgroup: three workgroups per CU overlap load / walk / store phases
-    if (N / 32 < 512) epb = 16;      // small N: more, narrower strips so every CU gets a workgroup
+    // Strip width, measured on MI355X (tools/gae_sweep.py): 32 columns (48 KB of LDS, three workgroups per CU overlapping their
+    // load / walk / store phases) is best from 32 768 envs up (4.5 TB/s); below ~8 192 envs 16 columns give every CU a workgroup.
+    int epb = N >= 8192 ? 32 : 16;
+    if (const char* e = getenv("PPO_GAE_EPB")) epb = atoi(e);   // tuning knob
 #define PPO_GAE_LAUNCH(EPB)                                                                                                   \
     do {                                                                                                                      \
         const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \
@@ -203,7 +208,8 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
             hipLaunchKernelGGL((gae_kernel<EPB, MODE, false>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
                                (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
     } while (0)
-    if (epb == 32) PPO_GAE_LAUNCH(32);
+    if (epb == 64) PPO_GAE_LAUNCH(64);
+    else if (epb == 32) PPO_GAE_LAUNCH(32);
     else PPO_GAE_LAUNCH(16);
 #undef PPO_GAE_LAUNCH
     return hipGetLastError();
