@@ -435,8 +435,9 @@ void orc_act(const orc_net* c, const float* params, const float* x, const uint8_
             int Ah = c->head_dims[h];
             categorical_row(c->dist_kind, logits + off, mask ? mask + i * A + off : NULL, Ah, ml, mp, &e1);
             uint32_t w[4];
-            orc_philox4x32((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(env_offset + i), (uint32_t)step, (uint32_t)h, 0u, w);
-            float u = (float)(w[0] >> 8) * 0x1p-24f;
+            /* one Philox call feeds four consecutive steps: counter (row, step / 4, head, 0), word step % 4 */
+            orc_philox4x32((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(env_offset + i), (uint32_t)((uint64_t)step >> 2), (uint32_t)h, 0u, w);
+            float u = (float)(w[step & 3] >> 8) * 0x1p-24f;
             int a = 0, last = 0;
             float acc = 0.0f;
             int hit = 0;

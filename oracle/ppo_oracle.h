@@ -86,7 +86,7 @@ void orc_categorical(int32_t dist_kind, const float* logits, const uint8_t* mask
 void orc_evaluate(const orc_net*, const float* params, const float* x, const uint8_t* mask, const int64_t* action, int64_t n,
                   float* logprob, float* entropy, float* value);
 /* Sampling with the build's own generator: inverse-CDF on softmax probabilities with
- * u = philox(seed; env, step, head, 0).x >> 8 scaled by 2^-24.  (The reference samples with torch::multinomial on
+ * u = word (step % 4) of philox(seed; env, step / 4, head, 0), >> 8, scaled by 2^-24.  (The reference samples with torch::multinomial on
  * LibTorch's global CPU generator, Categorical.cpp:73-79 -- not reproducible off that generator.) */
 void orc_act(const orc_net*, const float* params, const float* x, const uint8_t* mask, int64_t n, int64_t seed,
              int64_t env_offset, int64_t step, int64_t* action, float* logprob, float* entropy, float* value);

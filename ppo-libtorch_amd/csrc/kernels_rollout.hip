@@ -38,7 +38,7 @@ __device__ __forceinline__ float trunk_forward(const LaneNet<OBS>& n, const floa
 #pragma unroll
     for (int k = 0; k < OBS; k++) z = __builtin_fmaf(obs[k], n.w1[k], z);
     __syncthreads();  // previous readers of lds are done (single-wave workgroup: a wait, no s_barrier)
-    lds[lane] = tanhf(z);
+    lds[lane] = tanhf(z);   // library tanh: the branch-free tanh_fast lets the scheduler stretch live ranges past the 128-VGPR budget here
     __syncthreads();
     float acc = n.b2;
     const float4* h4 = reinterpret_cast<const float4*>(lds);
@@ -86,13 +86,14 @@ __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const N
         for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) mx = z[a] > mx ? z[a] : mx;
         float se = 0.0f;
 #pragma unroll
-        for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) { pr[a] = expf(z[a] - mx); se += pr[a]; }
-        const float lse = logf(se) + mx;
+        for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) { pr[a] = fast_exp(z[a] - mx); se += pr[a]; }
+        const float lse = fast_log(se) + mx;
+        const float rse = __builtin_amdgcn_rcpf(se);
         float ent = 0.0f;
 #pragma unroll
         for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) {
             z[a] = z[a] - lse;          // m_logits
-            pr[a] = pr[a] / se;         // m_probs
+            pr[a] = pr[a] * rse;        // m_probs
             if (DIST == PPO_DIST_CATEGORICAL) {
                 const float l = z[a] > 1.17549435e-38f ? z[a] : 1.17549435e-38f;  // clamp(m_logits, FLT_MIN), Categorical.cpp:115
                 ent += l * pr[a];
@@ -103,9 +104,11 @@ __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const N
         }
         ent = -ent;
         if (sample) {
-            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)step_index,
+            // one Philox call feeds four consecutive steps: counter (row, step / 4, head, 0), word step % 4
+            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)(step_index >> 2),
                                           (uint32_t)h, 0u);
-            const float u = (float)(w.x >> 8) * 0x1p-24f;
+            const uint32_t wsel = (step_index & 3) == 0 ? w.x : ((step_index & 3) == 1 ? w.y : ((step_index & 3) == 2 ? w.z : w.w));
+            const float u = (float)(wsel >> 8) * 0x1p-24f;
             int pick = 0, last = 0;
             float acc = 0.0f;
             bool hit = false;
@@ -439,8 +442,9 @@ __global__ void categorical_sample_kernel(const float* __restrict__ probs, int64
     if (i >= n) return;
     float p[PPO_MAX_ACT];
     for (int a = 0; a < A; a++) p[a] = probs[i * A + a];
-    const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(row_offset + i), (uint32_t)step_index, (uint32_t)head, 0u);
-    out[i] = sample_head(p, A, (float)(w.x >> 8) * 0x1p-24f);
+    const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(row_offset + i), (uint32_t)(step_index >> 2), (uint32_t)head, 0u);
+    const uint32_t wsel = (step_index & 3) == 0 ? w.x : ((step_index & 3) == 1 ? w.y : ((step_index & 3) == 2 ? w.z : w.w));
+    out[i] = sample_head(p, A, (float)(wsel >> 8) * 0x1p-24f);
 }
 
 }  // namespace

@@ -28,10 +28,6 @@ constexpr int LS = 68;              // padded LDS row stride (floats)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-// exp / log on the hardware exp2 / log2 units (v_exp_f32, v_log_f32; ~1 ULP of the base-2 result): the loss only needs them to
-// ~1e-6 relative (north_star: losses within 1e-5), and the correctly rounded library versions cost ~10x the instructions.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -100.0f) * 1.4426950408889634f); }
-__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ int umap(int r, int hi, int t) { return (r & 3) + 8 * (r >> 2) + 4 * hi + 32 * t; }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

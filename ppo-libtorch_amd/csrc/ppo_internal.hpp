@@ -262,6 +262,10 @@ __device__ __forceinline__ int sample_head(const float* p, int A, float u) {
 // tanh for the update kernels: branch-free, ~3 ULP.  |x| >= 0.12: (1 - t) / (1 + t) with t = exp(-2|x|) on the hardware
 // exp2 / rcp (v_exp_f32, v_rcp_f32); below that the odd Taylor polynomial to x^7 (truncation < 2e-9 relative at 0.12) avoids the
 // cancellation in 1 - t.  The clamp keeps the exp2 argument inside the range where v_exp_f32 needs no denormal pre-scaling.
+// exp / log on the hardware exp2 / log2 units (v_exp_f32, v_log_f32; ~1 ULP of the base-2 result).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -100.0f) * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 __device__ __forceinline__ float tanh_fast(float x) {
     const float ax = fminf(fabsf(x), 20.0f);
     const float t = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);   // exp(-2|x|)
@@ -273,10 +277,20 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return ax < 0.12f ? small : bigs;
 }
 
+// Wave-wide float sum, result in every lane, on the DPP cross-lane network (no LDS crossbar round trips, which cost ~100+
+// cycles each and are on the rollout's per-step dependency chain): butterfly inside each row of 16 lanes with
+// quad_perm / row_half_mirror / row_mirror, then the four row sums are read through scalar registers.  Fixed order.
+#define PPO_DPP_ADD(v, CTRL) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xf, 0xf, false)))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = PPO_DPP_ADD(v, 0xB1);    // quad_perm:[1,0,3,2]
+    v = PPO_DPP_ADD(v, 0x4E);    // quad_perm:[2,3,0,1]
+    v = PPO_DPP_ADD(v, 0x141);   // row_half_mirror
+    v = PPO_DPP_ADD(v, 0x140);   // row_mirror: every lane of a row now holds the row's sum
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return ((r0 + r1) + r2) + r3;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
