@@ -42,18 +42,41 @@ def flops_per_sample(obs, act):
     return 3 * 2 * macs
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch of the kernel whose name starts with `prefix`, from the newest committed rocprofv3 --pmc summary
+    (profiles/*_pmc_per_dispatch.json, written by tools/collect_profiles.sh: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
+    passes).  Counters cannot be read from inside the timed run, so this is the committed measurement of the same command, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_dispatch.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            d = json.load(fh)
+        for k, v in d.items():
+            if k.startswith(prefix) and "hbm_read_bytes" in v and "hbm_write_bytes" in v:
+                return {"bytes": v["hbm_read_bytes"] + v["hbm_write_bytes"], "read": v["hbm_read_bytes"], "write": v["hbm_write_bytes"],
+                        "source": "profiles/" + os.path.basename(files[-1])}
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(num_envs, num_steps, obs, act):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     cores = os.cpu_count() or 1
     if os.path.exists(ref):
         try:
-            updates = 2
+            # bounded sample (~20 s on the GPU box's host cores): one full update iteration on a quarter of the envs; env-steps/s of the
+            # reference's ThreadPool path is per-env-step work, so the rate carries to the full workload (measured 7.0k at 4096 envs x 2)
+            updates = 1
+            num_envs = min(num_envs, 1024)
             out = subprocess.run([ref, "bench", str(num_envs), str(num_steps), str(updates)], capture_output=True, text=True, timeout=900).stdout
             m = re.search(r"REF_BENCH (\{.*\})", out)
             if m:
                 r = json.loads(m.group(1))
                 return {"value": r["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(r["threads"]), "kind": "reference",
-                        "sample": "%d full update iterations (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch "
+                        "sample": "%d full update iteration(s) (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch "
                                   "CPU, ThreadPool(hardware_concurrency), %d envs x %d steps" % (updates, num_envs, num_steps)}
         except Exception as ex:  # fall through to the port
             sys.stderr.write("reference harness failed: %r\n" % (ex,))
@@ -154,10 +177,10 @@ def main():
                                    % (N, T, 1 if world == 1 else 2), "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
                        "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 RCCL grad all-reduce per optimizer step)" % world},
             "roofline": {"kernel": "fwd_bwd_kernel (gather+forward+PPO loss+backward, fp32)", "bound": "mfma", "achieved": fl / (fb_ms * 1e-3) / 1e12,
-                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": None,
+                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": pmc_traffic("fwd_bwd_mfma_kernel"),
                          "flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"]},
             "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_bytes / (gae_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": gae_bytes,
+                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("gae_kernel"), "bytes_per_launch": gae_bytes,
                              "avg_launch_ms": gae_ms, "launches": prof["gae_launches"]},
             "phase_ms_per_step": {"rollout": prof["rollout_ms"] / args.steps, "gae": prof["gae_ms"] / args.steps, "fwd_bwd": prof["fwd_bwd_ms"] / args.steps,
                                   "grad_reduce": prof["reduce_ms"] / args.steps, "clip_adamw": prof["optimizer_ms"] / args.steps},

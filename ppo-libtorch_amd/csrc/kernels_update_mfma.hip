@@ -83,7 +83,17 @@ __device__ __forceinline__ void store_dlayout(float* img, const float* v, int s,
         }                                                                                      \
     } while (0)
 
-template <int NET, int DIST, int OBS, int AMAX, bool STAMP>
+// tanh on the transcendental pipe: 1 - 2 / (1 + e^(2x)), five instructions (v_mul, v_exp, v_add, v_rcp, v_fma), absolute error
+// <= ~2e-7 (the library tanhf costs ~40 and a sign-symmetric form 14; 64 tanh per lane per tile made them half of the kernel's
+// vector instructions).  Saturates correctly: e = inf -> 1, e = 0 -> -1.
+__device__ __forceinline__ float tanh_mufu(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+
+// EXACT: the policy has ONE head of exactly AMAX actions (the reference's PPO_Discrete / MountainCar shapes): every head loop
+// folds at compile time.  Otherwise head count and widths are run-time values bounded by AMAX.
+template <int NET, int DIST, int OBS, int AMAX, bool EXACT, bool STAMP>
 __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
     unsigned long long ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long t_prev = 0;
@@ -91,7 +101,8 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     const NetLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, hi = lane >> 5;
-    const int AOUT = NET == 0 ? 1 : L.act;
+    const int AOUT = NET == 0 ? 1 : (EXACT ? AMAX : L.act);
+    const int n_heads = EXACT ? 1 : L.n_heads;
     const MfSmem m = mf_smem(OBS, AOUT);
     float* sW2 = smem + m.w2;
     float* sW2T = smem + m.w2t;
@@ -202,11 +213,11 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             s_oldlp = a.logprobs[row];
             s_adv = a.advantages[row];
 #pragma unroll
-            for (int h = 0; h < AMAX; h++) if (h < L.n_heads) act_s[h] = a.actions[(size_t)row * L.n_heads + h];
+            for (int h = 0; h < AMAX; h++) if (h < n_heads) act_s[h] = a.actions[(size_t)row * n_heads + h];
             if (DIST == PPO_DIST_MASKED && a.masks) {
                 s_maskbits = 0u;
 #pragma unroll
-                for (int k = 0; k < AMAX; k++) if (k < L.act) s_maskbits |= (a.masks[(size_t)row * L.act + k] ? 1u : 0u) << k;
+                for (int k = 0; k < AMAX; k++) if (k < AOUT) s_maskbits |= (a.masks[(size_t)row * AOUT + k] ? 1u : 0u) << k;
             }
         } else {
             s_ret = a.returns[row];
@@ -240,7 +251,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1op[t][stp], xb, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_fast(acc[r]);
+            for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_mufu(acc[r]);
         }
 
         MF_STAMP(2);   // layer 1 + tanh
@@ -265,7 +276,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[16 * tk + 4 * q + 3], acc, 0, 0, 0);
                 }
 #pragma unroll
-            for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_fast(acc[r]);
+            for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_mufu(acc[r]);
         }
 
         MF_STAMP(3);   // layer 2 MFMA + tanh
@@ -303,7 +314,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             if (valid && hi == 0) st0 += (double)lossv;
             dOut[0] = valid ? g_v : 0.0f;
         } else {
-            const int A = L.act;
+            const int A = AOUT;
             float z[AMAX], pr[AMAX];
             bool ok[AMAX];
 #pragma unroll
@@ -330,8 +341,8 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             int off = 0;
 #pragma unroll
             for (int h = 0; h < AMAX; h++) {
-                if (h >= L.n_heads) break;
-                const int Ah = L.head_dims[h];
+                if (h >= n_heads) break;
+                const int Ah = EXACT ? AMAX : L.head_dims[h];
                 const int act_h = act_s[h];
                 float mx = -INFINITY;
 #pragma unroll
@@ -380,8 +391,8 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             off = 0;
 #pragma unroll
             for (int h = 0; h < AMAX; h++) {
-                if (h >= L.n_heads) break;
-                const int Ah = L.head_dims[h];
+                if (h >= n_heads) break;
+                const int Ah = EXACT ? AMAX : L.head_dims[h];
                 const int act_h = act_s[h];
 #pragma unroll
                 for (int k = 0; k < AMAX; k++) if (k >= off && k < off + Ah) {
@@ -583,14 +594,13 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     }
 }
 
-template <int DIST, int OBS, int AMAX, bool STAMP>
+template <int DIST, int OBS, int AMAX, bool EXACT, bool STAMP>
 __global__ __launch_bounds__(MF_THREADS, 2) void fwd_bwd_mfma_kernel(UpdateArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor (the actor's loss makes its tiles dearer, so it
-    // gets the larger share of the workgroups)
+    // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor
     const int b = blockIdx.x;
-    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, STAMP>(a, smem, b, a.n_blocks[0]);
-    else mf_body<1, DIST, OBS, AMAX, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
+    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, true, STAMP>(a, smem, b, a.n_blocks[0]);
+    else mf_body<1, DIST, OBS, AMAX, EXACT, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
 
 }  // namespace
@@ -617,25 +627,36 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
         if (need > shmem) shmem = need;
     }
     const dim3 grid((unsigned)(a.n_blocks[0] + a.n_blocks[1])), block(MF_THREADS);
-#define PPO_LAUNCH_MF(DIST, OBS)                                                                                       \
+#define PPO_LAUNCH_MF(DIST, OBS, AMAX, EXACT)                                                                          \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, 4, false>), \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
             if (e == hipSuccess)                                                                                       \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, 4, true>),       \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        if (a.stamps) hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, 4, true>), grid, block, shmem, s, a);         \
-        else hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, 4, false>), grid, block, shmem, s, a);                 \
+        if (a.stamps) hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>), grid, block, shmem, s, a); \
+        else hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>), grid, block, shmem, s, a);       \
     } while (0)
+    // the reference's two shapes get fully folded head code: CartPole (obs 4, one head of 2) and MountainCar (obs 2, one masked
+    // head of 3); anything else with <= 4 logits runs the generic variant
+    const bool one = a.L.n_heads == 1;
     if (a.L.obs == 4) {
-        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 4); else PPO_LAUNCH_MF(PPO_DIST_MASKED, 4);
+        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) {
+            if (one && a.L.act == 2) PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 4, 2, true); else PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 4, 4, false);
+        } else {
+            PPO_LAUNCH_MF(PPO_DIST_MASKED, 4, 4, false);
+        }
     } else if (a.L.obs == 2) {
-        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 2); else PPO_LAUNCH_MF(PPO_DIST_MASKED, 2);
+        if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) {
+            PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 2, 4, false);
+        } else {
+            if (one && a.L.act == 3) PPO_LAUNCH_MF(PPO_DIST_MASKED, 2, 3, true); else PPO_LAUNCH_MF(PPO_DIST_MASKED, 2, 4, false);
+        }
     } else {
         return hipErrorNotSupported;
     }
