@@ -115,6 +115,7 @@ struct ppo_ctx {
     double actor_share = 0.5;       // share of the fwd/bwd workgroups given to the actor (measured: with 4 tiles per wave an uneven
                                     // split only moves the integer tile count of the slower side up; kept as a tuning knob)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
+    int mfma_prec = 1;               // 0: exact fp32 MFMA, 1: three-term bf16 split (env PPO_UPDATE_KERNEL=mfma_f32 selects 0)
     bool stamping = false;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
 
     // host-side training state
@@ -381,6 +382,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     {
         const char* k = getenv("PPO_UPDATE_KERNEL");
         c->use_mfma = (A <= 4) && !(k && std::strcmp(k, "valu") == 0);
+        c->mfma_prec = (k && std::strcmp(k, "mfma_f32") == 0) ? 0 : 1;
         const char* sh = getenv("PPO_ACTOR_SHARE");
         if (sh) c->actor_share = atof(sh);
 
@@ -827,11 +829,11 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
     a.slab = c->slab;
     a.stat_slab = c->stat_slab;
     a.stamps = c->stamping ? c->stamps : nullptr;
-    if (c->use_mfma) update_blocks_mfma((int)M, c->actor_share, a.n_blocks);
+    if (c->use_mfma) update_blocks_mfma((int)M, c->actor_share, c->mfma_prec, a.n_blocks);
     else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
         ProfScope ps(c, PROF_FWD_BWD);
-        if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
+        if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->mfma_prec, c->stream));
         else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
     {

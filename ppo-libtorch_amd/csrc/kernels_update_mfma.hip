@@ -21,10 +21,55 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MF_THREADS = 256;
-constexpr int MF_WAVES = 4;
 constexpr int MT = 32;              // samples per wave tile
 constexpr int LS = 68;              // padded LDS row stride (floats)
+constexpr int WS = 72;              // bf16 per padded row of a split weight operand (144 B: 16 rows x 16 B land on 16 distinct bank groups)
+
+// PREC selects the arithmetic of the three 64-wide contractions:
+//   PREC_F32    v_mfma_f32_32x32x2_f32: exact fp32 (an fmaf chain in k order).  On gfx950 this instruction runs at the vector fp32
+//               rate and, measured (tools/probes/mfma_coexec.hip), excludes every other vector instruction of the SIMD while it
+//               executes: matrix and vector time ADD, so the kernel cannot pass MFMA / (MFMA + VALU) of the fp32 matrix peak.
+//   PREC_BF16X3 fp32 operands are cut (by truncation, exactly: x = t1 + t2 + t3, 8 mantissa bits each) into three bf16 terms and
+//               every fp32 product a.b is issued as the six bf16 products a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 on
+//               v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped products are <= 3 x 2^-24 |a||b|, i.e. the result
+//               carries fp32 accuracy (no range loss: bf16 has the fp32 exponent).  16x the k-depth per instruction at half the
+//               cycles makes the matrix time ~2.7x smaller, and bf16 MFMAs do co-execute with vector instructions.
+constexpr int PREC_F32 = 0, PREC_BF16X3 = 1;
+__host__ __device__ constexpr int mf_waves(int prec) { return prec == PREC_BF16X3 ? 8 : 4; }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+// (x0, x1) -> three dwords of packed bf16 pairs (low half = x0's term), exact: x = t1 + t2 + t3 when the exponent does not underflow
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const uint32_t u0 = f2u(x0), u1 = f2u(x1);
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - u2f(u0 & 0xffff0000u), r1 = x1 - u2f(u1 & 0xffff0000u);
+    const uint32_t v0 = f2u(r0), v1 = f2u(r1);
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - u2f(v0 & 0xffff0000u), q1 = r1 - u2f(v1 & 0xffff0000u);
+    p3 = __builtin_amdgcn_perm(f2u(q1), f2u(q0), 0x07060302u);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// the six products of one (A chunk, B chunk) pair, small terms first
+__device__ __forceinline__ f32x16 mfma_x3(const u32x4 a1, const u32x4 a2, const u32x4 a3, const u32x4 b1, const u32x4 b2, const u32x4 b3, f32x16 acc) {
+    acc = mfma_bf16(a3, b1, acc);
+    acc = mfma_bf16(a1, b3, acc);
+    acc = mfma_bf16(a2, b2, acc);
+    acc = mfma_bf16(a2, b1, acc);
+    acc = mfma_bf16(a1, b2, acc);
+    acc = mfma_bf16(a1, b1, acc);
+    return acc;
+}
+// slot (chunk c, half h, element e) of hidden unit k inside a 64-wide operand row: unit U(r, h, t) sits at c = 2 t + (r >> 3), e = r & 7,
+// which is where a D-layout register vector presents it (register 8 c + e of half h)
+__host__ __device__ inline int slot_of_unit(int k) {
+    const int t = k >> 5, kk = k & 31, h = (kk >> 2) & 1, r = (kk & 3) | ((kk >> 3) << 2);
+    return (2 * t + (r >> 3)) * 16 + h * 8 + (r & 7);
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -38,12 +83,17 @@ __device__ __forceinline__ void wave_lds_fence() {
 struct MfSmem {
     int w2, w2t, w1, b1, b2, w3, b3, wave0, wave_stride, s_img, s_x, s_do, total;  // offsets in floats
 };
-__host__ __device__ inline MfSmem mf_smem(int obs, int aout) {
+__host__ __device__ inline MfSmem mf_smem(int obs, int aout, int prec) {
     MfSmem m;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    m.w2 = take(64 * LS);     // [n][k], padded rows
-    m.w2t = take(64 * LS);    // [k][n]
+    if (prec == PREC_BF16X3) {
+        m.w2 = take(3 * 64 * WS / 2);    // [term][n][slot of k]  bf16
+        m.w2t = take(3 * 64 * WS / 2);   // [term][k][slot of n]  bf16
+    } else {
+        m.w2 = take(64 * LS);     // [n][k], padded rows
+        m.w2t = take(64 * LS);    // [k][n]
+    }
     m.w1 = take(64 * obs);
     m.b1 = take(64);
     m.b2 = take(64);
@@ -56,7 +106,7 @@ __host__ __device__ inline MfSmem mf_smem(int obs, int aout) {
     m.s_x = takew(obs * MT);    // [o][sample]
     m.s_do = takew(aout * MT);  // [a][sample]
     m.wave_stride = w;
-    m.total = o + MF_WAVES * w;
+    m.total = o + mf_waves(prec) * w;
     return m;
 }
 
@@ -93,7 +143,11 @@ __device__ __forceinline__ float tanh_mufu(float x) {
 
 // EXACT: the policy has ONE head of exactly AMAX actions (the reference's PPO_Discrete / MountainCar shapes): every head loop
 // folds at compile time.  Otherwise head count and widths are run-time values bounded by AMAX.
-template <int NET, int DIST, int OBS, int AMAX, bool EXACT, bool STAMP>
+// Scheduling pin between an operand prefetch and the MFMA group it must stay ahead of: vector ALU, scalar and transcendental
+// instructions may still move across it, LDS reads and MFMAs may not.
+#define MF_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400)
+
+template <int NET, int DIST, int OBS, int AMAX, bool EXACT, int PREC, bool STAMP>
 __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
     unsigned long long ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long t_prev = 0;
@@ -103,7 +157,10 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     const int s = lane & 31, hi = lane >> 5;
     const int AOUT = NET == 0 ? 1 : (EXACT ? AMAX : L.act);
     const int n_heads = EXACT ? 1 : L.n_heads;
-    const MfSmem m = mf_smem(OBS, AOUT);
+    constexpr int MF_WAVES = mf_waves(PREC), MF_THREADS = 64 * MF_WAVES;
+    const MfSmem m = mf_smem(OBS, AOUT, PREC);
+    const uint16_t* sW2p = reinterpret_cast<const uint16_t*>(smem + m.w2);    // PREC_BF16X3 views
+    const uint16_t* sW2Tp = reinterpret_cast<const uint16_t*>(smem + m.w2t);
     float* sW2 = smem + m.w2;
     float* sW2T = smem + m.w2t;
     float* sW1 = smem + m.w1;
@@ -118,7 +175,28 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     const float* __restrict__ P = a.params;
 
     // ---- weights of this net -> LDS (once per launch) ----
-    {
+    if constexpr (PREC == PREC_BF16X3) {
+        // 4096 weights, 8 per thread: each is cut into its three bf16 terms once per launch and stored at its operand slot in the
+        // forward ([n][slot of k]) and the transposed ([k][slot of n]) image
+        uint16_t* wf = reinterpret_cast<uint16_t*>(smem + m.w2);
+        uint16_t* wt = reinterpret_cast<uint16_t*>(smem + m.w2t);
+        float wv[4096 / MF_THREADS];
+#pragma unroll
+        for (int i = 0; i < 4096 / MF_THREADS; i++) wv[i] = P[L.w2[NET] + tid + i * MF_THREADS];
+#pragma unroll
+        for (int i = 0; i < 4096 / MF_THREADS; i++) {
+            const int e = tid + i * MF_THREADS;
+            const int n = e >> 6, k = e & 63;
+            const uint32_t u0 = f2u(wv[i]);
+            const float r1 = wv[i] - u2f(u0 & 0xffff0000u);
+            const uint32_t u1 = f2u(r1);
+            const float r2 = r1 - u2f(u1 & 0xffff0000u);
+            const uint16_t t1 = (uint16_t)(u0 >> 16), t2 = (uint16_t)(u1 >> 16), t3 = (uint16_t)(f2u(r2) >> 16);
+            const int pf = n * WS + slot_of_unit(k), pt = k * WS + slot_of_unit(n);
+            wf[pf] = t1; wf[64 * WS + pf] = t2; wf[2 * 64 * WS + pf] = t3;
+            wt[pt] = t1; wt[64 * WS + pt] = t2; wt[2 * 64 * WS + pt] = t3;
+        }
+    } else {
         // 4096 weights, 16 per thread, every global load issued before the first LDS store
         float wv[16];
 #pragma unroll
@@ -257,26 +335,67 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         MF_STAMP(2);   // layer 1 + tanh
         // ---------------- layer 2 forward (MFMA): z2^T[n][s] = b2[n] + sum_k W2[n][k] h1[s][k] ----------------
         float h2[32];
+        if constexpr (PREC == PREC_BF16X3) {
+            // B operand = h1 itself (D layout): chunk c of the contraction is registers 8c .. 8c+7, cut into bf16 terms in place
+            uint32_t hp[3][16];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+            for (int j = 0; j < 16; j++) split3(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j], hp[2][j]);
+            auto aptr = [&](int g, int term) {   // g = 4 t + c: row n = s + 32 t of the forward image, chunk c, this lane's half
+                return reinterpret_cast<const u32x4*>(sW2p + term * 64 * WS + (s + 32 * (g >> 2)) * WS + (g & 3) * 16 + hi * 8);
+            };
             f32x16 acc;
+            u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1), an3 = *aptr(0, 2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 b = ld4(&sB2[8 * q + 4 * hi + 32 * t]);
-                acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
-            }
+            for (int g = 0; g < 8; g++) {
+                const int t = g >> 2, c = g & 3;
+                if (c == 0) {
 #pragma unroll
-            for (int tk = 0; tk < 2; tk++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 w = ld4(&sW2[(s + 32 * t) * LS + 8 * q + 4 * hi + 32 * tk]);  // W2[n][U(4q.., hi, tk)]
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, h1[16 * tk + 4 * q + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, h1[16 * tk + 4 * q + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, h1[16 * tk + 4 * q + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[16 * tk + 4 * q + 3], acc, 0, 0, 0);
+                    for (int qq = 0; qq < 4; qq++) {
+                        const float4 b = ld4(&sB2[8 * qq + 4 * hi + 32 * t]);
+                        acc[4 * qq] = b.x; acc[4 * qq + 1] = b.y; acc[4 * qq + 2] = b.z; acc[4 * qq + 3] = b.w;
+                    }
                 }
+                const u32x4 a1 = an1, a2 = an2, a3 = an3;
+                if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); an3 = *aptr(g + 1, 2); }
+                MF_PIN();
+                const u32x4 b1 = { hp[0][4 * c], hp[0][4 * c + 1], hp[0][4 * c + 2], hp[0][4 * c + 3] };
+                const u32x4 b2 = { hp[1][4 * c], hp[1][4 * c + 1], hp[1][4 * c + 2], hp[1][4 * c + 3] };
+                const u32x4 b3 = { hp[2][4 * c], hp[2][4 * c + 1], hp[2][4 * c + 2], hp[2][4 * c + 3] };
+                acc = mfma_x3(a1, a2, a3, b1, b2, b3, acc);
+                if (c == 3) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_mufu(acc[r]);
+                    for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_mufu(acc[r]);
+                }
+            }
+        } else
+        {
+            // 16 groups of 4 MFMAs (g = 8 t + 4 tk + q); the 16-byte weight operand of group g + 1 is read from LDS while group g
+            // runs (PIN keeps the scheduler from sinking the read back next to its use, where its ~120-cycle latency is exposed)
+            auto wptr = [&](int g) { return &sW2[(s + 32 * (g >> 3)) * LS + 8 * (g & 3) + 4 * hi + 32 * ((g >> 2) & 1)]; };  // W2[n][U(4q.., hi, tk)]
+            f32x16 acc;
+            float4 wn = ld4(wptr(0));
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const int t = g >> 3, tk = (g >> 2) & 1, q = g & 3;
+                if ((g & 7) == 0) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const float4 b = ld4(&sB2[8 * qq + 4 * hi + 32 * t]);
+                        acc[4 * qq] = b.x; acc[4 * qq + 1] = b.y; acc[4 * qq + 2] = b.z; acc[4 * qq + 3] = b.w;
+                    }
+                }
+                const float4 w = wn;
+                if (g + 1 < 16) wn = ld4(wptr(g + 1));
+                MF_PIN();
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, h1[16 * tk + 4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, h1[16 * tk + 4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, h1[16 * tk + 4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[16 * tk + 4 * q + 3], acc, 0, 0, 0);
+                if ((g & 7) == 7) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_mufu(acc[r]);
+                }
+            }
         }
 
         MF_STAMP(3);   // layer 2 MFMA + tanh
@@ -451,67 +570,167 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         }
 #pragma unroll
         for (int e = 0; e < 32; e++) dz2[e] = dz2[e] * (1.0f - h2[e] * h2[e]);
-        wave_lds_fence();  // dW3 reads of the image are done
-        store_dlayout(img, dz2, s, hi);
-        wave_lds_fence();
-        // A operands of dW2: dz2[sample 2 st + hi][unit s + 32 tn]  (lane index s plays the unit here)
-        float opA[2][16];
-#pragma unroll
-        for (int tn = 0; tn < 2; tn++)
-#pragma unroll
-            for (int stp = 0; stp < 16; stp++) opA[tn][stp] = img[(2 * stp + hi) * LS + s + 32 * tn];
-        {   // db2[n = s + 32 tn] = sum over samples
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                float c = 0.0f;
-#pragma unroll
-                for (int stp = 0; stp < 16; stp++) c += opA[tn][stp];
-                c += __shfl_xor(c, 32, 64);
-                gb2[tn] += c;
-            }
-        }
-        wave_lds_fence();
-        store_dlayout(img, h1, s, hi);
-        wave_lds_fence();
-        MF_STAMP(6);   // dz2, images, opA, db2
-        // ---------------- dW2[n][k] += sum_s dz2[s][n] h1[s][k] (MFMA, contraction over samples) ----------------
-#pragma unroll
-        for (int stp = 0; stp < 16; stp++) {
-            const float b0 = img[(2 * stp + hi) * LS + s];        // h1[sample][k = s]
-            const float b1 = img[(2 * stp + hi) * LS + s + 32];   // h1[sample][k = s + 32]
-            gW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][stp], b0, gW2[0][0], 0, 0, 0);
-            gW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][stp], b1, gW2[0][1], 0, 0, 0);
-            gW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[1][stp], b0, gW2[1][0], 0, 0, 0);
-            gW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[1][stp], b1, gW2[1][1], 0, 0, 0);
-        }
-
-        MF_STAMP(7);   // dW2 MFMA
-        // ---------------- dh1^T[k][s] = sum_n W2[n][k] dz2[s][n] (MFMA), dz1 = dh1 (1 - h1^2) ----------------
         float dz1[32];
+        if constexpr (PREC == PREC_BF16X3) {
+            // B operand of d(hidden 1): dz2 in place (D layout), cut into its bf16 terms before the registers are recycled
+            uint32_t zp[3][16];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+            for (int j = 0; j < 16; j++) split3(dz2[2 * j], dz2[2 * j + 1], zp[0][j], zp[1][j], zp[2][j]);
+            wave_lds_fence();  // dW3 reads of the image are done
+            store_dlayout(img, dz2, s, hi);
+            wave_lds_fence();
+            // A operand of dW2: dz2[sample 16 c + 8 hi + e][unit s + 32 tn]  (lane index s plays the unit here), fp32 for now
+            float opA[2][16];
 #pragma unroll
             for (int tn = 0; tn < 2; tn++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 w = ld4(&sW2T[(s + 32 * t) * LS + 8 * q + 4 * hi + 32 * tn]);  // W2[U(4q.., hi, tn)][k = s + 32 t]
+                for (int i = 0; i < 16; i++) opA[tn][i] = img[(16 * (i >> 3) + 8 * hi + (i & 7)) * LS + s + 32 * tn];
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {   // db2[n = s + 32 tn] = sum over samples
+                float c = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) c += opA[tn][i];
+                c += __shfl_xor(c, 32, 64);
+                gb2[tn] += c;
+            }
+            wave_lds_fence();
+            store_dlayout(img, h1, s, hi);
+            wave_lds_fence();
+            MF_STAMP(6);   // dz2, images, opA, db2
+            // ---------------- dW2[n][k] += sum_s dz2[s][n] h1[s][k]: two chunks of 16 samples, 24 MFMAs each ----------------
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                u32x4 A[2][3], B[2][3];
+#pragma unroll
+                for (int tk = 0; tk < 2; tk++) {
+                    float hb[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) hb[e] = img[(16 * c + 8 * hi + e) * LS + s + 32 * tk];   // h1[sample][k = s + 32 tk]
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t p1, p2, p3;
+                        split3(hb[2 * j], hb[2 * j + 1], p1, p2, p3);
+                        B[tk][0][j] = p1; B[tk][1][j] = p2; B[tk][2][j] = p3;
+                    }
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t p1, p2, p3;
+                        split3(opA[tn][8 * c + 2 * j], opA[tn][8 * c + 2 * j + 1], p1, p2, p3);
+                        A[tn][0][j] = p1; A[tn][1][j] = p2; A[tn][2][j] = p3;
+                    }
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                    for (int tk = 0; tk < 2; tk++)
+                        gW2[tn][tk] = mfma_x3(A[tn][0], A[tn][1], A[tn][2], B[tk][0], B[tk][1], B[tk][2], gW2[tn][tk]);
+            }
+            MF_STAMP(7);   // dW2 MFMA
+            // ---------------- dh1^T[k][s] = sum_n W2[n][k] dz2[s][n], dz1 = dh1 (1 - h1^2) ----------------
+            auto aptr = [&](int g, int term) {   // g = 4 t + c: row k = s + 32 t of the transposed image, chunk c of n, this lane's half
+                return reinterpret_cast<const u32x4*>(sW2Tp + term * 64 * WS + (s + 32 * (g >> 2)) * WS + (g & 3) * 16 + hi * 8);
+            };
+            f32x16 acc;
+            u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1), an3 = *aptr(0, 2);
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                const int t = g >> 2, c = g & 3;
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+                }
+                const u32x4 a1 = an1, a2 = an2, a3 = an3;
+                if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); an3 = *aptr(g + 1, 2); }
+                MF_PIN();
+                const u32x4 b1 = { zp[0][4 * c], zp[0][4 * c + 1], zp[0][4 * c + 2], zp[0][4 * c + 3] };
+                const u32x4 b2 = { zp[1][4 * c], zp[1][4 * c + 1], zp[1][4 * c + 2], zp[1][4 * c + 3] };
+                const u32x4 b3 = { zp[2][4 * c], zp[2][4 * c + 1], zp[2][4 * c + 2], zp[2][4 * c + 3] };
+                acc = mfma_x3(a1, a2, a3, b1, b2, b3, acc);
+                if (c == 3) {   // h1 comes back from its [sample][unit] image (still intact: dW2 only read it)
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const float4 hb = ld4(&img[s * LS + 8 * qq + 4 * hi + 32 * t]);
+                        dz1[16 * t + 4 * qq + 0] = acc[4 * qq + 0] * (1.0f - hb.x * hb.x);
+                        dz1[16 * t + 4 * qq + 1] = acc[4 * qq + 1] * (1.0f - hb.y * hb.y);
+                        dz1[16 * t + 4 * qq + 2] = acc[4 * qq + 2] * (1.0f - hb.z * hb.z);
+                        dz1[16 * t + 4 * qq + 3] = acc[4 * qq + 3] * (1.0f - hb.w * hb.w);
+                    }
+                }
+            }
+        } else {
+            wave_lds_fence();  // dW3 reads of the image are done
+            store_dlayout(img, dz2, s, hi);
+            wave_lds_fence();
+            // A operands of dW2: dz2[sample 2 st + hi][unit s + 32 tn]  (lane index s plays the unit here)
+            float opA[2][16];
+    #pragma unroll
+            for (int tn = 0; tn < 2; tn++)
+    #pragma unroll
+                for (int stp = 0; stp < 16; stp++) opA[tn][stp] = img[(2 * stp + hi) * LS + s + 32 * tn];
+            {   // db2[n = s + 32 tn] = sum over samples
+    #pragma unroll
+                for (int tn = 0; tn < 2; tn++) {
+                    float c = 0.0f;
+    #pragma unroll
+                    for (int stp = 0; stp < 16; stp++) c += opA[tn][stp];
+                    c += __shfl_xor(c, 32, 64);
+                    gb2[tn] += c;
+                }
+            }
+            wave_lds_fence();
+            store_dlayout(img, h1, s, hi);
+            wave_lds_fence();
+            MF_STAMP(6);   // dz2, images, opA, db2
+            // ---------------- dW2[n][k] += sum_s dz2[s][n] h1[s][k] (MFMA, contraction over samples) ----------------
+            {
+                float b0n = img[hi * LS + s], b1n = img[hi * LS + s + 32];   // h1[sample 2 stp + hi][k = s], [k = s + 32]; read one step ahead
+    #pragma unroll
+                for (int stp = 0; stp < 16; stp++) {
+                    const float b0 = b0n, b1 = b1n;
+                    if (stp + 1 < 16) { b0n = img[(2 * stp + 2 + hi) * LS + s]; b1n = img[(2 * stp + 2 + hi) * LS + s + 32]; }
+                    MF_PIN();
+                    gW2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][stp], b0, gW2[0][0], 0, 0, 0);
+                    gW2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][stp], b1, gW2[0][1], 0, 0, 0);
+                    gW2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[1][stp], b0, gW2[1][0], 0, 0, 0);
+                    gW2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[1][stp], b1, gW2[1][1], 0, 0, 0);
+                }
+            }
+
+            MF_STAMP(7);   // dW2 MFMA
+            // ---------------- dh1^T[k][s] = sum_n W2[n][k] dz2[s][n] (MFMA), dz1 = dh1 (1 - h1^2) ----------------
+            {
+                auto wptr = [&](int g) { return &sW2T[(s + 32 * (g >> 3)) * LS + 8 * (g & 3) + 4 * hi + 32 * ((g >> 2) & 1)]; };  // W2[U(4q.., hi, tn)][k = s + 32 t]
+                f32x16 acc;
+                float4 wn = ld4(wptr(0));
+    #pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const int t = g >> 3, tn = (g >> 2) & 1, q = g & 3;
+                    if ((g & 7) == 0) {
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+                    }
+                    const float4 w = wn;
+                    if (g + 1 < 16) wn = ld4(wptr(g + 1));
+                    MF_PIN();
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, dz2[16 * tn + 4 * q + 0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, dz2[16 * tn + 4 * q + 1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, dz2[16 * tn + 4 * q + 2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, dz2[16 * tn + 4 * q + 3], acc, 0, 0, 0);
+                    if ((g & 7) == 7) {
+                        // h1 comes back from its [sample][unit] image (still intact: dW2 only read it), so its 32 registers are free
+                        // during the dW2 / d(hidden) MFMA phases
+    #pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            const float4 hb = ld4(&img[s * LS + 8 * qq + 4 * hi + 32 * t]);
+                            dz1[16 * t + 4 * qq + 0] = acc[4 * qq + 0] * (1.0f - hb.x * hb.x);
+                            dz1[16 * t + 4 * qq + 1] = acc[4 * qq + 1] * (1.0f - hb.y * hb.y);
+                            dz1[16 * t + 4 * qq + 2] = acc[4 * qq + 2] * (1.0f - hb.z * hb.z);
+                            dz1[16 * t + 4 * qq + 3] = acc[4 * qq + 3] * (1.0f - hb.w * hb.w);
+                        }
+                    }
                 }
-            // h1 comes back from its [sample][unit] image (still intact: dW2 only read it), so its 32 registers are free
-            // during the dW2 / d(hidden) MFMA phases
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 hb = ld4(&img[s * LS + 8 * q + 4 * hi + 32 * t]);
-                dz1[16 * t + 4 * q + 0] = acc[4 * q + 0] * (1.0f - hb.x * hb.x);
-                dz1[16 * t + 4 * q + 1] = acc[4 * q + 1] * (1.0f - hb.y * hb.y);
-                dz1[16 * t + 4 * q + 2] = acc[4 * q + 2] * (1.0f - hb.z * hb.z);
-                dz1[16 * t + 4 * q + 3] = acc[4 * q + 3] * (1.0f - hb.w * hb.w);
             }
         }
         MF_STAMP(8);   // dh1 MFMA + dz1
@@ -547,8 +766,8 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         MF_STAMP(9);   // dz1 image + dW1
     }
 
-    // ---------------- the four waves park their accumulators in private LDS regions (plain stores), then every thread adds the
-    //                  four regions in a fixed order into the workgroup's slab ----------------
+    // ---------------- the waves park their accumulators in private LDS regions (plain stores), then every thread adds the
+    //                  regions in a fixed order into the workgroup's slab ----------------
     __syncthreads();   // weights and images are dead: the whole dynamic LDS block is reused
     const int base = L.net_off[NET];
     const int nsz = L.net_size[NET];
@@ -574,17 +793,24 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     __syncthreads();
     const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
     float* slab = a.slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * Pmax;
-    for (int e = tid; e < nsz; e += MF_THREADS)
-        slab[e] = ((smem[e] + smem[rstride + e]) + smem[2 * rstride + e]) + smem[3 * rstride + e];
+    for (int e = tid; e < nsz; e += MF_THREADS) {
+        float t = smem[e];
+#pragma unroll
+        for (int w = 1; w < MF_WAVES; w++) t += smem[w * rstride + e];   // fixed order
+        slab[e] = t;
+    }
     // loss sums
     st0 = wave_sum_d(st0); st1 = wave_sum_d(st1); st2 = wave_sum_d(st2); st3 = wave_sum_d(st3);
     __syncthreads();
-    double* dred = reinterpret_cast<double*>(smem + 4 * rstride + 4);
+    double* dred = reinterpret_cast<double*>(smem + MF_WAVES * rstride + 4);
     if (lane == 0) { dred[wave * 4 + 0] = st0; dred[wave * 4 + 1] = st1; dred[wave * 4 + 2] = st2; dred[wave * 4 + 3] = st3; }
     __syncthreads();
     if (tid < 4) {
         double* o = a.stat_slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * 8;
-        o[tid] = ((dred[0 + tid] + dred[4 + tid]) + dred[8 + tid]) + dred[12 + tid];
+        double t = dred[tid];
+#pragma unroll
+        for (int w = 1; w < MF_WAVES; w++) t += dred[4 * w + tid];
+        o[tid] = t;
     }
     MF_STAMP(10);  // epilogue
     if constexpr (STAMP) {
@@ -594,53 +820,63 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     }
 }
 
-template <int DIST, int OBS, int AMAX, bool EXACT, bool STAMP>
-__global__ __launch_bounds__(MF_THREADS, 2) void fwd_bwd_mfma_kernel(UpdateArgs a) {
+template <int DIST, int OBS, int AMAX, bool EXACT, int PREC, bool STAMP>
+__global__ __launch_bounds__(64 * mf_waves(PREC), PREC == PREC_BF16X3 ? 1 : 2) void fwd_bwd_mfma_kernel(UpdateArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor
     const int b = blockIdx.x;
-    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, true, STAMP>(a, smem, b, a.n_blocks[0]);
-    else mf_body<1, DIST, OBS, AMAX, EXACT, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
+    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, true, PREC, STAMP>(a, smem, b, a.n_blocks[0]);
+    else mf_body<1, DIST, OBS, AMAX, EXACT, PREC, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
 
 }  // namespace
 
-void update_blocks_mfma(int M, double actor_share, int n_blocks[2]) {
+// Both flavours keep two waves on every SIMD: PREC_F32 as two 4-wave workgroups per CU, PREC_BF16X3 (whose split weight images
+// need 55 KB) as one 8-wave workgroup per CU.
+void update_blocks_mfma(int M, double actor_share, int prec, int n_blocks[2]) {
+    const int waves = mf_waves(prec);
+    const int total = prec == PREC_BF16X3 ? 256 : 512;           // resident workgroups of the chip
     const int tiles = (M + MT - 1) / MT;
-    const int per_net = (tiles + MF_WAVES - 1) / MF_WAVES;       // workgroups that still get a tile per wave
-    if (per_net <= 256) { n_blocks[0] = n_blocks[1] = per_net > 0 ? per_net : 1; return; }
-    // 512 workgroups (two per CU) split by the relative cost of an actor tile and a critic tile
-    int na = (int)(512.0 * actor_share + 0.5);
-    na = na < 64 ? 64 : (na > 448 ? 448 : na);
+    const int per_net = (tiles + waves - 1) / waves;             // workgroups that still get a tile per wave
+    if (per_net <= total / 2) { n_blocks[0] = n_blocks[1] = per_net > 0 ? per_net : 1; return; }
+    int na = (int)(total * actor_share + 0.5);
+    na = na < total / 8 ? total / 8 : (na > total - total / 8 ? total - total / 8 : na);
     n_blocks[1] = na;
-    n_blocks[0] = 512 - na;
+    n_blocks[0] = total - na;
 }
 
-hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
+hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, int prec, hipStream_t s) {
     if (a.M <= 0) return hipErrorInvalidValue;
     if (a.L.act > 4) return hipErrorNotSupported;  // wider heads run on the VALU kernel
     const int aout = a.L.act > 1 ? a.L.act : 1;
-    size_t shmem = (size_t)mf_smem(a.L.obs, aout).total * sizeof(float);
-    {   // the epilogue parks four per-wave gradient images (+ 16 doubles of loss sums) in the same block
+    const int waves = mf_waves(prec);
+    size_t shmem = (size_t)mf_smem(a.L.obs, aout, prec).total * sizeof(float);
+    {   // the epilogue parks one gradient image per wave (+ 4 doubles of loss sums each) in the same block
         const int nmax = a.L.net_size[0] > a.L.net_size[1] ? a.L.net_size[0] : a.L.net_size[1];
-        const size_t need = ((size_t)4 * ((nmax + 3) & ~3) + 4 + 40) * sizeof(float);
+        const size_t need = ((size_t)waves * ((nmax + 3) & ~3) + 4 + 8 * waves + 8) * sizeof(float);
         if (need > shmem) shmem = need;
     }
-    const dim3 grid((unsigned)(a.n_blocks[0] + a.n_blocks[1])), block(MF_THREADS);
-#define PPO_LAUNCH_MF(DIST, OBS, AMAX, EXACT)                                                                          \
+    if (shmem > 160 * 1024) return hipErrorNotSupported;
+    const dim3 grid((unsigned)(a.n_blocks[0] + a.n_blocks[1])), block(64 * waves);
+#define PPO_LAUNCH_MF2(DIST, OBS, AMAX, EXACT, PREC)                                                                   \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>), \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, PREC, false>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
             if (e == hipSuccess)                                                                                       \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>), \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, PREC, true>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        if (a.stamps) hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>), grid, block, shmem, s, a); \
-        else hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>), grid, block, shmem, s, a);       \
+        if (a.stamps) hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, PREC, true>), grid, block, shmem, s, a); \
+        else hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, PREC, false>), grid, block, shmem, s, a); \
+    } while (0)
+#define PPO_LAUNCH_MF(DIST, OBS, AMAX, EXACT)                                                                          \
+    do {                                                                                                               \
+        if (prec == PREC_BF16X3) PPO_LAUNCH_MF2(DIST, OBS, AMAX, EXACT, PREC_BF16X3);                                  \
+        else PPO_LAUNCH_MF2(DIST, OBS, AMAX, EXACT, PREC_F32);                                                         \
     } while (0)
     // the reference's two shapes get fully folded head code: CartPole (obs 4, one head of 2) and MountainCar (obs 2, one masked
     // head of 3); anything else with <= 4 logits runs the generic variant
@@ -661,5 +897,6 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
         return hipErrorNotSupported;
     }
 #undef PPO_LAUNCH_MF
+#undef PPO_LAUNCH_MF2
     return hipGetLastError();
 }

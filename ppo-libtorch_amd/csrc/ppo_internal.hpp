@@ -387,9 +387,10 @@ struct UpdateArgs {
 };
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
-// MFMA (v_mfma_f32_32x32x2_f32) version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}
-void update_blocks_mfma(int M, double actor_share, int n_blocks[2]);
-hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
+// matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}.  prec 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
+// prec 1: fp32 carried as three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product (fp32 accuracy)
+void update_blocks_mfma(int M, double actor_share, int prec, int n_blocks[2]);
+hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, int prec, hipStream_t s);
 // grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s);
