@@ -152,6 +152,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     unsigned long long ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long t_prev = 0;
     if constexpr (STAMP) t_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_prev0 = t_prev;
     const NetLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, hi = lane >> 5;
@@ -274,7 +275,13 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     float x_n[OBS];
 #pragma unroll
     for (int o = 0; o < OBS; o++) x_n[o] = row_n >= 0 ? a.obs[(size_t)row_n * OBS + o] : 0.0f;
-    for (; tile < n_tiles; tile += tile_step) {
+    const int wave_half = __builtin_amdgcn_readfirstlane(wave >> 2) & 1;   // SIMD partners are waves w and w + 4
+    for (int it = 0; tile < n_tiles; tile += tile_step, it++) {
+        if constexpr (MF_WAVES == 8) {
+            // issue priority alternates between the two waves of a SIMD tile by tile: with equal priorities the older wave wins every
+            // arbitration and finishes its tiles ~25% earlier, leaving its partner to run the tail alone
+            if ((it ^ wave_half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         // ---------------- gather (K5): lanes (s, 0) and (s, 1) read the same batch row ----------------
         const bool valid = row_n >= 0;
         const int row = valid ? row_n : 0;
@@ -766,6 +773,9 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         MF_STAMP(9);   // dz1 image + dW1
     }
 
+    if constexpr (STAMP) {   // slot 11: tile-loop cycles of wave 4 (wave 0's SIMD partner), to compare with wave 0's phases 1..9
+        if (blk == 0 && tid == (MF_WAVES > 4 ? 256 : 64) && a.stamps) a.stamps[NET * 12 + 11] += __builtin_amdgcn_s_memtime() - t_prev0;
+    }
     // ---------------- the waves park their accumulators in private LDS regions (plain stores), then every thread adds the
     //                  regions in a fixed order into the workgroup's slab ----------------
     __syncthreads();   // weights and images are dead: the whole dynamic LDS block is reused
@@ -815,7 +825,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     MF_STAMP(10);  // epilogue
     if constexpr (STAMP) {
         if (blk == 0 && tid == 0 && a.stamps) {
-            for (int i = 0; i < 12; i++) a.stamps[NET * 12 + i] += ph[i];
+            for (int i = 0; i < 11; i++) a.stamps[NET * 12 + i] += ph[i];
         }
     }
 }

@@ -20,7 +20,7 @@ ctx.profile_enable(3)
 ctx.train_iteration()
 p = ctx.profile_read()
 names = ["prologue", "gather", "L1+tanh", "L2mfma+tanh", "head+loss", "h2img+dW3", "dz2+imgs+opA", "dW2mfma", "dh1mfma+dz1", "dz1img+dW1",
-         "epilogue", "-"]
+         "epilogue", "partner_wave_loop"]
 for net in (0, 1):
     ph = p["phase_cycles"][net * 12:net * 12 + 12]
     tot = sum(ph)
