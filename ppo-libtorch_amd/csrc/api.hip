@@ -115,6 +115,9 @@ struct ppo_ctx {
     double actor_share = 0.5;       // share of the fwd/bwd workgroups given to the actor (measured: with 4 tiles per wave an uneven
                                     // split only moves the integer tile count of the slower side up; kept as a tuning knob)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
+    bool fused_opt = true;           // single-rank contexts: optimizer step in two launches instead of three (env PPO_FUSED_OPT=0 disables)
+    double* fused_partial = nullptr; // [fused_opt_blocks][12] per-workgroup sums of squares of the gradient
+    int last_n_blocks[2] = { 0, 0 };
     int mfma_prec = 1;               // 0: exact fp32 MFMA, 1: three-term bf16 split (env PPO_UPDATE_KERNEL=mfma_f32 selects 0)
     bool stamping = false;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
 
@@ -383,6 +386,8 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         const char* k = getenv("PPO_UPDATE_KERNEL");
         c->use_mfma = (A <= 4) && !(k && std::strcmp(k, "valu") == 0);
         c->mfma_prec = (k && std::strcmp(k, "mfma_f32") == 0) ? 0 : 1;
+        const char* fo = getenv("PPO_FUSED_OPT");
+        if (fo && std::strcmp(fo, "0") == 0) c->fused_opt = false;
         const char* sh = getenv("PPO_ACTOR_SHARE");
         if (sh) c->actor_share = atof(sh);
 
@@ -400,6 +405,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
     CK(dalloc(c, &c->clipfrac_accum, 2));
     CK(dalloc(c, &c->norm2, 16));
+    CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
     CK(dalloc(c, &c->ev_sums, 64 * 4));
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
     CK(dalloc(c, &c->group_bits, (size_t)c->T * ((N + 63) / 64)));
@@ -808,7 +814,7 @@ static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
     return PPO_OK;
 }
 
-static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
+static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, bool reduce = true) {
     UpdateArgs a{};
     a.params = B_<float>(c, PPO_BUF_PARAMS);
     a.L = c->L;
@@ -836,7 +842,8 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
         if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->mfma_prec, c->stream));
         else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
-    {
+    c->last_n_blocks[0] = a.n_blocks[0]; c->last_n_blocks[1] = a.n_blocks[1];
+    if (reduce) {
         ProfScope ps(c, PROF_REDUCE);
         HIPCHK(c, launch_reduce_grads(c->slab, c->stat_slab, a.n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, c->stream));
     }
@@ -929,8 +936,20 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         for (int mbi = 0; mbi < nmb; mbi++, k++) {
             const int64_t start = (int64_t)mbi * c->MB;
             const int64_t M = std::min<int64_t>(c->MB, c->B - start);
-            s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k);
+            const bool fused = c->fused_opt && c->world == 1;
+            s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !fused);
             if (s != PPO_OK) return s;
+            if (fused) {
+                // single rank: two launches (reduction + sums of squares, clip + AdamW) instead of three
+                c->opt_step += 1;
+                ProfScope ps(c, PROF_OPT);
+                HIPCHK(c, launch_reduce_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums,
+                                                   B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                                                   c->cfg.max_grad_norm, c->adam_coefs + k, (double)M, c->hp, c->step_stats + k,
+                                                   c->clipfrac_accum, c->fused_partial, c->stream));
+                c->last_stat_slot = k;
+                continue;
+            }
             s = ppo_allreduce_grads(c);
             if (s != PPO_OK) return s;
             s = optimizer_step_slot(c, k, (double)M * c->world, true);

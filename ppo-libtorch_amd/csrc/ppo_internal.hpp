@@ -397,6 +397,12 @@ hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
                              StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s);
+// single-rank optimizer step: (slab reduction + per-workgroup sums of squares) then (norm from the partials + clip + AdamW)
+int fused_opt_blocks(const NetLayout& L);
+hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
+                                    double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
+                                    const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
+                                    double* partial, hipStream_t s);
 hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t s);
 
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
