@@ -38,7 +38,7 @@ __device__ __forceinline__ float trunk_forward(const LaneNet<OBS>& n, const floa
 #pragma unroll
     for (int k = 0; k < OBS; k++) z = __builtin_fmaf(obs[k], n.w1[k], z);
     __syncthreads();  // previous readers of lds are done (single-wave workgroup: a wait, no s_barrier)
-    lds[lane] = tanhf(z);   // library tanh: the branch-free tanh_fast lets the scheduler stretch live ranges past the 128-VGPR budget here
+    lds[lane] = tanhf(z);   // library tanh on purpose: with a branch-free tanh the step body is scheduled past the 128-VGPR budget (140 B of spills, 1.7x slower)
     __syncthreads();
     float acc = n.b2;
     const float4* h4 = reinterpret_cast<const float4*>(lds);
@@ -60,11 +60,15 @@ __device__ __forceinline__ float critic_head(const float* __restrict__ p, const 
 //   AMAX == 4  : sum(head_dims) <= 4 (CartPole 2, MountainCar 3): everything statically indexed -> registers;
 //   AMAX == 32 : generic (runtime-indexed small arrays, compiler places them in scratch).
 // Wave-uniform arithmetic (every lane computes the same values).  act[] in (forced) / out (sampled).
-template <int DIST, int AMAX>
+// EXACTA > 0: the policy has ONE head of exactly EXACTA actions (the reference's two shapes): every loop bound is a constant.
+// philox_cache (optional): the four 32-bit words of the Philox call that serves steps 4k .. 4k+3 of head 0, kept by the caller
+// across steps and refreshed here when step_index % 4 == 0 (or when *cache_valid is false).
+template <int DIST, int AMAX, int EXACTA = 0>
 __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const NetLayout& L, float h2a, int lane, const uint8_t* mask_row,
                                             bool all_valid, bool sample, int64_t seed, int64_t row_global, int64_t step_index, int* act,
-                                            float& logprob, float& entropy) {
-    const int A = L.act;
+                                            float& logprob, float& entropy, uint4* philox_cache = nullptr, bool* cache_valid = nullptr) {
+    const int A = EXACTA ? EXACTA : L.act;
+    const int n_heads = EXACTA ? 1 : L.n_heads;
     float z[AMAX], pr[AMAX];
     bool ok[AMAX];
 #pragma unroll
@@ -79,8 +83,8 @@ __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const N
     logprob = 0.0f;
     entropy = 0.0f;
     int off = 0;
-    for (int h = 0; h < L.n_heads; h++) {
-        const int Ah = L.head_dims[h];
+    for (int h = 0; h < n_heads; h++) {
+        const int Ah = EXACTA ? EXACTA : L.head_dims[h];
         float mx = -INFINITY;
 #pragma unroll
         for (int a = 0; a < AMAX; a++) if (a >= off && a < off + Ah) mx = z[a] > mx ? z[a] : mx;
@@ -105,8 +109,16 @@ __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const N
         ent = -ent;
         if (sample) {
             // one Philox call feeds four consecutive steps: counter (row, step / 4, head, 0), word step % 4
-            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)(step_index >> 2),
-                                          (uint32_t)h, 0u);
+            uint4 w;
+            if (philox_cache && h == 0) {
+                if (!*cache_valid || (step_index & 3) == 0) {
+                    *philox_cache = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)(step_index >> 2), 0u, 0u);
+                    *cache_valid = true;
+                }
+                w = *philox_cache;
+            } else {
+                w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)(step_index >> 2), (uint32_t)h, 0u);
+            }
             const uint32_t wsel = (step_index & 3) == 0 ? w.x : ((step_index & 3) == 1 ? w.y : ((step_index & 3) == 2 ? w.z : w.w));
             const float u = (float)(wsel >> 8) * 0x1p-24f;
             int pick = 0, last = 0;
@@ -133,7 +145,7 @@ __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const N
 // (obs -> logits -> action -> physics -> next obs); the critic's values are a pure function of the stored observations
 // and are produced afterwards by values_kernel over all T*N + N rows at once (same per-row arithmetic).
 // ---------------------------------------------------------------------------------------------------------
-template <int ENV, int DIST, int OBS, int AMAX>
+template <int ENV, int DIST, int OBS, int AMAX, int EXACTA>
 __global__ __launch_bounds__(64, (AMAX <= 4 ? 4 : 1)) void rollout_kernel(RolloutArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[PPO_HIDDEN];
     const int lane = threadIdx.x;
@@ -146,8 +158,10 @@ __global__ __launch_bounds__(64, (AMAX <= 4 ? 4 : 1)) void rollout_kernel(Rollou
     }
     if (env >= a.N) return;
     const NetLayout& L = a.L;
-    const int N = a.N, H = L.n_heads, A = L.act;
+    const int N = a.N, H = EXACTA ? 1 : L.n_heads, A = EXACTA ? EXACTA : L.act;
     const int64_t env_global = a.env_offset + env;
+    uint4 philox_words = make_uint4(0u, 0u, 0u, 0u);
+    bool philox_valid = false;
 
     LaneNet<OBS> actor;
     load_lane_net<OBS>(actor, a.params, L, 1, lane);
@@ -172,7 +186,8 @@ __global__ __launch_bounds__(64, (AMAX <= 4 ? 4 : 1)) void rollout_kernel(Rollou
         }
         float logprob, entropy;
         // MountainCar::getActionMask is all-ones (MountainCar.cpp:69-77): every action valid
-        actor_heads<DIST, AMAX>(a.params, L, h2a, lane, nullptr, true, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy);
+        actor_heads<DIST, AMAX, EXACTA>(a.params, L, h2a, lane, nullptr, true, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy,
+                                        &philox_words, &philox_valid);
 
         // env step + truncation + auto-reset (PPO_Discrete.cpp:440-458)
         int term;
@@ -456,8 +471,10 @@ hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.N), block(64);
 #define PPO_LAUNCH_ROLLOUT(ENV, DIST, OBS)                                                                       \
     do {                                                                                                         \
-        if (a.L.act <= 4) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4>), grid, block, 0, s, a);         \
-        else hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, PPO_MAX_ACT>), grid, block, 0, s, a);            \
+        if (a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 2>), grid, block, 0, s, a);      \
+        else if (a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 3>), grid, block, 0, s, a); \
+        else if (a.L.act <= 4) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 0>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, PPO_MAX_ACT, 0>), grid, block, 0, s, a);         \
     } while (0)
     if (a.env_kind == PPO_ENV_CARTPOLE && a.L.obs == 4) {
         if (a.dist_kind == PPO_DIST_CATEGORICAL) PPO_LAUNCH_ROLLOUT(PPO_ENV_CARTPOLE, PPO_DIST_CATEGORICAL, 4);
@@ -471,7 +488,8 @@ hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
 #undef PPO_LAUNCH_ROLLOUT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // m_values and the bootstrap value in one batched launch
+    // m_values and the bootstrap value in one batched launch (matrix cores for the reference's observation widths)
+    if (a.L.obs == 4 || a.L.obs == 2) return launch_values_mfma(a.params, a.L, a.obs, (int64_t)a.T * a.N, a.values, a.next_obs, a.N, a.next_value, s);
     return launch_values(a.params, a.L, a.obs, (int64_t)a.T * a.N, a.values, a.next_obs, a.N, a.next_value, s);
 }
 
@@ -537,7 +555,15 @@ hipError_t launch_policy_act(const float* params, const NetLayout& L, int dist_k
                              const int64_t* forced_action, int64_t n, int64_t seed, int64_t env_offset, int64_t step_index,
                              int64_t* action, float* logprob, float* entropy, float* value, bool value_only, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    if (value_only) return launch_values(params, L, obs, n, value, nullptr, 0, nullptr, s);
+    // every critic evaluation of a context goes through ONE kernel (the matrix-core one for the reference's observation widths), so
+    // stand-alone calls reproduce the fused rollout's values bit for bit
+    const bool mfma_values = L.obs == 4 || L.obs == 2;
+    if (value_only) return mfma_values ? launch_values_mfma(params, L, obs, n, value, nullptr, 0, nullptr, s) : launch_values(params, L, obs, n, value, nullptr, 0, nullptr, s);
+    if (value && mfma_values) {
+        hipError_t e = launch_values_mfma(params, L, obs, n, value, nullptr, 0, nullptr, s);
+        if (e != hipSuccess) return e;
+        value = nullptr;
+    }
     const unsigned grid = (unsigned)(n < 8192 ? n : 8192);
 #define PPO_LAUNCH_ACT(DIST, OBS)                                                                                                     \
     do {                                                                                                                              \

@@ -133,14 +133,6 @@ __device__ __forceinline__ void store_dlayout(float* img, const float* v, int s,
         }                                                                                      \
     } while (0)
 
-// tanh on the transcendental pipe: 1 - 2 / (1 + e^(2x)), five instructions (v_mul, v_exp, v_add, v_rcp, v_fma), absolute error
-// <= ~2e-7 (the library tanhf costs ~40 and a sign-symmetric form 14; 64 tanh per lane per tile made them half of the kernel's
-// vector instructions).  Saturates correctly: e = inf -> 1, e = 0 -> -1.
-__device__ __forceinline__ float tanh_mufu(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
-}
-
 // EXACT: the policy has ONE head of exactly AMAX actions (the reference's PPO_Discrete / MountainCar shapes): every head loop
 // folds at compile time.  Otherwise head count and widths are run-time values bounded by AMAX.
 // Scheduling pin between an operand prefetch and the MFMA group it must stay ahead of: vector ALU, scalar and transcendental
@@ -839,6 +831,115 @@ __global__ __launch_bounds__(64 * mf_waves(PREC), PREC == PREC_BF16X3 ? 1 : 2) v
     else mf_body<1, DIST, OBS, AMAX, EXACT, PREC, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Critic over rows [0, n0) of obs0 and [0, n1) of obs1 on the matrix cores (m_values[step] = Critic(obs[step]),
+// PPO_Discrete.cpp:534-536, and the bootstrap value, :280): the forward half of mf_body<0> -- one wave per 32-row tile, layer 1 as
+// fp32 MFMA, layer 2 as three-term bf16 products, head as a 32-term dot product per half-lane.  Rows are contiguous, so the
+// "gather" is one coalesced 16-byte load per row.
+// ---------------------------------------------------------------------------------------------------------
+template <int OBS>
+__global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __restrict__ P, NetLayout L, const float* __restrict__ obs0, int64_t n0,
+                                                             float* __restrict__ out0, const float* __restrict__ obs1, int64_t n1,
+                                                             float* __restrict__ out1) {
+    __shared__ __attribute__((aligned(16))) uint16_t sW2p[3 * 64 * WS];
+    __shared__ __attribute__((aligned(16))) float sB1[64], sB2[64], sW3[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 31, hi = lane >> 5;
+    {
+        float wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = P[L.w2[0] + tid + i * 256];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + i * 256;
+            const int n = e >> 6, k = e & 63;
+            const uint32_t u0 = f2u(wv[i]);
+            const float r1 = wv[i] - u2f(u0 & 0xffff0000u);
+            const uint32_t u1 = f2u(r1);
+            const float r2 = r1 - u2f(u1 & 0xffff0000u);
+            const int pf = n * WS + slot_of_unit(k);
+            sW2p[pf] = (uint16_t)(u0 >> 16); sW2p[64 * WS + pf] = (uint16_t)(u1 >> 16); sW2p[2 * 64 * WS + pf] = (uint16_t)(f2u(r2) >> 16);
+        }
+    }
+    if (tid < 64) { sB1[tid] = P[L.b1[0] + tid]; sB2[tid] = P[L.b2[0] + tid]; sW3[tid] = P[L.w3[0] + tid]; }
+    const float b3 = P[L.b3[0]];
+    constexpr int L1S = (OBS + 1) / 2;
+    float w1op[2][L1S];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int stp = 0; stp < L1S; stp++) {
+            const int o = 2 * stp + hi;
+            w1op[t][stp] = o < OBS ? P[L.w1[0] + (s + 32 * t) * OBS + o] : 0.0f;
+        }
+    __syncthreads();
+    const int64_t n = n0 + n1;
+    const int64_t n_tiles = (n + MT - 1) / MT;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row = tile * MT + s;
+        const bool valid = row < n;
+        const float* src = !valid ? obs0 : (row < n0 ? obs0 + row * OBS : obs1 + (row - n0) * OBS);
+        float x[OBS];
+#pragma unroll
+        for (int o = 0; o < OBS; o++) x[o] = valid ? src[o] : 0.0f;
+        float h1[32];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 b = ld4(&sB1[8 * q + 4 * hi + 32 * t]);
+                acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+            }
+#pragma unroll
+            for (int stp = 0; stp < L1S; stp++) {
+                const float xb = (2 * stp + 1 < OBS) ? (hi ? x[2 * stp + 1] : x[2 * stp]) : (hi ? 0.0f : x[2 * stp]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1op[t][stp], xb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_mufu(acc[r]);
+        }
+        uint32_t hp[3][16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) split3(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j], hp[2][j]);
+        auto aptr = [&](int g, int term) {
+            return reinterpret_cast<const u32x4*>(sW2p + term * 64 * WS + (s + 32 * (g >> 2)) * WS + (g & 3) * 16 + hi * 8);
+        };
+        float part = 0.0f;
+        f32x16 acc;
+        u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1), an3 = *aptr(0, 2);
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int t = g >> 2, c = g & 3;
+            if (c == 0) {
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const float4 b = ld4(&sB2[8 * qq + 4 * hi + 32 * t]);
+                    acc[4 * qq] = b.x; acc[4 * qq + 1] = b.y; acc[4 * qq + 2] = b.z; acc[4 * qq + 3] = b.w;
+                }
+            }
+            const u32x4 a1 = an1, a2 = an2, a3 = an3;
+            if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); an3 = *aptr(g + 1, 2); }
+            MF_PIN();
+            const u32x4 b1 = { hp[0][4 * c], hp[0][4 * c + 1], hp[0][4 * c + 2], hp[0][4 * c + 3] };
+            const u32x4 b2 = { hp[1][4 * c], hp[1][4 * c + 1], hp[1][4 * c + 2], hp[1][4 * c + 3] };
+            const u32x4 b3v = { hp[2][4 * c], hp[2][4 * c + 1], hp[2][4 * c + 2], hp[2][4 * c + 3] };
+            acc = mfma_x3(a1, a2, a3, b1, b2, b3v, acc);
+            if (c == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {   // units 8q + 4hi + 32t .. +3 are registers 4q .. 4q+3
+                    const float4 w = ld4(&sW3[8 * q + 4 * hi + 32 * t]);
+                    part = __builtin_fmaf(tanh_mufu(acc[4 * q]), w.x, part); part = __builtin_fmaf(tanh_mufu(acc[4 * q + 1]), w.y, part);
+                    part = __builtin_fmaf(tanh_mufu(acc[4 * q + 2]), w.z, part); part = __builtin_fmaf(tanh_mufu(acc[4 * q + 3]), w.w, part);
+                }
+            }
+        }
+        const float other = __shfl_xor(part, 32, 64);
+        const float v = (part + other) + b3;
+        if (valid && hi == 0) { if (row < n0) out0[row] = v; else out1[row - n0] = v; }
+    }
+}
+
 }  // namespace
 
 // Both flavours keep two waves on every SIMD: PREC_F32 as two 4-wave workgroups per CU, PREC_BF16X3 (whose split weight images
@@ -908,5 +1009,17 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, int prec, hipStrea
     }
 #undef PPO_LAUNCH_MF
 #undef PPO_LAUNCH_MF2
+    return hipGetLastError();
+}
+
+hipError_t launch_values_mfma(const float* params, const NetLayout& L, const float* obs0, int64_t n0, float* out0, const float* obs1, int64_t n1,
+                              float* out1, hipStream_t s) {
+    const int64_t n = n0 + n1;
+    if (n <= 0) return hipSuccess;
+    const int64_t wg_needed = ((n + MT - 1) / MT + 3) / 4;
+    const unsigned grid = (unsigned)(wg_needed < 1024 ? wg_needed : 1024);
+    if (L.obs == 4) hipLaunchKernelGGL((values_mfma_kernel<4>), dim3(grid), dim3(256), 0, s, params, L, obs0, n0, out0, obs1, n1, out1);
+    else if (L.obs == 2) hipLaunchKernelGGL((values_mfma_kernel<2>), dim3(grid), dim3(256), 0, s, params, L, obs0, n0, out0, obs1, n1, out1);
+    else return hipErrorNotSupported;
     return hipGetLastError();
 }

@@ -266,6 +266,14 @@ __device__ __forceinline__ int sample_head(const float* p, int A, float u) {
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -100.0f) * 1.4426950408889634f); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
+// tanh on the transcendental pipe: 1 - 2 / (1 + e^(2x)), five instructions (v_mul, v_exp, v_add, v_rcp, v_fma), absolute error
+// <= ~2e-7 (the library tanhf costs ~40 and a sign-symmetric form 14; 64 tanh per lane per tile made them half of the kernel's
+// vector instructions).  Saturates correctly: e = inf -> 1, e = 0 -> -1.
+__device__ __forceinline__ float tanh_mufu(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+
 __device__ __forceinline__ float tanh_fast(float x) {
     const float ax = fminf(fabsf(x), 20.0f);
     const float t = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);   // exp(-2|x|)
@@ -397,6 +405,9 @@ hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
                              StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s);
+// batched critic on the matrix cores (obs in {2, 4}); same contract as launch_values
+hipError_t launch_values_mfma(const float* params, const NetLayout& L, const float* obs0, int64_t n0, float* out0, const float* obs1, int64_t n1,
+                              float* out1, hipStream_t s);
 // single-rank optimizer step: (slab reduction + per-workgroup sums of squares) then (norm from the partials + clip + AdamW)
 int fused_opt_blocks(const NetLayout& L);
 hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
