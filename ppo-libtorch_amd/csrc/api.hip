@@ -872,7 +872,7 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
 extern "C" ppo_status ppo_allreduce_grads(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
     if (c->world <= 1) return PPO_OK;
-    HIPCHK(c, launch_append_sums(c->loss_sums, B_<float>(c, PPO_BUF_GRADS) + c->L.P, c->stream));
+    // the slab reduction already left float copies of the loss sums behind the gradient: one collective carries both
     return allreduce_sum(c, c->buf[PPO_BUF_GRADS], (size_t)c->L.P + 8, false);
 }
 

@@ -492,9 +492,10 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
                 double s = 0.0;
                 for (int i = 0; i < 16; i++) s += part[0][i];
                 sums_out[k] = s;
+                grads[L.P + k] = (float)s;   // float copies ride behind the gradient so ONE all-reduce carries both
             }
         }
-        if (threadIdx.x >= 5 && threadIdx.x < 8) sums_out[threadIdx.x] = 0.0;
+        if (threadIdx.x >= 5 && threadIdx.x < 8) { sums_out[threadIdx.x] = 0.0; grads[L.P + threadIdx.x] = 0.0f; }
     }
 }
 
