@@ -585,7 +585,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
 // of its 64 gradients split by tensor (K8-reduce + the first half of K9), and the AdamW kernel adds those partials in a fixed order
 // instead of re-reading the gradient in a norm kernel of its own.  (With several ranks the RCCL all-reduce changes the gradient
 // between the two, so that path keeps reduce -> all-reduce -> norm -> AdamW.)  A one-launch version with a grid-wide rendezvous
-// was measured slower (18 us against 16: two device-scope fences and the polling cost more than the launch they save).
+// was measured slower (18 us against 16: two device-scope fences and the polling cost more than the launch they save), and so was
+// a last-arriver version without any waiting (every workgroup publishes, takes a ticket, the last one applies AdamW to all P
+// parameters: 23 us) -- on this part an agent-scope fence per workgroup costs more than a kernel boundary.
 struct FusedOptArgs {
     const float* slab; const double* stat_slab; int nb0, nb1;
     NetLayout L;
