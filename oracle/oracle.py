@@ -111,26 +111,22 @@ def philox4x32(k0, k1, c0, c1, c2, c3):
 
 
 # ---------------------------------------------------------------------------------------------- environments
-def _step_many(fn, obs_dim, state, action):
+def _step_many(kind, obs_dim, state, action):
     state = _f32(state).reshape(-1, obs_dim).copy()
     action = _i64(action).ravel()
     n = state.shape[0]
     rew = np.empty(n, np.float32)
     term = np.empty(n, np.int32)
-    t = C.c_int32()
-    for i in range(n):
-        row = state[i]
-        rew[i] = fn(_p(row), C.c_int64(int(action[i])), C.byref(t))
-        term[i] = t.value
+    lib().orc_step_many(C.c_int32(kind), _p(state), _p(action), C.c_int64(n), _p(rew), _p(term))
     return state, rew, term
 
 
 def cartpole_step(state, action):
-    return _step_many(lib().orc_cartpole_step, 4, state, action)
+    return _step_many(0, 4, state, action)
 
 
 def mountaincar_step(state, action):
-    return _step_many(lib().orc_mountaincar_step, 2, state, action)
+    return _step_many(1, 2, state, action)
 
 
 class VecEnv:

@@ -178,6 +178,13 @@ float orc_mountaincar_step(float* st, int64_t action, int32_t* terminated) {
     return -1.0f;
 }
 
+void orc_step_many(int32_t kind, float* state, const int64_t* action, int64_t n, float* reward, int32_t* terminated) {
+    const int obs = kind == 0 ? 4 : 2;
+    for (int64_t i = 0; i < n; i++)
+        reward[i] = kind == 0 ? orc_cartpole_step(state + i * obs, action[i], terminated + i)
+                              : orc_mountaincar_step(state + i * obs, action[i], terminated + i);
+}
+
 struct orc_vecenv {
     int32_t kind;
     int64_t n, seed, max_steps, env_offset;

@@ -56,6 +56,8 @@ void orc_philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t
 float orc_cartpole_step(float* state, int64_t action, int32_t* terminated);
 /* MountainCar::step, MountainCar.cpp:29-57. */
 float orc_mountaincar_step(float* state, int64_t action, int32_t* terminated);
+/* n independent transitions through the two functions above (kind: 0 CartPole, 1 MountainCar), in place on state [n, obs]. */
+void orc_step_many(int32_t kind, float* state, const int64_t* action, int64_t n, float* reward, int32_t* terminated);
 
 /* Vectorised env with the semantics of PPO_Discrete::initEnvs/stepEnvs (PPO_Discrete.cpp:365-483). */
 typedef struct orc_vecenv orc_vecenv;
