@@ -726,11 +726,6 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
     }
 }
 
-// when sharded: float copies of the loss sums ride behind the gradient so ONE all-reduce carries both
-__global__ void append_sums_kernel(const double* sums, float* grads_tail) {
-    if (threadIdx.x < 8) grads_tail[threadIdx.x] = (float)sums[threadIdx.x];
-}
-
 // Sum and sum of squares of the advantages of every minibatch of the coming update: PPO_ADV_PARTS workgroups per minibatch,
 // each over a contiguous slice, eight gathered loads in flight per thread.
 __global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ adv, const int32_t* __restrict__ perm, int64_t B,
@@ -877,11 +872,6 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
     a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.partial = partial;
     hipLaunchKernelGGL(reduce_grads_sumsq_kernel, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t s) {
-    hipLaunchKernelGGL(append_sums_kernel, dim3(1), dim3(64), 0, s, sums, grads_tail);
     return hipGetLastError();
 }
 

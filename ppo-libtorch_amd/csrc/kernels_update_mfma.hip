@@ -1,19 +1,22 @@
 // ppo-libtorch_amd/csrc/kernels_update_mfma.hip -- K5-K8 (gather + forward + PPO loss + backward) on the CDNA4 matrix cores.
 //
 // Same contract as fwd_bwd_kernel in kernels_update.hip (reference PPO_Discrete.cpp:576-638), different machine mapping:
-// the three 64x64 contractions per sample and net -- layer-2 forward, d(hidden 1), and the weight gradient dW2 -- are
-// 32x32x2 fp32 MFMAs (v_mfma_f32_32x32x2_f32: exact fp32, bit-for-bit an fmaf chain in k order), 192 MFMAs per 32-sample
-// tile.  MFMA is used only here because only here is the minibatch (131 072 rows at BASELINE configs[1]) a real contraction.
+// the three 64x64 contractions per sample and net -- layer-2 forward, d(hidden 1), and the weight gradient dW2 -- run on the
+// matrix cores, either as exact-fp32 MFMAs (PREC_F32) or as bf16 MFMAs over exact three-term splits of the fp32 operands
+// (PREC_BF16X3, the default; see the PREC comment below).  Matrix cores are used only here because only here is the minibatch
+// (131 072 rows at BASELINE configs[1]) a real contraction.  values_mfma_kernel at the end of the file is the forward half of
+// the same mapping for the batched critic evaluation of the rollout.
 //
-// One WAVE owns a 32-sample tile of one net from gather to weight gradient; a workgroup is four such waves of the same net
-// (blockIdx.y) sharing LDS copies of the weights.  Register layout of every hidden vector is the MFMA C/D layout
+// One WAVE owns a 32-sample tile of one net from gather to weight gradient; a workgroup is four (PREC_F32) or eight
+// (PREC_BF16X3) such waves of the same net sharing LDS copies of the weights.  Register layout of every hidden vector is the
+// MFMA C/D layout
 //     lane (s = lane & 31, hi = lane >> 5), element e = r + 16 t   <->   unit  U(r, hi, t) = (r & 3) + 8 (r >> 2) + 4 hi + 32 t
 // i.e. lane = sample, registers = 32 of the 64 units.  Because the contraction index of an MFMA may be enumerated in any
-// order as long as A and B agree, a D-layout vector is directly the B operand of the next product (k-index (e, hi) <-> unit
-// U(e%16, hi, e/16)) when the weight operand is fetched in that same order: forward and d(hidden) need NO data movement.
+// order as long as A and B agree, a D-layout vector is directly the B operand of the next product when the weight operand is
+// fetched in that same order: forward and d(hidden) need NO data movement.
 // Only the products that contract over SAMPLES (dW2, dW3, dW1, bias gradients) need lane = unit: the tile is bounced through
-// a private 32 x 68-float LDS image (4 times per tile, ~64 KB of LDS traffic against 12 288 MFMA cycles).
-// Weight-gradient accumulators (64 registers for dW2) live in registers across all tiles of the wave; the four waves of a
+// a private 32 x 68-float LDS image (4 times per tile).
+// Weight-gradient accumulators (64 registers for dW2) live in registers across all tiles of the wave; the waves of a
 // workgroup are then added in a fixed order through LDS and leave as ONE partial slab (deterministic, no float atomics).
 #include "ppo_internal.hpp"
 

@@ -414,7 +414,6 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
                                     double* partial, hipStream_t s);
-hipError_t launch_append_sums(const double* sums, float* grads_tail, hipStream_t s);
 
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
 struct EpisodeRing {
