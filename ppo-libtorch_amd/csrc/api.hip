@@ -105,7 +105,7 @@ struct ppo_ctx {
     StepStats* step_stats = nullptr;    // device [steps_per_update + 1]
     double* clipfrac_accum = nullptr;   // {sum, count}
     double* norm2 = nullptr;            // [12] per-tensor squared gradient norms of the current step
-    double* ev_sums = nullptr;          // [64][4]
+    double* ev_sums = nullptr;          // [PPO_EV_BLOCKS][4]
     int32_t* row_counts = nullptr;      // [T]
     uint64_t* group_bits = nullptr;     // [T, ceil(N/64)] ballots of finished episodes
     EpisodeRing* ring = nullptr;
@@ -406,7 +406,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->clipfrac_accum, 2));
     CK(dalloc(c, &c->norm2, 16));
     CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
-    CK(dalloc(c, &c->ev_sums, 64 * 4));
+    CK(dalloc(c, &c->ev_sums, PPO_EV_BLOCKS * 4));
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
     CK(dalloc(c, &c->group_bits, (size_t)c->T * ((N + 63) / 64)));
     CK(dalloc(c, &c->ring, 1));
@@ -995,10 +995,11 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
     HIPCHK(c, hipMemcpy(cf, c->clipfrac_accum, sizeof cf, hipMemcpyDeviceToHost));
     out->clipfrac_mean = cf[1] > 0 ? cf[0] / cf[1] : 0.0;
     if (c->have_ev) {
-        double ev[64 * 4];
+        static_assert(PPO_EV_BLOCKS * 4 * sizeof(double) <= 32768, "stack buffer");
+        double ev[PPO_EV_BLOCKS * 4];
         HIPCHK(c, hipMemcpy(ev, c->ev_sums, sizeof ev, hipMemcpyDeviceToHost));
         double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
-        for (int b = 0; b < 64; b++) { sy += ev[b * 4]; sy2 += ev[b * 4 + 1]; sd += ev[b * 4 + 2]; sd2 += ev[b * 4 + 3]; }
+        for (int b = 0; b < PPO_EV_BLOCKS; b++) { sy += ev[b * 4]; sy2 += ev[b * 4 + 1]; sd += ev[b * 4 + 2]; sd2 += ev[b * 4 + 3]; }
         const double n = (double)c->B;
         const double var_y = (sy2 - sy * sy / n) / (n - 1.0), var_d = (sd2 - sd * sd / n) / (n - 1.0);
         out->explained_variance = (double)(1.0f - (float)var_d / (float)var_y);  // :647-648 (float tensors)

@@ -767,13 +767,22 @@ __device__ __forceinline__ uint32_t mix_bits(uint32_t x, uint32_t mask, int bits
     return x;
 }
 __global__ void permutation_kernel(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the round keys depend only on (seed, update, epoch, rank): one Philox call per workgroup, not per element
+    __shared__ uint4 s_key;
+    __shared__ int s_bits;
     const int e = blockIdx.y;
+    if (threadIdx.x == 0) {
+        int bits = 1;
+        while ((1ll << bits) < B) bits++;
+        s_bits = bits;
+        s_key = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)update_index, (uint32_t)e, (uint32_t)rank_salt, 2u);
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B || e >= E) return;
-    int bits = 1;
-    while ((1ll << bits) < B) bits++;
+    const int bits = s_bits;
     const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
-    const uint4 k = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)update_index, (uint32_t)e, (uint32_t)rank_salt, 2u);
+    const uint4 k = s_key;
     uint32_t x = (uint32_t)i;
     do { x = mix_bits(x, mask, bits, k); } while (x >= (uint64_t)B);
     perm[(size_t)e * B + i] = (int32_t)x;
@@ -888,7 +897,7 @@ hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, in
 }
 
 hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s) {
-    hipLaunchKernelGGL(explained_variance_kernel, dim3(64), dim3(256), 0, s, returns, values, B, sums4);
+    hipLaunchKernelGGL(explained_variance_kernel, dim3(PPO_EV_BLOCKS), dim3(256), 0, s, returns, values, B, sums4);
     return hipGetLastError();
 }
 

@@ -65,7 +65,8 @@ struct LossParams {
 
 // Per-minibatch advantage statistics (sum, sum of squares over the GLOBAL minibatch) and the scalars derived from them.
 struct AdvStat { double s1, s2; };
-#define PPO_ADV_PARTS 8   // partial sums per minibatch (one workgroup each), added in order by the consumer
+#define PPO_ADV_PARTS 32  // partial sums per minibatch (one workgroup each), added in order by the consumer
+#define PPO_EV_BLOCKS 512 // partial rows of the explained-variance sums, added in order by the host
 
 // Device-side record of one optimizer step's scalars (doubles so the host reads them as-is).
 struct StepStats {
