@@ -415,36 +415,56 @@ __global__ __launch_bounds__(256) void episode_count_kernel(const int32_t* __res
 __global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restrict__ fin_len, const float* __restrict__ fin_rew, int T, int N,
                                                           const int32_t* __restrict__ row_counts, const uint64_t* __restrict__ group_bits,
                                                           EpisodeRing* ring) {
+    // Only the last 100 finished episodes of the rollout survive in the ring.  The window of rows that holds them is found from
+    // the row counts (kept in LDS: the serial loops below must not pay a memory round trip per row); inside the window every
+    // finished episode knows its rank j in (step, env) order from prefix popcounts, and exactly those with j >= W - 100 are
+    // written, each to its own slot (head + j) % 100 -- lanes work on different env groups in parallel, no ordering hazard.
+    constexpr int MAXT = 2048;
+    __shared__ int s_cnt[MAXT];
     const int lane = threadIdx.x;
     const int G = (N + 63) / 64;
     int64_t total = 0;
-    for (int t = lane; t < T; t += 64) total += row_counts[t];
+    for (int t = lane; t < T; t += 64) {
+        const int c = row_counts[t];
+        if (t < MAXT) s_cnt[t] = c;
+        total += c;
+    }
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
-    int t_start = T, have = 0;
-    while (t_start > 0 && have < 100) { t_start--; have += row_counts[t_start]; }
-    int head = ring->head;
+    __syncthreads();
+    auto cnt = [&](int t) { return t < MAXT ? s_cnt[t] : row_counts[t]; };
+    int t_start = T, W = 0;
+    while (t_start > 0 && W < 100) { t_start--; W += cnt(t_start); }
+    const int head = ring->head;
+    const int first = W > 100 ? W - 100 : 0;   // rank of the oldest episode that is still in the ring afterwards
+    int rowbase = 0;
     for (int t = t_start; t < T; t++) {
-        if (row_counts[t] == 0) continue;
+        const int rc = cnt(t);
+        if (rc == 0) continue;
+        int gbase = rowbase;
         for (int g0 = 0; g0 < G; g0 += 64) {
             const int g = g0 + lane;
-            const unsigned long long bits = g < G ? group_bits[(size_t)t * G + g] : 0ull;
-            unsigned long long nz = __ballot(bits != 0ull);      // groups of this stripe that hold a finished episode
-            while (nz) {
-                const int src = __ffsll((long long)nz) - 1;
-                nz &= nz - 1;
-                const unsigned long long m = __shfl(bits, src, 64);
-                const int n = (g0 + src) * 64 + lane;
-                if ((m >> lane) & 1ull) {
-                    const int slot = (head + __popcll(m & ((1ull << lane) - 1ull))) % 100;
+            unsigned long long bits = g < G ? group_bits[(size_t)t * G + g] : 0ull;
+            const int mine = __popcll(bits);
+            int incl = mine;   // inclusive prefix of the per-group counts across the lanes of this stripe
+            for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+            int j = gbase + incl - mine;
+            while (bits) {
+                const int b = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                if (j >= first) {
+                    const int n = g * 64 + b;
+                    const int slot = (head + j) % 100;
                     ring->len[slot] = fin_len[(size_t)t * N + n];
                     ring->rew[slot] = fin_rew[(size_t)t * N + n];
                 }
-                head = (head + __popcll(m)) % 100;
+                j++;
             }
+            gbase += __shfl(incl, 63, 64);
         }
+        rowbase += rc;
     }
     if (lane == 0) {
-        ring->head = head;
+        ring->head = (head + W) % 100;
         const int64_t sz = (int64_t)ring->size + total;
         ring->size = (int32_t)(sz > 100 ? 100 : sz);
         ring->total += total;
