@@ -415,11 +415,12 @@ def test_update_equals_stepwise_path_and_permutations_are_permutations(P):
 
 
 def test_mfma_and_valu_update_kernels_agree(P, monkeypatch):
-    """The matrix-core kernel (default) and the VALU kernel implement the same minibatch step: identical loss scalars to 1e-6
-    and gradients to 1e-5 relative on a 131 072-row minibatch drawn from a real rollout (BASELINE configs[1] shape)."""
+    """The three flavours of the minibatch step -- bf16 matrix cores over exact three-term splits (default), exact-fp32 MFMA, plain
+    VALU -- agree: loss scalars to 1e-6 and gradients to 1e-5 relative on a 131 072-row minibatch drawn from a real rollout
+    (BASELINE configs[1] shape).  The VALU kernel is the yardstick (library tanhf, fmaf chains)."""
     cfg = dict(num_envs=4096, num_steps=128, num_minibatches=4, update_epochs=1, seed=3, total_timesteps=4096 * 128 * 2)
     grads, stats = [], []
-    for kernel in ("mfma", "valu"):
+    for kernel in ("mfma", "mfma_f32", "valu"):
         monkeypatch.setenv("PPO_UPDATE_KERNEL", kernel)
         ctx = P.Context(P.make_config(**cfg))
         ctx.init_orthogonal(5)
@@ -430,9 +431,10 @@ def test_mfma_and_valu_update_kernels_agree(P, monkeypatch):
         grads.append(ctx.minibatch_forward_backward(perm[0, :131072]))
         stats.append(ctx.stats())
         ctx.close()
-    for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss", "total_norm"):
-        assert abs(stats[0][key] - stats[1][key]) <= 1e-6 * max(1.0, abs(stats[1][key])), (key, stats[0][key], stats[1][key])
-    assert np.abs(grads[0] - grads[1]).max() <= 1e-5 * np.abs(grads[1]).max()
+    for i in (0, 1):
+        for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss", "total_norm"):
+            assert abs(stats[i][key] - stats[2][key]) <= 1e-6 * max(1.0, abs(stats[2][key])), (i, key, stats[i][key], stats[2][key])
+        assert np.abs(grads[i] - grads[2]).max() <= 1e-5 * np.abs(grads[2]).max(), i
 
 
 def test_ragged_minibatches(P):
