@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm-selftest", action="store_true", help="N = 1 only: drive the multi-rank code path (RCCL all-reduces over a one-rank communicator, "
+                    "three-kernel optimizer step) to see its per-step cost on one GPU; not a valid headline number")
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel + GAE")
     args = ap.parse_args()
 
@@ -138,6 +140,10 @@ def main():
                               total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98, gae_lambda=0.95, clip_coef=0.2,
                               ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank)
     ctx = P.Context(cfg)
+    if args.comm_selftest and world == 1:
+        os.environ["PPO_COMM_SELFTEST"] = "1"
+        ctx.comm_init(P.comm_unique_id(), 0, 1)
+        del os.environ["PPO_COMM_SELFTEST"]
     P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id)
     ctx.init_orthogonal(2)   # same seed on every rank: replicated weights
     ctx.env_reset()
@@ -177,7 +183,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (fixed-seed CartPole-v1, random-init 2x64 actor/critic)",
             "config": {"workload": "CartPole-v1 PPO_Discrete, %d envs x %d steps per GPU, 2x64 MLP, 4 minibatches x 10 epochs (BASELINE.json configs[%d])"
                                    % (N, T, 1 if world == 1 else 2), "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
-                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 RCCL grad all-reduce per optimizer step)" % world},
+                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 RCCL grad all-reduce per optimizer step)" % world + (" [comm self-test]" if args.comm_selftest else "")},
             "roofline": {"kernel": "fwd_bwd_mfma_kernel (gather+forward+PPO loss+backward; fp32 via 3-term bf16 splits)", "bound": "mfma", "achieved": fl / (fb_ms * 1e-3) / 1e12,
                          "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": pmc_traffic("fwd_bwd_mfma_kernel"),
                          "flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],

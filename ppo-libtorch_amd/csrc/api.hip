@@ -115,6 +115,7 @@ struct ppo_ctx {
     double actor_share = 0.5;       // share of the fwd/bwd workgroups given to the actor (measured: with 4 tiles per wave an uneven
                                     // split only moves the integer tile count of the slower side up; kept as a tuning knob)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
+    bool force_collectives = false;  // PPO_COMM_SELFTEST: world == 1 but the multi-rank path (RCCL included) is taken
     bool fused_opt = true;           // single-rank contexts: optimizer step in two launches instead of three (env PPO_FUSED_OPT=0 disables)
     double* fused_partial = nullptr; // [fused_opt_blocks][12] per-workgroup sums of squares of the gradient
     int last_n_blocks[2] = { 0, 0 };
@@ -783,7 +784,7 @@ static AdamCoef adam_coef(double lr, int64_t t) {
 }
 
 static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
-    if (c->world <= 1) return PPO_OK;
+    if (c->world <= 1 && !c->force_collectives) return PPO_OK;
     if (c->lgroup) {
         LocalGroup* g = c->lgroup.get();
         HIPCHK(c, hipEventRecord(c->lg_ready, c->stream));
@@ -871,7 +872,7 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
 
 extern "C" ppo_status ppo_allreduce_grads(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
-    if (c->world <= 1) return PPO_OK;
+    if (c->world <= 1 && !c->force_collectives) return PPO_OK;
     // the slab reduction already left float copies of the loss sums behind the gradient: one collective carries both
     return allreduce_sum(c, c->buf[PPO_BUF_GRADS], (size_t)c->L.P + 8, false);
 }
@@ -885,7 +886,8 @@ static ppo_status optimizer_step_slot(ppo_ctx* c, int slot, double global_M, boo
     {
         ProfScope ps(c, PROF_OPT);
         HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
-                                    c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, c->world, true,
+                                    c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp,
+                                    c->force_collectives ? 2 : c->world /* self-test: read the loss sums from the all-reduced tail */, true,
                                     c->step_stats + slot, c->clipfrac_accum, c->norm2, c->stream));
     }
     c->last_stat_slot = slot;
@@ -936,7 +938,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         for (int mbi = 0; mbi < nmb; mbi++, k++) {
             const int64_t start = (int64_t)mbi * c->MB;
             const int64_t M = std::min<int64_t>(c->MB, c->B - start);
-            const bool fused = c->fused_opt && c->world == 1;
+            const bool fused = c->fused_opt && c->world == 1 && !c->force_collectives;
             s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !fused);
             if (s != PPO_OK) return s;
             if (fused) {
@@ -1074,7 +1076,12 @@ extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, 
     NEED(c, c && id_h, "null argument");
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
     NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
-    if (nranks == 1) { c->world = 1; c->rank = 0; return PPO_OK; }
+    // PPO_COMM_SELFTEST=1: a ONE-rank communicator is really created and every collective of the multi-rank path is really issued
+    // (sums over one rank = identity).  The only way to drive the RCCL calls -- library lookup, datatype / op enums, stream
+    // ordering, the three-kernel optimizer path -- on a box with a single GPU.
+    const char* st = getenv("PPO_COMM_SELFTEST");
+    const bool selftest = nranks == 1 && st && std::strcmp(st, "1") == 0;
+    if (nranks == 1 && !selftest) { c->world = 1; c->rank = 0; return PPO_OK; }
     std::string err;
     if (!rccl::load(err)) return fail(c, PPO_ERR_COMM, "%s", err.c_str());
     rccl::UniqueId id;
@@ -1084,6 +1091,7 @@ extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, 
     if (rc != 0) return fail(c, PPO_ERR_COMM, "ncclCommInitRank failed: %s", rccl::GetErrorString ? rccl::GetErrorString(rc) : "?");
     c->world = nranks;
     c->rank = rank;
+    c->force_collectives = selftest;
     return PPO_OK;
 }
 

@@ -623,3 +623,34 @@ def test_two_rank_update_equals_single_context(P):
                 assert abs(st2[key] - st[key]) <= 2e-6 * max(1.0, abs(st[key])), (k, r, key, st2[key], st[key])
             assert np.abs(p2 - params).max() <= 2e-6, (k, r)
         assert np.array_equal(bits(out[0][k][2]), bits(out[1][k][2]))   # replicas stay bit-identical
+
+
+def test_rccl_single_rank_selftest(P, monkeypatch):
+    """The RCCL calls of the multi-rank path on ONE GPU: with PPO_COMM_SELFTEST=1 a one-rank communicator is really created
+    (ncclGetUniqueId / ncclCommInitRank from the dlopen'ed librccl) and every collective of an update really goes through
+    ncclAllReduce (f32 gradient + loss-sum tail per optimizer step, f64 advantage sums per update), followed by the three-kernel
+    optimizer path the ranks of a multi-GPU job take.  Sums over one rank are the identity, so the update must reproduce the
+    plain single-context update: same kernels upstream, same arithmetic downstream."""
+    cfg = dict(num_envs=256, num_steps=64, num_minibatches=4, update_epochs=2, seed=7, total_timesteps=256 * 64 * 4)
+
+    def run(selftest):
+        ctx = P.Context(P.make_config(**cfg))
+        if selftest:
+            monkeypatch.setenv("PPO_COMM_SELFTEST", "1")
+            ctx.comm_init(P.comm_unique_id(), 0, 1)
+            monkeypatch.delenv("PPO_COMM_SELFTEST")
+        ctx.init_orthogonal(7)
+        ctx.env_reset()
+        for _ in range(2):
+            ctx.train_iteration()
+        out = (ctx.get_params(), ctx.stats())
+        ctx.close()
+        return out
+
+    p0, s0 = run(False)
+    p1, s1 = run(True)
+    assert np.all(np.isfinite(p1))
+    # the two optimizer paths add the gradient norm in different orders (partials vs per-tensor kernel): float noise only
+    assert np.abs(p1 - p0).max() <= 2e-5, np.abs(p1 - p0).max()
+    for key in ("pg_loss", "v_loss", "loss", "approx_kl", "total_norm"):
+        assert abs(s1[key] - s0[key]) <= 1e-4 * max(1.0, abs(s0[key])), (key, s1[key], s0[key])
