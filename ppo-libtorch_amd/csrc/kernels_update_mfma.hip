@@ -261,15 +261,32 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     int tile = blk * MF_WAVES + wave;
     // software pipeline of the gather: batch-row indices are fetched TWO tiles ahead and the observation row ONE tile ahead, so
     // neither of the two dependent HBM round trips is ever waited for inside a tile
+    // Every load of the pipeline is UNCONDITIONAL (clamped address, value selected afterwards): a load inside a branch makes the
+    // compiler's wait-count bookkeeping give up at the join and emit s_waitcnt vmcnt(0) at the next use of ANY loaded value, which
+    // stalled every tile for a full memory round trip on the prefetches just issued.
     auto fetch_row = [&](int tl) -> int {
         const int j = tl * MT + s;
-        return (tl < n_tiles && j < a.M) ? a.idx[j] : -1;
+        const bool ok = tl < n_tiles && j < a.M;
+        const int v = a.idx[ok ? j : 0];
+        return ok ? v : -1;
+    };
+    auto load_obs = [&](int rown, float* xo) {   // row 0 stands in for a missing row; the caller zeroes it at the point of use
+        const size_t rn = rown < 0 ? 0 : rown;
+        if constexpr (OBS == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(a.obs + rn * 4);
+            xo[0] = v.x; xo[1] = v.y; xo[2] = v.z; xo[3] = v.w;
+        } else if constexpr (OBS == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(a.obs + rn * 2);
+            xo[0] = v.x; xo[1] = v.y;
+        } else {
+#pragma unroll
+            for (int o = 0; o < OBS; o++) xo[o] = a.obs[rn * OBS + o];
+        }
     };
     int row_n = fetch_row(tile);
     int row_nn = fetch_row(tile + tile_step);
     float x_n[OBS];
-#pragma unroll
-    for (int o = 0; o < OBS; o++) x_n[o] = row_n >= 0 ? a.obs[(size_t)row_n * OBS + o] : 0.0f;
+    load_obs(row_n, x_n);
     const int wave_half = __builtin_amdgcn_readfirstlane(wave >> 2) & 1;   // SIMD partners are waves w and w + 4
     for (int it = 0; tile < n_tiles; tile += tile_step, it++) {
         if constexpr (MF_WAVES == 8) {
@@ -282,7 +299,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         const int row = valid ? row_n : 0;
         float x[OBS];
 #pragma unroll
-        for (int o = 0; o < OBS; o++) x[o] = x_n[o];
+        for (int o = 0; o < OBS; o++) x[o] = valid ? x_n[o] : 0.0f;
         // per-sample scalars of this tile: issued now, consumed at the loss
         float s_oldlp = 0.0f, s_adv = 0.0f, s_ret = 0.0f, s_oldv = 0.0f;
         int act_s[AMAX];
@@ -305,8 +322,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         }
         {   // next tile's observation row (its index arrived a tile ago); the index after that
             row_n = row_nn;
-#pragma unroll
-            for (int o = 0; o < OBS; o++) x_n[o] = row_n >= 0 ? a.obs[(size_t)row_n * OBS + o] : 0.0f;
+            load_obs(row_n, x_n);
             row_nn = fetch_row(tile + 2 * tile_step);
         }
         if (hi == 0) {
@@ -401,6 +417,13 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         }
 
         MF_STAMP(3);   // layer 2 MFMA + tanh
+        // The per-sample scalars were requested at the top of the tile; nothing may touch them before this point (left alone, the
+        // scheduler hoists the cheap `action == k` compare to the top of the tile, right behind the load, and the wave then sits
+        // out a memory round trip there).  An empty asm that "redefines" them pins every use below this line.
+        asm volatile("" : "+v"(s_oldlp), "+v"(s_adv), "+v"(s_ret), "+v"(s_oldv));
+#pragma unroll
+        for (int h = 0; h < AMAX; h++) asm volatile("" : "+v"(act_s[h]));
+        asm volatile("" : "+v"(s_maskbits));
         // ---------------- head + loss (K6, K7): both half-lanes of a sample compute the same scalars ----------------
         float dOut[AMAX];
 #pragma unroll
