@@ -901,13 +901,32 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
     __syncthreads();
     const int64_t n = n0 + n1;
     const int64_t n_tiles = (n + MT - 1) / MT;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    // the observation row of a tile is requested one tile ahead (unconditional loads: a missing row reads row 0 and is zeroed at use)
+    auto load_x = [&](int64_t tl, float* xo) {
+        const int64_t r = tl * MT + s;
+        const bool ok = r < n;
+        const float* src = !ok ? obs0 : (r < n0 ? obs0 + r * OBS : obs1 + (r - n0) * OBS);
+        if constexpr (OBS == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            xo[0] = v.x; xo[1] = v.y; xo[2] = v.z; xo[3] = v.w;
+        } else if constexpr (OBS == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(src);
+            xo[0] = v.x; xo[1] = v.y;
+        } else {
+#pragma unroll
+            for (int o = 0; o < OBS; o++) xo[o] = src[o];
+        }
+    };
+    const int64_t tile_step = (int64_t)gridDim.x * 4;
+    float x_n[OBS];
+    load_x((int64_t)blockIdx.x * 4 + wave, x_n);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_step) {
         const int64_t row = tile * MT + s;
         const bool valid = row < n;
-        const float* src = !valid ? obs0 : (row < n0 ? obs0 + row * OBS : obs1 + (row - n0) * OBS);
         float x[OBS];
 #pragma unroll
-        for (int o = 0; o < OBS; o++) x[o] = valid ? src[o] : 0.0f;
+        for (int o = 0; o < OBS; o++) x[o] = valid ? x_n[o] : 0.0f;
+        load_x(tile + tile_step, x_n);
         float h1[32];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
