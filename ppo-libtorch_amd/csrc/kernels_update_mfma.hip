@@ -796,10 +796,17 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     }
     // ---------------- the waves park their accumulators in private LDS regions (plain stores), then every thread adds the
     //                  regions in a fixed order into the workgroup's slab ----------------
-    __syncthreads();   // weights and images are dead: the whole dynamic LDS block is reused
+    // loss sums first: registers only, and their landing place lies beyond every live byte of LDS, so this needs no barrier
+    st0 = wave_sum_d_dpp(st0); st1 = wave_sum_d_dpp(st1); st2 = wave_sum_d_dpp(st2); st3 = wave_sum_d_dpp(st3);
     const int base = L.net_off[NET];
     const int nsz = L.net_size[NET];
     const int rstride = (nsz + 3) & ~3;
+    int dred_off = MF_WAVES * rstride + 4;
+    if (dred_off < m.total) dred_off = m.total;
+    dred_off = (dred_off + 1) & ~1;
+    double* dred = reinterpret_cast<double*>(smem + dred_off);
+    if (lane == 0) { dred[wave * 4 + 0] = st0; dred[wave * 4 + 1] = st1; dred[wave * 4 + 2] = st2; dred[wave * 4 + 3] = st3; }
+    __syncthreads();   // weights and images are dead: the rest of the dynamic LDS block is reused
     float* red = smem + wave * rstride;
 #pragma unroll
     for (int tn = 0; tn < 2; tn++)
@@ -827,12 +834,6 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         for (int w = 1; w < MF_WAVES; w++) t += smem[w * rstride + e];   // fixed order
         slab[e] = t;
     }
-    // loss sums
-    st0 = wave_sum_d(st0); st1 = wave_sum_d(st1); st2 = wave_sum_d(st2); st3 = wave_sum_d(st3);
-    __syncthreads();
-    double* dred = reinterpret_cast<double*>(smem + MF_WAVES * rstride + 4);
-    if (lane == 0) { dred[wave * 4 + 0] = st0; dred[wave * 4 + 1] = st1; dred[wave * 4 + 2] = st2; dred[wave * 4 + 3] = st3; }
-    __syncthreads();
     if (tid < 4) {
         double* o = a.stat_slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * 8;
         double t = dred[tid];
@@ -1009,7 +1010,9 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, int prec, hipStrea
     size_t shmem = (size_t)mf_smem(a.L.obs, aout, prec).total * sizeof(float);
     {   // the epilogue parks one gradient image per wave (+ 4 doubles of loss sums each) in the same block
         const int nmax = a.L.net_size[0] > a.L.net_size[1] ? a.L.net_size[0] : a.L.net_size[1];
-        const size_t need = ((size_t)waves * ((nmax + 3) & ~3) + 4 + 8 * waves + 8) * sizeof(float);
+        size_t dred_off = (size_t)waves * ((nmax + 3) & ~3) + 4;
+        if (dred_off < (size_t)mf_smem(a.L.obs, aout, prec).total) dred_off = (size_t)mf_smem(a.L.obs, aout, prec).total;
+        const size_t need = (dred_off + 2 + 8 * waves + 8) * sizeof(float);
         if (need > shmem) shmem = need;
     }
     if (shmem > 160 * 1024) return hipErrorNotSupported;

@@ -306,6 +306,25 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The same sum on the DPP network (no ds_bpermute round trips: a double butterfly through LDS costs twelve of them); result in
+// every lane, fixed order (inside rows of 16 by butterfly, then the four row sums in order).
+#define PPO_DPP_ADD_D(v, CTRL)                                                                                              \
+    do {                                                                                                                    \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), (CTRL), 0xf, 0xf, false);                         \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), (CTRL), 0xf, 0xf, false);                         \
+        (v) += __hiloint2double(hi_, lo_);                                                                                  \
+    } while (0)
+__device__ __forceinline__ double wave_sum_d_dpp(double v) {
+    PPO_DPP_ADD_D(v, 0xB1);    // quad_perm:[1,0,3,2]
+    PPO_DPP_ADD_D(v, 0x4E);    // quad_perm:[2,3,0,1]
+    PPO_DPP_ADD_D(v, 0x141);   // row_half_mirror
+    PPO_DPP_ADD_D(v, 0x140);   // row_mirror: every lane of a row now holds the row's sum
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * i), __builtin_amdgcn_readlane(__double2loint(v), 16 * i));
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------------------
