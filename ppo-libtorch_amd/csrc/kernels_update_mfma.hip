@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MT = 32;              // samples per wave tile
 constexpr int LS = 68;              // padded LDS row stride (floats)
+constexpr int NS = 68;              // bf16 per row of the update kernel's weight image (136 B: 32 rows x 8 B land on 64 distinct banks)
 constexpr int WS = 72;              // bf16 per padded row of a split weight operand (144 B: 16 rows x 16 B land on 16 distinct bank groups)
 
 // PREC selects the arithmetic of the three 64-wide contractions:
@@ -67,6 +68,15 @@ __device__ __forceinline__ f32x16 mfma_x3(const u32x4 a1, const u32x4 a2, const 
     acc = mfma_bf16(a1, b1, acc);
     return acc;
 }
+// ds_read_b64_tr_b16: per group of 16 lanes a 4-row x 16-column block of 16-bit elements is read and delivered column-major: lane
+// 4q + p of the group supplies the address of row q, columns 4p .. 4p+3; lane i receives column i of the four rows (row q in its
+// element q).  EXEC must be all ones.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const uint16_t* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
 // slot (chunk c, half h, element e) of hidden unit k inside a 64-wide operand row: unit U(r, h, t) sits at c = 2 t + (r >> 3), e = r & 7,
 // which is where a D-layout register vector presents it (register 8 c + e of half h)
 __host__ __device__ inline int slot_of_unit(int k) {
@@ -91,8 +101,10 @@ __host__ __device__ inline MfSmem mf_smem(int obs, int aout, int prec) {
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
     if (prec == PREC_BF16X3) {
-        m.w2 = take(3 * 64 * WS / 2);    // [term][n][slot of k]  bf16
-        m.w2t = take(3 * 64 * WS / 2);   // [term][k][slot of n]  bf16
+        // ONE image per term, natural [n][k] order: the forward product reads rows (two 8-byte pieces per fragment), the backward
+        // product reads the same bytes column-wise with the transposing LDS read ds_read_b64_tr_b16
+        m.w2 = take(3 * 64 * NS / 2);
+        m.w2t = m.w2;
     } else {
         m.w2 = take(64 * LS);     // [n][k], padded rows
         m.w2t = take(64 * LS);    // [k][n]
@@ -174,8 +186,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     if constexpr (PREC == PREC_BF16X3) {
         // 4096 weights, 8 per thread: each is cut into its three bf16 terms once per launch and stored at its operand slot in the
         // forward ([n][slot of k]) and the transposed ([k][slot of n]) image
-        uint16_t* wf = reinterpret_cast<uint16_t*>(smem + m.w2);
-        uint16_t* wt = reinterpret_cast<uint16_t*>(smem + m.w2t);
+        uint16_t* wn = reinterpret_cast<uint16_t*>(smem + m.w2);
         float wv[4096 / MF_THREADS];
 #pragma unroll
         for (int i = 0; i < 4096 / MF_THREADS; i++) wv[i] = P[L.w2[NET] + tid + i * MF_THREADS];
@@ -187,10 +198,8 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             const float r1 = wv[i] - u2f(u0 & 0xffff0000u);
             const uint32_t u1 = f2u(r1);
             const float r2 = r1 - u2f(u1 & 0xffff0000u);
-            const uint16_t t1 = (uint16_t)(u0 >> 16), t2 = (uint16_t)(u1 >> 16), t3 = (uint16_t)(f2u(r2) >> 16);
-            const int pf = n * WS + slot_of_unit(k), pt = k * WS + slot_of_unit(n);
-            wf[pf] = t1; wf[64 * WS + pf] = t2; wf[2 * 64 * WS + pf] = t3;
-            wt[pt] = t1; wt[64 * WS + pt] = t2; wt[2 * 64 * WS + pt] = t3;
+            const int pn = n * NS + k;
+            wn[pn] = (uint16_t)(u0 >> 16); wn[64 * NS + pn] = (uint16_t)(u1 >> 16); wn[2 * 64 * NS + pn] = (uint16_t)(f2u(r2) >> 16);
         }
     } else {
         // 4096 weights, 16 per thread, every global load issued before the first LDS store
@@ -358,11 +367,16 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             uint32_t hp[3][16];
 #pragma unroll
             for (int j = 0; j < 16; j++) split3(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j], hp[2][j]);
-            auto aptr = [&](int g, int term) {   // g = 4 t + c: row n = s + 32 t of the forward image, chunk c, this lane's half
-                return reinterpret_cast<const u32x4*>(sW2p + term * 64 * WS + (s + 32 * (g >> 2)) * WS + (g & 3) * 16 + hi * 8);
+            // g = 4 t + c: row n = s + 32 t, contraction chunk c.  Fragment element e <-> k = 16 c + 8 (e >> 2) + 4 hi + (e & 3), the
+            // unit register 8 c + e of a D-layout vector holds: two 8-byte pieces of the natural row
+            auto afrag = [&](int g, int term) -> u32x4 {
+                const uint16_t* q = sW2p + term * 64 * NS + (s + 32 * (g >> 2)) * NS + (g & 3) * 16 + hi * 4;
+                const uint2 lo2 = *reinterpret_cast<const uint2*>(q), hi2 = *reinterpret_cast<const uint2*>(q + 8);
+                const u32x4 r = { lo2.x, lo2.y, hi2.x, hi2.y };
+                return r;
             };
             f32x16 acc;
-            u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1), an3 = *aptr(0, 2);
+            u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1), an3 = afrag(0, 2);
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 const int t = g >> 2, c = g & 3;
@@ -374,7 +388,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                     }
                 }
                 const u32x4 a1 = an1, a2 = an2, a3 = an3;
-                if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); an3 = *aptr(g + 1, 2); }
+                if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); an3 = afrag(g + 1, 2); }
                 MF_PIN();
                 const u32x4 b1 = { hp[0][4 * c], hp[0][4 * c + 1], hp[0][4 * c + 2], hp[0][4 * c + 3] };
                 const u32x4 b2 = { hp[1][4 * c], hp[1][4 * c + 1], hp[1][4 * c + 2], hp[1][4 * c + 3] };
@@ -654,11 +668,17 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             }
             MF_STAMP(7);   // dW2 MFMA
             // ---------------- dh1^T[k][s] = sum_n W2[n][k] dz2[s][n], dz1 = dh1 (1 - h1^2) ----------------
-            auto aptr = [&](int g, int term) {   // g = 4 t + c: row k = s + 32 t of the transposed image, chunk c of n, this lane's half
-                return reinterpret_cast<const u32x4*>(sW2Tp + term * 64 * WS + (s + 32 * (g >> 2)) * WS + (g & 3) * 16 + hi * 8);
+            // g = 4 t + c: output row k = s + 32 t, contraction chunk c over n.  Fragment element e <-> n = 16 c + 8 (e >> 2) + 4 hi + (e & 3):
+            // column k of rows 16 c + 4 hi .. +3 (first transposing read) and of rows 16 c + 8 + 4 hi .. +3 (second)
+            const int tq = (lane & 15) >> 2, tp = lane & 3, tkb = 16 * ((lane >> 4) & 1);
+            auto afrag = [&](int g, int term) -> u32x4 {
+                const uint16_t* q = sW2Tp + term * 64 * NS + (16 * (g & 3) + 4 * hi + tq) * NS + 32 * (g >> 2) + tkb + 4 * tp;
+                const uint2 lo2 = lds_read_tr16(q), hi2 = lds_read_tr16(q + 8 * NS);
+                const u32x4 r = { lo2.x, lo2.y, hi2.x, hi2.y };
+                return r;
             };
             f32x16 acc;
-            u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1), an3 = *aptr(0, 2);
+            u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1), an3 = afrag(0, 2);
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 const int t = g >> 2, c = g & 3;
@@ -667,7 +687,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
                 }
                 const u32x4 a1 = an1, a2 = an2, a3 = an3;
-                if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); an3 = *aptr(g + 1, 2); }
+                if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); an3 = afrag(g + 1, 2); }
                 MF_PIN();
                 const u32x4 b1 = { zp[0][4 * c], zp[0][4 * c + 1], zp[0][4 * c + 2], zp[0][4 * c + 3] };
                 const u32x4 b2 = { zp[1][4 * c], zp[1][4 * c + 1], zp[1][4 * c + 2], zp[1][4 * c + 3] };
