@@ -265,7 +265,7 @@ static ppo_status ensure_reset_table(ppo_ctx* c, int64_t need) {
     HIPCHK(c, hipMemcpy(d, h.data(), (size_t)cap * 4 * sizeof(float), hipMemcpyHostToDevice));
     if (c->reset_table) {
         c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void*)c->reset_table), c->allocs.end());
-        hipFree(c->reset_table);
+        (void)hipFree(c->reset_table);
     }
     c->allocs.push_back(d);
     c->reset_table = d;
@@ -290,16 +290,17 @@ extern "C" const char* ppo_last_error(const ppo_ctx* ctx) { return ctx ? ctx->er
 
 extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->cfg.device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    // teardown is best effort: nothing useful can be done with a failing release, and there is no caller to tell
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl::CommDestroy) rccl::CommDestroy(c->comm);
-    if (c->lg_ready) hipEventDestroy(c->lg_ready);
-    for (auto& sp : c->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
-    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
-    for (void* p : c->allocs) hipFree(p);
-    if (c->adam_coefs_h) hipHostFree(c->adam_coefs_h);
-    for (hipEvent_t e : c->coef_copied) if (e) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->lg_ready) (void)hipEventDestroy(c->lg_ready);
+    for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->adam_coefs_h) (void)hipHostFree(c->adam_coefs_h);
+    for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
