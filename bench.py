@@ -177,6 +177,7 @@ def main():
         fb_ms = prof["fwd_bwd_ms"] / max(prof["fwd_bwd_launches"], 1) or float("nan")
         gae_ms = prof["gae_ms"] / max(prof["gae_launches"], 1) or float("nan")
         gae_bytes = 20 * N * T + 8 * N
+        fb_tr, gae_tr = pmc_traffic("fwd_bwd_mfma_kernel"), pmc_traffic("gae_kernel")
         out = {
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
@@ -185,14 +186,16 @@ def main():
                                    % (N, T, 1 if world == 1 else 2), "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
                        "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 RCCL grad all-reduce per optimizer step)" % world + (" [comm self-test]" if args.comm_selftest else "")},
             "roofline": {"kernel": "fwd_bwd_mfma_kernel (gather+forward+PPO loss+backward; fp32 via 3-term bf16 splits)", "bound": "mfma", "achieved": fl / (fb_ms * 1e-3) / 1e12,
-                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": pmc_traffic("fwd_bwd_mfma_kernel"),
+                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
+                         "traffic": (fb_tr or {}).get("bytes"), "traffic_detail": fb_tr,
                          "flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
                          # what the matrix cores actually execute: per 32-sample tile and net 144 v_mfma_f32_32x32x16_bf16 (fp32 products as
                          # six bf16 products over exact three-term splits) -- reported beside the algorithmic fp32 rate
                          "executed": {"unit": "TFLOP/s bf16", "achieved": bf16_fl / (fb_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS,
                                       "frac": bf16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS}},
             "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_bytes / (gae_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("gae_kernel"), "bytes_per_launch": gae_bytes,
+                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": (gae_tr or {}).get("bytes"), "traffic_detail": gae_tr, "bytes_per_launch": gae_bytes,
                              "avg_launch_ms": gae_ms, "launches": prof["gae_launches"]},
             "phase_ms_per_step": {"rollout": prof["rollout_ms"] / args.steps, "gae": prof["gae_ms"] / args.steps, "fwd_bwd": prof["fwd_bwd_ms"] / args.steps,
                                   "grad_reduce": prof["reduce_ms"] / args.steps, "clip_adamw": prof["optimizer_ms"] / args.steps},
