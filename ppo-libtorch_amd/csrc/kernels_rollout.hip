@@ -11,6 +11,8 @@
 // read back as wave-uniform (broadcast) 16-byte reads; head outputs are wave reductions (__shfl_xor).  Envs never
 // interact inside a rollout, so no grid-level synchronisation exists: the T-step loop runs inside the kernel.
 // Per step a wave touches HBM only for the stores of K3 (obs 4*O B, action, log-prob, value, reward, done).
+#include <cstdlib>
+
 #include "ppo_internal.hpp"
 
 namespace {
@@ -38,7 +40,7 @@ __device__ __forceinline__ float trunk_forward(const LaneNet<OBS>& n, const floa
 #pragma unroll
     for (int k = 0; k < OBS; k++) z = __builtin_fmaf(obs[k], n.w1[k], z);
     __syncthreads();  // previous readers of lds are done (single-wave workgroup: a wait, no s_barrier)
-    lds[lane] = tanhf(z);   // library tanh on purpose: with a branch-free tanh the step body is scheduled past the 128-VGPR budget (140 B of spills, 1.7x slower)
+    lds[lane] = tanh_mufu(z);
     __syncthreads();
     float acc = n.b2;
     const float4* h4 = reinterpret_cast<const float4*>(lds);
@@ -48,7 +50,7 @@ __device__ __forceinline__ float trunk_forward(const LaneNet<OBS>& n, const floa
         acc = __builtin_fmaf(h.x, n.w2[4 * k], acc); acc = __builtin_fmaf(h.y, n.w2[4 * k + 1], acc);
         acc = __builtin_fmaf(h.z, n.w2[4 * k + 2], acc); acc = __builtin_fmaf(h.w, n.w2[4 * k + 3], acc);
     }
-    return tanhf(acc);
+    return tanh_mufu(acc);
 }
 
 // Heads: value = b3c + sum_j h2c[j] W3c[j];  logits[a] = b3a[a] + sum_j h2a[j] W3a[a][j]  (wave reductions).
@@ -63,19 +65,19 @@ __device__ __forceinline__ float critic_head(const float* __restrict__ p, const 
 // EXACTA > 0: the policy has ONE head of exactly EXACTA actions (the reference's two shapes): every loop bound is a constant.
 // philox_cache (optional): the four 32-bit words of the Philox call that serves steps 4k .. 4k+3 of head 0, kept by the caller
 // across steps and refreshed here when step_index % 4 == 0 (or when *cache_valid is false).
+// heads_from_logits: everything after the actor's output layer (z[] = raw logits in, consumed).
 template <int DIST, int AMAX, int EXACTA = 0>
-__device__ __forceinline__ void actor_heads(const float* __restrict__ p, const NetLayout& L, float h2a, int lane, const uint8_t* mask_row,
-                                            bool all_valid, bool sample, int64_t seed, int64_t row_global, int64_t step_index, int* act,
-                                            float& logprob, float& entropy, uint4* philox_cache = nullptr, bool* cache_valid = nullptr) {
+__device__ __forceinline__ void heads_from_logits(float* z, const NetLayout& L, const uint8_t* mask_row, bool all_valid, bool sample, int64_t seed,
+                                                  int64_t row_global, int64_t step_index, int* act, float& logprob, float& entropy,
+                                                  uint4* philox_cache = nullptr, bool* cache_valid = nullptr) {
     const int A = EXACTA ? EXACTA : L.act;
     const int n_heads = EXACTA ? 1 : L.n_heads;
-    float z[AMAX], pr[AMAX];
+    float pr[AMAX];
     bool ok[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; a++) {
-        z[a] = 0.0f; pr[a] = 0.0f; ok[a] = true;
+        pr[a] = 0.0f; ok[a] = true;
         if (a < A) {
-            z[a] = wave_sum(h2a * p[L.w3[1] + a * PPO_HIDDEN + lane]) + p[L.b3[1] + a];
             if (DIST == PPO_DIST_MASKED && !all_valid && mask_row) ok[a] = mask_row[a] != 0;
             if (DIST == PPO_DIST_MASKED && !ok[a]) z[a] = -1e8f;   // torch::where(mask, logits, -1e8f), CategoricalMasked.cpp:34-35
         }
@@ -140,13 +142,27 @@ __device__ __forceinline__ void actor_heads(const float* __restrict__ p, const N
     }
 }
 
+template <int DIST, int AMAX, int EXACTA = 0>
+__device__ __forceinline__ void actor_heads(const float* __restrict__ p, const NetLayout& L, float h2a, int lane, const uint8_t* mask_row,
+                                            bool all_valid, bool sample, int64_t seed, int64_t row_global, int64_t step_index, int* act,
+                                            float& logprob, float& entropy, uint4* philox_cache = nullptr, bool* cache_valid = nullptr) {
+    const int A = EXACTA ? EXACTA : L.act;
+    float z[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; a++) {
+        z[a] = 0.0f;
+        if (a < A) z[a] = wave_sum(h2a * p[L.w3[1] + a * PPO_HIDDEN + lane]) + p[L.b3[1] + a];
+    }
+    heads_from_logits<DIST, AMAX, EXACTA>(z, L, mask_row, all_valid, sample, seed, row_global, step_index, act, logprob, entropy, philox_cache, cache_valid);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Fused rollout: grid = N workgroups of one wave.  Only the ACTOR sits on the env loop's dependency chain
 // (obs -> logits -> action -> physics -> next obs); the critic's values are a pure function of the stored observations
 // and are produced afterwards by values_kernel over all T*N + N rows at once (same per-row arithmetic).
 // ---------------------------------------------------------------------------------------------------------
 template <int ENV, int DIST, int OBS, int AMAX, int EXACTA>
-__global__ __launch_bounds__(64, (AMAX <= 4 ? 4 : 1)) void rollout_kernel(RolloutArgs a) {
+__global__ __launch_bounds__(64, (AMAX <= 4 ? 2 : 1)) void rollout_kernel(RolloutArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[PPO_HIDDEN];
     const int lane = threadIdx.x;
     // Blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of envs so the partial-line stores
@@ -228,6 +244,154 @@ __global__ __launch_bounds__(64, (AMAX <= 4 ? 4 : 1)) void rollout_kernel(Rollou
     if (lane < OBS) {
         a.next_obs[(size_t)env * OBS + lane] = st[lane];
         a.env_state[(size_t)lane * N + env] = st[lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused rollout, TWO envs per wave (the reference's single-head policies): lanes 0-31 run env 2b, lanes 32-63 env 2b + 1, and lane l
+// of a half owns hidden units l and l + 32 of its env's actor.  The per-unit work (layers 1 and 2) is the same number of fmas
+// per env as in rollout_kernel; everything that rollout_kernel computes redundantly in all 64 lanes -- softmax, sampling, Philox,
+// env physics with its fp64 sin/cos, episode bookkeeping, stores -- is now done for two envs by one instruction stream.
+// Arithmetic per env is bit-identical to rollout_kernel / policy_act_kernel: unit j's products are summed inside rows of 16
+// units with the same DPP butterfly, and the four row sums are added in the same order ((R0 + R1) + R2) + R3.
+// ---------------------------------------------------------------------------------------------------------
+// row sums of a per-lane value: after the butterfly every lane of a 16-lane row holds the row's sum (same steps as wave_sum)
+__device__ __forceinline__ float row16_sum(float v) {
+    v = PPO_DPP_ADD(v, 0xB1);
+    v = PPO_DPP_ADD(v, 0x4E);
+    v = PPO_DPP_ADD(v, 0x141);
+    v = PPO_DPP_ADD(v, 0x140);
+    return v;
+}
+
+template <int ENV, int DIST, int OBS, int EXACTA>
+__global__ __launch_bounds__(64, 2) void rollout2_kernel(RolloutArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PPO_HIDDEN];
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+    int pair = blockIdx.x;
+    {   // contiguous env ranges per XCD, as in rollout_kernel
+        const int nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8, i = blockIdx.x / 8;
+        pair = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int N = a.N;
+    int env = 2 * pair + half;
+    const bool live = env < N;          // odd N: the last wave's upper half idles (computes on env N - 1, stores nothing)
+    if (!live) env = N - 1;
+    const NetLayout& L = a.L;
+    constexpr int H = 1, A = EXACTA;
+    const int64_t env_global = a.env_offset + env;
+    const float* __restrict__ P = a.params;
+
+    // this lane's two units of the actor (net 1): rows u0 = l and u1 = l + 32 of W1 / W2
+    float w1[2][OBS], b1[2], w2[2][PPO_HIDDEN], b2[2], w3[A][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int u = l + 32 * j;
+#pragma unroll
+        for (int k = 0; k < OBS; k++) w1[j][k] = P[L.w1[1] + u * OBS + k];
+        b1[j] = P[L.b1[1] + u];
+#pragma unroll
+        for (int k = 0; k < PPO_HIDDEN; k++) w2[j][k] = P[L.w2[1] + u * PPO_HIDDEN + k];
+        b2[j] = P[L.b2[1] + u];
+#pragma unroll
+        for (int aa = 0; aa < A; aa++) w3[aa][j] = P[L.w3[1] + aa * PPO_HIDDEN + u];
+    }
+    float b3[A];
+#pragma unroll
+    for (int aa = 0; aa < A; aa++) b3[aa] = P[L.b3[1] + aa];
+
+    float st[OBS];
+#pragma unroll
+    for (int k = 0; k < OBS; k++) st[k] = a.env_state[(size_t)k * N + env];
+    int ep_len = a.ep_len[env];
+    float ep_rew = a.ep_rew[env];
+    int resets = a.reset_count[env];
+    int done = a.next_done[env];
+    uint4 philox_words = make_uint4(0u, 0u, 0u, 0u);
+    bool philox_valid = false;
+    float* slab = lds + half * PPO_HIDDEN;
+
+    for (int t = 0; t < a.T; t++) {
+        const size_t tn = (size_t)t * N + env;
+        if (live && l < OBS) a.obs[tn * OBS + l] = st[l];          // m_obs[step] = next_obs (PPO_Discrete.cpp:529)
+        // layer 1
+        float z1[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float z = b1[j];
+#pragma unroll
+            for (int k = 0; k < OBS; k++) z = __builtin_fmaf(st[k], w1[j][k], z);
+            z1[j] = tanh_mufu(z);
+        }
+        __syncthreads();
+        slab[l] = z1[0];
+        slab[l + 32] = z1[1];
+        __syncthreads();
+        // layer 2: this env's 64 activations, broadcast inside the half
+        float acc0 = b2[0], acc1 = b2[1];
+        const float4* h4 = reinterpret_cast<const float4*>(slab);
+#pragma unroll
+        for (int k = 0; k < PPO_HIDDEN / 4; k++) {
+            const float4 h = h4[k];
+            acc0 = __builtin_fmaf(h.x, w2[0][4 * k], acc0); acc0 = __builtin_fmaf(h.y, w2[0][4 * k + 1], acc0);
+            acc0 = __builtin_fmaf(h.z, w2[0][4 * k + 2], acc0); acc0 = __builtin_fmaf(h.w, w2[0][4 * k + 3], acc0);
+            acc1 = __builtin_fmaf(h.x, w2[1][4 * k], acc1); acc1 = __builtin_fmaf(h.y, w2[1][4 * k + 1], acc1);
+            acc1 = __builtin_fmaf(h.z, w2[1][4 * k + 2], acc1); acc1 = __builtin_fmaf(h.w, w2[1][4 * k + 3], acc1);
+        }
+        const float h2_0 = tanh_mufu(acc0), h2_1 = tanh_mufu(acc1);
+        // logits: rows of 16 units, then ((R0 + R1) + R2) + R3 with R0, R1 = units 0-31 (first register), R2, R3 = units 32-63
+        float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int aa = 0; aa < A; aa++) {
+            const float p = row16_sum(h2_0 * w3[aa][0]), q = row16_sum(h2_1 * w3[aa][1]);
+            const int r0 = 32 * half;      // first lane of this env's first row
+            const float R0 = __shfl(p, r0, 64), R1 = __shfl(p, r0 + 16, 64), R2 = __shfl(q, r0, 64), R3 = __shfl(q, r0 + 16, 64);
+            z[aa] = (((R0 + R1) + R2) + R3) + b3[aa];
+        }
+        int act[PPO_MAX_HEADS];
+        const bool forced = a.forced_actions != nullptr;
+        if (forced) act[0] = (int)a.forced_actions[tn * H];
+        float logprob, entropy;
+        heads_from_logits<DIST, 4, EXACTA>(z, L, nullptr, true, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy,
+                                           &philox_words, &philox_valid);
+
+        // env step + truncation + auto-reset (PPO_Discrete.cpp:440-458)
+        int term;
+        const float reward = env_step<ENV>(st, act[0], term);
+        ep_len += 1;
+        ep_rew += reward;
+        if (ep_len == a.max_episode_steps) term = 1;
+        int fin_len = 0;
+        float fin_rew = 0.0f;
+        if (term) {
+            fin_len = ep_len;
+            fin_rew = ep_rew;
+            int k = resets++;
+            if (ENV == PPO_ENV_CARTPOLE && k >= a.reset_cap) { k = a.reset_cap - 1; if (l == 0) atomicOr(a.error_flag, 1); }
+            env_reset<ENV>(st, a.reset_table, k, a.seed, env_global);
+            ep_len = 0;
+            ep_rew = 0.0f;
+        }
+        if (live && l == 0) {
+            a.dones[tn] = (float)done;
+            a.logprobs[tn] = logprob;
+            a.rewards[tn] = reward;
+            a.fin_len[tn] = fin_len;
+            a.fin_rew[tn] = fin_rew;
+            a.actions[tn * H] = act[0];
+        }
+        if (DIST == PPO_DIST_MASKED && a.masks && live && l < A) a.masks[tn * A + l] = 1;
+        done = term;
+    }
+    if (live && l == 0) {
+        a.next_done[env] = done;
+        a.ep_len[env] = ep_len;
+        a.ep_rew[env] = ep_rew;
+        a.reset_count[env] = resets;
+    }
+    if (live && l < OBS) {
+        a.next_obs[(size_t)env * OBS + l] = st[l];
+        a.env_state[(size_t)l * N + env] = st[l];
     }
 }
 
@@ -489,9 +653,13 @@ __global__ void categorical_sample_kernel(const float* __restrict__ probs, int64
 // ---------------------------------------------------------------------------------------------------------
 hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.N), block(64);
+    static const bool two_per_wave = [] { const char* e = getenv("PPO_ROLLOUT_2PW"); return !(e && e[0] == '0'); }();
+    const dim3 grid2((unsigned)((a.N + 1) / 2));
 #define PPO_LAUNCH_ROLLOUT(ENV, DIST, OBS)                                                                       \
     do {                                                                                                         \
-        if (a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 2>), grid, block, 0, s, a);      \
+        if (two_per_wave && a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 2>), grid2, block, 0, s, a);      \
+        else if (two_per_wave && a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 3>), grid2, block, 0, s, a); \
+        else if (a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 2>), grid, block, 0, s, a);      \
         else if (a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 3>), grid, block, 0, s, a); \
         else if (a.L.act <= 4) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 0>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, PPO_MAX_ACT, 0>), grid, block, 0, s, a);         \
