@@ -452,9 +452,10 @@ def test_ragged_minibatches(P):
 
 
 # ------------------------------------------------------------------------------------------- end to end
-def test_fused_rollout_equals_stepwise_api(P):
+@pytest.mark.parametrize("N", [96, 7])   # 7: odd env count, the last wave of the two-envs-per-wave rollout is half empty
+def test_fused_rollout_equals_stepwise_api(P, N):
     """ppo_rollout (one launch) == T x { policy_act, env_step } through the stand-alone entry points, bit for bit."""
-    cfg = dict(num_envs=96, num_steps=40, num_minibatches=4, update_epochs=1, seed=5, max_episode_steps=30)
+    cfg = dict(num_envs=N, num_steps=40, num_minibatches=1, update_epochs=1, seed=5, max_episode_steps=30)
     a = P.Context(P.make_config(**cfg))
     b = P.Context(P.make_config(**cfg))
     a.init_orthogonal(11)
@@ -465,7 +466,7 @@ def test_fused_rollout_equals_stepwise_api(P):
     a.env_reset()
     obs = b.env_reset()
     a.rollout()
-    T, N = 40, 96
+    T = 40
     r_obs, r_act, r_lp, r_v, r_rew, r_done = (a.read("OBS", (T, N, 4)), a.read("ACTIONS", (T, N)), a.read("LOGPROBS", (T, N)),
                                               a.read("VALUES", (T, N)), a.read("REWARDS", (T, N)), a.read("DONES", (T, N)))
     done = np.zeros(N, np.float32)
