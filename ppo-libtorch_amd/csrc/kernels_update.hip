@@ -587,7 +587,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
 // between the two, so that path keeps reduce -> all-reduce -> norm -> AdamW.)  A one-launch version with a grid-wide rendezvous
 // was measured slower (18 us against 16: two device-scope fences and the polling cost more than the launch they save), and so was
 // a last-arriver version without any waiting (every workgroup publishes, takes a ticket, the last one applies AdamW to all P
-// parameters: 23 us) -- on this part an agent-scope fence per workgroup costs more than a kernel boundary.
+// parameters: 23 us with fences, 21 us with device-coherent stores / loads and no fence at all) -- on this part every
+// device-scope operation (store acknowledgement, atomic, coherent load) is a 1-2 us trip to the memory side, and three of them in a
+// row cost more than a kernel boundary.
 struct FusedOptArgs {
     const float* slab; const double* stat_slab; int nb0, nb1;
     NetLayout L;
