@@ -640,7 +640,7 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
             for (int t = 0; t < 12; t++) {
                 double v = 0.0;
                 const bool touches = t < L.n_tensors && L.tensor_off[t] < (int)(blockIdx.x + 1) * 64 && L.tensor_off[t + 1] > (int)blockIdx.x * 64;
-                if (touches) v = wave_sum_d(tl == t ? g2 : 0.0);
+                if (touches) v = wave_sum_d_dpp(tl == t ? g2 : 0.0);
                 if (lane == 0) a.partial[(size_t)blockIdx.x * 12 + t] = v;
             }
         }
@@ -681,16 +681,23 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
         if (a.clipfrac_accum) { cf0 = a.clipfrac_accum[0]; cf1 = a.clipfrac_accum[1]; }
     }
     // squared norms of the 12 tensors: wave w adds the partials of the workgroups that touch tensors w, w + 4, w + 8, in a fixed order
+    // (all three loads in flight together, sums on the DPP network)
+    {
+        double v[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const int t = w + 4 * j;
-        double v = 0.0;
-        if (t < L.n_tensors) {
-            const int blo = L.tensor_off[t] / 64, bhi = (L.tensor_off[t + 1] - 1) / 64;
-            for (int b = blo + lane; b <= bhi; b += 64) v += a.partial[(size_t)b * 12 + t];
+        for (int j = 0; j < 3; j++) {
+            const int t = w + 4 * j;
+            v[j] = 0.0;
+            if (t < L.n_tensors) {
+                const int blo = L.tensor_off[t] / 64, bhi = (L.tensor_off[t + 1] - 1) / 64;
+                for (int b = blo + lane; b <= bhi; b += 64) v[j] += a.partial[(size_t)b * 12 + t];
+            }
         }
-        v = wave_sum_d(v);
-        if (lane == 0) n2s[t] = v;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double r = wave_sum_d_dpp(v[j]);
+            if (lane == 0) n2s[w + 4 * j] = r;
+        }
     }
     __syncthreads();
     double tot = 0.0;
