@@ -33,7 +33,9 @@ extern "C" {
 typedef int32_t ppo_status;
 enum { PPO_OK = 0, PPO_ERR_INVALID = 1, PPO_ERR_HIP = 2, PPO_ERR_STATE = 3, PPO_ERR_COMM = 4, PPO_ERR_UNSUPPORTED = 5 };
 
-enum { PPO_ENV_CARTPOLE = 0, PPO_ENV_MOUNTAINCAR = 1 };
+/* PPO_ENV_SYNTHETIC: the synthetic env of BASELINE configs[4] (obs ~ N(0,1) of any width, reward ~ U(-1,1), done ~ Bernoulli(0.01), random
+ * action masks); it is the env with which networks other than the reference's 2 x 64 (hidden / n_hidden) are accepted. */
+enum { PPO_ENV_CARTPOLE = 0, PPO_ENV_MOUNTAINCAR = 1, PPO_ENV_SYNTHETIC = 2 };
 /* PPO_DIST_CATEGORICAL reproduces Distributions/Categorical.cpp including its entropy clamp (:112-119);
  * PPO_DIST_MASKED reproduces Distributions/CategoricalMasked.cpp (true entropy, -1e8 masking). */
 enum { PPO_DIST_CATEGORICAL = 0, PPO_DIST_MASKED = 1 };

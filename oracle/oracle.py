@@ -121,6 +121,34 @@ def _step_many(kind, obs_dim, state, action):
     return state, rew, term
 
 
+def synthetic_obs(seed, envs, step, obs_size):
+    """Observations of the synthetic env (BASELINE configs[4]) of the given global envs at global step `step`: [len(envs), obs_size]."""
+    envs = np.asarray(envs, np.int64).ravel()
+    out = np.empty((envs.size, obs_size), np.float32)
+    for i, e in enumerate(envs):
+        lib().orc_synthetic_obs(C.c_int64(seed), C.c_int64(int(e)), C.c_int64(step), C.c_int32(obs_size), _p(out[i]))
+    return out
+
+
+def synthetic_mask(seed, envs, step, head_dims):
+    envs = np.asarray(envs, np.int64).ravel()
+    hd = (C.c_int32 * len(head_dims))(*head_dims)
+    out = np.empty((envs.size, sum(head_dims)), np.uint8)
+    for i, e in enumerate(envs):
+        lib().orc_synthetic_mask(C.c_int64(seed), C.c_int64(int(e)), C.c_int64(step), C.c_int32(len(head_dims)), hd, _p(out[i]))
+    return out
+
+
+def synthetic_transition(seed, envs, step):
+    envs = np.asarray(envs, np.int64).ravel()
+    rew, done = np.empty(envs.size, np.float32), np.empty(envs.size, np.int32)
+    r, d = C.c_float(), C.c_int32()
+    for i, e in enumerate(envs):
+        lib().orc_synthetic_transition(C.c_int64(seed), C.c_int64(int(e)), C.c_int64(step), C.byref(r), C.byref(d))
+        rew[i], done[i] = r.value, d.value
+    return rew, done
+
+
 def cartpole_step(state, action):
     return _step_many(0, 4, state, action)
 

@@ -178,6 +178,33 @@ float orc_mountaincar_step(float* st, int64_t action, int32_t* terminated) {
     return -1.0f;
 }
 
+void orc_synthetic_obs(int64_t seed, int64_t env, int64_t step, int32_t obs_size, float* out) {
+    for (int j = 0; j < obs_size; j++) {
+        uint32_t w[4];
+        orc_philox4x32((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)env, (uint32_t)step, (uint32_t)(j >> 2), 0x10u, w);
+        const uint32_t x = w[j & 3];
+        const int sum = (int)(x & 255u) + (int)((x >> 8) & 255u) + (int)((x >> 16) & 255u) + (int)(x >> 24);
+        out[j] = (float)(sum - 510) * 0.0067658990621566772f;   /* four uniform bytes: variance 4 (256^2 - 1) / 12 */
+    }
+}
+void orc_synthetic_mask(int64_t seed, int64_t env, int64_t step, int32_t n_heads, const int32_t* head_dims, uint8_t* out) {
+    uint32_t w[4];
+    orc_philox4x32((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)env, (uint32_t)step, 0u, 0x12u, w);
+    int off = 0;
+    for (int h = 0; h < n_heads; h++) {
+        int any = 0;
+        for (int k = 0; k < head_dims[h]; k++) { const int v = (w[0] >> (off + k)) & 1u; any |= v; out[off + k] = (uint8_t)v; }
+        if (!any) out[off] = 1;
+        off += head_dims[h];
+    }
+}
+void orc_synthetic_transition(int64_t seed, int64_t env, int64_t step, float* reward, int32_t* done) {
+    uint32_t w[4];
+    orc_philox4x32((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)env, (uint32_t)step, 0u, 0x11u, w);
+    *reward = (float)(w[0] >> 8) * 0x1p-23f - 1.0f;
+    *done = (w[1] >> 8) < 167772u ? 1 : 0;
+}
+
 void orc_step_many(int32_t kind, float* state, const int64_t* action, int64_t n, float* reward, int32_t* terminated) {
     const int obs = kind == 0 ? 4 : 2;
     for (int64_t i = 0; i < n; i++)

@@ -59,6 +59,14 @@ float orc_mountaincar_step(float* state, int64_t action, int32_t* terminated);
 /* n independent transitions through the two functions above (kind: 0 CartPole, 1 MountainCar), in place on state [n, obs]. */
 void orc_step_many(int32_t kind, float* state, const int64_t* action, int64_t n, float* reward, int32_t* terminated);
 
+/* Synthetic environment of BASELINE configs[4] (obs ~ N(0,1), reward ~ U(-1,1), done ~ Bernoulli(0.01), random masks
+ * with at least one valid action per head).  No reference counterpart: it is the build's own definition, memoryless and
+ * counter-based (Philox keyed by seed; global env, global step, block, tag), restated here with integer arithmetic so that the device
+ * kernels (ppo-libtorch_amd/csrc/kernels_generic.hip) can be checked bit for bit. */
+void orc_synthetic_obs(int64_t seed, int64_t env, int64_t step, int32_t obs_size, float* out);
+void orc_synthetic_mask(int64_t seed, int64_t env, int64_t step, int32_t n_heads, const int32_t* head_dims, uint8_t* out);
+void orc_synthetic_transition(int64_t seed, int64_t env, int64_t step, float* reward, int32_t* done);
+
 /* Vectorised env with the semantics of PPO_Discrete::initEnvs/stepEnvs (PPO_Discrete.cpp:365-483). */
 typedef struct orc_vecenv orc_vecenv;
 orc_vecenv* orc_vecenv_create(int32_t kind, int64_t num_envs, int64_t seed, int64_t max_episode_steps, int64_t env_offset);

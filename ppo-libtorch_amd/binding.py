@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libppo_hip.so")
 
 MAX_HEADS = 8
-ENV_CARTPOLE, ENV_MOUNTAINCAR = 0, 1
+ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_SYNTHETIC = 0, 1, 2
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
 COMM_ID_BYTES = 128
 

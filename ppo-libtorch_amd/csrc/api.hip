@@ -15,6 +15,7 @@
 #include <mutex>
 #include <vector>
 
+#include "generic.hpp"
 #include "ppo_internal.hpp"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -115,6 +116,8 @@ struct ppo_ctx {
     double actor_share = 0.5;       // share of the fwd/bwd workgroups given to the actor (measured: with 4 tiles per wave an uneven
                                     // split only moves the integer tile count of the slower side up; kept as a tuning knob)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
+    GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
+    uint8_t* cur_mask = nullptr;     // generic path: action mask of the observation in NEXT_OBS, [N, A]
     bool force_collectives = false;  // PPO_COMM_SELFTEST: world == 1 but the multi-rank path (RCCL included) is taken
     bool fused_opt = true;           // single-rank contexts: optimizer step in two launches instead of three (env PPO_FUSED_OPT=0 disables)
     double* fused_partial = nullptr; // [fused_opt_blocks][12] per-workgroup sums of squares of the gradient
@@ -297,6 +300,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (c->lg_ready) (void)hipEventDestroy(c->lg_ready);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->gen) { gen_blas_destroy(c->gen->blas); delete c->gen; c->gen = nullptr; }
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->adam_coefs_h) (void)hipHostFree(c->adam_coefs_h);
     for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
@@ -308,11 +312,17 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     if (!cfg || !out) return fail(nullptr, PPO_ERR_INVALID, "null argument");
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(ppo_config)) return fail(nullptr, PPO_ERR_INVALID, "ppo_config.struct_size %d != %zu", cfg->struct_size, sizeof(ppo_config));
-    if (cfg->hidden != PPO_HIDDEN || cfg->n_hidden != 2)
-        return fail(nullptr, PPO_ERR_UNSUPPORTED, "only the reference architecture (2 hidden layers of 64, Agent.cpp:25-59) is built; got %d x %d", cfg->n_hidden, cfg->hidden);
-    if (cfg->env_kind != PPO_ENV_CARTPOLE && cfg->env_kind != PPO_ENV_MOUNTAINCAR) return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
+    const bool generic = cfg->env_kind == PPO_ENV_SYNTHETIC;
+    if (!generic && (cfg->hidden != PPO_HIDDEN || cfg->n_hidden != 2))
+        return fail(nullptr, PPO_ERR_UNSUPPORTED, "only the reference architecture (2 hidden layers of 64, Agent.cpp:25-59) is built for the reference's "
+                    "environments; got %d x %d (other shapes run with env_kind = PPO_ENV_SYNTHETIC)", cfg->n_hidden, cfg->hidden);
+    if (generic && (cfg->hidden < 1 || cfg->hidden > 2048 || cfg->n_hidden < 1 || cfg->n_hidden > GEN_MAX_LAYERS - 1 || cfg->obs_size < 1 || cfg->obs_size > 8192))
+        return fail(nullptr, PPO_ERR_UNSUPPORTED, "generic network out of range: hidden %d (1..2048), n_hidden %d (1..%d), obs %d (1..8192)", cfg->hidden,
+                    cfg->n_hidden, GEN_MAX_LAYERS - 1, cfg->obs_size);
+    if (cfg->env_kind != PPO_ENV_CARTPOLE && cfg->env_kind != PPO_ENV_MOUNTAINCAR && cfg->env_kind != PPO_ENV_SYNTHETIC)
+        return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     if (cfg->dist_kind != PPO_DIST_CATEGORICAL && cfg->dist_kind != PPO_DIST_MASKED) return fail(nullptr, PPO_ERR_INVALID, "unknown dist_kind %d", cfg->dist_kind);
-    const int env_obs = cfg->env_kind == PPO_ENV_CARTPOLE ? 4 : 2;
+    const int env_obs = cfg->env_kind == PPO_ENV_CARTPOLE ? 4 : (cfg->env_kind == PPO_ENV_MOUNTAINCAR ? 2 : cfg->obs_size);
     if (cfg->obs_size != env_obs) {
         // the reference's runtime check in initEnvs (PPO_Discrete.cpp:370-375), same wording
         return fail(nullptr, PPO_ERR_INVALID,
@@ -338,6 +348,14 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.global_num_envs <= 0) c->cfg.global_num_envs = cfg->num_envs;
     c->L = make_layout(cfg->obs_size, cfg->n_heads, cfg->head_dims);
+    if (generic) {
+        c->gen = new GenericCtx();
+        c->gen->L = make_gen_layout(cfg->obs_size, cfg->hidden, cfg->n_hidden, cfg->n_heads, cfg->head_dims);
+        // the shared code sizes the flat parameter / gradient / moment buffers from L.P; the 2 x 64 offsets in L are not used
+        c->L.P = c->gen->L.P;
+        c->L.n_tensors = c->gen->L.n_tensors;
+        c->L.net_size[0] = c->L.net_size[1] = 1;   // no per-workgroup gradient slabs on this path
+    }
     c->hp = LossParams{ cfg->clip_coef, cfg->ent_coef, cfg->vf_coef, cfg->norm_adv, cfg->clip_vloss, cfg->dist_kind };
     c->T = cfg->num_steps; c->N = cfg->num_envs; c->O = cfg->obs_size; c->H = cfg->n_heads; c->A = A;
     c->B = B;
@@ -406,7 +424,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(hipEventCreateWithFlags(&c->coef_copied[1], hipEventDisableTiming));
     CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
     CK(dalloc(c, &c->clipfrac_accum, 2));
-    CK(dalloc(c, &c->norm2, 16));
+    CK(dalloc(c, &c->norm2, 64));
     CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
     CK(dalloc(c, &c->ev_sums, PPO_EV_BLOCKS * 4));
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
@@ -414,6 +432,33 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->ring, 1));
     CK(dalloc(c, &c->scratch_obs, N * c->O));
     CK(dalloc(c, &c->stamps, 24));
+    if (c->gen) {
+        GenericCtx& g = *c->gen;
+        const GenLayout& GL = g.L;
+        g.rows_max = std::max<int64_t>(c->MB, c->N);
+        const size_t R = (size_t)g.rows_max;
+        for (int net = 0; net < 2; net++)
+            for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts[net][l], R * GL.hidden));
+        for (int i = 0; i < 2; i++) CK(dalloc(c, &g.dz[i], R * GL.hidden));
+        CK(dalloc(c, &g.xin, R * GL.obs));
+        CK(dalloc(c, &g.logits, R * GL.act));
+        CK(dalloc(c, &g.dlogits, R * GL.act));
+        CK(dalloc(c, &g.val, R));
+        CK(dalloc(c, &g.dval, R));
+        for (int i = 0; i < 4; i++) CK(dalloc(c, &g.row_f[i], R));
+        CK(dalloc(c, &g.row_f[4], R + 2));
+        CK(dalloc(c, &g.row_act, R * GL.n_heads));
+        CK(dalloc(c, &g.row_mask, R * GL.act));
+        CK(dalloc(c, &g.loss_part, (size_t)GEN_LOSS_BLOCKS * 8));
+        CK(dalloc(c, &g.act64, N * GL.n_heads));
+        CK(dalloc(c, &g.step_lp, N));
+        CK(dalloc(c, &g.step_en, N));
+        CK(dalloc(c, &c->cur_mask, N * GL.act));
+        CK(gen_fill(g.row_f[4] + 2, (int64_t)R, 1.0f, c->stream));   // the ones vector of the bias-gradient gemv
+        std::string berr;
+        hipError_t be = gen_blas_create(&g.blas, c->stream, berr);
+        if (be != hipSuccess) { fail(nullptr, PPO_ERR_UNSUPPORTED, "%s", berr.c_str()); ppo_ctx_destroy(c); return PPO_ERR_UNSUPPORTED; }
+    }
 #undef CK
     // every env can reset at most once per step: steps per env over the whole run bounds the shared reset stream
     const int64_t steps_per_env = cfg->total_timesteps > 0 ? cfg->total_timesteps / std::max<int64_t>(c->cfg.global_num_envs, 1) : 0;
@@ -474,6 +519,16 @@ extern "C" int64_t ppo_param_count(const ppo_ctx* c) { return c ? c->L.P : -1; }
 extern "C" ppo_status ppo_param_shapes(const ppo_ctx* c, int64_t* shapes_h, int32_t* n_tensors) {
     if (!c) return PPO_ERR_INVALID;
     if (n_tensors) *n_tensors = c->L.n_tensors;
+    if (shapes_h && c->gen) {
+        const GenLayout& GL = c->gen->L;
+        int k = 0;
+        for (int net = 0; net < 2; net++)
+            for (int l = 0; l < GL.n_layers; l++) {
+                shapes_h[k++] = GL.out_dim[net][l]; shapes_h[k++] = GL.in_dim[l];
+                shapes_h[k++] = GL.out_dim[net][l]; shapes_h[k++] = 1;
+            }
+        return PPO_OK;
+    }
     if (shapes_h) {
         int k = 0;
         for (int net = 0; net < 2; net++) {
@@ -586,6 +641,15 @@ static void orthogonal_fill(float* W, int rows, int cols, double gain, int64_t s
 extern "C" ppo_status ppo_params_init_orthogonal(ppo_ctx* c, int64_t seed) {
     NEED(c, c != nullptr, "null ctx");
     std::vector<float> p((size_t)c->L.P, 0.0f);
+    if (c->gen) {   // Agent.cpp:25-59 generalised: sqrt(2) on hidden layers, 1.0 on the value head, 0.01 on the policy head
+        const GenLayout& GL = c->gen->L;
+        for (int net = 0; net < 2; net++)
+            for (int l = 0; l < GL.n_layers; l++) {
+                const double gain = l < GL.n_hidden ? std::sqrt(2.0) : (net == 0 ? 1.0 : 0.01);
+                orthogonal_fill(p.data() + GL.w_off[net][l], GL.out_dim[net][l], GL.in_dim[l], gain, seed, net * GEN_MAX_LAYERS + l);
+            }
+        return ppo_params_set_h(c, p.data(), c->L.P);
+    }
     for (int net = 0; net < 2; net++) {
         const int out3 = net == 0 ? 1 : c->A;
         orthogonal_fill(p.data() + c->L.w1[net], PPO_HIDDEN, c->O, std::sqrt(2.0), seed, net * 3 + 0);
@@ -595,8 +659,31 @@ extern "C" ppo_status ppo_params_init_orthogonal(ppo_ctx* c, int64_t seed) {
     return ppo_params_set_h(c, p.data(), c->L.P);
 }
 
+// ---- generic networks (generic.hpp): critic / actor over n rows, chunked to the workspace size ----
+static ppo_status gen_values(ppo_ctx* c, const float* obs, int64_t n, float* value) {
+    GenericCtx& g = *c->gen;
+    for (int64_t off = 0; off < n; off += g.rows_max) {
+        const int64_t rows = std::min<int64_t>(g.rows_max, n - off);
+        HIPCHK(c, gen_forward(g, B_<float>(c, PPO_BUF_PARAMS), 0, obs + off * g.L.obs, rows, nullptr, g.dz[0], g.dz[1], value + off, c->stream));
+    }
+    return PPO_OK;
+}
+static ppo_status gen_policy(ppo_ctx* c, const float* obs, const uint8_t* mask, const int64_t* forced, int64_t n, int64_t step_index, int64_t* action,
+                             float* logprob, float* entropy) {
+    GenericCtx& g = *c->gen;
+    for (int64_t off = 0; off < n; off += g.rows_max) {
+        const int64_t rows = std::min<int64_t>(g.rows_max, n - off);
+        HIPCHK(c, gen_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, rows, nullptr, g.dz[0], g.dz[1], g.logits, c->stream));
+        HIPCHK(c, gen_heads(g.L, c->cfg.dist_kind, g.logits, mask ? mask + off * g.L.act : nullptr, forced ? forced + off * g.L.n_heads : nullptr, rows,
+                            c->cfg.seed, c->cfg.env_offset + off, step_index, action ? action + off * g.L.n_heads : nullptr,
+                            logprob ? logprob + off : nullptr, entropy ? entropy + off : nullptr, c->stream));
+    }
+    return PPO_OK;
+}
+
 extern "C" ppo_status ppo_get_value(ppo_ctx* c, const float* obs, int64_t n, float* value) {
     NEED(c, c && obs && value, "null argument");
+    if (c->gen) return gen_values(c, obs, n, value);
     HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, obs, nullptr, nullptr, n, c->cfg.seed, c->cfg.env_offset, 0,
                                 nullptr, nullptr, nullptr, value, true, c->stream));
     return PPO_OK;
@@ -606,6 +693,11 @@ extern "C" ppo_status ppo_policy_act(ppo_ctx* c, const float* obs, const uint8_t
                                      int64_t step_index, int64_t* action, float* logprob, float* entropy, float* value) {
     NEED(c, c && obs, "null argument");
     NEED(c, forced_action || action, "sampling needs an action output");
+    if (c->gen) {
+        ppo_status s = gen_policy(c, obs, mask, forced_action, n, step_index, action, logprob, entropy);
+        if (s == PPO_OK && value) s = gen_values(c, obs, n, value);
+        return s;
+    }
     HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, obs, mask, forced_action, n, c->cfg.seed, c->cfg.env_offset,
                                 step_index, action, logprob, entropy, value, false, c->stream));
     return PPO_OK;
@@ -634,6 +726,14 @@ extern "C" ppo_status ppo_env_transition(int32_t env_kind, const float* state_in
 
 extern "C" ppo_status ppo_env_reset(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    if (c->gen) {   // synthetic env: memoryless, the observation of global step `rollout_steps` (0 after creation)
+        HIPCHK(c, hipMemsetAsync(c->buf[PPO_BUF_EP_LEN], 0, (size_t)c->N * sizeof(int32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->buf[PPO_BUF_EP_REW], 0, (size_t)c->N * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->buf[PPO_BUF_NEXT_DONE], 0, (size_t)c->N * sizeof(int32_t), c->stream));
+        HIPCHK(c, gen_synthetic_step(c->gen->L, c->N, c->cfg.seed, c->cfg.env_offset, c->rollout_steps, c->cfg.max_episode_steps, nullptr, nullptr,
+                                     B_<float>(c, PPO_BUF_NEXT_OBS), c->cur_mask, nullptr, nullptr, nullptr, nullptr, c->stream));
+        return PPO_OK;
+    }
     HIPCHK(c, launch_env_reset(c->cfg.env_kind, c->N, c->cfg.seed, c->cfg.env_offset, B_<float>(c, PPO_BUF_ENV_STATE), B_<int32_t>(c, PPO_BUF_EP_LEN),
                                B_<float>(c, PPO_BUF_EP_REW), B_<int32_t>(c, PPO_BUF_RESET_COUNT), c->reset_table, c->reset_cap,
                                B_<float>(c, PPO_BUF_NEXT_OBS), B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->error_flag, c->stream));
@@ -642,6 +742,12 @@ extern "C" ppo_status ppo_env_reset(ppo_ctx* c) {
 
 extern "C" ppo_status ppo_env_step(ppo_ctx* c, const int64_t* action, float* obs, float* reward, int32_t* done) {
     NEED(c, c && action && obs && reward && done, "null argument");
+    if (c->gen) {   // synthetic env: one step at the context's global step counter (the action does not influence it)
+        HIPCHK(c, gen_synthetic_step(c->gen->L, c->N, c->cfg.seed, c->cfg.env_offset, c->rollout_steps, c->cfg.max_episode_steps,
+                                     B_<int32_t>(c, PPO_BUF_EP_LEN), B_<float>(c, PPO_BUF_EP_REW), obs, c->cur_mask, reward, done, nullptr, nullptr, c->stream));
+        c->rollout_steps += 1;
+        return PPO_OK;
+    }
     HIPCHK(c, launch_env_step(c->cfg.env_kind, c->N, c->H, c->cfg.max_episode_steps, c->cfg.seed, c->cfg.env_offset, B_<float>(c, PPO_BUF_ENV_STATE),
                               B_<int32_t>(c, PPO_BUF_EP_LEN), B_<float>(c, PPO_BUF_EP_REW), B_<int32_t>(c, PPO_BUF_RESET_COUNT), c->reset_table,
                               c->reset_cap, action, obs, reward, done, c->error_flag, c->stream));
@@ -680,6 +786,7 @@ extern "C" ppo_status ppo_env_get_state_h(ppo_ctx* c, float* state_h, int32_t* e
 // ---------------------------------------------------------------------------------------------------------
 // Rollout and advantages
 // ---------------------------------------------------------------------------------------------------------
+static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced);
 static ppo_status consume_finished_episodes(ppo_ctx* c) {
     if (!c->fin_pending) return PPO_OK;
     HIPCHK(c, launch_episode_ring_update(B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), c->T, c->N, c->row_counts, c->group_bits, c->ring, c->stream));
@@ -691,6 +798,7 @@ extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     NEED(c, c != nullptr, "null ctx");
     ppo_status s = consume_finished_episodes(c);
     if (s != PPO_OK) return s;
+    if (c->gen) return gen_rollout(c, forced_actions);
     // worst case one reset per env per step
     s = ensure_reset_table(c, c->rollout_steps + c->T + 4);
     if (s != PPO_OK) return s;
@@ -758,8 +866,8 @@ static ppo_status run_scan(ppo_ctx* c) {
 extern "C" ppo_status ppo_calc_advantage(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
     // bootstrap value if not done: next_value = Critic(next_obs) (PPO_Discrete.cpp:280)
-    HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, B_<float>(c, PPO_BUF_NEXT_OBS), nullptr, nullptr, c->N, c->cfg.seed,
-                                c->cfg.env_offset, 0, nullptr, nullptr, nullptr, B_<float>(c, PPO_BUF_NEXT_VALUE), true, c->stream));
+    const ppo_status s = ppo_get_value(c, B_<float>(c, PPO_BUF_NEXT_OBS), c->N, B_<float>(c, PPO_BUF_NEXT_VALUE));
+    if (s != PPO_OK) return s;
     return run_scan(c);
 }
 
@@ -816,7 +924,67 @@ static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
     return PPO_OK;
 }
 
+// ---- generic networks: one minibatch step = gather, two forward passes that keep their activations, loss, two backward passes ----
+static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot) {
+    GenericCtx& g = *c->gen;
+    const GenLayout& GL = g.L;
+    NEED(c, M >= 1 && M <= g.rows_max, "minibatch larger than the workspace");
+    const double global_M = (double)M * c->world;
+    c->last_global_M = global_M;
+    float* params = B_<float>(c, PPO_BUF_PARAMS);
+    float* grads = B_<float>(c, PPO_BUF_GRADS);
+    {
+        ProfScope ps(c, PROF_FWD_BWD);
+        HIPCHK(c, gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
+                             B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), idx, M, g, c->stream));
+        HIPCHK(c, gen_forward(g, params, 1, g.xin, M, g.acts[1], nullptr, nullptr, g.logits, c->stream));
+        HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, c->stream));
+        HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
+        HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream));
+        HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, c->stream));
+    }
+    {
+        ProfScope ps(c, PROF_REDUCE);
+        HIPCHK(c, gen_loss_sums(g, c->loss_sums, grads + GL.P, c->stream));
+    }
+    return PPO_OK;
+}
+
+// the T-step rollout as T x { actor GEMMs + heads, stores, env step } and one critic batch at the end (PPO_MultiDiscrete.cpp:547-575)
+static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced) {
+    GenericCtx& g = *c->gen;
+    const GenLayout& GL = g.L;
+    const int N = c->N;
+    float* params = B_<float>(c, PPO_BUF_PARAMS);
+    float* next_obs = B_<float>(c, PPO_BUF_NEXT_OBS);
+    const uint8_t* mask = c->cfg.dist_kind == PPO_DIST_MASKED ? c->cur_mask : nullptr;
+    {
+        ProfScope ps(c, PROF_ROLLOUT);
+        for (int t = 0; t < c->T; t++) {
+            const size_t tn = (size_t)t * N;
+            const int64_t step = c->rollout_steps + t;
+            HIPCHK(c, gen_forward(g, params, 1, next_obs, N, nullptr, g.dz[0], g.dz[1], g.logits, c->stream));
+            HIPCHK(c, gen_heads(GL, c->cfg.dist_kind, g.logits, mask, forced ? forced + tn * GL.n_heads : nullptr, N, c->cfg.seed, c->cfg.env_offset, step,
+                                g.act64, g.step_lp, g.step_en, c->stream));
+            HIPCHK(c, gen_store_step(GL, N, next_obs, mask /* plain Categorical: masks are stored as all ones */, g.act64, g.step_lp, B_<int32_t>(c, PPO_BUF_NEXT_DONE), B_<float>(c, PPO_BUF_OBS) + tn * GL.obs,
+                                     B_<uint8_t>(c, PPO_BUF_MASKS) + tn * GL.act, B_<int32_t>(c, PPO_BUF_ACTIONS) + tn * GL.n_heads,
+                                     B_<float>(c, PPO_BUF_LOGPROBS) + tn, B_<float>(c, PPO_BUF_DONES) + tn, c->stream));
+            HIPCHK(c, gen_synthetic_step(GL, N, c->cfg.seed, c->cfg.env_offset, step, c->cfg.max_episode_steps, B_<int32_t>(c, PPO_BUF_EP_LEN),
+                                         B_<float>(c, PPO_BUF_EP_REW), next_obs, c->cur_mask, B_<float>(c, PPO_BUF_REWARDS) + tn,
+                                         B_<int32_t>(c, PPO_BUF_NEXT_DONE), B_<int32_t>(c, PPO_BUF_FIN_LEN) + tn, B_<float>(c, PPO_BUF_FIN_REW) + tn, c->stream));
+        }
+        ppo_status s = gen_values(c, B_<float>(c, PPO_BUF_OBS), (int64_t)c->T * N, B_<float>(c, PPO_BUF_VALUES));
+        if (s == PPO_OK) s = gen_values(c, next_obs, N, B_<float>(c, PPO_BUF_NEXT_VALUE));
+        if (s != PPO_OK) return s;
+    }
+    c->rollout_steps += c->T;
+    c->global_step += (int64_t)c->T * c->cfg.global_num_envs;
+    c->fin_pending = true;
+    return PPO_OK;
+}
+
 static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, bool reduce = true) {
+    if (c->gen) return gen_fwd_bwd(c, idx, M, slot);
     UpdateArgs a{};
     a.params = B_<float>(c, PPO_BUF_PARAMS);
     a.L = c->L;
@@ -852,6 +1020,17 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     return PPO_OK;
 }
 
+// clip + AdamW (or, with do_step false, just the loss scalars and the gradient norm) on whichever parameter layout the context has
+static hipError_t clip_adamw_any(ppo_ctx* c, int slot, double global_M, int world, bool do_step, double* clipfrac_accum) {
+    if (c->gen)
+        return gen_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                              c->gen->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, world, do_step,
+                              c->step_stats + slot, clipfrac_accum, c->norm2, c->stream);
+    return launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                             c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, world, do_step,
+                             c->step_stats + slot, clipfrac_accum, c->norm2, c->stream);
+}
+
 extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* idx, int64_t M) {
     NEED(c, c && idx, "null argument");
     NEED(c, M >= 1 && M <= c->B, "minibatch size out of range");
@@ -864,9 +1043,7 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
     ppo_status s = fwd_bwd(c, idx, M, slot);
     if (s != PPO_OK) return s;
     // loss scalars and the norm of the unclipped gradient, without touching parameters
-    HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
-                                c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, (double)M * c->world, c->hp, 1, false,
-                                c->step_stats + slot, nullptr, c->norm2, c->stream));
+    HIPCHK(c, clip_adamw_any(c, slot, (double)M * c->world, 1, false, nullptr));
     c->last_stat_slot = slot;
     return PPO_OK;
 }
@@ -886,10 +1063,8 @@ static ppo_status optimizer_step_slot(ppo_ctx* c, int slot, double global_M, boo
     }
     {
         ProfScope ps(c, PROF_OPT);
-        HIPCHK(c, launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
-                                    c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp,
-                                    c->force_collectives ? 2 : c->world /* self-test: read the loss sums from the all-reduced tail */, true,
-                                    c->step_stats + slot, c->clipfrac_accum, c->norm2, c->stream));
+        HIPCHK(c, clip_adamw_any(c, slot, global_M, c->force_collectives ? 2 : c->world /* self-test: read the loss sums from the all-reduced tail */, true,
+                                 c->clipfrac_accum));
     }
     c->last_stat_slot = slot;
     return PPO_OK;
@@ -939,7 +1114,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         for (int mbi = 0; mbi < nmb; mbi++, k++) {
             const int64_t start = (int64_t)mbi * c->MB;
             const int64_t M = std::min<int64_t>(c->MB, c->B - start);
-            const bool fused = c->fused_opt && c->world == 1 && !c->force_collectives;
+            const bool fused = c->fused_opt && c->world == 1 && !c->force_collectives && !c->gen;
             s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !fused);
             if (s != PPO_OK) return s;
             if (fused) {

@@ -1,0 +1,97 @@
+// ppo-libtorch_amd/csrc/generic.hpp -- networks other than the reference's 2 x 64 (BASELINE configs[4]: obs 376, 4 x 256, heads
+// [3,3,3,2]; SURVEY 8(a) a6 "hidden width / depth configurable", cf. the commented 256-wide third layer of Agent.cpp:27,32,45-46).
+//
+// Same contract and the same C-ABI as the specialised path; different machine mapping: at these widths every layer is a real GEMM
+// (M = rows of the step or of the minibatch, N = K = hidden), so layers are plain library GEMMs (rocBLAS sgemm, fp32, atomics off:
+// deterministic) glued by small hand-written kernels for what is not a GEMM -- bias + tanh, the categorical heads, the PPO loss
+// and its gradient, tanh', column sums for the bias gradients, the gather, clip + AdamW over an arbitrary tensor list.
+// Parameter order is the reference's generalised: critic layers (W [out][in] row-major, b) then actor layers (Agent.cpp:65-66).
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "ppo_internal.hpp"
+
+constexpr int GEN_MAX_LAYERS = 8;   // linear layers per net (n_hidden + 1)
+
+struct GenLayout {
+    int obs, act, n_heads, hidden, n_hidden;
+    int head_dims[PPO_MAX_HEADS];
+    int n_layers;                          // n_hidden + 1
+    int in_dim[GEN_MAX_LAYERS];            // per layer (same for both nets)
+    int out_dim[2][GEN_MAX_LAYERS];        // [net][layer]: hidden ... hidden, then 1 (critic) / act (actor)
+    int w_off[2][GEN_MAX_LAYERS], b_off[2][GEN_MAX_LAYERS];
+    int net_off[2], net_size[2];
+    int P;
+    int n_tensors;
+    int tensor_off[4 * GEN_MAX_LAYERS + 1];
+};
+
+inline GenLayout make_gen_layout(int obs, int hidden, int n_hidden, int n_heads, const int* head_dims) {
+    GenLayout L{};
+    L.obs = obs; L.hidden = hidden; L.n_hidden = n_hidden; L.n_heads = n_heads; L.n_layers = n_hidden + 1;
+    for (int h = 0; h < n_heads; h++) { L.head_dims[h] = head_dims[h]; L.act += head_dims[h]; }
+    int o = 0, t = 0;
+    for (int net = 0; net < 2; net++) {
+        L.net_off[net] = o;
+        for (int l = 0; l < L.n_layers; l++) {
+            L.in_dim[l] = l == 0 ? obs : hidden;
+            L.out_dim[net][l] = l == n_hidden ? (net == 0 ? 1 : L.act) : hidden;
+            L.tensor_off[t++] = o; L.w_off[net][l] = o; o += L.out_dim[net][l] * L.in_dim[l];
+            L.tensor_off[t++] = o; L.b_off[net][l] = o; o += L.out_dim[net][l];
+        }
+        L.net_size[net] = o - L.net_off[net];
+    }
+    L.tensor_off[t] = o;
+    L.n_tensors = t;
+    L.P = o;
+    return L;
+}
+
+// Device workspace and library handle of one generic context (owned by ppo_ctx; see api.hip).
+struct GenericCtx {
+    GenLayout L{};
+    void* blas = nullptr;          // rocblas_handle
+    int64_t rows_max = 0;          // rows the workspaces are sized for: max(minibatch, T*N + N for the critic batch is chunked to it)
+    float* acts[2][GEN_MAX_LAYERS] = {};   // [net][l]: post-tanh activations of hidden layer l, [rows_max, hidden]
+    float* dz[2] = {};             // ping-pong d(pre-activation), [rows_max, hidden]
+    float* xin = nullptr;          // gathered observations of the minibatch, [rows_max, obs]
+    float* logits = nullptr;       // [rows_max, act]
+    float* dlogits = nullptr;      // [rows_max, act]
+    float* val = nullptr;          // [rows_max]
+    float* dval = nullptr;         // [rows_max]
+    float* row_f[5] = {};          // gathered per-row scalars: old log-prob, advantage, return, old value; [4] = {adv mean, 1/(std+eps)} then a ones vector
+    int32_t* row_act = nullptr;    // gathered actions [rows_max, n_heads]
+    uint8_t* row_mask = nullptr;   // gathered masks [rows_max, act]
+    double* loss_part = nullptr;   // [GEN_LOSS_BLOCKS, 8] partial loss sums
+    int64_t* act64 = nullptr;      // [N, n_heads] actions of the current rollout step (int64, the stand-alone API's type)
+    float* step_lp = nullptr;      // [N] log-prob / entropy of the current rollout step
+    float* step_en = nullptr;
+};
+constexpr int GEN_LOSS_BLOCKS = 256;
+
+// kernels_generic.hip
+struct ppo_ctx;
+hipError_t gen_blas_create(void** handle, hipStream_t s, std::string& err);
+void gen_blas_destroy(void* handle);
+// out[rows, out_dim(last)] = net(x[rows, obs]); acts != nullptr keeps every hidden layer's activations (for the backward pass)
+hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, float* const* acts, float* scratch0,
+                       float* scratch1, float* out, hipStream_t s);
+hipError_t gen_heads(const GenLayout& L, int dist_kind, const float* logits, const uint8_t* mask, const int64_t* forced, int64_t n, int64_t seed,
+                     int64_t row_offset, int64_t step_index, int64_t* action, float* logprob, float* entropy, hipStream_t s);
+hipError_t gen_gather(const GenLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs, const float* adv,
+                      const float* ret, const float* values, const int32_t* idx, int64_t M, GenericCtx& g, hipStream_t s);
+hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& g, int64_t M, double inv_global_M, double global_M,
+                    const AdvStat* adv_stat, hipStream_t s);
+hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
+                        hipStream_t s);
+hipError_t gen_loss_sums(const GenericCtx& g, double* sums_out, float* grads_tail, hipStream_t s);
+hipError_t gen_fill(float* p, int64_t n, float v, hipStream_t s);
+hipError_t gen_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const GenLayout& L, float max_grad_norm, const AdamCoef* coef,
+                          const double* loss_sums, double global_M, LossParams hp, int world, bool do_step, StepStats* stats_out,
+                          double* clipfrac_accum, double* norm2_scratch, hipStream_t s);
+hipError_t gen_synthetic_step(const GenLayout& L, int N, int64_t seed, int64_t env_offset, int64_t step_index, int max_episode_steps, int32_t* ep_len,
+                              float* ep_rew, float* obs_out, uint8_t* mask_out, float* reward, int32_t* done, int32_t* fin_len, float* fin_rew,
+                              hipStream_t s);
+hipError_t gen_store_step(const GenLayout& L, int N, const float* obs, const uint8_t* mask, const int64_t* act64, const float* lp, const int32_t* done_prev,
+                          float* obs_t, uint8_t* mask_t, int32_t* act_t, float* lp_t, float* dones_t, hipStream_t s);

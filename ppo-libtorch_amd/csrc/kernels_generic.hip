@@ -1,0 +1,472 @@
+// ppo-libtorch_amd/csrc/kernels_generic.hip -- networks other than the reference's 2 x 64 (see generic.hpp).
+//
+// Layers are rocBLAS sgemm calls (fp32, atomics off: bit-reproducible); this file holds the glue that is not a GEMM, written for
+// wave64: bias + tanh, categorical heads (one thread per row), the PPO loss and its gradient, tanh', the gather, clip + AdamW
+// over an arbitrary tensor list, and the synthetic environment of BASELINE configs[4].
+// Row-major X[rows, K] is column-major X^T[K, rows] with leading dimension K, so  Y = X W^T  is  sgemm(T, N, N, rows, K, W, X).
+#include <dlfcn.h>
+
+#include <mutex>
+#include <string>
+
+#include "generic.hpp"
+
+namespace rb {
+typedef int (*create_t)(void**);
+typedef int (*destroy_t)(void*);
+typedef int (*set_stream_t)(void*, hipStream_t);
+typedef int (*set_atomics_t)(void*, int);
+typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
+typedef int (*sgemv_t)(void*, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
+static create_t create;
+static destroy_t destroy;
+static set_stream_t set_stream;
+static set_atomics_t set_atomics;
+static sgemm_t sgemm;
+static sgemv_t sgemv;
+constexpr int OP_N = 111, OP_T = 112, ATOMICS_NOT_ALLOWED = 0;
+static bool load(std::string& err) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (sgemm) return true;
+    void* h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { err = std::string("cannot load librocblas (needed for networks other than 2 x 64): ") + dlerror(); return false; }
+    create = (create_t)dlsym(h, "rocblas_create_handle");
+    destroy = (destroy_t)dlsym(h, "rocblas_destroy_handle");
+    set_stream = (set_stream_t)dlsym(h, "rocblas_set_stream");
+    set_atomics = (set_atomics_t)dlsym(h, "rocblas_set_atomics_mode");
+    sgemm = (sgemm_t)dlsym(h, "rocblas_sgemm");
+    sgemv = (sgemv_t)dlsym(h, "rocblas_sgemv");
+    if (!create || !destroy || !set_stream || !set_atomics || !sgemm || !sgemv) { err = "librocblas lacks rocblas_* symbols"; sgemm = nullptr; return false; }
+    return true;
+}
+}  // namespace rb
+
+hipError_t gen_blas_create(void** handle, hipStream_t s, std::string& err) {
+    if (!rb::load(err)) return hipErrorNotSupported;
+    if (rb::create(handle) != 0) { err = "rocblas_create_handle failed"; return hipErrorUnknown; }
+    if (rb::set_stream(*handle, s) != 0 || rb::set_atomics(*handle, rb::ATOMICS_NOT_ALLOWED) != 0) { err = "rocblas handle setup failed"; return hipErrorUnknown; }
+    return hipSuccess;
+}
+void gen_blas_destroy(void* handle) { if (handle && rb::destroy) rb::destroy(handle); }
+
+namespace {
+
+// h[r][n] = tanh(z[r][n] + b[n])   (ACT) or z + b (last layer).  Library tanhf: this path is the yardstick-accurate one.
+template <bool ACT>
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ z, const float* __restrict__ b, int64_t rows, int n) {
+    const int64_t total = rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float v = z[i] + b[i % n];
+        z[i] = ACT ? tanhf(v) : v;
+    }
+}
+// d[r][n] *= 1 - h[r][n]^2
+__global__ __launch_bounds__(256) void dtanh_kernel(float* __restrict__ d, const float* __restrict__ h, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) d[i] = d[i] * (1.0f - h[i] * h[i]);
+}
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// One thread per row: per-head (masked) categorical over the row's logits; samples (Philox, same keying as the specialised path:
+// counter (row, step / 4, head, 0), word step % 4) unless an action is forced.  Agent.cpp:137-170.
+template <int DIST>
+__global__ __launch_bounds__(128) void heads_kernel(GenLayout L, const float* __restrict__ logits, const uint8_t* __restrict__ mask,
+                                                    const int64_t* __restrict__ forced, int64_t n, int64_t seed, int64_t row_offset, int64_t step_index,
+                                                    int64_t* action, float* logprob, float* entropy) {
+    const int64_t r = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (r >= n) return;
+    float lp_sum = 0.0f, en_sum = 0.0f;
+    int off = 0;
+    for (int h = 0; h < L.n_heads; h++) {
+        const int A = L.head_dims[h];
+        float z[PPO_MAX_ACT], p[PPO_MAX_ACT];
+        for (int k = 0; k < A; k++) z[k] = logits[r * L.act + off + k];
+        const uint8_t* mrow = (DIST == PPO_DIST_MASKED && mask) ? mask + r * L.act + off : nullptr;
+        const float en = categorical_head<DIST>(z, p, mrow, A);
+        int a;
+        if (forced) {
+            a = (int)forced[r * L.n_heads + h];
+        } else {
+            const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(row_offset + r), (uint32_t)(step_index >> 2), (uint32_t)h, 0u);
+            const uint32_t ws = (step_index & 3) == 0 ? w.x : ((step_index & 3) == 1 ? w.y : ((step_index & 3) == 2 ? w.z : w.w));
+            a = sample_head(p, A, (float)(ws >> 8) * 0x1p-24f);
+        }
+        if (action) action[r * L.n_heads + h] = a;
+        float lp = 0.0f;
+        for (int k = 0; k < A; k++) if (k == a) lp = z[k];
+        if (h == 0) { lp_sum = lp; en_sum = en; } else { lp_sum += lp; en_sum += en; }   // stack(...).sum(0), Agent.cpp:165-168
+        off += A;
+    }
+    if (logprob) logprob[r] = lp_sum;
+    if (entropy) entropy[r] = en_sum;
+}
+
+// Minibatch gather (PPO_Discrete.cpp:576-582): observation rows and per-row scalars into dense workspaces.
+__global__ __launch_bounds__(256) void gather_kernel(GenLayout L, const float* __restrict__ obs, const int32_t* __restrict__ actions,
+                                                     const uint8_t* __restrict__ masks, const float* __restrict__ logprobs, const float* __restrict__ adv,
+                                                     const float* __restrict__ ret, const float* __restrict__ values, const int32_t* __restrict__ idx,
+                                                     int64_t M, float* xin, int32_t* row_act, uint8_t* row_mask, float* f0, float* f1, float* f2, float* f3) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per row
+    if (r >= M) return;
+    const int64_t src = idx[r];
+    for (int o = lane; o < L.obs; o += 64) xin[r * L.obs + o] = obs[src * L.obs + o];
+    if (lane < L.n_heads) row_act[r * L.n_heads + lane] = actions[src * L.n_heads + lane];
+    if (masks && lane < L.act) row_mask[r * L.act + lane] = masks[src * L.act + lane];
+    if (lane == 0) { f0[r] = logprobs[src]; f1[r] = adv[src]; f2[r] = ret[src]; f3[r] = values[src]; }
+}
+
+// PPO loss and its gradient w.r.t. logits / value, one thread per row (PPO_Discrete.cpp:585-631 and the autograd of it; the formulas
+// are those of the specialised kernels).  Block partial sums of {pg, entropy, kl, clip count, value loss} go to loss_part.
+template <int DIST>
+__global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, const float* __restrict__ logits, const float* __restrict__ val,
+                                                   const int32_t* __restrict__ row_act, const uint8_t* __restrict__ row_mask,
+                                                   const float* __restrict__ oldlp, const float* __restrict__ advs, const float* __restrict__ rets,
+                                                   const float* __restrict__ oldv, int64_t M, float invM, const float* __restrict__ stat2,
+                                                   float* dlogits, float* dval, double* loss_part) {
+    __shared__ double red[5][4];
+    double s[5] = { 0, 0, 0, 0, 0 };
+    const float mean_f = stat2[0], inv_std = stat2[1];   // advantage mean and 1 / (std + 1e-8) of the (global) minibatch
+    const float clip = hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < M; r += (int64_t)gridDim.x * 256) {
+        float nlp = 0.0f, ent = 0.0f;
+        float z[PPO_MAX_ACT], p[PPO_MAX_ACT], headH[PPO_MAX_HEADS];
+        int off = 0;
+        for (int h = 0; h < L.n_heads; h++) {
+            const int A = L.head_dims[h];
+            for (int k = 0; k < A; k++) z[off + k] = logits[r * L.act + off + k];
+            const uint8_t* mrow = (DIST == PPO_DIST_MASKED && row_mask) ? row_mask + r * L.act + off : nullptr;
+            headH[h] = categorical_head<DIST>(z + off, p + off, mrow, A);
+            const int a = row_act[r * L.n_heads + h];
+            float lp = 0.0f;
+            for (int k = 0; k < A; k++) if (k == a) lp = z[off + k];
+            if (h == 0) { nlp = lp; ent = headH[h]; } else { nlp += lp; ent += headH[h]; }
+            off += A;
+        }
+        const float logratio = nlp - oldlp[r];
+        const float ratio = expf(logratio);
+        float adv = advs[r];
+        if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
+        const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
+        const float l1 = -adv * ratio, l2 = -adv * rc;
+        const bool inside = (ratio >= lo && ratio <= hi_c);
+        float d_ratio;
+        if (l1 > l2) d_ratio = -adv;
+        else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+        else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half/half
+        const float g_nlp = invM * d_ratio * ratio;
+        const float g_ent = -hp.ent_coef * invM;
+        off = 0;
+        for (int h = 0; h < L.n_heads; h++) {
+            const int A = L.head_dims[h];
+            const int a = row_act[r * L.n_heads + h];
+            for (int k = 0; k < A; k++) {
+                const bool ok = !(DIST == PPO_DIST_MASKED && row_mask) || row_mask[r * L.act + off + k] != 0;
+                float d = g_nlp * ((k == a ? 1.0f : 0.0f) - p[off + k]);
+                if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[off + k] * (z[off + k] + headH[h]));
+                dlogits[r * L.act + off + k] = ok ? d : 0.0f;
+            }
+            off += A;
+        }
+        s[0] += (double)(l1 > l2 ? l1 : l2);
+        s[1] += (double)ent;
+        s[2] += (double)((ratio - 1.0f) - logratio);
+        s[3] += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
+        // value loss (:603-625)
+        const float v = val[r], R = rets[r], vold = oldv[r];
+        const float un = (v - R) * (v - R);
+        float g_v, lossv;
+        if (hp.clip_vloss) {
+            const float dv = v - vold;
+            const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+            const float vc = vold + dvc;
+            const float cl = (vc - R) * (vc - R);
+            lossv = un > cl ? un : cl;
+            const bool vin = (dv >= -clip && dv <= clip);
+            const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+            const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);
+            g_v = hp.vf_coef * 0.5f * invM * d;
+        } else {
+            lossv = un;
+            g_v = hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+        }
+        dval[r] = g_v;
+        s[4] += (double)lossv;
+    }
+    for (int k = 0; k < 5; k++) {
+        const double t = wave_sum_d_dpp(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) loss_part[blockIdx.x * 8 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(256) void loss_sums_kernel(const double* __restrict__ loss_part, int blocks, double* sums_out, float* grads_tail) {
+    __shared__ double red[5][4];
+    for (int k = 0; k < 5; k++) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += 256) v += loss_part[b * 8 + k];
+        v = wave_sum_d_dpp(v);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const double t = threadIdx.x < 5 ? ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3] : 0.0;
+        sums_out[threadIdx.x] = t;
+        grads_tail[threadIdx.x] = (float)t;   // float copies ride behind the gradient so ONE all-reduce carries both
+    }
+}
+
+// clip_grad_norm_ (clip_grad.h:58-85) + AdamW over an arbitrary tensor list: one workgroup per tensor for the squared norms, then
+// element-parallel AdamW where every thread forms the same clip coefficient.  Arithmetic per element = clip_adamw_kernel.
+__global__ __launch_bounds__(256) void gen_norm_kernel(const float* __restrict__ grads, GenLayout L, double* __restrict__ norm2) {
+    __shared__ double red[4];
+    const int t = blockIdx.x;
+    const int a0 = L.tensor_off[t], a1 = L.tensor_off[t + 1];
+    double acc = 0.0;
+    for (int p = a0 + threadIdx.x; p < a1; p += 256) acc += (double)grads[p] * (double)grads[p];
+    acc = wave_sum_d_dpp(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) norm2[t] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void gen_adamw_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ exp_avg,
+                                                        float* __restrict__ exp_avg_sq, GenLayout L, float max_norm, const double* __restrict__ norm2,
+                                                        const AdamCoef* __restrict__ coef_p, const double* __restrict__ loss_sums, double global_M,
+                                                        LossParams hp, int world, int do_step, StepStats* stats_out, double* clipfrac_accum) {
+    double tot = 0.0;
+    for (int t = 0; t < L.n_tensors; t++) { const float nrm = (float)sqrt(norm2[t]); tot += (double)nrm * nrm; }
+    const float total = (float)sqrt(tot);
+    float c = max_norm / (total + 1e-6f);
+    if (c > 1.0f) c = 1.0f;
+    const AdamCoef k = *coef_p;
+    const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
+    if (do_step) {
+        for (int p = blockIdx.x * 256 + threadIdx.x; p < L.P; p += gridDim.x * 256) {
+            const float g = grads[p] * c;
+            const float pi = params[p] * k.decay;
+            const float mi = __builtin_fmaf(g, omb1, exp_avg[p] * b1);
+            const float vi = __builtin_fmaf(omb2 * g, g, exp_avg_sq[p] * b2);
+            const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
+            params[p] = pi + (k.neg_step * mi) / denom;
+            exp_avg[p] = mi;
+            exp_avg_sq[p] = vi;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double ls[5];
+        for (int i = 0; i < 5; i++) ls[i] = world > 1 ? (double)grads[L.P + i] : loss_sums[i];
+        const float pg = (float)(ls[0] / global_M), vl = 0.5f * (float)(ls[4] / global_M), el = (float)(ls[1] / global_M);
+        StepStats o;
+        o.pg_loss = pg; o.v_loss = vl; o.entropy_loss = el;
+        o.approx_kl = (float)(ls[2] / global_M);
+        o.clipfrac = (float)ls[3] / (float)global_M;
+        o.loss = (pg - hp.ent_coef * el) + vl * hp.vf_coef;
+        o.total_norm = total;
+        o.pad = 0.0;
+        *stats_out = o;
+        if (clipfrac_accum && do_step) { clipfrac_accum[0] += o.clipfrac; clipfrac_accum[1] += 1.0; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Synthetic environment of BASELINE configs[4] (obs ~ N(0,1), reward ~ U(-1,1), done ~ Bernoulli(0.01), random masks with
+// at least one valid action per head).  Memoryless and counter-based, so that the oracle restates it bit for bit with integer
+// arithmetic only (oracle/ppo_oracle.c:orc_synthetic_*):
+//   obs_j(env, step)  = (sum of the four bytes of Philox(seed; env, step, j / 4, 0x10)[j % 4] - 510) / sqrt(4 (256^2 - 1) / 12)
+//   reward(env, step) = Philox(seed; env, step, 0, 0x11).x >> 8  scaled to [-1, 1);   done = (.y >> 8) < 0.01 * 2^24
+//   mask_k(env, step) = bit k of Philox(seed; env, step, 0, 0x12).x, bit 0 of a head forced on when the head has none.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float syn_obs(int64_t seed, int64_t env, int64_t step, int j) {
+    const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)env, (uint32_t)step, (uint32_t)(j >> 2), 0x10u);
+    const uint32_t x = (j & 3) == 0 ? w.x : ((j & 3) == 1 ? w.y : ((j & 3) == 2 ? w.z : w.w));
+    const int sum = (int)(x & 255u) + (int)((x >> 8) & 255u) + (int)((x >> 16) & 255u) + (int)(x >> 24);
+    return (float)(sum - 510) * 0.0067658990621566772f;
+}
+__global__ __launch_bounds__(64) void synthetic_obs_kernel(GenLayout L, int N, int64_t seed, int64_t env_offset, int64_t step, float* obs_out, uint8_t* mask_out) {
+    const int env = blockIdx.x;
+    if (env >= N) return;
+    const int64_t eg = env_offset + env;
+    for (int j = threadIdx.x; j < L.obs; j += 64) obs_out[(size_t)env * L.obs + j] = syn_obs(seed, eg, step, j);
+    if (mask_out && threadIdx.x == 0) {
+        const uint32_t bits = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)eg, (uint32_t)step, 0u, 0x12u).x;
+        int off = 0;
+        for (int h = 0; h < L.n_heads; h++) {
+            bool any = false;
+            for (int k = 0; k < L.head_dims[h]; k++) { const bool v = (bits >> (off + k)) & 1u; any |= v; mask_out[(size_t)env * L.act + off + k] = v ? 1 : 0; }
+            if (!any) mask_out[(size_t)env * L.act + off] = 1;
+            off += L.head_dims[h];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void synthetic_transition_kernel(int N, int64_t seed, int64_t env_offset, int64_t step, int max_episode_steps,
+                                                                   int32_t* ep_len, float* ep_rew, float* reward, int32_t* done, int32_t* fin_len, float* fin_rew) {
+    const int env = blockIdx.x * 256 + threadIdx.x;
+    if (env >= N) return;
+    const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)(env_offset + env), (uint32_t)step, 0u, 0x11u);
+    const float r = (float)(w.x >> 8) * 0x1p-23f - 1.0f;
+    int term = (w.y >> 8) < 167772u ? 1 : 0;
+    int len = ep_len[env] + 1;
+    float rew = ep_rew[env] + r;
+    if (len == max_episode_steps) term = 1;
+    int fl = 0;
+    float fr = 0.0f;
+    if (term) { fl = len; fr = rew; len = 0; rew = 0.0f; }
+    ep_len[env] = len;
+    ep_rew[env] = rew;
+    reward[env] = r;
+    done[env] = term;
+    if (fin_len) { fin_len[env] = fl; fin_rew[env] = fr; }
+}
+// rollout stores of one step (PPO_MultiDiscrete.cpp:547-562): obs, masks, actions, log-probs, the PREVIOUS step's done flags
+__global__ __launch_bounds__(256) void store_step_kernel(GenLayout L, int N, const float* __restrict__ obs, const uint8_t* __restrict__ mask,
+                                                         const int64_t* __restrict__ act64, const float* __restrict__ lp, const int32_t* __restrict__ done_prev,
+                                                         float* obs_t, uint8_t* mask_t, int32_t* act_t, float* lp_t, float* dones_t) {
+    const int64_t total = (int64_t)N * L.obs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) obs_t[i] = obs[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * L.act; i += (int64_t)gridDim.x * 256) if (mask_t) mask_t[i] = mask ? mask[i] : 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * L.n_heads; i += (int64_t)gridDim.x * 256) act_t[i] = (int32_t)act64[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) { lp_t[i] = lp[i]; dones_t[i] = (float)done_prev[i]; }
+}
+
+inline unsigned grid_for(int64_t n, int per_block) { const int64_t g = (n + per_block - 1) / per_block; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace
+
+#define RBCHK(x) do { if ((x) != 0) return hipErrorUnknown; } while (0)
+
+hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, float* const* acts, float* scratch0,
+                       float* scratch1, float* out, hipStream_t s) {
+    const GenLayout& L = g.L;
+    const float one = 1.0f, zero = 0.0f;
+    const float* in = x;
+    for (int l = 0; l < L.n_layers; l++) {
+        const int K = L.in_dim[l], N = L.out_dim[net][l];
+        const bool last = l == L.n_layers - 1;
+        float* dst = last ? out : (acts ? acts[l] : ((l & 1) ? scratch1 : scratch0));
+        RBCHK(rb::sgemm(g.blas, rb::OP_T, rb::OP_N, N, (int)rows, K, &one, params + L.w_off[net][l], K, in, K, &zero, dst, N));
+        if (last) hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid_for(rows * N, 256)), dim3(256), 0, s, dst, params + L.b_off[net][l], rows, N);
+        else hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid_for(rows * N, 256)), dim3(256), 0, s, dst, params + L.b_off[net][l], rows, N);
+        in = dst;
+    }
+    return hipGetLastError();
+}
+
+hipError_t gen_heads(const GenLayout& L, int dist_kind, const float* logits, const uint8_t* mask, const int64_t* forced, int64_t n, int64_t seed,
+                     int64_t row_offset, int64_t step_index, int64_t* action, float* logprob, float* entropy, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    if (dist_kind == PPO_DIST_MASKED)
+        hipLaunchKernelGGL(heads_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, logits, mask, forced, n, seed, row_offset, step_index, action, logprob, entropy);
+    else
+        hipLaunchKernelGGL(heads_kernel<PPO_DIST_CATEGORICAL>, grid, block, 0, s, L, logits, mask, forced, n, seed, row_offset, step_index, action, logprob, entropy);
+    return hipGetLastError();
+}
+
+hipError_t gen_gather(const GenLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs, const float* adv,
+                      const float* ret, const float* values, const int32_t* idx, int64_t M, GenericCtx& g, hipStream_t s) {
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, L, obs, actions, masks, logprobs, adv, ret, values, idx, M, g.xin,
+                       g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2], g.row_f[3]);
+    return hipGetLastError();
+}
+
+// mean and 1 / (Bessel std + 1e-8) of the minibatch's advantages (PPO_Discrete.cpp:592-594) from the PPO_ADV_PARTS partial sums,
+// formed on the device by one thread (no host round trip); the loss kernel reads the two floats
+namespace {
+__global__ void adv_finish_kernel(const AdvStat* adv_stat, double global_M, int norm_adv, float* out2) {
+    float mean_f = 0.0f, std_f = 0.0f;
+    if (norm_adv) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += adv_stat[i].s1; t2 += adv_stat[i].s2; }
+        const double mean = t1 / global_M;
+        const double var = (t2 - t1 * mean) / (global_M - 1.0);
+        mean_f = (float)mean;
+        std_f = (float)sqrt(var > 0.0 ? var : 0.0);
+    }
+    out2[0] = mean_f;
+    out2[1] = 1.0f / (std_f + 1e-8f);
+}
+}  // namespace
+
+hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& g, int64_t M, double inv_global_M, double global_M,
+                    const AdvStat* adv_stat, hipStream_t s) {
+    hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(1), 0, s, adv_stat, global_M, (adv_stat && hp.norm_adv) ? 1 : 0, g.row_f[4]);
+    const dim3 grid(GEN_LOSS_BLOCKS), block(256);
+    if (hp.dist_kind == PPO_DIST_MASKED)
+        hipLaunchKernelGGL(loss_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2],
+                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part);
+    else
+        hipLaunchKernelGGL(loss_kernel<PPO_DIST_CATEGORICAL>, grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, nullptr, g.row_f[0], g.row_f[1], g.row_f[2],
+                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part);
+    return hipGetLastError();
+}
+
+// Backward of one net: dout = d(loss)/d(output layer) [rows, out]; fills the net's slice of the flat gradient.  Needs the activations
+// kept by gen_forward(..., acts = g.acts[net]).  `ones` = g.dz[1] + rows * hidden is NOT used: bias gradients are a gemv with the
+// ones vector kept in g.row_f[4] + 2 (see api.hip: filled once at creation).
+hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
+                        hipStream_t s) {
+    const GenLayout& L = g.L;
+    const float one = 1.0f, zero = 0.0f;
+    const float* ones = g.row_f[4] + 2;
+    const float* d = dout;
+    for (int l = L.n_layers - 1; l >= 0; l--) {
+        const int K = L.in_dim[l], N = L.out_dim[net][l];
+        const float* in = l == 0 ? x : g.acts[net][l - 1];
+        // dW[N, K] = d^T[N, rows] . in[rows, K]
+        RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rows, &one, in, K, d, N, &zero, grads + L.w_off[net][l], K));
+        // db[N] = d^T . 1
+        RBCHK(rb::sgemv(g.blas, rb::OP_N, N, (int)rows, &one, d, N, ones, 1, &zero, grads + L.b_off[net][l], 1));
+        if (l > 0) {
+            float* nd = g.dz[(l & 1)];
+            // dH[rows, K] = d[rows, N] . W[N, K]
+            RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_N, K, (int)rows, N, &one, params + L.w_off[net][l], K, d, N, &zero, nd, K));
+            hipLaunchKernelGGL(dtanh_kernel, dim3(grid_for(rows * K, 256)), dim3(256), 0, s, nd, g.acts[net][l - 1], rows * K);
+            d = nd;
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t gen_fill(float* p, int64_t n, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t gen_loss_sums(const GenericCtx& g, double* sums_out, float* grads_tail, hipStream_t s) {
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(1), dim3(256), 0, s, g.loss_part, GEN_LOSS_BLOCKS, sums_out, grads_tail);
+    return hipGetLastError();
+}
+
+hipError_t gen_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const GenLayout& L, float max_grad_norm, const AdamCoef* coef,
+                          const double* loss_sums, double global_M, LossParams hp, int world, bool do_step, StepStats* stats_out,
+                          double* clipfrac_accum, double* norm2_scratch, hipStream_t s) {
+    hipLaunchKernelGGL(gen_norm_kernel, dim3(L.n_tensors), dim3(256), 0, s, grads, L, norm2_scratch);
+    const int blocks = do_step ? (int)grid_for(L.P, 256) : 1;
+    hipLaunchKernelGGL(gen_adamw_kernel, dim3(blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, norm2_scratch, coef, loss_sums,
+                       global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum);
+    return hipGetLastError();
+}
+
+// One env step of the synthetic env at global step `step_index`: rewards / dones of the step, then the observation (and mask) the
+// agent sees next, i.e. those of step_index + 1.  obs_out == nullptr skips the observation (bookkeeping only).
+hipError_t gen_synthetic_step(const GenLayout& L, int N, int64_t seed, int64_t env_offset, int64_t step_index, int max_episode_steps, int32_t* ep_len,
+                              float* ep_rew, float* obs_out, uint8_t* mask_out, float* reward, int32_t* done, int32_t* fin_len, float* fin_rew,
+                              hipStream_t s) {
+    if (reward) hipLaunchKernelGGL(synthetic_transition_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, seed, env_offset, step_index, max_episode_steps, ep_len,
+                                   ep_rew, reward, done, fin_len, fin_rew);
+    if (obs_out) hipLaunchKernelGGL(synthetic_obs_kernel, dim3(N), dim3(64), 0, s, L, N, seed, env_offset, step_index + (reward ? 1 : 0), obs_out, mask_out);
+    return hipGetLastError();
+}
+
+hipError_t gen_store_step(const GenLayout& L, int N, const float* obs, const uint8_t* mask, const int64_t* act64, const float* lp, const int32_t* done_prev,
+                          float* obs_t, uint8_t* mask_t, int32_t* act_t, float* lp_t, float* dones_t, hipStream_t s) {
+    hipLaunchKernelGGL(store_step_kernel, dim3(grid_for((int64_t)N * L.obs, 256)), dim3(256), 0, s, L, N, obs, mask, act64, lp, done_prev, obs_t, mask_t, act_t,
+                       lp_t, dones_t);
+    return hipGetLastError();
+}

@@ -1,0 +1,147 @@
+"""Networks other than the reference's 2 x 64 and the synthetic env of BASELINE configs[4] (obs 376, heads [3, 3, 3, 2], 4 x 256 MLP),
+through the same C-ABI, against the oracle -- which is generic in width, depth and head list (oracle/ppo_oracle.c:mlp_forward1 /
+mlp_backward1) and restates the synthetic env with integer arithmetic (orc_synthetic_*).
+
+Per shape: the env's observations / masks / rewards / done flags in the rollout buffers bit-exact; log-probs, values and the sampler
+against the oracle's forward; advantages / returns bit-exact; one minibatch step (losses 1e-5, gradient 1e-4 of max) and the
+optimizer step; then whole updates run.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def P():
+    return load_package()
+
+
+def _check_shape(P, obs_dim, hidden, n_hidden, heads, N, T, nmb, masked, seed, max_steps=40):
+    A, H = sum(heads), len(heads)
+    hp = dict(gamma=0.99, gae_lambda=0.95, clip_coef=0.2, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+    dist = P.DIST_MASKED if masked else P.DIST_CATEGORICAL
+    ctx = P.Context(P.make_config(env_kind=P.ENV_SYNTHETIC, dist_kind=dist, obs_size=obs_dim, head_dims=tuple(heads), hidden=hidden, n_hidden=n_hidden,
+                                  num_envs=N, num_steps=T, num_minibatches=nmb, update_epochs=2, max_episode_steps=max_steps, seed=seed,
+                                  total_timesteps=8 * N * T, learning_rate=1e-3, anneal_lr=False, **hp))
+    net = O.Net.make(obs_dim, list(heads), hidden=hidden, n_hidden=n_hidden, dist_kind=O.DIST_MASKED if masked else O.DIST_CATEGORICAL)
+    assert ctx.P == O.param_count(net)
+    ctx.init_orthogonal(seed)
+    params = ctx.get_params()
+    # every parameter tensor of the oracle's shape list, in order (critic layers then actor layers)
+    shp = O.param_shapes(net)
+    assert int(sum(a * b for a, b in shp)) == params.size
+    params[-(A * hidden + A):] *= 30.0    # a policy that is not uniform
+    ctx.set_params(params)
+
+    obs0 = ctx.env_reset()
+    envs = np.arange(N)
+    assert np.array_equal(bits(obs0), bits(O.synthetic_obs(seed, envs, 0, obs_dim)))
+    ctx.rollout()
+    obs = ctx.read("OBS", (T, N, obs_dim))
+    masks = ctx.read("MASKS", (T, N, A))
+    actions = ctx.read("ACTIONS", (T, N, H)).astype(np.int64)
+    logp, values = ctx.read("LOGPROBS", (T, N)), ctx.read("VALUES", (T, N))
+    rewards, dones = ctx.read("REWARDS", (T, N)), ctx.read("DONES", (T, N))
+    next_obs, next_done, next_value = ctx.read("NEXT_OBS", (N, obs_dim)), ctx.read("NEXT_DONE", (N,)), ctx.read("NEXT_VALUE", (N,))
+    # ---- the env, bit for bit ----
+    ep_len = np.zeros(N, np.int64)
+    for t in range(T):
+        assert np.array_equal(bits(obs[t]), bits(O.synthetic_obs(seed, envs, t, obs_dim))), t
+        assert np.array_equal(masks[t], O.synthetic_mask(seed, envs, t, list(heads)) if masked else np.ones((N, A), np.uint8)), t
+        r, d = O.synthetic_transition(seed, envs, t)
+        ep_len += 1
+        d = np.where(ep_len == max_steps, 1, d)          # time-limit truncation counts as done (PPO_Discrete.cpp:443-445)
+        ep_len[d != 0] = 0
+        assert np.array_equal(rewards[t], r), t
+        assert np.array_equal(dones[t + 1] if t + 1 < T else next_done.astype(np.float32), d.astype(np.float32)), t
+    assert np.array_equal(bits(next_obs), bits(O.synthetic_obs(seed, envs, T, obs_dim)))
+    assert dones.sum() > 0
+    if masked:   # sampled actions respect the masks
+        off = 0
+        for h, w in enumerate(heads):
+            picked = np.take_along_axis(masks[:, :, off:off + w], actions[:, :, h:h + 1], axis=2)
+            assert picked.all()
+            off += w
+    # ---- policy and critic against the oracle's forward ----
+    flat_obs, flat_act, flat_mask = obs.reshape(T * N, obs_dim), actions.reshape(T * N, H), masks.reshape(T * N, A)
+    rows = np.random.default_rng(0).choice(T * N, min(T * N, 1024), replace=False)
+    lp_o, en_o, v_o = O.evaluate(net, params, flat_obs[rows], flat_act[rows], flat_mask[rows] if masked else None)
+    np.testing.assert_allclose(logp.reshape(-1)[rows], lp_o, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(values.reshape(-1)[rows], v_o, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(next_value[:64], O.get_value(net, params, next_obs[:64]), rtol=0, atol=5e-6)
+    a_o, _, _, _ = O.act(net, params, obs[3], seed, 3, 0, masks[3] if masked else None)
+    assert (a_o == actions[3]).mean() >= 0.995
+    # stand-alone entry points agree with the rollout's stores
+    a2, lp2, en2, v2 = ctx.policy_act(obs[3], mask=masks[3] if masked else None, action=actions[3], step_index=3)
+    np.testing.assert_allclose(lp2, logp[3], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(v2, values[3], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(en2[:256], O.evaluate(net, params, obs[3][:256], actions[3][:256], masks[3][:256] if masked else None)[1], rtol=1e-5, atol=5e-6)
+    # ---- advantages / returns, bit for bit ----
+    adv, ret = ctx.calc_advantage()
+    adv_o, ret_o = O.gae(rewards, values, dones, next_value, next_done, hp["gamma"], hp["gae_lambda"])
+    assert np.array_equal(bits(adv), bits(adv_o)) and np.array_equal(bits(ret), bits(ret_o))
+    # ---- one minibatch step ----
+    B = T * N
+    MB = B // nmb
+    idx = np.random.default_rng(1).permutation(B)[:MB].astype(np.int32)
+    grads = ctx.minibatch_forward_backward(idx)
+    st = ctx.stats()
+    hpo = O.HParams(norm_adv=1, clip_vloss=1, **hp)
+    g_o, s_o = O.minibatch_grads(net, hpo, params, flat_obs, flat_act.astype(np.float32), logp.reshape(B), adv.reshape(B), ret.reshape(B), values.reshape(B),
+                                 idx.astype(np.int64), flat_mask if masked else None)[:2]
+    for key, okey in (("pg_loss", "pg_loss"), ("v_loss", "v_loss"), ("entropy_loss", "entropy_loss"), ("approx_kl", "approx_kl"),
+                      ("clipfrac_last", "clipfrac"), ("loss", "loss")):
+        assert abs(st[key] - s_o[okey]) <= 1e-5 * max(1.0, abs(s_o[okey])), (key, st[key], s_o[okey])
+    assert np.abs(grads - g_o).max() <= 1e-6 + 1e-4 * np.abs(g_o).max()
+    ctx.set_learning_rate(1e-3)
+    ctx.optimizer_step()
+    m, v, step = ctx.get_optimizer()
+    gc, total = O.clip_grad_norm(net, grads, 0.5)
+    assert abs(ctx.stats()["total_norm"] - float(total)) <= 2e-6 * float(total)
+    p_o, m_o, v_o2 = O.adamw_step(params, gc, np.zeros_like(params), np.zeros_like(params), 1e-3, 1)
+    np.testing.assert_allclose(m, m_o, rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(v, v_o2, rtol=2e-5, atol=1e-18)
+    np.testing.assert_allclose(ctx.get_params(), p_o, rtol=0, atol=1e-6)
+    # ---- whole iterations ----
+    ctx.update()
+    for _ in range(2):
+        ctx.train_iteration()
+    st = ctx.stats()
+    assert np.isfinite(st["loss"]) and st["optimizer_steps"] == 1 + 3 * 2 * nmb and st["ep_count"] > 0
+    ctx.close()
+
+
+def test_small_multihead_masked_three_layers(P):
+    _check_shape(P, obs_dim=12, hidden=32, n_hidden=3, heads=(3, 2), N=64, T=16, nmb=2, masked=True, seed=5)
+
+
+def test_plain_categorical_one_layer(P):
+    _check_shape(P, obs_dim=7, hidden=48, n_hidden=1, heads=(4,), N=32, T=12, nmb=3, masked=False, seed=9)
+
+
+def test_config4_shape_obs376_4x256_heads_3332(P):
+    """BASELINE configs[4]'s network and head list on a batch the scalar oracle can still check (256 envs x 32 steps)."""
+    _check_shape(P, obs_dim=376, hidden=256, n_hidden=4, heads=(3, 3, 3, 2), N=256, T=32, nmb=4, masked=True, seed=3, max_steps=25)
+
+
+def test_config4_per_gpu_size_runs(P):
+    """configs[4] per-GPU share (16 384 envs / 8 GPUs = 2048 envs x 128 steps, 4 minibatches): two whole iterations."""
+    ctx = P.Context(P.make_config(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=376, head_dims=(3, 3, 3, 2), hidden=256, n_hidden=4,
+                                  num_envs=2048, num_steps=128, num_minibatches=4, update_epochs=2, max_episode_steps=200, seed=1,
+                                  total_timesteps=4 * 2048 * 128, ent_coef=0.01))
+    ctx.init_orthogonal(1)
+    ctx.env_reset()
+    for _ in range(2):
+        ctx.train_iteration()
+    st = ctx.stats()
+    assert np.isfinite(st["loss"]) and st["optimizer_steps"] == 16 and st["global_step"] == 2 * 2048 * 128
+    assert 0.0 < st["entropy_loss"] <= 3 * np.log(3) + np.log(2) + 1e-3
+    ctx.close()
