@@ -454,6 +454,8 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         CK(dalloc(c, &g.step_lp, N));
         CK(dalloc(c, &g.step_en, N));
         CK(dalloc(c, &c->cur_mask, N * GL.act));
+        // the zero-fills above ran on the null stream, which a non-blocking stream does not wait for: drain them before the first write
+        CK(hipDeviceSynchronize());
         CK(gen_fill(g.row_f[4] + 2, (int64_t)R, 1.0f, c->stream));   // the ones vector of the bias-gradient gemv
         std::string berr;
         hipError_t be = gen_blas_create(&g.blas, c->stream, berr);
@@ -464,6 +466,8 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     const int64_t steps_per_env = cfg->total_timesteps > 0 ? cfg->total_timesteps / std::max<int64_t>(c->cfg.global_num_envs, 1) : 0;
     ppo_status st = ensure_reset_table(c, std::max<int64_t>(steps_per_env + cfg->num_steps + 4, 4096));
     if (st != PPO_OK) { g_create_error = c->err; ppo_ctx_destroy(c); return st; }
+    // the zero-fills of the allocations ran on the null stream, which the context's non-blocking stream does not wait for
+    if (hipDeviceSynchronize() != hipSuccess) { fail(nullptr, PPO_ERR_HIP, "hipDeviceSynchronize failed at the end of ppo_ctx_create"); ppo_ctx_destroy(c); return PPO_ERR_HIP; }
     *out = c;
     return PPO_OK;
 }
