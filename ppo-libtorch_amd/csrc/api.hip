@@ -450,6 +450,12 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         CK(dalloc(c, &g.row_act, R * GL.n_heads));
         CK(dalloc(c, &g.row_mask, R * GL.act));
         CK(dalloc(c, &g.loss_part, (size_t)GEN_LOSS_BLOCKS * 8));
+        {
+            int64_t mx = 0;
+            for (int l = 0; l < GL.n_layers; l++) mx = std::max<int64_t>(mx, (int64_t)std::max(GL.out_dim[0][l], GL.out_dim[1][l]) * (GL.in_dim[l] + 1));
+            g.wslab_stride = (mx + 3) & ~3ll;
+            CK(dalloc(c, &g.wslab, (size_t)(GEN_SPLIT + 1) * g.wslab_stride));
+        }
         CK(dalloc(c, &g.act64, N * GL.n_heads));
         CK(dalloc(c, &g.step_lp, N));
         CK(dalloc(c, &g.step_en, N));

@@ -18,12 +18,15 @@ typedef int (*set_stream_t)(void*, hipStream_t);
 typedef int (*set_atomics_t)(void*, int);
 typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
 typedef int (*sgemv_t)(void*, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
+typedef int (*sgemm_sb_t)(void*, int, int, int, int, int, const float*, const float*, int, int64_t, const float*, int, int64_t, const float*, float*, int,
+                          int64_t, int);
 static create_t create;
 static destroy_t destroy;
 static set_stream_t set_stream;
 static set_atomics_t set_atomics;
 static sgemm_t sgemm;
 static sgemv_t sgemv;
+static sgemm_sb_t sgemm_sb;
 constexpr int OP_N = 111, OP_T = 112, ATOMICS_NOT_ALLOWED = 0;
 static bool load(std::string& err) {
     static std::mutex mu;
@@ -40,7 +43,8 @@ static bool load(std::string& err) {
     set_atomics = (set_atomics_t)dlsym(h, "rocblas_set_atomics_mode");
     sgemm = (sgemm_t)dlsym(h, "rocblas_sgemm");
     sgemv = (sgemv_t)dlsym(h, "rocblas_sgemv");
-    if (!create || !destroy || !set_stream || !set_atomics || !sgemm || !sgemv) { err = "librocblas lacks rocblas_* symbols"; sgemm = nullptr; return false; }
+    sgemm_sb = (sgemm_sb_t)dlsym(h, "rocblas_sgemm_strided_batched");
+    if (!create || !destroy || !set_stream || !set_atomics || !sgemm || !sgemv || !sgemm_sb) { err = "librocblas lacks rocblas_* symbols"; sgemm = nullptr; return false; }
     return true;
 }
 }  // namespace rb
@@ -334,6 +338,28 @@ __global__ __launch_bounds__(256) void store_step_kernel(GenLayout L, int N, con
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) { lp_t[i] = lp[i]; dones_t[i] = (float)done_prev[i]; }
 }
 
+// column sums of d[rows, n] over the row chunk blockIdx.y (rows [y * chunk, min(rows, (y + 1) * chunk))): 64 columns x 4 row lanes per block
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(const float* __restrict__ d, int64_t rows, int n, int64_t chunk, float* __restrict__ slab,
+                                                           int64_t slab_stride, int64_t slab_off) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    float acc = 0.0f;
+    if (col < n) for (int64_t r = r0 + rl; r < r1; r += 4) acc += d[r * n + col];
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < n) slab[(size_t)blockIdx.y * slab_stride + slab_off + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// out[i] = sum over the S partial slabs, in order
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int S, int64_t n_w, int64_t n_b, float* __restrict__ gw,
+                                                       float* __restrict__ gb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_w + n_b) return;
+    float acc = slab[i];
+    for (int sidx = 1; sidx < S; sidx++) acc += slab[(size_t)sidx * slab_stride + i];
+    if (i < n_w) gw[i] = acc; else gb[i - n_w] = acc;
+}
+
 inline unsigned grid_for(int64_t n, int per_block) { const int64_t g = (n + per_block - 1) / per_block; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace
@@ -413,15 +439,26 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
                         hipStream_t s) {
     const GenLayout& L = g.L;
     const float one = 1.0f, zero = 0.0f;
-    const float* ones = g.row_f[4] + 2;
     const float* d = dout;
     for (int l = L.n_layers - 1; l >= 0; l--) {
         const int K = L.in_dim[l], N = L.out_dim[net][l];
         const float* in = l == 0 ? x : g.acts[net][l - 1];
-        // dW[N, K] = d^T[N, rows] . in[rows, K]
-        RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rows, &one, in, K, d, N, &zero, grads + L.w_off[net][l], K));
-        // db[N] = d^T . 1
-        RBCHK(rb::sgemv(g.blas, rb::OP_N, N, (int)rows, &one, d, N, ones, 1, &zero, grads + L.b_off[net][l], 1));
+        // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single GEMM would have N K / tile
+        // workgroups walking all rows (and rocBLAS may not split the contraction without atomics), so the rows are cut into GEN_SPLIT
+        // chunks -- one strided-batched GEMM, every chunk its own partial slab -- and the slabs are added in a fixed order.
+        const int64_t chunk = (rows + GEN_SPLIT - 1) / GEN_SPLIT;
+        const int full = (int)(rows / chunk);            // chunks of exactly `chunk` rows
+        const int64_t rem = rows - (int64_t)full * chunk;
+        const int S = full + (rem > 0 ? 1 : 0);
+        const int64_t n_w = (int64_t)N * K;
+        if (full > 0)
+            RBCHK(rb::sgemm_sb(g.blas, rb::OP_N, rb::OP_T, K, N, (int)chunk, &one, in, K, chunk * K, d, N, chunk * N, &zero, g.wslab, K, g.wslab_stride, full));
+        if (rem > 0)
+            RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rem, &one, in + (size_t)full * chunk * K, K, d + (size_t)full * chunk * N, N, &zero,
+                            g.wslab + (size_t)full * g.wslab_stride, K));
+        hipLaunchKernelGGL(colsum_chunk_kernel, dim3((N + 63) / 64, S), dim3(256), 0, s, d, rows, N, chunk, g.wslab, g.wslab_stride, n_w);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 255) / 256)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, (int64_t)N,
+                           grads + L.w_off[net][l], grads + L.b_off[net][l]);
         if (l > 0) {
             float* nd = g.dz[(l & 1)];
             // dH[rows, K] = d[rows, N] . W[N, K]
