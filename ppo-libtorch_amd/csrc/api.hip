@@ -424,7 +424,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(hipEventCreateWithFlags(&c->coef_copied[1], hipEventDisableTiming));
     CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
     CK(dalloc(c, &c->clipfrac_accum, 2));
-    CK(dalloc(c, &c->norm2, 64));
+    CK(dalloc(c, &c->norm2, 4 * GEN_MAX_LAYERS * GEN_NORM_PARTS));
     CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
     CK(dalloc(c, &c->ev_sums, PPO_EV_BLOCKS * 4));
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
@@ -455,6 +455,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             for (int l = 0; l < GL.n_layers; l++) mx = std::max<int64_t>(mx, (int64_t)std::max(GL.out_dim[0][l], GL.out_dim[1][l]) * (GL.in_dim[l] + 1));
             g.wslab_stride = (mx + 3) & ~3ll;
             CK(dalloc(c, &g.wslab, (size_t)(GEN_SPLIT + 1) * g.wslab_stride));
+            CK(dalloc(c, &g.db_part, (size_t)GEN_DB_CHUNKS * std::max(GL.hidden, GL.act)));
         }
         CK(dalloc(c, &g.act64, N * GL.n_heads));
         CK(dalloc(c, &g.step_lp, N));

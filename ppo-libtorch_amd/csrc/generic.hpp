@@ -66,11 +66,13 @@ struct GenericCtx {
     double* loss_part = nullptr;   // [GEN_LOSS_BLOCKS, 8] partial loss sums
     float* wslab = nullptr;        // [GEN_SPLIT + 1][max over layers of out * in + out]: row-chunk partials of one layer's dW | db
     int64_t wslab_stride = 0;
+    float* db_part = nullptr;      // [GEN_DB_CHUNKS][max out]: row-chunk partials of one layer's bias gradient
     int64_t* act64 = nullptr;      // [N, n_heads] actions of the current rollout step (int64, the stand-alone API's type)
     float* step_lp = nullptr;      // [N] log-prob / entropy of the current rollout step
     float* step_en = nullptr;
 };
 constexpr int GEN_LOSS_BLOCKS = 256;
+constexpr int GEN_DB_CHUNKS = 256, GEN_NORM_PARTS = 16;
 constexpr int GEN_SPLIT = 32;   // row chunks of a weight-gradient GEMM (the contraction runs over the minibatch rows; see gen_backward)
 
 // kernels_generic.hip

@@ -229,22 +229,29 @@ __global__ __launch_bounds__(256) void loss_sums_kernel(const double* __restrict
 // clip_grad_norm_ (clip_grad.h:58-85) + AdamW over an arbitrary tensor list: one workgroup per tensor for the squared norms, then
 // element-parallel AdamW where every thread forms the same clip coefficient.  Arithmetic per element = clip_adamw_kernel.
 __global__ __launch_bounds__(256) void gen_norm_kernel(const float* __restrict__ grads, GenLayout L, double* __restrict__ norm2) {
+    // grid (tensor, part): GEN_NORM_PARTS contiguous slices per tensor, added in order by the consumer
     __shared__ double red[4];
-    const int t = blockIdx.x;
-    const int a0 = L.tensor_off[t], a1 = L.tensor_off[t + 1];
+    const int t = blockIdx.x, part = blockIdx.y;
+    const int t0 = L.tensor_off[t], len = L.tensor_off[t + 1] - t0;
+    const int a0 = t0 + (int)(((int64_t)len * part) / GEN_NORM_PARTS), a1 = t0 + (int)(((int64_t)len * (part + 1)) / GEN_NORM_PARTS);
     double acc = 0.0;
     for (int p = a0 + threadIdx.x; p < a1; p += 256) acc += (double)grads[p] * (double)grads[p];
     acc = wave_sum_d_dpp(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) norm2[t] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) norm2[t * GEN_NORM_PARTS + part] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 __global__ __launch_bounds__(256) void gen_adamw_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ exp_avg,
                                                         float* __restrict__ exp_avg_sq, GenLayout L, float max_norm, const double* __restrict__ norm2,
                                                         const AdamCoef* __restrict__ coef_p, const double* __restrict__ loss_sums, double global_M,
                                                         LossParams hp, int world, int do_step, StepStats* stats_out, double* clipfrac_accum) {
     double tot = 0.0;
-    for (int t = 0; t < L.n_tensors; t++) { const float nrm = (float)sqrt(norm2[t]); tot += (double)nrm * nrm; }
+    for (int t = 0; t < L.n_tensors; t++) {
+        double n2 = 0.0;
+        for (int k = 0; k < GEN_NORM_PARTS; k++) n2 += norm2[t * GEN_NORM_PARTS + k];
+        const float nrm = (float)sqrt(n2);
+        tot += (double)nrm * nrm;
+    }
     const float total = (float)sqrt(tot);
     float c = max_norm / (total + 1e-6f);
     if (c > 1.0f) c = 1.0f;
@@ -339,8 +346,7 @@ __global__ __launch_bounds__(256) void store_step_kernel(GenLayout L, int N, con
 }
 
 // column sums of d[rows, n] over the row chunk blockIdx.y (rows [y * chunk, min(rows, (y + 1) * chunk))): 64 columns x 4 row lanes per block
-__global__ __launch_bounds__(256) void colsum_chunk_kernel(const float* __restrict__ d, int64_t rows, int n, int64_t chunk, float* __restrict__ slab,
-                                                           int64_t slab_stride, int64_t slab_off) {
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(const float* __restrict__ d, int64_t rows, int n, int64_t chunk, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
@@ -348,16 +354,23 @@ __global__ __launch_bounds__(256) void colsum_chunk_kernel(const float* __restri
     if (col < n) for (int64_t r = r0 + rl; r < r1; r += 4) acc += d[r * n + col];
     red[rl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (rl == 0 && col < n) slab[(size_t)blockIdx.y * slab_stride + slab_off + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (rl == 0 && col < n) part[(size_t)blockIdx.y * n + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 // out[i] = sum over the S partial slabs, in order
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int S, int64_t n_w, int64_t n_b, float* __restrict__ gw,
-                                                       float* __restrict__ gb) {
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int S, int64_t n_w, const float* __restrict__ db_part,
+                                                       int db_chunks, int64_t n_b, float* __restrict__ gw, float* __restrict__ gb) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_w + n_b) return;
-    float acc = slab[i];
-    for (int sidx = 1; sidx < S; sidx++) acc += slab[(size_t)sidx * slab_stride + i];
-    if (i < n_w) gw[i] = acc; else gb[i - n_w] = acc;
+    if (i < n_w) {
+        float acc = slab[i];
+        for (int sidx = 1; sidx < S; sidx++) acc += slab[(size_t)sidx * slab_stride + i];
+        gw[i] = acc;
+    } else {
+        const int64_t c = i - n_w;
+        float acc = db_part[c];
+        for (int k = 1; k < db_chunks; k++) acc += db_part[(size_t)k * n_b + c];
+        gb[c] = acc;
+    }
 }
 
 inline unsigned grid_for(int64_t n, int per_block) { const int64_t g = (n + per_block - 1) / per_block; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
@@ -456,8 +469,10 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
         if (rem > 0)
             RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rem, &one, in + (size_t)full * chunk * K, K, d + (size_t)full * chunk * N, N, &zero,
                             g.wslab + (size_t)full * g.wslab_stride, K));
-        hipLaunchKernelGGL(colsum_chunk_kernel, dim3((N + 63) / 64, S), dim3(256), 0, s, d, rows, N, chunk, g.wslab, g.wslab_stride, n_w);
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 255) / 256)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, (int64_t)N,
+        const int64_t dbc = (rows + GEN_DB_CHUNKS - 1) / GEN_DB_CHUNKS;
+        const int n_dbc = (int)((rows + dbc - 1) / dbc);
+        hipLaunchKernelGGL(colsum_chunk_kernel, dim3((N + 63) / 64, n_dbc), dim3(256), 0, s, d, rows, N, dbc, g.db_part);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 255) / 256)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, n_dbc, (int64_t)N,
                            grads + L.w_off[net][l], grads + L.b_off[net][l]);
         if (l > 0) {
             float* nd = g.dz[(l & 1)];
@@ -483,7 +498,7 @@ hipError_t gen_loss_sums(const GenericCtx& g, double* sums_out, float* grads_tai
 hipError_t gen_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const GenLayout& L, float max_grad_norm, const AdamCoef* coef,
                           const double* loss_sums, double global_M, LossParams hp, int world, bool do_step, StepStats* stats_out,
                           double* clipfrac_accum, double* norm2_scratch, hipStream_t s) {
-    hipLaunchKernelGGL(gen_norm_kernel, dim3(L.n_tensors), dim3(256), 0, s, grads, L, norm2_scratch);
+    hipLaunchKernelGGL(gen_norm_kernel, dim3(L.n_tensors, GEN_NORM_PARTS), dim3(256), 0, s, grads, L, norm2_scratch);
     const int blocks = do_step ? (int)grid_for(L.P, 256) : 1;
     hipLaunchKernelGGL(gen_adamw_kernel, dim3(blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, norm2_scratch, coef, loss_sums,
                        global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum);
