@@ -145,3 +145,67 @@ def test_config4_per_gpu_size_runs(P):
     assert np.isfinite(st["loss"]) and st["optimizer_steps"] == 16 and st["global_step"] == 2 * 2048 * 128
     assert 0.0 < st["entropy_loss"] <= 3 * np.log(3) + np.log(2) + 1e-3
     ctx.close()
+
+
+def test_generic_two_rank_shards_equal_single_context(P):
+    """Data parallelism on the generic path: two shards (env_offset / global_num_envs) reproduce their columns of the single-context rollout
+    -- env buffers and actions bit for bit, network outputs to float noise (the library GEMM picks its kernel, and with it the order of
+    the K-sum, by batch size) -- and one optimizer step over the in-process communicator (same protocol as RCCL: global advantage sums, then ONE
+    all-reduce of the 1/M_global-scaled gradient) equals the single-context step on the concatenated minibatch."""
+    import threading
+    N, T, heads, obs_dim = 64, 16, (3, 2), 20
+    A = sum(heads)
+    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=obs_dim, head_dims=heads, hidden=32, n_hidden=2, num_steps=T, num_minibatches=2,
+              update_epochs=1, max_episode_steps=30, seed=11, total_timesteps=4 * N * T, ent_coef=0.01, anneal_lr=False)
+    whole = P.Context(P.make_config(num_envs=N, **kw))
+    whole.init_orthogonal(4)
+    params = whole.get_params()
+    whole.env_reset(); whole.rollout(); whole.calc_advantage()
+    rows_t = np.random.default_rng(2).choice(T, 8, replace=False)
+    rows = np.array([t * N + e for t in rows_t for e in range(N)], np.int32)       # whole time rows: both shards hold half of each
+    g_ref = whole.minibatch_forward_backward(rows)
+    st_ref = whole.stats()
+    whole.set_learning_rate(1e-3); whole.optimizer_step()
+    p_ref = whole.get_params()
+    out, errors = [None, None], []
+
+    def run(rank):
+        try:
+            n, off = P.dist.shard_envs(N, rank, 2)
+            ctx = P.Context(P.make_config(num_envs=n, env_offset=off, global_num_envs=N, **kw))
+            ctx.comm_init_local(4321, rank, 2)
+            ctx.set_params(params)
+            ctx.env_reset(); ctx.rollout(); ctx.calc_advantage()
+            sl = slice(off, off + n)
+            for name, shape in (("OBS", (T, N, obs_dim)), ("MASKS", (T, N, A)), ("ACTIONS", (T, N, 2)), ("LOGPROBS", (T, N)), ("REWARDS", (T, N)),
+                                ("VALUES", (T, N)), ("ADVANTAGES", (T, N))):
+                full, part = whole.read(name, shape), ctx.read(name, (T, n) + shape[2:])
+                if name in ("LOGPROBS", "VALUES", "ADVANTAGES"):
+                    np.testing.assert_allclose(part, full[:, sl], rtol=0, atol=2e-5, err_msg=name)
+                else:
+                    assert np.array_equal(full[:, sl].view(np.uint8), part.view(np.uint8)), (rank, name)
+            local = np.array(P.dist.local_rows_of_global_rows(rows, T, N, rank, 2), np.int32)
+            d = ctx.dev(local, np.int32)
+            P.binding._check(P.binding.lib().ppo_minibatch_forward_backward(ctx.h, d.ptr, __import__("ctypes").c_int64(local.size)), ctx.h)
+            P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
+            grads = ctx.read("GRADS")
+            ctx.set_learning_rate(1e-3); ctx.optimizer_step()
+            out[rank] = (grads, ctx.stats(), ctx.get_params())
+            ctx.close()
+        except Exception as ex:
+            errors.append(ex)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    for r in range(2):
+        g2, st2, p2 = out[r]
+        assert np.abs(g2 - g_ref).max() <= 2e-5 * max(1.0, np.abs(g_ref).max()), r
+        for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "loss", "total_norm"):
+            assert abs(st2[key] - st_ref[key]) <= 2e-5 * max(1.0, abs(st_ref[key])), (r, key, st2[key], st_ref[key])
+        assert np.abs(p2 - p_ref).max() <= 2e-5, r
+    assert np.array_equal(bits(out[0][2]), bits(out[1][2]))   # replicas stay bit-identical
+    whole.close()
