@@ -168,6 +168,22 @@ PPO_API ppo_status ppo_categorical_sample(const float* m_probs, int64_t n, int32
                                   int32_t head, int64_t* sample, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Linear layers of networks wider than the reference's 2 x 64 (Agent.cpp:25-59 with the widths of BASELINE configs[4]), stateless
+ * ------------------------------------------------------------------------------------------------------- */
+/* c[M,N] = epilogue(sum_k A(m,k) B(n,k)) on the matrix cores, all operands f32 on the device:
+ *   A(m,k) = trans_a ? a[k * lda + m] : a[m * lda + k],  B(n,k) = trans_b ? b[k * ldb + n] : b[n * ldb + k]
+ *   forward  h = tanh(x W^T + b): (0, 0, rows, out, in, x, W, EPI_BIAS_TANH, aux = b)
+ *   d(input) dz' = (dz W)(1 - h'^2): (0, 1, rows, in, out, dz, W, EPI_DTANH, aux = h' [M, ld_aux])
+ *   d(weight) dW = dz^T x: (1, 1, out, in, rows, dz, x, EPI_NONE)
+ * precision PPO_MM_F32X3: every f32 operand is carried as three bf16 terms (exact split) and every product as six bf16 MFMAs with
+ * f32 accumulation -- f32 accuracy; PPO_MM_BF16: one round-to-nearest bf16 term per operand, f32 accumulation. */
+enum { PPO_MM_EPI_NONE = 0, PPO_MM_EPI_BIAS = 1, PPO_MM_EPI_BIAS_TANH = 2, PPO_MM_EPI_DTANH = 3 };
+enum { PPO_MM_F32X3 = 0, PPO_MM_BF16 = 1 };
+PPO_API ppo_status ppo_matmul(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* a, int64_t lda, const float* b,
+                      int64_t ldb, float* c, int64_t ldc, int32_t epilogue, const float* aux, int64_t ld_aux, int32_t precision,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Environments (Environments/CartPole.h, MountainCar.h) and their vectorised driver
  * ------------------------------------------------------------------------------------------------------- */
 /* Stateless batched CartPole::step (CartPole.cpp:47-94) / MountainCar::step (MountainCar.cpp:29-57) on injected

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libppo_hip.so")
 
 MAX_HEADS = 8
 ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_SYNTHETIC = 0, 1, 2
+MM_EPI_NONE, MM_EPI_BIAS, MM_EPI_BIAS_TANH, MM_EPI_DTANH = 0, 1, 2, 3
+MM_F32X3, MM_BF16 = 0, 1
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
 COMM_ID_BYTES = 128
 
@@ -31,7 +33,7 @@ ABI_SYMBOLS = [
     "ppo_abi_version", "ppo_ctx_create", "ppo_ctx_destroy", "ppo_last_error", "ppo_sync", "ppo_stream", "ppo_get_config",
     "ppo_buffer", "ppo_device_alloc", "ppo_device_free", "ppo_memcpy_h2d", "ppo_memcpy_d2h", "ppo_param_count",
     "ppo_param_shapes", "ppo_params_init_orthogonal", "ppo_params_set_h", "ppo_params_get_h", "ppo_optimizer_set_h",
-    "ppo_optimizer_get_h", "ppo_get_value", "ppo_policy_act", "ppo_categorical", "ppo_categorical_sample", "ppo_env_transition",
+    "ppo_optimizer_get_h", "ppo_get_value", "ppo_policy_act", "ppo_categorical", "ppo_categorical_sample", "ppo_matmul", "ppo_env_transition",
     "ppo_cartpole_reset_stream_h", "ppo_env_reset", "ppo_env_step", "ppo_env_set_state_h", "ppo_env_get_state_h",
     "ppo_rollout", "ppo_calc_advantage", "ppo_gae", "ppo_nstep_returns", "ppo_generate_permutations",
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",
@@ -408,6 +410,32 @@ def categorical(ctx, dist_kind, logits, mask=None, value=None):
                                  C.c_void_p(ctx.stream())), ctx.h)
     ctx.sync()
     return {k: v.download() for k, v in o.items()}
+
+
+def matmul_launch(ctx, trans_a, trans_b, M, N, K, d_a, lda, d_b, ldb, d_c, ldc, epilogue=MM_EPI_NONE, d_aux=None, ld_aux=0, precision=MM_F32X3):
+    """Enqueues ppo_matmul on device arrays (no copies, no synchronisation)."""
+    _check(lib().ppo_matmul(C.c_int32(int(trans_a)), C.c_int32(int(trans_b)), C.c_int64(M), C.c_int64(N), C.c_int64(K), d_a.ptr, C.c_int64(lda), d_b.ptr,
+                            C.c_int64(ldb), d_c.ptr, C.c_int64(ldc), C.c_int32(epilogue), d_aux.ptr if d_aux is not None else None, C.c_int64(ld_aux),
+                            C.c_int32(precision), C.c_void_p(ctx.stream())), ctx.h)
+
+
+def matmul(ctx, a, b, trans_a=False, trans_b=False, epilogue=MM_EPI_NONE, aux=None, precision=MM_F32X3):
+    """c[M, N] = epilogue(sum_k A(m, k) B(n, k)) with A = a or a^T, B = b or b^T as stored (see ppo_matmul in ppo_hip.h)."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    if trans_a:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    N = b.shape[1] if trans_b else b.shape[0]
+    assert (b.shape[0] if trans_b else b.shape[1]) == K
+    d_a, d_b, d_c = ctx.dev(a), ctx.dev(b), ctx.empty((M, N), np.float32)
+    d_x = ctx.dev(aux, np.float32) if aux is not None else None
+    matmul_launch(ctx, trans_a, trans_b, M, N, K, d_a, a.shape[1], d_b, b.shape[1], d_c, N, epilogue, d_x, N if epilogue == MM_EPI_DTANH else 0, precision)
+    ctx.sync()
+    out = d_c.download()
+    for x in (d_a, d_b, d_c) + ((d_x,) if d_x is not None else ()):
+        x.free()
+    return out
 
 
 def cartpole_reset_stream(seed, n_resets):

@@ -454,7 +454,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             int64_t mx = 0;
             for (int l = 0; l < GL.n_layers; l++) mx = std::max<int64_t>(mx, (int64_t)std::max(GL.out_dim[0][l], GL.out_dim[1][l]) * (GL.in_dim[l] + 1));
             g.wslab_stride = (mx + 3) & ~3ll;
-            CK(dalloc(c, &g.wslab, (size_t)(GEN_SPLIT + 1) * g.wslab_stride));
+            CK(dalloc(c, &g.wslab, (size_t)(std::max(GEN_SPLIT, GEN_SPLIT_MFMA) + 1) * g.wslab_stride));
             CK(dalloc(c, &g.db_part, (size_t)GEN_DB_CHUNKS * std::max(GL.hidden, GL.act)));
         }
         CK(dalloc(c, &g.act64, N * GL.n_heads));
@@ -464,9 +464,21 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         // the zero-fills above ran on the null stream, which a non-blocking stream does not wait for: drain them before the first write
         CK(hipDeviceSynchronize());
         CK(gen_fill(g.row_f[4] + 2, (int64_t)R, 1.0f, c->stream));   // the ones vector of the bias-gradient gemv
-        std::string berr;
-        hipError_t be = gen_blas_create(&g.blas, c->stream, berr);
-        if (be != hipSuccess) { fail(nullptr, PPO_ERR_UNSUPPORTED, "%s", berr.c_str()); ppo_ctx_destroy(c); return PPO_ERR_UNSUPPORTED; }
+        // layer products: hand-written matrix-core kernels (kernels_gemm.hip) unless the library yardstick is asked for
+        const char* gb = getenv("PPO_GENERIC_GEMM");
+        const char* gp = getenv("PPO_GENERIC_PREC");
+        g.gemm_backend = (gb && !strcmp(gb, "rocblas")) ? GEN_GEMM_ROCBLAS : GEN_GEMM_MFMA;
+        g.gemm_prec = (gp && !strcmp(gp, "bf16")) ? PPO_MM_BF16 : PPO_MM_F32X3;
+        if ((gb && strcmp(gb, "rocblas") && strcmp(gb, "mfma")) || (gp && strcmp(gp, "bf16") && strcmp(gp, "f32x3"))) {
+            fail(nullptr, PPO_ERR_INVALID, "PPO_GENERIC_GEMM must be mfma|rocblas and PPO_GENERIC_PREC f32x3|bf16");
+            ppo_ctx_destroy(c);
+            return PPO_ERR_INVALID;
+        }
+        if (g.gemm_backend == GEN_GEMM_ROCBLAS) {
+            std::string berr;
+            hipError_t be = gen_blas_create(&g.blas, c->stream, berr);
+            if (be != hipSuccess) { fail(nullptr, PPO_ERR_UNSUPPORTED, "%s", berr.c_str()); ppo_ctx_destroy(c); return PPO_ERR_UNSUPPORTED; }
+        }
     }
 #undef CK
     // every env can reset at most once per step: steps per env over the whole run bounds the shared reset stream
@@ -849,6 +861,15 @@ extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     return PPO_OK;
 }
 
+// Stateless Linear-layer product on the matrix cores (kernels_gemm.hip).
+extern "C" ppo_status ppo_matmul(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb,
+                                 float* c, int64_t ldc, int32_t epilogue, const float* aux, int64_t ld_aux, int32_t precision, void* stream) {
+    if (!a || !b || !c || M < 0 || N < 0 || K < 0 || epilogue < PPO_MM_EPI_NONE || epilogue > PPO_MM_EPI_DTANH) return PPO_ERR_INVALID;
+    if (epilogue != PPO_MM_EPI_NONE && !aux) return PPO_ERR_INVALID;
+    if (precision != PPO_MM_F32X3 && precision != PPO_MM_BF16) return PPO_ERR_INVALID;
+    return launch_matmul(trans_a != 0, trans_b != 0, M, N, K, a, lda, b, ldb, c, ldc, epilogue, aux, ld_aux, precision, 1, 0, nullptr, 0, (hipStream_t)stream) == hipSuccess
+               ? PPO_OK : PPO_ERR_HIP;
+}
 extern "C" ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value, const int32_t* next_done,
                               int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
     if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;

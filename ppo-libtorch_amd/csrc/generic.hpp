@@ -51,7 +51,9 @@ inline GenLayout make_gen_layout(int obs, int hidden, int n_hidden, int n_heads,
 // Device workspace and library handle of one generic context (owned by ppo_ctx; see api.hip).
 struct GenericCtx {
     GenLayout L{};
-    void* blas = nullptr;          // rocblas_handle
+    void* blas = nullptr;          // rocblas_handle (only with PPO_GENERIC_GEMM=rocblas)
+    int gemm_backend = 0;          // GEN_GEMM_MFMA (kernels_gemm.hip, default) or GEN_GEMM_ROCBLAS (library sgemm: the yardstick)
+    int gemm_prec = 0;             // PPO_MM_F32X3 (default) or PPO_MM_BF16 (PPO_GENERIC_PREC=bf16)
     int64_t rows_max = 0;          // rows the workspaces are sized for: max(minibatch, T*N + N for the critic batch is chunked to it)
     float* acts[2][GEN_MAX_LAYERS] = {};   // [net][l]: post-tanh activations of hidden layer l, [rows_max, hidden]
     float* dz[2] = {};             // ping-pong d(pre-activation), [rows_max, hidden]
@@ -73,7 +75,16 @@ struct GenericCtx {
 };
 constexpr int GEN_LOSS_BLOCKS = 256;
 constexpr int GEN_DB_CHUNKS = 256, GEN_NORM_PARTS = 16;
+constexpr int GEN_GEMM_MFMA = 0, GEN_GEMM_ROCBLAS = 1;
+constexpr int GEN_SPLIT_MFMA = 128;   // row ranges of a weight-gradient product on the matrix cores: (out / 128)(in / 128) tiles x ranges >= 2 workgroups per CU
 constexpr int GEN_SPLIT = 32;   // row chunks of a weight-gradient GEMM (the contraction runs over the minibatch rows; see gen_backward)
+
+// kernels_gemm.hip: c[z][M, N] (z < splits, slabs c_zstride floats apart) = epilogue(sum over the z-th range of k of A(m, k) B(n, k));
+// see ppo_matmul in ppo_hip.h.  splits > 1 cuts the contraction into equal ranges (multiples of 64) and requires PPO_MM_EPI_NONE.
+// colsum (trans_a only, may be null): colsum[z * colsum_zstride + m] = sum over the z-th range of k of A(m, k).
+hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
+                         int64_t ldc, int epilogue, const float* aux, int64_t ld_aux, int precision, int splits, int64_t c_zstride, float* colsum,
+                         int64_t colsum_zstride, hipStream_t s);
 
 // kernels_generic.hip
 struct ppo_ctx;

@@ -1,0 +1,413 @@
+// ppo-libtorch_amd/csrc/kernels_gemm.hip -- the Linear layers of networks wider than 2 x 64 (BASELINE configs[4]: obs 376, 4 x 256,
+// heads [3,3,3,2]) on the CDNA4 matrix cores: Agent.cpp:25-59's `torch::nn::Linear` forward, and the two products of its backward,
+// as ONE kernel template
+//
+//      c[m][n] = epilogue( sum_k A(m, k) B(n, k) ),     A(m, k) = TA ? a[k * lda + m] : a[m * lda + k],   B likewise
+//
+//   forward      h = tanh(x W^T + b)        A = x [rows, K]            B = W [N, K]              epilogue bias (+ tanh)
+//   d(input)     dz' = (dz W) (1 - h'^2)    A = dz [rows, N]           B = W read as [k = n][K]  epilogue tanh'
+//   d(weight)    dW = dz^T x                A = dz read as [k = row][N]  B = x read as [k = row][K]   split over rows (gridDim.z slabs)
+//
+// Operands stay fp32 in HBM.  A workgroup (4 waves, 128 x 128 output tile, k step 32) loads its two operand tiles as fp32, cuts every
+// value by truncation into three bf16 terms (x = t1 + t2 + t3 exactly; see kernels_update_mfma.hip) while staging them into LDS, and
+// issues each fp32 product as the six bf16 products a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: fp32 accuracy at (1/6 of) the bf16 matrix rate, which on gfx950 is ~2.7x the rate of the fp32 MFMA a library sgemm
+// uses.  PREC 1 keeps one (round-to-nearest) bf16 term per operand: the "bf16 with MFMA GEMMs" arithmetic BASELINE configs[4] names.
+//
+// LDS tiles: a k-contiguous operand is stored [row][32 k] (80-byte rows: a lane's 16-byte fragment read is conflict-free); an operand
+// whose contraction index is the slow one in memory is stored as it comes, [32 k][128 cols], and its fragments are fetched with the
+// transposing LDS read ds_read_b64_tr_b16 -- no transpose in registers, coalesced global loads either way.
+// Two workgroups per CU: while one stages (vector ALU: splits, LDS writes) the other's waves keep the matrix pipe busy; the next
+// chunk's global loads are in flight during the current chunk's MFMAs.
+#include "ppo_internal.hpp"
+#include "generic.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte global load from a 4-byte aligned address
+
+constexpr int BK = 32;   // contraction elements per chunk (two MFMA k steps)
+constexpr int KS = 40;   // bf16 per row of a k-contiguous tile: 32 + 8 pad (80 B; 16 rows x 16 B land on 64 distinct banks)
+__host__ __device__ constexpr int tr_stride(int bx) { return bx == 128 ? 160 : 32; }   // bf16 per k row of an as-it-comes tile (= 16 dwords mod 64)
+__host__ __device__ constexpr int tile_elems(int bx, bool trans) { return trans ? BK * tr_stride(bx) : bx * KS; }
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+struct GemmArgs {
+    const float* a; int64_t lda;
+    const float* b; int64_t ldb;
+    float* c; int64_t ldc;
+    int M, N;
+    int64_t K;            // contraction length
+    int64_t k_chunk;      // contraction range of one blockIdx.z (a multiple of 2 BK); slab z is written at c + z * c_zstride
+    int64_t c_zstride;
+    int epi;              // PPO_MM_EPI_*
+    const float* aux;     // bias [N] or h [M, ld_aux]
+    int64_t ld_aux;
+    float* colsum;        // TA only, may be null: colsum[z * colsum_zstride + m] = sum over the z-th k range of A(m, k) (the bias gradient beside dW)
+    int64_t colsum_zstride;
+};
+
+// Four consecutive floats from global memory, branch-free (a load inside a branch makes the compiler wait for every outstanding load at the
+// join, which serialises the eight loads of a chunk into eight memory round trips): elements that do not exist are read from `safe` (any
+// valid address of the operand) and zeroed by the consumer (Stage::store), which first pins the raw values with an empty asm -- that keeps
+// the compiler from (a) proving the value unused and predicating the load after all, and (b) hoisting the zeroing up behind the load,
+// where it would wait for the data a whole chunk early.
+//   VEC:  the four elements exist or not together (host-checked: the contiguous extent is a multiple of 4) -> one 16-byte load
+//   !VEC: four 4-byte loads, element e exists iff e < nvalid
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* p, const float* safe, int nvalid) {
+    if constexpr (VEC) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(nvalid > 0 ? p : safe);
+        const f32x4 r = { v[0], v[1], v[2], v[3] };
+        return r;
+    }
+    const f32x4 r = { *(nvalid > 0 ? p : safe), *(nvalid > 1 ? p + 1 : safe), *(nvalid > 2 ? p + 2 : safe), *(nvalid > 3 ? p + 3 : safe) };
+    return r;
+}
+// the pin takes the quad as ONE 128-bit register operand, so it stays in the registers the load wrote (four scalar operands made the
+// allocator copy elements out right behind the load, which waits for it)
+__device__ __forceinline__ float4 pin_and_zero(f32x4 v, int nvalid) {
+    asm volatile("" : "+v"(v));
+    return make_float4(nvalid > 0 ? v[0] : 0.0f, nvalid > 1 ? v[1] : 0.0f, nvalid > 2 ? v[2] : 0.0f, nvalid > 3 ? v[3] : 0.0f);
+}
+
+// (x0, x1) -> packed bf16 pairs of the three truncation terms (low half = x0's)
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const uint32_t u0 = f2u(x0), u1 = f2u(x1);
+    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - u2f(u0 & 0xffff0000u), r1 = x1 - u2f(u1 & 0xffff0000u);
+    const uint32_t v0 = f2u(r0), v1 = f2u(r1);
+    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - u2f(v0 & 0xffff0000u), q1 = r1 - u2f(v1 & 0xffff0000u);
+    p3 = __builtin_amdgcn_perm(f2u(q1), f2u(q0), 0x07060302u);
+}
+__device__ __forceinline__ uint32_t pack_rne(float x0, float x1) {
+    const bf16x2 v = { (__bf16)x0, (__bf16)x1 };
+    return __builtin_bit_cast(uint32_t, v);
+}
+// four consecutive elements -> 8 bytes in each of the T term planes at bf16 index `off` (a multiple of 4)
+template <int T>
+__device__ __forceinline__ void split_store(uint16_t* plane0, int plane_elems, int off, const float4 v) {
+    if constexpr (T == 3) {
+        uint32_t a1, a2, a3, b1, b2, b3;
+        split3(v.x, v.y, a1, a2, a3);
+        split3(v.z, v.w, b1, b2, b3);
+        *reinterpret_cast<uint2*>(plane0 + off) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(plane0 + plane_elems + off) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(plane0 + 2 * plane_elems + off) = make_uint2(a3, b3);
+    } else {
+        *reinterpret_cast<uint2*>(plane0 + off) = make_uint2(pack_rne(v.x, v.y), pack_rne(v.z, v.w));
+    }
+}
+
+__device__ __forceinline__ uint2 lds_read_tr16(const uint16_t* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+// MFMA operand fragment of the 32 tile rows (or columns) xb .. xb + 31 for k step ks: lane (i = lane & 31, kg = lane >> 5) gets the
+// eight contraction elements 16 ks + 8 kg .. + 7 of row i
+template <bool TRANS, int BX>
+__device__ __forceinline__ u32x4 frag(const uint16_t* plane, int xb, int ks, int lane) {
+    if constexpr (!TRANS) {
+        return *reinterpret_cast<const u32x4*>(plane + (xb + (lane & 31)) * KS + 16 * ks + 8 * (lane >> 5));
+    } else {
+        // ds_read_b64_tr_b16: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p + 3, and receives column (lane % 16) of the four rows
+        constexpr int STR = tr_stride(BX);
+        const uint16_t* q = plane + (16 * ks + 8 * (lane >> 5) + ((lane & 15) >> 2)) * STR + xb + 16 * ((lane & 31) >> 4) + 4 * (lane & 3);
+        const uint2 lo = lds_read_tr16(q), hi = lds_read_tr16(q + 4 * STR);
+        const u32x4 r = { lo.x, lo.y, hi.x, hi.y };
+        return r;
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// Per-thread share of one operand tile: BX rows (or columns) x 32 contraction elements as float4s.
+//   k-contiguous (TRANS = false): thread (row = stage_row(tid) + 32 p, k quad = tid % 8), p < BX / 32.  stage_row spreads the four rows
+//       a 32-lane half writes at once over LDS rows r, r + 4, r + 8, r + 12: with 80-byte rows their 64-byte pieces then fall on disjoint
+//       banks (rows r and r + 1 would overlap: measured 33 % of the LDS cycles were bank conflicts with the plain tid / 8 mapping)
+//   as-it-comes  (TRANS = true):  thread (column quad = tid % (BX / 4), k rows 4 (tid / (BX / 4)) .. + 3)
+// The thread's global addresses are formed once (rows / columns that do not exist point at the operand's first element and never move) and
+// advance by one chunk per load; every load is unconditional (see load4).
+__device__ __forceinline__ int stage_row(int tid) {
+    const int l = tid & 63, w = tid >> 6;
+    return 4 * ((l >> 3) & 3) + 2 * (l >> 5) + (w & 1) + 16 * (w >> 1);
+}
+template <int NV>
+struct Loaded {
+    f32x4 v[NV];
+    int kvalid;   // !TRANS: leading contraction elements of every quad that exist;  TRANS: leading k rows (of the thread's four) that exist
+};
+template <int BX, bool TRANS, bool VEC>
+struct Stage {
+    static constexpr int NV = TRANS ? 4 : BX / 32;
+    const float* ptr[NV];     // next chunk's address of quad p (its first element)
+    int xvalid[NV];           // !TRANS: 4 if the row exists else 0;  TRANS: valid columns of the quad (0 .. 4), same for every p
+    int64_t k;                // contraction index of the thread's first element in the next chunk
+    int64_t step;             // pointer advance per chunk
+    const float* safe;
+    bool active;
+    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int x0, int X, int64_t k0, int tid) {
+        safe = src;
+        if constexpr (!TRANS) {
+            active = true;
+            k = k0 + 4 * (tid & 7);
+            step = BK;
+#pragma unroll
+            for (int p = 0; p < NV; p++) {
+                const int row = x0 + stage_row(tid) + 32 * p;
+                xvalid[p] = row < X ? 4 : 0;
+                ptr[p] = src + (int64_t)(row < X ? row : 0) * ld + k;
+            }
+        } else {
+            constexpr int MQ = BX / 4;
+            const int mq = tid % MQ, kq = tid / MQ;
+            active = BX >= 128 || kq < 8;   // BX = 32: whole waves are idle
+            const int col = x0 + 4 * mq;
+            const int cleft = X - col;
+            k = k0 + 4 * kq;
+            step = BK * ld;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                xvalid[j] = cleft >= 4 ? 4 : (cleft > 0 ? cleft : 0);
+                ptr[j] = src + (k + j) * ld + (cleft > 0 ? col : 0);
+            }
+        }
+    }
+    // issues the loads of the next chunk and advances
+    __device__ __forceinline__ void load(Loaded<NV>& o, int64_t kend) {
+        const int64_t left = kend - k;
+        o.kvalid = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+        if constexpr (!TRANS) {
+#pragma unroll
+            for (int p = 0; p < NV; p++) {
+                o.v[p] = load4<VEC>(ptr[p], safe, xvalid[p] ? o.kvalid : 0);
+                ptr[p] += step;
+            }
+        } else {
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    o.v[j] = load4<VEC>(ptr[j], safe, j < o.kvalid ? xvalid[j] : 0);
+                    ptr[j] += step;
+                }
+            }
+        }
+        k += BK;
+    }
+    template <int T>
+    __device__ __forceinline__ void store(const Loaded<NV>& o, uint16_t* planes, int tid, float* cs = nullptr) const {
+        constexpr int PE = tile_elems(BX, TRANS);
+        if constexpr (!TRANS) {
+            const int kq = tid & 7;
+#pragma unroll
+            for (int p = 0; p < NV; p++)
+                split_store<T>(planes, PE, (stage_row(tid) + 32 * p) * KS + 4 * kq, pin_and_zero(o.v[p], xvalid[p] ? o.kvalid : 0));
+        } else {
+            constexpr int MQ = BX / 4, STR = tr_stride(BX);
+            const int mq = tid % MQ, kq = tid / MQ;
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float4 q = pin_and_zero(o.v[j], j < o.kvalid ? xvalid[j] : 0);
+                    if (cs) { cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w; }   // running sums of the thread's four columns over k
+                    split_store<T>(planes, PE, (4 * kq + j) * STR + 4 * mq, q);
+                }
+            }
+        }
+    }
+};
+
+// BM x BN output tile, WM x WN waves (WM * WN = 4), each wave FM x FN blocks of 32 x 32.  VEC: the contiguous extent of BOTH operands is a
+// multiple of 4 (every layer product of a network whose widths are; heads and odd shapes take the 4-byte loads)
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+    constexpr int EA = tile_elems(BM, TA), EB = tile_elems(BN, TB);
+    __shared__ __attribute__((aligned(16))) uint16_t sA[T * EA];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[T * EB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
+    const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
+
+    // The two workgroups of a CU put one wave each on every SIMD.  With equal priorities the issue arbiter alternates between them, both walk
+    // through their staging (vector) and MFMA phases in step, and the matrix pipe idles while both stage (measured: 6 % of the MFMA cycles
+    // overlapped with vector work).  The wave in the odd hardware slot gets priority: it runs as if alone, the other fills the gaps.
+    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(1);   // HW_ID.wave_id[3:0]
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // Two chunks of operands are in flight in registers: the loads of chunk c + 2 are issued when chunk c has been staged, so a load has two
+    // chunks of MFMAs (not one) to cover its trip to HBM.  The contraction range is walked in PAIRS of chunks (the host rounds k_chunk
+    // to a multiple of 64; chunks past the end load zeros) so that the loop body has no branch around a load.
+    Stage<BM, TA, VEC> sa;
+    Stage<BN, TB, VEC> sb;
+    sa.init(g.a, g.lda, m0, g.M, kbeg, tid);
+    sb.init(g.b, g.ldb, n0, g.N, kbeg, tid);
+    Loaded<Stage<BM, TA, VEC>::NV> va0, va1;
+    Loaded<Stage<BN, TB, VEC>::NV> vb0, vb1;
+    sa.load(va0, kend); sb.load(vb0, kend);
+    __builtin_amdgcn_sched_barrier(0);   // set 0 strictly before set 1: the in-order load counter then lets the loop wait for set 0 alone
+    sa.load(va1, kend); sb.load(vb1, kend);
+    __builtin_amdgcn_sched_barrier(0);
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            u32x4 af[FM][T], bf[FN][T];
+#pragma unroll
+            for (int i = 0; i < FM; i++)
+#pragma unroll
+                for (int t = 0; t < T; t++) af[i][t] = frag<TA, BM>(sA + t * EA, (wm * FM + i) * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < FN; j++)
+#pragma unroll
+                for (int t = 0; t < T; t++) bf[j][t] = frag<TB, BN>(sB + t * EB, (wn * FN + j) * 32, ks, lane);
+            // small terms first; the FM x FN accumulators of one product are independent MFMAs
+            constexpr int NP = T == 3 ? 6 : 1;
+            constexpr int pa[6] = { T == 3 ? 2 : 0, 0, 1, 1, 0, 0 }, pb[6] = { 0, 2, 1, 0, 1, 0 };
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+                for (int i = 0; i < FM; i++)
+#pragma unroll
+                    for (int j = 0; j < FN; j++) acc[i][j] = mfma_bf16(af[i][pa[p]], bf[j][pb[p]], acc[i][j]);
+        }
+    };
+    float cs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const bool do_cs = TA && g.colsum != nullptr && blockIdx.x == 0;   // every blockIdx.x stages the same A tile: one of them sums it
+    for (int64_t kc = kbeg; kc < kend; kc += 2 * BK) {
+        sa.template store<T>(va0, sA, tid, do_cs ? cs : nullptr);
+        sb.template store<T>(vb0, sB, tid);
+        __syncthreads();
+        sa.load(va0, kend); sb.load(vb0, kend);
+        compute();
+        __syncthreads();
+        sa.template store<T>(va1, sA, tid, do_cs ? cs : nullptr);
+        sb.template store<T>(vb1, sB, tid);
+        __syncthreads();
+        sa.load(va1, kend); sb.load(vb1, kend);
+        compute();
+        __syncthreads();
+    }
+
+    if constexpr (TA) {
+        if (do_cs) {   // the eight k-row groups of threads that share a column quad are added in a fixed order through LDS (the tiles are dead)
+            constexpr int MQ = BM / 4;
+            float* red = reinterpret_cast<float*>(sA);   // [8][BM]
+            const int mq = tid % MQ, kq = tid / MQ;
+            if (kq < 8) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) red[kq * BM + 4 * mq + e] = cs[e];
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < g.M) {
+                float t = red[tid];
+#pragma unroll
+                for (int q = 1; q < 8; q++) t += red[q * BM + tid];
+                g.colsum[(int64_t)blockIdx.z * g.colsum_zstride + m0 + tid] = t;
+            }
+        }
+    }
+
+    // ---- epilogue: D layout = lane's column n = lane & 31, register r <-> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the block ----
+    float* __restrict__ c = g.c + (int64_t)blockIdx.z * g.c_zstride;
+    const int hi = lane >> 5;
+    const bool interior = m0 + BM <= g.M && n0 + BN <= g.N;
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+        const int n = n0 + (wn * FN + j) * 32 + (lane & 31);
+        const bool n_ok = n < g.N;
+        const float bias = ((g.epi == PPO_MM_EPI_BIAS || g.epi == PPO_MM_EPI_BIAS_TANH) && n_ok) ? g.aux[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < FM; i++) {
+            const int mb = m0 + (wm * FM + i) * 32 + 4 * hi;
+            float v[16];
+            if (g.epi == PPO_MM_EPI_BIAS_TANH) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = tanh_mufu(acc[i][j][r] + bias);
+            } else if (g.epi == PPO_MM_EPI_DTANH) {
+                float h[16];   // all sixteen loads in flight together (clamped address where the element does not exist)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    h[r] = g.aux[(n_ok && m < g.M) ? (int64_t)m * g.ld_aux + n : 0];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = acc[i][j][r] * (1.0f - h[r] * h[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = acc[i][j][r] + bias;
+            }
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) c[(int64_t)(mb + (r & 3) + 8 * (r >> 2)) * g.ldc + n] = v[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (n_ok && m < g.M) c[(int64_t)m * g.ldc + n] = v[r];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int T, bool VEC>
+hipError_t launch_cfg(const GemmArgs& g, bool ta, bool tb, int splits, hipStream_t s) {
+    const dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits), block(256);
+    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, T, VEC>), grid, block, 0, s, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, T, VEC>), grid, block, 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, T, VEC>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, T, VEC>), grid, block, 0, s, g);
+    return hipGetLastError();
+}
+template <int T, bool VEC>
+hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStream_t s) {
+    if (g.N <= 32) return launch_cfg<128, 32, 4, 1, T, VEC>(g, ta, tb, splits, s);
+    if (g.M <= 32) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, s);
+    return launch_cfg<128, 128, 2, 2, T, VEC>(g, ta, tb, splits, s);
+}
+
+}  // namespace
+
+// c[z][M, N] (z < splits, slabs c_zstride apart) = epilogue(sum over the z-th k range of A(m, k) B(n, k)); splits > 1 cuts the contraction
+// into ranges of k_chunk (rounded up to a multiple of 32) and requires the plain epilogue.
+hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
+                         int64_t ldc, int epilogue, const float* aux, int64_t ld_aux, int precision, int splits, int64_t c_zstride, float* colsum,
+                         int64_t colsum_zstride, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (M > 0x7fffffff || N > 0x7fffffff || K < 0 || splits < 1) return hipErrorInvalidValue;
+    if (splits > 1 && epilogue != PPO_MM_EPI_NONE) return hipErrorInvalidValue;
+    GemmArgs g;
+    g.a = a; g.lda = lda; g.b = b; g.ldb = ldb; g.c = c; g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = K;
+    int64_t kc = (K + splits - 1) / splits;
+    kc = (kc + 2 * BK - 1) / (2 * BK) * (2 * BK);   // the kernel walks pairs of chunks
+    if (kc < 2 * BK) kc = 2 * BK;
+    g.k_chunk = kc;
+    g.c_zstride = c_zstride;
+    g.epi = epilogue; g.aux = aux; g.ld_aux = ld_aux;
+    g.colsum = trans_a ? colsum : nullptr; g.colsum_zstride = colsum_zstride;
+    // contiguous extent of an operand: k (plain) or its row / column index (transposed)
+    const bool vec = ((trans_a ? M : K) % 4 == 0) && ((trans_b ? N : K) % 4 == 0);
+    if (precision == PPO_MM_BF16) return vec ? launch_prec<1, true>(g, trans_a, trans_b, splits, s) : launch_prec<1, false>(g, trans_a, trans_b, splits, s);
+    return vec ? launch_prec<3, true>(g, trans_a, trans_b, splits, s) : launch_prec<3, false>(g, trans_a, trans_b, splits, s);
+}

@@ -356,20 +356,35 @@ __global__ __launch_bounds__(256) void colsum_chunk_kernel(const float* __restri
     __syncthreads();
     if (rl == 0 && col < n) part[(size_t)blockIdx.y * n + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
-// out[i] = sum over the S partial slabs, in order
+// out[i] = sum over the S partial slabs in a fixed order: 64 elements per block, four lanes per element each adding a quarter of the slabs
+// (eight loads in flight at a time), then ((q0 + q1) + q2) + q3
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int S, int64_t n_w, const float* __restrict__ db_part,
                                                        int db_chunks, int64_t n_b, float* __restrict__ gw, float* __restrict__ gb) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_w + n_b) return;
-    if (i < n_w) {
-        float acc = slab[i];
-        for (int sidx = 1; sidx < S; sidx++) acc += slab[(size_t)sidx * slab_stride + i];
-        gw[i] = acc;
-    } else {
-        const int64_t c = i - n_w;
-        float acc = db_part[c];
-        for (int k = 1; k < db_chunks; k++) acc += db_part[(size_t)k * n_b + c];
-        gb[c] = acc;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
+    float acc = 0.0f;
+    if (i < n_w + n_b) {
+        const bool w = i < n_w;
+        const float* src = w ? slab + i : db_part + (i - n_w);
+        const int64_t stride = w ? slab_stride : n_b;
+        const int n = w ? S : db_chunks;
+        const int per = (n + 3) / 4, k0 = q * per, k1 = k0 + per < n ? k0 + per : n;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = src[(size_t)(k + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += v[j];
+        }
+        for (; k < k1; k++) acc += src[(size_t)k * stride];
+    }
+    red[q][e] = acc;
+    __syncthreads();
+    if (q == 0 && i < n_w + n_b) {
+        const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        if (i < n_w) gw[i] = t; else gb[i - n_w] = t;
     }
 }
 
@@ -388,6 +403,13 @@ hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const 
         const int K = L.in_dim[l], N = L.out_dim[net][l];
         const bool last = l == L.n_layers - 1;
         float* dst = last ? out : (acts ? acts[l] : ((l & 1) ? scratch1 : scratch0));
+        if (g.gemm_backend == GEN_GEMM_MFMA) {   // one launch per layer: product, bias and tanh (kernels_gemm.hip)
+            const hipError_t e = launch_matmul(false, false, rows, N, K, in, K, params + L.w_off[net][l], K, dst, N, last ? PPO_MM_EPI_BIAS : PPO_MM_EPI_BIAS_TANH,
+                                               params + L.b_off[net][l], 0, g.gemm_prec, 1, 0, nullptr, 0, s);
+            if (e != hipSuccess) return e;
+            in = dst;
+            continue;
+        }
         RBCHK(rb::sgemm(g.blas, rb::OP_T, rb::OP_N, N, (int)rows, K, &one, params + L.w_off[net][l], K, in, K, &zero, dst, N));
         if (last) hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid_for(rows * N, 256)), dim3(256), 0, s, dst, params + L.b_off[net][l], rows, N);
         else hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid_for(rows * N, 256)), dim3(256), 0, s, dst, params + L.b_off[net][l], rows, N);
@@ -459,26 +481,49 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
         // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single GEMM would have N K / tile
         // workgroups walking all rows (and rocBLAS may not split the contraction without atomics), so the rows are cut into GEN_SPLIT
         // chunks -- one strided-batched GEMM, every chunk its own partial slab -- and the slabs are added in a fixed order.
-        const int64_t chunk = (rows + GEN_SPLIT - 1) / GEN_SPLIT;
-        const int full = (int)(rows / chunk);            // chunks of exactly `chunk` rows
-        const int64_t rem = rows - (int64_t)full * chunk;
-        const int S = full + (rem > 0 ? 1 : 0);
         const int64_t n_w = (int64_t)N * K;
-        if (full > 0)
-            RBCHK(rb::sgemm_sb(g.blas, rb::OP_N, rb::OP_T, K, N, (int)chunk, &one, in, K, chunk * K, d, N, chunk * N, &zero, g.wslab, K, g.wslab_stride, full));
-        if (rem > 0)
-            RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rem, &one, in + (size_t)full * chunk * K, K, d + (size_t)full * chunk * N, N, &zero,
-                            g.wslab + (size_t)full * g.wslab_stride, K));
-        const int64_t dbc = (rows + GEN_DB_CHUNKS - 1) / GEN_DB_CHUNKS;
-        const int n_dbc = (int)((rows + dbc - 1) / dbc);
-        hipLaunchKernelGGL(colsum_chunk_kernel, dim3((N + 63) / 64, n_dbc), dim3(256), 0, s, d, rows, N, dbc, g.db_part);
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 255) / 256)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, n_dbc, (int64_t)N,
+        int S;
+        if (g.gemm_backend == GEN_GEMM_MFMA) {
+            // dW = d^T in on the matrix cores: row ranges -> slabs, enough of them for two workgroups per CU, each a multiple of 64 rows
+            const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 127) / 128);
+            int64_t want = (512 + tiles - 1) / tiles;
+            if (want > GEN_SPLIT_MFMA) want = GEN_SPLIT_MFMA;
+            int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;
+            S = (int)((rows + range - 1) / range);
+            // ... and db beside it: the workgroups of the first column of tiles also sum their d tile over the rows (db_part[z][N])
+            const hipError_t e = launch_matmul(true, true, N, K, rows, d, N, in, K, g.wslab, K, PPO_MM_EPI_NONE, nullptr, 0, g.gemm_prec, S, g.wslab_stride,
+                                               g.db_part, N, s);
+            if (e != hipSuccess) return e;
+        } else {
+            const int64_t chunk = (rows + GEN_SPLIT - 1) / GEN_SPLIT;
+            const int full = (int)(rows / chunk);            // chunks of exactly `chunk` rows
+            const int64_t rem = rows - (int64_t)full * chunk;
+            S = full + (rem > 0 ? 1 : 0);
+            if (full > 0)
+                RBCHK(rb::sgemm_sb(g.blas, rb::OP_N, rb::OP_T, K, N, (int)chunk, &one, in, K, chunk * K, d, N, chunk * N, &zero, g.wslab, K, g.wslab_stride, full));
+            if (rem > 0)
+                RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rem, &one, in + (size_t)full * chunk * K, K, d + (size_t)full * chunk * N, N, &zero,
+                                g.wslab + (size_t)full * g.wslab_stride, K));
+        }
+        int n_dbc = S;
+        if (g.gemm_backend != GEN_GEMM_MFMA) {
+            const int64_t dbc = (rows + GEN_DB_CHUNKS - 1) / GEN_DB_CHUNKS;
+            n_dbc = (int)((rows + dbc - 1) / dbc);
+            hipLaunchKernelGGL(colsum_chunk_kernel, dim3((N + 63) / 64, n_dbc), dim3(256), 0, s, d, rows, N, dbc, g.db_part);
+        }
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, n_dbc, (int64_t)N,
                            grads + L.w_off[net][l], grads + L.b_off[net][l]);
         if (l > 0) {
             float* nd = g.dz[(l & 1)];
-            // dH[rows, K] = d[rows, N] . W[N, K]
-            RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_N, K, (int)rows, N, &one, params + L.w_off[net][l], K, d, N, &zero, nd, K));
-            hipLaunchKernelGGL(dtanh_kernel, dim3(grid_for(rows * K, 256)), dim3(256), 0, s, nd, g.acts[net][l - 1], rows * K);
+            // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2): one launch on the matrix cores, two with the library
+            if (g.gemm_backend == GEN_GEMM_MFMA) {
+                const hipError_t e = launch_matmul(false, true, rows, K, N, d, N, params + L.w_off[net][l], K, nd, K, PPO_MM_EPI_DTANH, g.acts[net][l - 1], K,
+                                                   g.gemm_prec, 1, 0, nullptr, 0, s);
+                if (e != hipSuccess) return e;
+            } else {
+                RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_N, K, (int)rows, N, &one, params + L.w_off[net][l], K, d, N, &zero, nd, K));
+                hipLaunchKernelGGL(dtanh_kernel, dim3(grid_for(rows * K, 256)), dim3(256), 0, s, nd, g.acts[net][l - 1], rows * K);
+            }
             d = nd;
         }
     }
