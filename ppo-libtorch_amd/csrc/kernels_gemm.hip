@@ -19,6 +19,8 @@
 // transposing LDS read ds_read_b64_tr_b16 -- no transpose in registers, coalesced global loads either way.
 // Two workgroups per CU: while one stages (vector ALU: splits, LDS writes) the other's waves keep the matrix pipe busy; the next
 // chunk's global loads are in flight during the current chunk's MFMAs.
+#include <type_traits>
+
 #include "ppo_internal.hpp"
 #include "generic.hpp"
 
@@ -183,42 +185,46 @@ struct Stage {
             }
         }
     }
-    // issues the loads of the next chunk and advances
+    // issues the loads of the next chunk and advances.  GUARD = false: the caller knows every element of the chunk exists (interior tile, chunk
+    // inside the contraction range): no address select, no zeroing -- a third of the loop's vector instructions
+    template <bool GUARD>
     __device__ __forceinline__ void load(Loaded<NV>& o, int64_t kend) {
-        const int64_t left = kend - k;
-        o.kvalid = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+        if constexpr (GUARD) {
+            const int64_t left = kend - k;
+            o.kvalid = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+        }
         if constexpr (!TRANS) {
 #pragma unroll
             for (int p = 0; p < NV; p++) {
-                o.v[p] = load4<VEC>(ptr[p], safe, xvalid[p] ? o.kvalid : 0);
+                o.v[p] = load4<VEC>(ptr[p], safe, GUARD ? (xvalid[p] ? o.kvalid : 0) : 4);
                 ptr[p] += step;
             }
         } else {
             if (active) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    o.v[j] = load4<VEC>(ptr[j], safe, j < o.kvalid ? xvalid[j] : 0);
+                    o.v[j] = load4<VEC>(ptr[j], safe, GUARD ? (j < o.kvalid ? xvalid[j] : 0) : 4);
                     ptr[j] += step;
                 }
             }
         }
         k += BK;
     }
-    template <int T>
+    template <int T, bool GUARD>
     __device__ __forceinline__ void store(const Loaded<NV>& o, uint16_t* planes, int tid, float* cs = nullptr) const {
         constexpr int PE = tile_elems(BX, TRANS);
         if constexpr (!TRANS) {
             const int kq = tid & 7;
 #pragma unroll
             for (int p = 0; p < NV; p++)
-                split_store<T>(planes, PE, (stage_row(tid) + 32 * p) * KS + 4 * kq, pin_and_zero(o.v[p], xvalid[p] ? o.kvalid : 0));
+                split_store<T>(planes, PE, (stage_row(tid) + 32 * p) * KS + 4 * kq, pin_and_zero(o.v[p], GUARD ? (xvalid[p] ? o.kvalid : 0) : 4));
         } else {
             constexpr int MQ = BX / 4, STR = tr_stride(BX);
             const int mq = tid % MQ, kq = tid / MQ;
             if (active) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const float4 q = pin_and_zero(o.v[j], j < o.kvalid ? xvalid[j] : 0);
+                    const float4 q = pin_and_zero(o.v[j], GUARD ? (j < o.kvalid ? xvalid[j] : 0) : 4);
                     if (cs) { cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w; }   // running sums of the thread's four columns over k
                     split_store<T>(planes, PE, (4 * kq + j) * STR + 4 * mq, q);
                 }
@@ -241,10 +247,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
     const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
 
-    // The two workgroups of a CU put one wave each on every SIMD.  With equal priorities the issue arbiter alternates between them, both walk
-    // through their staging (vector) and MFMA phases in step, and the matrix pipe idles while both stage (measured: 6 % of the MFMA cycles
-    // overlapped with vector work).  The wave in the odd hardware slot gets priority: it runs as if alone, the other fills the gaps.
-    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(1);   // HW_ID.wave_id[3:0]
+    // The two workgroups of a CU put one wave each on every SIMD.  With equal priorities both walk through their staging (vector) and MFMA
+    // phases in step -- sharing the vector ALU, then sharing the matrix pipe, never overlapping the two (measured: 6 % of the MFMA cycles
+    // overlapped with vector work).  One of the two -- the one whose LDS allocation starts at 0, the same answer on all four SIMDs, which
+    // matters because the waves of a workgroup meet at barriers -- gets issue priority: it pulls ahead by a phase and the two then alternate.
+    if ((__builtin_amdgcn_s_getreg((7 << 11) | 6) & 0xff) == 0) __builtin_amdgcn_s_setprio(1);   // HW_REG_LDS_ALLOC.lds_base
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -263,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     sb.init(g.b, g.ldb, n0, g.N, kbeg, tid);
     Loaded<Stage<BM, TA, VEC>::NV> va0, va1;
     Loaded<Stage<BN, TB, VEC>::NV> vb0, vb1;
-    sa.load(va0, kend); sb.load(vb0, kend);
+    sa.template load<true>(va0, kend); sb.template load<true>(vb0, kend);
     __builtin_amdgcn_sched_barrier(0);   // set 0 strictly before set 1: the in-order load counter then lets the loop wait for set 0 alone
-    sa.load(va1, kend); sb.load(vb1, kend);
+    sa.template load<true>(va1, kend); sb.template load<true>(vb1, kend);
     __builtin_amdgcn_sched_barrier(0);
     auto compute = [&]() {
 #pragma unroll
@@ -292,20 +299,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     };
     float cs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     const bool do_cs = TA && g.colsum != nullptr && blockIdx.x == 0;   // every blockIdx.x stages the same A tile: one of them sums it
-    for (int64_t kc = kbeg; kc < kend; kc += 2 * BK) {
-        sa.template store<T>(va0, sA, tid, do_cs ? cs : nullptr);
-        sb.template store<T>(vb0, sB, tid);
+    auto pair = [&](auto guard) {   // stages and multiplies the two chunks in registers, fetches the two after them
+        constexpr bool G = decltype(guard)::value;
+        sa.template store<T, G>(va0, sA, tid, do_cs ? cs : nullptr);
+        sb.template store<T, G>(vb0, sB, tid);
         __syncthreads();
-        sa.load(va0, kend); sb.load(vb0, kend);
+        sa.template load<G>(va0, kend); sb.template load<G>(vb0, kend);
         compute();
         __syncthreads();
-        sa.template store<T>(va1, sA, tid, do_cs ? cs : nullptr);
-        sb.template store<T>(vb1, sB, tid);
+        sa.template store<T, G>(va1, sA, tid, do_cs ? cs : nullptr);
+        sb.template store<T, G>(vb1, sB, tid);
         __syncthreads();
-        sa.load(va1, kend); sb.load(vb1, kend);
+        sa.template load<G>(va1, kend); sb.template load<G>(vb1, kend);
         compute();
         __syncthreads();
+    };
+    int64_t kc = kbeg;
+    if (m0 + BM <= g.M && n0 + BN <= g.N) {
+        // interior tile: while this pair AND the pair fetched during it lie inside the range, nothing needs a guard
+        for (; kc + 4 * BK <= kend; kc += 2 * BK) pair(std::false_type{});
     }
+    for (; kc < kend; kc += 2 * BK) pair(std::true_type{});
 
     if constexpr (TA) {
         if (do_cs) {   // the eight k-row groups of threads that share a column quad are added in a fixed order through LDS (the tiles are dead)
