@@ -17,8 +17,10 @@
 // LDS tiles: a k-contiguous operand is stored [row][32 k] (80-byte rows: a lane's 16-byte fragment read is conflict-free); an operand
 // whose contraction index is the slow one in memory is stored as it comes, [32 k][128 cols], and its fragments are fetched with the
 // transposing LDS read ds_read_b64_tr_b16 -- no transpose in registers, coalesced global loads either way.
-// Two workgroups per CU: while one stages (vector ALU: splits, LDS writes) the other's waves keep the matrix pipe busy; the next
-// chunk's global loads are in flight during the current chunk's MFMAs.
+// Two workgroups per CU: while one stages (vector ALU: splits, LDS writes) the other's waves can keep the matrix pipe busy; the operands of
+// the next TWO chunks are in flight in registers during the current chunk's MFMAs.  Measured on the 65 536 x 256 x 1024 product
+// (rocprofv3 PMC): matrix pipe busy 60 % of the CU's cycles, no LDS bank conflicts, ~200 vector instructions per 48 MFMAs in the unguarded
+// loop; issue priority for one of the two workgroups, or starting it half a period late, changed nothing and is not in the code.
 #include <type_traits>
 
 #include "ppo_internal.hpp"
@@ -246,12 +248,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
     const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
-
-    // The two workgroups of a CU put one wave each on every SIMD.  With equal priorities both walk through their staging (vector) and MFMA
-    // phases in step -- sharing the vector ALU, then sharing the matrix pipe, never overlapping the two (measured: 6 % of the MFMA cycles
-    // overlapped with vector work).  One of the two -- the one whose LDS allocation starts at 0, the same answer on all four SIMDs, which
-    // matters because the waves of a workgroup meet at barriers -- gets issue priority: it pulls ahead by a phase and the two then alternate.
-    if ((__builtin_amdgcn_s_getreg((7 << 11) | 6) & 0xff) == 0) __builtin_amdgcn_s_setprio(1);   // HW_REG_LDS_ALLOC.lds_base
 
     f32x16 acc[FM][FN];
 #pragma unroll
