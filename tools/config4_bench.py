@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of one GPU's share of BASELINE configs[4] (synthetic env, obs 376, heads [3,3,3,2], 4 x 256 MLP; 16 384 envs over 8 GPUs =
 2048 envs x 128 steps per GPU, 4 minibatches x 10 epochs): env-steps/s of whole iterations, same timing discipline as bench.py.
-Layers are rocBLAS sgemm in fp32 on this path (generic.hpp)."""
+Layers: kernels_gemm.hip (fp32 as three bf16 terms; PPO_GENERIC_PREC=bf16 for plain bf16; PPO_GENERIC_GEMM=rocblas for the library yardstick)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
