@@ -121,6 +121,11 @@ struct ppo_ctx {
     bool force_collectives = false;  // PPO_COMM_SELFTEST: world == 1 but the multi-rank path (RCCL included) is taken
     bool fused_opt = true;           // single-rank contexts: optimizer step in two launches instead of three (env PPO_FUSED_OPT=0 disables)
     double* fused_partial = nullptr; // [fused_opt_blocks][12] per-workgroup sums of squares of the gradient
+    bool defer_opt = false;          // PPO_DEFER_OPT=1: clip + AdamW of step k applied by step k + 1's update kernel while it loads its weights.  Bit-identical,
+                                     // measured SLOWER (the update kernel grows by 5.8 us, the launch it replaces took 5.0): off by default, kept as a tested experiment
+    float* alt_state[3] = { nullptr, nullptr, nullptr };   // second set of params / exp_avg / exp_avg_sq the deferred steps alternate with
+    DeferredOpt pending_opt{};       // consumed by the next fwd_bwd()
+    bool state_in_alt = false;       // inside ppo_update: the committed params / moments live in alt_state (always false between updates)
     int last_n_blocks[2] = { 0, 0 };
     int mfma_prec = 1;               // 0: exact fp32 MFMA, 1: three-term bf16 split (env PPO_UPDATE_KERNEL=mfma_f32 selects 0)
     bool stamping = false;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
@@ -408,6 +413,8 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         c->mfma_prec = (k && std::strcmp(k, "mfma_f32") == 0) ? 0 : 1;
         const char* fo = getenv("PPO_FUSED_OPT");
         if (fo && std::strcmp(fo, "0") == 0) c->fused_opt = false;
+        const char* dfo = getenv("PPO_DEFER_OPT");
+        if (dfo && std::strcmp(dfo, "1") == 0) c->defer_opt = true;
         const char* sh = getenv("PPO_ACTOR_SHARE");
         if (sh) c->actor_share = atof(sh);
 
@@ -426,6 +433,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->clipfrac_accum, 2));
     CK(dalloc(c, &c->norm2, 4 * GEN_MAX_LAYERS * GEN_NORM_PARTS));
     CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
+    for (int i = 0; i < 3; i++) CK(dalloc(c, &c->alt_state[i], (size_t)c->L.P + 8));
     CK(dalloc(c, &c->ev_sums, PPO_EV_BLOCKS * 4));
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
     CK(dalloc(c, &c->group_bits, (size_t)c->T * ((N + 63) / 64)));
@@ -1018,7 +1026,10 @@ static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced) {
 static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, bool reduce = true) {
     if (c->gen) return gen_fwd_bwd(c, idx, M, slot);
     UpdateArgs a{};
-    a.params = B_<float>(c, PPO_BUF_PARAMS);
+    a.params = c->state_in_alt ? c->alt_state[0] : B_<float>(c, PPO_BUF_PARAMS);
+    a.opt = c->pending_opt;          // a deferred optimizer step rides on this launch (ppo_update) ...
+    c->pending_opt = DeferredOpt{};  // ... exactly once;
+    if (a.opt.pending) c->state_in_alt = !c->state_in_alt;   // ... and moves the committed state to the other set of buffers
     a.L = c->L;
     a.hp = c->hp;
     a.obs = B_<float>(c, PPO_BUF_OBS);
@@ -1147,16 +1158,40 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
             const int64_t start = (int64_t)mbi * c->MB;
             const int64_t M = std::min<int64_t>(c->MB, c->B - start);
             const bool fused = c->fused_opt && c->world == 1 && !c->force_collectives && !c->gen;
+            // deferred: step k's clip + AdamW is applied by step k + 1's update kernel (DeferredOpt); the state alternates between the
+            // context's buffers and alt_state, and the last step of the update runs the stand-alone kernel INTO the context's buffers
+            const bool defer = fused && c->defer_opt && c->use_mfma && !c->stamping;
             s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !fused);
             if (s != PPO_OK) return s;
             if (fused) {
-                // single rank: two launches (reduction + sums of squares, clip + AdamW) instead of three
                 c->opt_step += 1;
                 ProfScope ps(c, PROF_OPT);
-                HIPCHK(c, launch_reduce_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums,
-                                                   B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
-                                                   c->cfg.max_grad_norm, c->adam_coefs + k, (double)M, c->hp, c->step_stats + k,
-                                                   c->clipfrac_accum, c->fused_partial, c->stream));
+                float* canon[3] = { B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ) };
+                if (!defer) {
+                    // single rank: two launches (reduction + sums of squares, clip + AdamW) instead of three
+                    HIPCHK(c, launch_reduce_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, canon[0], canon[1],
+                                                       canon[2], c->cfg.max_grad_norm, c->adam_coefs + k, (double)M, c->hp, c->step_stats + k,
+                                                       c->clipfrac_accum, c->fused_partial, c->stream));
+                } else {
+                    HIPCHK(c, launch_reduce_grads_sumsq(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, c->fused_partial,
+                                                        c->stream));
+                    float* const* src = c->state_in_alt ? c->alt_state : canon;   // the state before this step
+                    if (k + 1 < E * nmb) {
+                        float* const* dst = c->state_in_alt ? canon : c->alt_state;
+                        DeferredOpt& o = c->pending_opt;
+                        o.pending = 1;
+                        o.grads = B_<float>(c, PPO_BUF_GRADS);
+                        o.p_src = src[0]; o.m_src = src[1]; o.v_src = src[2];
+                        o.p_dst = dst[0]; o.m_dst = dst[1]; o.v_dst = dst[2];
+                        o.coef = c->adam_coefs + k; o.partial = c->fused_partial; o.max_norm = c->cfg.max_grad_norm;
+                        o.sums = c->loss_sums; o.global_M = (double)M; o.hp = c->hp; o.stats_out = c->step_stats + k; o.clipfrac_accum = c->clipfrac_accum;
+                    } else {
+                        HIPCHK(c, launch_clip_adamw_sumsq(c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, src[0], src[1], src[2], canon[0], canon[1], canon[2],
+                                                          c->cfg.max_grad_norm, c->adam_coefs + k, (double)M, c->hp, c->step_stats + k, c->clipfrac_accum,
+                                                          c->fused_partial, c->stream));
+                        c->state_in_alt = false;
+                    }
+                }
                 c->last_stat_slot = k;
                 continue;
             }

@@ -594,7 +594,8 @@ struct FusedOptArgs {
     const float* slab; const double* stat_slab; int nb0, nb1;
     NetLayout L;
     float* grads; double* sums_out;
-    float* params; float* exp_avg; float* exp_avg_sq;
+    const float* p_src; const float* m_src; const float* v_src;   // optimizer state before the step ...
+    float* params; float* exp_avg; float* exp_avg_sq;             // ... and where the state after it goes (may be the same buffers)
     float max_norm; const AdamCoef* coef; double global_M; LossParams hp;
     StepStats* stats_out; double* clipfrac_accum;
     double* partial;            // [reduce workgroups][12] sums of squares
@@ -668,11 +669,11 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
 __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOptArgs a) {
     __shared__ double n2s[12];
     const NetLayout& L = a.L;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     const int p = blockIdx.x * ADAM_THREADS + tid;
     const bool own = p < L.P;
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
-    if (own) { u_g = a.grads[p]; u_p = a.params[p]; u_m = a.exp_avg[p]; u_v = a.exp_avg_sq[p]; }
+    if (own) { u_g = a.grads[p]; u_p = a.p_src[p]; u_m = a.m_src[p]; u_v = a.v_src[p]; }
     const AdamCoef k = *a.coef;
     double ls[5] = { 0, 0, 0, 0, 0 }, cf0 = 0.0, cf1 = 0.0;
     const bool stat_thread = tid == 0 && blockIdx.x == 0;
@@ -680,59 +681,15 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
         for (int i = 0; i < 5; i++) ls[i] = a.sums_out[i];
         if (a.clipfrac_accum) { cf0 = a.clipfrac_accum[0]; cf1 = a.clipfrac_accum[1]; }
     }
-    // squared norms of the 12 tensors: wave w adds the partials of the workgroups that touch tensors w, w + 4, w + 8, in a fixed order
-    // (all three loads in flight together, sums on the DPP network)
-    {
-        double v[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int t = w + 4 * j;
-            v[j] = 0.0;
-            if (t < L.n_tensors) {
-                const int blo = L.tensor_off[t] / 64, bhi = (L.tensor_off[t + 1] - 1) / 64;
-                for (int b = blo + lane; b <= bhi; b += 64) v[j] += a.partial[(size_t)b * 12 + t];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const double r = wave_sum_d_dpp(v[j]);
-            if (lane == 0) n2s[w + 4 * j] = r;
-        }
-    }
-    __syncthreads();
-    double tot = 0.0;
-#pragma unroll
-    for (int t = 0; t < 12; t++) { const float nrm = (float)sqrt(n2s[t]); tot += (double)nrm * nrm; }
-    const float total = (float)sqrt(tot);
-    float c = a.max_norm / (total + 1e-6f);   // clip_grad.h:76-78
-    if (c > 1.0f) c = 1.0f;
+    const float total = opt_total_norm(L, a.partial, n2s, tid);
+    const float c = opt_clip_coef(total, a.max_norm);
     if (own) {
-        const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
-        const float gc = u_g * c;
-        const float pi = u_p * k.decay;
-        const float mi = __builtin_fmaf(gc, omb1, u_m * b1);
-        const float vi = __builtin_fmaf(omb2 * gc, gc, u_v * b2);
-        const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
-        a.params[p] = pi + (k.neg_step * mi) / denom;
-        a.exp_avg[p] = mi;
-        a.exp_avg_sq[p] = vi;
+        adamw_apply(u_g, c, k, u_p, u_m, u_v);
+        a.params[p] = u_p;
+        a.exp_avg[p] = u_m;
+        a.exp_avg_sq[p] = u_v;
     }
-    if (stat_thread) {
-        const float pg = (float)(ls[0] / a.global_M);
-        const float vl = 0.5f * (float)(ls[4] / a.global_M);
-        const float el = (float)(ls[1] / a.global_M);
-        StepStats o;
-        o.pg_loss = pg;
-        o.v_loss = vl;
-        o.entropy_loss = el;
-        o.approx_kl = (float)(ls[2] / a.global_M);
-        o.clipfrac = (float)ls[3] / (float)a.global_M;
-        o.loss = (pg - a.hp.ent_coef * el) + vl * a.hp.vf_coef;
-        o.total_norm = total;
-        o.pad = 0.0;
-        *a.stats_out = o;
-        if (a.clipfrac_accum) { a.clipfrac_accum[0] = cf0 + o.clipfrac; a.clipfrac_accum[1] = cf1 + 1.0; }
-    }
+    if (stat_thread) opt_write_stats(ls, cf0, cf1, a.global_M, a.hp, total, a.stats_out, a.clipfrac_accum);
 }
 
 // Sum and sum of squares of the advantages of every minibatch of the coming update: PPO_ADV_PARTS workgroups per minibatch,
@@ -887,8 +844,27 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
     FusedOptArgs a;
     a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;
     a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M;
+    a.p_src = params; a.m_src = exp_avg; a.v_src = exp_avg_sq;
     a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.partial = partial;
     hipLaunchKernelGGL(reduce_grads_sumsq_kernel, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_reduce_grads_sumsq(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
+                                     double* sums_out, double* partial, hipStream_t s) {
+    FusedOptArgs a{};
+    a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out; a.partial = partial;
+    hipLaunchKernelGGL(reduce_grads_sumsq_kernel, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_clip_adamw_sumsq(const NetLayout& L, const float* grads, const double* sums, const float* p_src, const float* m_src,
+                                   const float* v_src, float* p_dst, float* m_dst, float* v_dst, float max_grad_norm, const AdamCoef* coef,
+                                   double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum, const double* partial, hipStream_t s) {
+    FusedOptArgs a{};
+    a.L = L; a.grads = const_cast<float*>(grads); a.sums_out = const_cast<double*>(sums);
+    a.p_src = p_src; a.m_src = m_src; a.v_src = v_src; a.params = p_dst; a.exp_avg = m_dst; a.exp_avg_sq = v_dst;
+    a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M; a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum;
+    a.partial = const_cast<double*>(partial);
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();
 }

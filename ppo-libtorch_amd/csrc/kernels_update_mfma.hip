@@ -183,15 +183,62 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     const float* __restrict__ P = a.params;
 
     // ---- weights of this net -> LDS (once per launch) ----
+    // With a deferred optimizer step (a.opt.pending; ppo_internal.hpp: DeferredOpt) the weights loaded here are those BEFORE that step:
+    // every thread applies clip + AdamW to the elements it loads (gradient, both moments: three more loads per element, issued together
+    // with the weight's), uses the result, and workgroup 0 of the net also writes the new state to the other set of buffers.  That folds
+    // the optimizer launch (5.0 us, 40 times per update) into a prologue that was loading these weights anyway -- and measured, it LOSES:
+    // 13 elements per thread of IEEE sqrt + two divisions, replicated in all 256 workgroups, plus the norm's barrier make this kernel
+    // 5.8 us longer (A/B in one gpurun call: 162.2 against 164.3 M env-steps/s).  Bit-identical to the stand-alone step (tested); enabled
+    // only by PPO_DEFER_OPT=1.
+    const bool opt = a.opt.pending != 0;
+    const bool opt_writer = opt && blk == 0;
+    // Every element this thread brings in is a slot: 4096 / threads of W2, then its share of W1, W3, b1, b2, b3.  ALL loads of all slots
+    // (weight, and with a pending step gradient + both moments) are issued before anything is used: one memory round trip for the prologue
+    // (a load-use-load chain per tensor cost 6 us per launch, more than the optimizer launch it replaces).
+    constexpr int NW2 = PREC == PREC_BF16X3 ? 4096 / MF_THREADS : 16;
+    constexpr int NW1 = (64 * OBS + MF_THREADS - 1) / MF_THREADS, NW3 = (AMAX * 64 + MF_THREADS - 1) / MF_THREADS;
+    constexpr int NS_ = NW2 + NW1 + NW3 + 3;
+    int se[NS_];          // global parameter index, -1: no element in this slot
+#pragma unroll
+    for (int i = 0; i < NW2; i++) se[i] = L.w2[NET] + tid + i * MF_THREADS;
+#pragma unroll
+    for (int i = 0; i < NW1; i++) { const int e = tid + i * MF_THREADS; se[NW2 + i] = e < 64 * OBS ? L.w1[NET] + e : -1; }
+#pragma unroll
+    for (int i = 0; i < NW3; i++) { const int e = tid + i * MF_THREADS; se[NW2 + NW1 + i] = e < AOUT * 64 ? L.w3[NET] + e : -1; }
+    se[NS_ - 3] = tid < 64 ? L.b1[NET] + tid : -1;
+    se[NS_ - 2] = tid < 64 ? L.b2[NET] + tid : -1;
+    se[NS_ - 1] = tid < AOUT ? L.b3[NET] + tid : -1;
+    float wv[NS_], og[NS_], om[NS_], ov[NS_];
+#pragma unroll
+    for (int i = 0; i < NS_; i++) wv[i] = P[se[i] < 0 ? 0 : se[i]];
+    if (opt) {
+#pragma unroll
+        for (int i = 0; i < NS_; i++) {
+            const int e = se[i] < 0 ? 0 : se[i];
+            og[i] = a.opt.grads[e]; om[i] = a.opt.m_src[e]; ov[i] = a.opt.v_src[e];
+        }
+        double* n2s = reinterpret_cast<double*>(smem + m.wave0);   // the wave regions are idle until the tile loop
+        double ls[5] = { 0, 0, 0, 0, 0 }, cf0 = 0.0, cf1 = 0.0;
+        const bool stat_thread = NET == 0 && blk == 0 && tid == 0;
+        if (stat_thread) {
+            for (int i = 0; i < 5; i++) ls[i] = a.opt.sums[i];
+            if (a.opt.clipfrac_accum) { cf0 = a.opt.clipfrac_accum[0]; cf1 = a.opt.clipfrac_accum[1]; }
+        }
+        const AdamCoef kco = *a.opt.coef;
+        const float total = opt_total_norm(L, a.opt.partial, n2s, tid);   // one barrier inside
+        const float clipc = opt_clip_coef(total, a.opt.max_norm);
+        if (stat_thread) opt_write_stats(ls, cf0, cf1, a.opt.global_M, a.opt.hp, total, a.opt.stats_out, a.opt.clipfrac_accum);
+#pragma unroll
+        for (int i = 0; i < NS_; i++) {
+            adamw_apply(og[i], clipc, kco, wv[i], om[i], ov[i]);
+            if (opt_writer && se[i] >= 0) { a.opt.p_dst[se[i]] = wv[i]; a.opt.m_dst[se[i]] = om[i]; a.opt.v_dst[se[i]] = ov[i]; }
+        }
+    }
     if constexpr (PREC == PREC_BF16X3) {
-        // 4096 weights, 8 per thread: each is cut into its three bf16 terms once per launch and stored at its operand slot in the
-        // forward ([n][slot of k]) and the transposed ([k][slot of n]) image
+        // 4096 weights, 8 per thread: each is cut into its three bf16 terms once per launch and stored at its natural [n][k] place
         uint16_t* wn = reinterpret_cast<uint16_t*>(smem + m.w2);
-        float wv[4096 / MF_THREADS];
 #pragma unroll
-        for (int i = 0; i < 4096 / MF_THREADS; i++) wv[i] = P[L.w2[NET] + tid + i * MF_THREADS];
-#pragma unroll
-        for (int i = 0; i < 4096 / MF_THREADS; i++) {
+        for (int i = 0; i < NW2; i++) {
             const int e = tid + i * MF_THREADS;
             const int n = e >> 6, k = e & 63;
             const uint32_t u0 = f2u(wv[i]);
@@ -202,22 +249,20 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             wn[pn] = (uint16_t)(u0 >> 16); wn[64 * NS + pn] = (uint16_t)(u1 >> 16); wn[2 * 64 * NS + pn] = (uint16_t)(f2u(r2) >> 16);
         }
     } else {
-        // 4096 weights, 16 per thread, every global load issued before the first LDS store
-        float wv[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) wv[i] = P[L.w2[NET] + tid + i * MF_THREADS];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < NW2; i++) {
             const int e = tid + i * MF_THREADS;
             const int n = e >> 6, k = e & 63;
             sW2[n * LS + k] = wv[i];
             sW2T[k * LS + n] = wv[i];
         }
     }
-    for (int e = tid; e < 64 * OBS; e += MF_THREADS) sW1[e] = P[L.w1[NET] + e];
-    for (int e = tid; e < AOUT * 64; e += MF_THREADS) sW3[e] = P[L.w3[NET] + e];
-    if (tid < 64) { sB1[tid] = P[L.b1[NET] + tid]; sB2[tid] = P[L.b2[NET] + tid]; }
-    if (tid < AOUT) sB3[tid] = P[L.b3[NET] + tid];
+#pragma unroll
+    for (int i = 0; i < NW1; i++) { const int e = tid + i * MF_THREADS; if (e < 64 * OBS) sW1[e] = wv[NW2 + i]; }
+#pragma unroll
+    for (int i = 0; i < NW3; i++) { const int e = tid + i * MF_THREADS; if (e < AOUT * 64) sW3[e] = wv[NW2 + NW1 + i]; }
+    if (tid < 64) { sB1[tid] = wv[NS_ - 3]; sB2[tid] = wv[NS_ - 2]; }
+    if (tid < AOUT) sB3[tid] = wv[NS_ - 1];
 
     // ---- gradient accumulators of this wave ----
     f32x16 gW2[2][2];  // [tn][tk]: D[i = n%32][j = k%32]
@@ -236,17 +281,6 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
     for (int k = 0; k < AMAX; k++) gb3[k] = 0.0f;
     double st0 = 0.0, st1 = 0.0, st2 = 0.0, st3 = 0.0;
-    // layer-1 A operands: W1[u = s + 32 t][o = 2 st + hi] (zero beyond OBS); K = OBS is contracted in ceil(OBS/2) MFMA steps
-    constexpr int L1S = (OBS + 1) / 2;
-    float w1op[2][L1S];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int stp = 0; stp < L1S; stp++) {
-            const int o = 2 * stp + hi;
-            w1op[t][stp] = o < OBS ? P[L.w1[NET] + (s + 32 * t) * OBS + o] : 0.0f;
-        }
-
     const float clip = a.hp.clip_coef;
     const float lo = 1 - clip, hi_c = 1 + clip;
     const float invM = (float)a.inv_global_M;
@@ -261,6 +295,17 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     }
     const float inv_std = 1.0f / (std_f + 1e-8f);
     __syncthreads();
+    // layer-1 A operands: W1[u = s + 32 t][o = 2 st + hi] (zero beyond OBS); K = OBS is contracted in ceil(OBS/2) MFMA steps
+    constexpr int L1S = (OBS + 1) / 2;
+    float w1op[2][L1S];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int stp = 0; stp < L1S; stp++) {
+            const int o = 2 * stp + hi;
+            w1op[t][stp] = o < OBS ? sW1[(s + 32 * t) * OBS + o] : 0.0f;   // from LDS: the weights there include a deferred step
+        }
+
     MF_STAMP(0);   // prologue: weights -> LDS
 
     const int n_tiles = (a.M + MT - 1) / MT;

@@ -325,6 +325,72 @@ __device__ __forceinline__ double wave_sum_d_dpp(double v) {
         r[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * i), __builtin_amdgcn_readlane(__double2loint(v), 16 * i));
     return ((r[0] + r[1]) + r[2]) + r[3];
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + AdamW::step (PPO_Discrete.cpp:640-641) pieces shared by the stand-alone optimizer kernel and the update kernel's
+// prologue (deferred step): ONE definition, so the two paths are bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+// Total gradient norm from the per-workgroup sums of squares: wave w (< 4) adds the partials of the workgroups that touch tensors w, w + 4,
+// w + 8 in a fixed order (all three loads in flight together, sums on the DPP network).  Every thread of the workgroup must call it
+// (one barrier inside); n2s: 12 doubles of shared memory.
+__device__ __forceinline__ float opt_total_norm(const NetLayout& L, const double* __restrict__ partial, double* n2s, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    if (w < 4) {
+        double v[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int t = w + 4 * j;
+            v[j] = 0.0;
+            if (t < L.n_tensors) {
+                const int blo = L.tensor_off[t] / 64, bhi = (L.tensor_off[t + 1] - 1) / 64;
+                for (int b = blo + lane; b <= bhi; b += 64) v[j] += partial[(size_t)b * 12 + t];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double r = wave_sum_d_dpp(v[j]);
+            if (lane == 0) n2s[w + 4 * j] = r;
+        }
+    }
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int t = 0; t < 12; t++) { const float nrm = (float)sqrt(n2s[t]); tot += (double)nrm * nrm; }
+    return (float)sqrt(tot);
+}
+__device__ __forceinline__ float opt_clip_coef(float total, float max_norm) {   // clip_grad.h:76-78
+    const float c = max_norm / (total + 1e-6f);
+    return c > 1.0f ? 1.0f : c;
+}
+__device__ __forceinline__ void adamw_apply(float g, float c, const AdamCoef& k, float& p, float& m, float& v) {
+    const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
+    const float gc = g * c;
+    const float pi = p * k.decay;
+    const float mi = __builtin_fmaf(gc, omb1, m * b1);
+    const float vi = __builtin_fmaf(omb2 * gc, gc, v * b2);
+    const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
+    p = pi + (k.neg_step * mi) / denom;
+    m = mi;
+    v = vi;
+}
+// printPPOResults' inputs of one step (PPO_Discrete.cpp:700-774) from its loss sums; one thread
+__device__ __forceinline__ void opt_write_stats(const double* ls, double cf0, double cf1, double global_M, const LossParams& hp, float total,
+                                                StepStats* stats_out, double* clipfrac_accum) {
+    const float pg = (float)(ls[0] / global_M);
+    const float vl = 0.5f * (float)(ls[4] / global_M);
+    const float el = (float)(ls[1] / global_M);
+    StepStats o;
+    o.pg_loss = pg;
+    o.v_loss = vl;
+    o.entropy_loss = el;
+    o.approx_kl = (float)(ls[2] / global_M);
+    o.clipfrac = (float)ls[3] / (float)global_M;
+    o.loss = (pg - hp.ent_coef * el) + vl * hp.vf_coef;
+    o.total_norm = total;
+    o.pad = 0.0;
+    *stats_out = o;
+    if (clipfrac_accum) { clipfrac_accum[0] = cf0 + o.clipfrac; clipfrac_accum[1] = cf1 + 1.0; }
+}
 #endif  // __HIPCC__
 
 // ---------------------------------------------------------------------------------------------------------
@@ -391,8 +457,27 @@ hipError_t launch_gae(const float* rewards, const float* values, const float* do
 hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
                         const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s);
 
+// An optimizer step whose clip + AdamW is applied by the NEXT update kernel while it loads its weights (single-rank fused loop, api.hip:
+// ppo_update): every workgroup forms the updated weights of its net for its own use, workgroup 0 of each net also writes the new
+// parameters and moments to the other set of buffers (p/m/v_dst != _src: no workgroup reads what another writes).
+struct DeferredOpt {
+    int pending;
+    const float* grads;                                          // reduced gradient of that step (reduce_grads_sumsq_kernel)
+    const float* p_src; const float* m_src; const float* v_src;  // state before the step
+    float* p_dst; float* m_dst; float* v_dst;                    // state after it
+    const AdamCoef* coef;
+    const double* partial;                                       // [reduce workgroups][12] sums of squares of the gradient
+    float max_norm;
+    const double* sums;                                          // loss sums of that step
+    double global_M;
+    LossParams hp;
+    StepStats* stats_out;
+    double* clipfrac_accum;
+};
+
 struct UpdateArgs {
     const float* params;
+    DeferredOpt opt;
     NetLayout L;
     LossParams hp;
     // flattened batch views [B,...]
@@ -434,6 +519,13 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
                                     double* partial, hipStream_t s);
+// the two halves on their own: the reduction (gradient, loss sums, per-workgroup sums of squares), and clip + AdamW reading the state at
+// p/m/v_src and writing it at p/m/v_dst (equal pointers: in place)
+hipError_t launch_reduce_grads_sumsq(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
+                                     double* sums_out, double* partial, hipStream_t s);
+hipError_t launch_clip_adamw_sumsq(const NetLayout& L, const float* grads, const double* sums, const float* p_src, const float* m_src,
+                                   const float* v_src, float* p_dst, float* m_dst, float* v_dst, float max_grad_norm, const AdamCoef* coef,
+                                   double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum, const double* partial, hipStream_t s);
 
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
 struct EpisodeRing {

@@ -655,3 +655,35 @@ def test_rccl_single_rank_selftest(P, monkeypatch):
     assert np.abs(p1 - p0).max() <= 2e-5, np.abs(p1 - p0).max()
     for key in ("pg_loss", "v_loss", "loss", "approx_kl", "total_norm"):
         assert abs(s1[key] - s0[key]) <= 1e-4 * max(1.0, abs(s0[key])), (key, s1[key], s0[key])
+
+
+@pytest.mark.parametrize("epochs,nmb", [(2, 4), (1, 3), (1, 1)])
+def test_deferred_optimizer_step_is_bit_identical(P, monkeypatch, epochs, nmb):
+    """PPO_DEFER_OPT=1 (an experiment kept in the tree, off by default because it measured slower): clip + AdamW of step k is applied by
+    step k + 1's update kernel while it loads its weights, the state alternating between two sets of buffers, the last step of the update
+    landing in the context's own.  Same arithmetic (one shared definition), so parameters, moments and every step's statistics must be
+    BIT-identical to the default two-launch optimizer step -- for even and odd step counts and for a single step."""
+    cfg = dict(num_envs=256, num_steps=64, num_minibatches=nmb, update_epochs=epochs, seed=3, total_timesteps=256 * 64 * 4)
+
+    def run(defer):
+        if defer:
+            monkeypatch.setenv("PPO_DEFER_OPT", "1")
+        ctx = P.Context(P.make_config(**cfg))
+        if defer:
+            monkeypatch.delenv("PPO_DEFER_OPT")
+        ctx.init_orthogonal(3)
+        ctx.env_reset()
+        for _ in range(2):
+            ctx.train_iteration()
+        m, v, step = ctx.get_optimizer()
+        out = (ctx.get_params(), m, v, step, ctx.stats())
+        ctx.close()
+        return out
+
+    a, b = run(False), run(True)
+    for i in range(3):
+        assert np.array_equal(bits(a[i]), bits(b[i])), i
+    assert a[3] == b[3] >= 2 * epochs * nmb   # a ragged tail adds a short minibatch per epoch (PPO_Discrete.cpp:573-576)
+    for key in a[4]:
+        if key not in ("fps", "elapsed_s", "update_ms"):
+            assert a[4][key] == b[4][key] or (a[4][key] != a[4][key] and b[4][key] != b[4][key]), (key, a[4][key], b[4][key])
