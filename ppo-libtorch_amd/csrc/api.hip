@@ -465,6 +465,18 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             CK(dalloc(c, &g.wslab, (size_t)(std::max(GEN_SPLIT, GEN_SPLIT_MFMA) + 1) * g.wslab_stride));
             CK(dalloc(c, &g.db_part, (size_t)GEN_DB_CHUNKS * std::max(GL.hidden, GL.act)));
         }
+        {   // bf16 planes of every layer's weights, padded to tile multiples (kernels_gemm.hip: PlaneStage)
+            int64_t off = 0;
+            for (int net = 0; net < 2; net++)
+                for (int l = 0; l < GL.n_layers; l++) {
+                    g.wp_npad[net][l] = (GL.out_dim[net][l] + 127) / 128 * 128;
+                    g.wp_kpad[l] = (GL.in_dim[l] + 127) / 128 * 128;
+                    g.wp_off[net][l] = off;
+                    off += 3ll * g.wp_npad[net][l] * g.wp_kpad[l];
+                }
+            CK(dalloc(c, &g.wplanes, (size_t)off));
+            g.planes_dirty = true;
+        }
         CK(dalloc(c, &g.act64, N * GL.n_heads));
         CK(dalloc(c, &g.step_lp, N));
         CK(dalloc(c, &g.step_en, N));
@@ -477,6 +489,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         const char* gp = getenv("PPO_GENERIC_PREC");
         g.gemm_backend = (gb && !strcmp(gb, "rocblas")) ? GEN_GEMM_ROCBLAS : GEN_GEMM_MFMA;
         g.gemm_prec = (gp && !strcmp(gp, "bf16")) ? PPO_MM_BF16 : PPO_MM_F32X3;
+        { const char* wp = getenv("PPO_GENERIC_WPLANES"); g.use_planes = !(wp && !strcmp(wp, "0")); }
         if ((gb && strcmp(gb, "rocblas") && strcmp(gb, "mfma")) || (gp && strcmp(gp, "bf16") && strcmp(gp, "f32x3"))) {
             fail(nullptr, PPO_ERR_INVALID, "PPO_GENERIC_GEMM must be mfma|rocblas and PPO_GENERIC_PREC f32x3|bf16");
             ppo_ctx_destroy(c);
@@ -533,6 +546,7 @@ extern "C" ppo_status ppo_memcpy_h2d(ppo_ctx* c, void* dst_dev, const void* src_
     NEED(c, c != nullptr, "null ctx");
     HIPCHK(c, hipMemcpyAsync(dst_dev, src_h, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->gen) c->gen->planes_dirty = true;   // the copy may have landed in the parameters: re-split the weights before their next use
     return PPO_OK;
 }
 extern "C" ppo_status ppo_memcpy_d2h(ppo_ctx* c, void* dst_h, const void* src_dev, size_t bytes) {
@@ -875,7 +889,7 @@ extern "C" ppo_status ppo_matmul(int32_t trans_a, int32_t trans_b, int64_t M, in
     if (!a || !b || !c || M < 0 || N < 0 || K < 0 || epilogue < PPO_MM_EPI_NONE || epilogue > PPO_MM_EPI_DTANH) return PPO_ERR_INVALID;
     if (epilogue != PPO_MM_EPI_NONE && !aux) return PPO_ERR_INVALID;
     if (precision != PPO_MM_F32X3 && precision != PPO_MM_BF16) return PPO_ERR_INVALID;
-    return launch_matmul(trans_a != 0, trans_b != 0, M, N, K, a, lda, b, ldb, c, ldc, epilogue, aux, ld_aux, precision, 1, 0, nullptr, 0, (hipStream_t)stream) == hipSuccess
+    return launch_matmul(trans_a != 0, trans_b != 0, M, N, K, a, lda, b, ldb, c, ldc, epilogue, aux, ld_aux, precision, 1, 0, nullptr, 0, nullptr, 0, 0, (hipStream_t)stream) == hipSuccess
                ? PPO_OK : PPO_ERR_HIP;
 }
 extern "C" ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value, const int32_t* next_done,
@@ -1065,10 +1079,12 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
 
 // clip + AdamW (or, with do_step false, just the loss scalars and the gradient norm) on whichever parameter layout the context has
 static hipError_t clip_adamw_any(ppo_ctx* c, int slot, double global_M, int world, bool do_step, double* clipfrac_accum) {
-    if (c->gen)
+    if (c->gen) {
+        if (do_step) c->gen->planes_dirty = true;
         return gen_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
                               c->gen->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, world, do_step,
                               c->step_stats + slot, clipfrac_accum, c->norm2, c->stream);
+    }
     return launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
                              c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, world, do_step,
                              c->step_stats + slot, clipfrac_accum, c->norm2, c->stream);

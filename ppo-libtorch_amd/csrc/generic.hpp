@@ -54,6 +54,13 @@ struct GenericCtx {
     void* blas = nullptr;          // rocblas_handle (only with PPO_GENERIC_GEMM=rocblas)
     int gemm_backend = 0;          // GEN_GEMM_MFMA (kernels_gemm.hip, default) or GEN_GEMM_ROCBLAS (library sgemm: the yardstick)
     int gemm_prec = 0;             // PPO_MM_F32X3 (default) or PPO_MM_BF16 (PPO_GENERIC_PREC=bf16)
+    // weights of every layer pre-split into bf16 planes [t][n_pad][k_pad] (n_pad, k_pad: multiples of 128, zero padded) for the B operand of
+    // the forward and d(input) products; rewritten (one launch) when the parameters have changed since the last use
+    uint16_t* wplanes = nullptr;
+    int64_t wp_off[2][GEN_MAX_LAYERS] = {};
+    int wp_npad[2][GEN_MAX_LAYERS] = {}, wp_kpad[GEN_MAX_LAYERS] = {};
+    mutable bool planes_dirty = true;
+    bool use_planes = true;        // PPO_GENERIC_WPLANES=0: split the weights on the fly in every workgroup instead (A/B switch)
     int64_t rows_max = 0;          // rows the workspaces are sized for: max(minibatch, T*N + N for the critic batch is chunked to it)
     float* acts[2][GEN_MAX_LAYERS] = {};   // [net][l]: post-tanh activations of hidden layer l, [rows_max, hidden]
     float* dz[2] = {};             // ping-pong d(pre-activation), [rows_max, hidden]
@@ -84,7 +91,9 @@ constexpr int GEN_SPLIT = 32;   // row chunks of a weight-gradient GEMM (the con
 // colsum (trans_a only, may be null): colsum[z * colsum_zstride + m] = sum over the z-th range of k of A(m, k).
 hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
                          int64_t ldc, int epilogue, const float* aux, int64_t ld_aux, int precision, int splits, int64_t c_zstride, float* colsum,
-                         int64_t colsum_zstride, hipStream_t s);
+                         int64_t colsum_zstride, const uint16_t* bplanes, int64_t bp_plane, int64_t bp_ld, hipStream_t s);
+struct GenericCtx;
+hipError_t gen_weight_planes(const GenericCtx& g, const float* params, hipStream_t s);
 
 // kernels_generic.hip
 struct ppo_ctx;

@@ -51,9 +51,12 @@ struct GemmArgs {
     int64_t K;            // contraction length
     int64_t k_chunk;      // contraction range of one blockIdx.z (a multiple of 2 BK); slab z is written at c + z * c_zstride
     int64_t c_zstride;
+    int m_tiles, n_tiles, splits;   // tile grid (the launch is 1-D: see tile_of_block)
     int epi;              // PPO_MM_EPI_*
     const float* aux;     // bias [N] or h [M, ld_aux]
     int64_t ld_aux;
+    const uint16_t* bplanes;   // BP kernels: B pre-split into T bf16 planes [t][rows_pad][bp_ld] (gen_weight_planes), zero padded to tile multiples
+    int64_t bp_plane, bp_ld;   // elements per plane, elements per plane row
     float* colsum;        // TA only, may be null: colsum[z * colsum_zstride + m] = sum over the z-th k range of A(m, k) (the bias gradient beside dW)
     int64_t colsum_zstride;
 };
@@ -235,9 +238,62 @@ struct Stage {
     }
 };
 
+// B operand that arrives already split: the weights of a layer as T bf16 planes (written once per optimizer step by gen_weight_planes;
+// every workgroup of the forward and d(input) products used to re-split the same 128 x K weights).  No vector work at all: 16-byte loads,
+// 16-byte LDS stores into the same tile layouts.  The planes are zero padded to tile multiples in both directions: no guards.
+//   plain  (rows = n, k contiguous): thread (row = 4 ((l >> 2) & 3) + (l >> 4) + 16 w + 64 p, 8 k at 8 (l & 3)): the four rows a
+//          256-byte LDS cycle writes are r, r + 4, r + 8, r + 12 (disjoint banks at the 80-byte pitch)
+//   as-it-comes (rows = k, n contiguous): thread (k row = tid / 16 + 16 p, 8 columns at 8 (tid & 15))
+template <int BX, bool TRANS, int T>
+struct PlaneStage {
+    static constexpr int NVP = BX == 128 ? 2 : 1;
+    struct Set { u32x4 v[T][NVP]; };
+    const uint16_t* ptr;    // plane 0, this thread's first element of the next chunk
+    int64_t plane, step, pstep;
+    int lds_off;            // bf16 index of the thread's first store in a plane tile
+    bool active;
+    __device__ __forceinline__ void init(const uint16_t* planes, int64_t plane_elems, int64_t ld, int x0, int64_t k0, int tid) {
+        plane = plane_elems;
+        const int l = tid & 63, w = tid >> 6;
+        if constexpr (!TRANS) {
+            const int row = 4 * ((l >> 2) & 3) + (l >> 4) + 16 * w;
+            active = BX == 128 || row < 32;
+            ptr = planes + (int64_t)(x0 + (active ? row : 0)) * ld + k0 + 8 * (l & 3);
+            step = BK; pstep = 64 * ld;
+            lds_off = row * KS + 8 * (l & 3);
+        } else {
+            constexpr int C8 = BX / 8;   // 16-byte pieces per k row
+            const int c8 = tid % C8, krow = tid / C8;
+            active = krow < (BX == 128 ? 16 : 32);
+            ptr = planes + (k0 + (active ? krow : 0)) * ld + x0 + 8 * c8;
+            step = BK * ld; pstep = 16 * ld;
+            lds_off = krow * tr_stride(BX) + 8 * c8;
+        }
+    }
+    __device__ __forceinline__ void load(Set& o) {
+        if (BX == 128 || active) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int p = 0; p < NVP; p++) o.v[t][p] = *reinterpret_cast<const u32x4*>(ptr + t * plane + p * pstep);
+        }
+        ptr += step;
+    }
+    __device__ __forceinline__ void store(const Set& o, uint16_t* tiles) const {
+        constexpr int PE = tile_elems(BX, TRANS);
+        constexpr int LP = TRANS ? 16 * tr_stride(BX) : 64 * KS;   // LDS distance of the thread's second piece
+        if (BX == 128 || active) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int p = 0; p < NVP; p++) *reinterpret_cast<u32x4*>(tiles + t * PE + lds_off + p * LP) = o.v[t][p];
+        }
+    }
+};
+
 // BM x BN output tile, WM x WN waves (WM * WN = 4), each wave FM x FN blocks of 32 x 32.  VEC: the contiguous extent of BOTH operands is a
 // multiple of 4 (every layer product of a network whose widths are; heads and odd shapes take the 4-byte loads)
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     constexpr int EA = tile_elems(BM, TA), EB = tile_elems(BN, TB);
@@ -245,8 +301,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) uint16_t sB[T * EB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
+    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Tiles that read the same
+    // operand rows -- the n tiles of one m tile (they share the A rows; with N = 256 every A row used to be fetched from HBM TWICE, by two
+    // XCDs, which alone put the 256-wide forward product within 25 % of the HBM roofline), or all tiles of one row range of a split
+    // product -- are therefore given ids that differ by multiples of 8: same XCD, consecutive dispatch slots, second reader hits L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int members = g.splits > 1 ? g.m_tiles * g.n_tiles : g.n_tiles;
+    const int member = slot % members, grp = (slot / members) * 8 + xcd;
+    int tm, tn, tz;
+    if (g.splits > 1) { tz = grp; tm = member / g.n_tiles; tn = member % g.n_tiles; if (tz >= g.splits) return; }
+    else { tz = 0; tm = grp; tn = member; if (tm >= g.m_tiles) return; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int64_t kbeg = (int64_t)tz * g.k_chunk;
     const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
 
     f32x16 acc[FM][FN];
@@ -261,14 +327,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // chunks of MFMAs (not one) to cover its trip to HBM.  The contraction range is walked in PAIRS of chunks (the host rounds k_chunk
     // to a multiple of 64; chunks past the end load zeros) so that the loop body has no branch around a load.
     Stage<BM, TA, VEC> sa;
-    Stage<BN, TB, VEC> sb;
     sa.init(g.a, g.lda, m0, g.M, kbeg, tid);
-    sb.init(g.b, g.ldb, n0, g.N, kbeg, tid);
     Loaded<Stage<BM, TA, VEC>::NV> va0, va1;
-    Loaded<Stage<BN, TB, VEC>::NV> vb0, vb1;
-    sa.template load<true>(va0, kend); sb.template load<true>(vb0, kend);
+    // B: split on the fly like A, or (BP) fetched as ready-made bf16 planes
+    typename std::conditional<BP, PlaneStage<BN, TB, T>, Stage<BN, TB, VEC>>::type sb;
+    typename std::conditional<BP, typename PlaneStage<BN, TB, T>::Set, Loaded<Stage<BN, TB, VEC>::NV>>::type vb0, vb1;
+    if constexpr (BP) sb.init(g.bplanes, g.bp_plane, g.bp_ld, n0, kbeg, tid);
+    else sb.init(g.b, g.ldb, n0, g.N, kbeg, tid);
+    auto load_b = [&](auto& set, auto guard) {
+        if constexpr (BP) sb.load(set);
+        else sb.template load<decltype(guard)::value>(set, kend);
+    };
+    auto store_b = [&](const auto& set, auto guard) {
+        if constexpr (BP) sb.store(set, sB);
+        else sb.template store<T, decltype(guard)::value>(set, sB, tid);
+    };
+    // Plane loads (BP) hit L2 and are fetched ONE chunk ahead into a single register set (two sets of six 16-byte registers on top of A's
+    // spilled); within a slot they are issued BEFORE A's loads, so that waiting for them leaves A's newer set in flight.
+    load_b(vb0, std::true_type{}); sa.template load<true>(va0, kend);
     __builtin_amdgcn_sched_barrier(0);   // set 0 strictly before set 1: the in-order load counter then lets the loop wait for set 0 alone
-    sa.template load<true>(va1, kend); sb.template load<true>(vb1, kend);
+    if constexpr (!BP) load_b(vb1, std::true_type{});
+    sa.template load<true>(va1, kend);
     __builtin_amdgcn_sched_barrier(0);
     auto compute = [&]() {
 #pragma unroll
@@ -294,24 +373,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     };
     float cs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    const bool do_cs = TA && g.colsum != nullptr && blockIdx.x == 0;   // every blockIdx.x stages the same A tile: one of them sums it
+    const bool do_cs = TA && g.colsum != nullptr && tn == 0;   // every blockIdx.x stages the same A tile: one of them sums it
     auto pair = [&](auto guard) {   // stages and multiplies the two chunks in registers, fetches the two after them
         constexpr bool G = decltype(guard)::value;
         sa.template store<T, G>(va0, sA, tid, do_cs ? cs : nullptr);
-        sb.template store<T, G>(vb0, sB, tid);
+        store_b(vb0, guard);
         __syncthreads();
-        sa.template load<G>(va0, kend); sb.template load<G>(vb0, kend);
+        load_b(vb0, guard);
+        __builtin_amdgcn_sched_barrier(0);
+        sa.template load<G>(va0, kend);
+        __builtin_amdgcn_sched_barrier(0);   // the loads go out BEFORE the MFMAs they are meant to hide behind (the scheduler sinks them otherwise)
         compute();
         __syncthreads();
         sa.template store<T, G>(va1, sA, tid, do_cs ? cs : nullptr);
-        sb.template store<T, G>(vb1, sB, tid);
+        if constexpr (BP) store_b(vb0, guard); else store_b(vb1, guard);
         __syncthreads();
-        sa.template load<G>(va1, kend); sb.template load<G>(vb1, kend);
+        if constexpr (BP) load_b(vb0, guard); else load_b(vb1, guard);
+        __builtin_amdgcn_sched_barrier(0);
+        sa.template load<G>(va1, kend);
+        __builtin_amdgcn_sched_barrier(0);
         compute();
         __syncthreads();
     };
     int64_t kc = kbeg;
-    if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    if (m0 + BM <= g.M && (BP || n0 + BN <= g.N)) {
         // interior tile: while this pair AND the pair fetched during it lie inside the range, nothing needs a guard
         for (; kc + 4 * BK <= kend; kc += 2 * BK) pair(std::false_type{});
     }
@@ -331,13 +416,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 float t = red[tid];
 #pragma unroll
                 for (int q = 1; q < 8; q++) t += red[q * BM + tid];
-                g.colsum[(int64_t)blockIdx.z * g.colsum_zstride + m0 + tid] = t;
+                g.colsum[(int64_t)tz * g.colsum_zstride + m0 + tid] = t;
             }
         }
     }
 
     // ---- epilogue: D layout = lane's column n = lane & 31, register r <-> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the block ----
-    float* __restrict__ c = g.c + (int64_t)blockIdx.z * g.c_zstride;
+    float* __restrict__ c = g.c + (int64_t)tz * g.c_zstride;
     const int hi = lane >> 5;
     const bool interior = m0 + BM <= g.M && n0 + BN <= g.N;
 #pragma unroll
@@ -380,20 +465,60 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 }
 
 template <int BM, int BN, int WM, int WN, int T, bool VEC>
-hipError_t launch_cfg(const GemmArgs& g, bool ta, bool tb, int splits, hipStream_t s) {
-    const dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)splits), block(256);
-    if (grid.y > 65535u || grid.z > 65535u) return hipErrorInvalidValue;
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, T, VEC>), grid, block, 0, s, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, T, VEC>), grid, block, 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, T, VEC>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, T, VEC>), grid, block, 0, s, g);
+hipError_t launch_cfg(const GemmArgs& g_in, bool ta, bool tb, int splits, hipStream_t s) {
+    GemmArgs g = g_in;
+    g.m_tiles = (g.M + BM - 1) / BM; g.n_tiles = (g.N + BN - 1) / BN; g.splits = splits;
+    const int64_t groups = splits > 1 ? splits : g.m_tiles, members = splits > 1 ? (int64_t)g.m_tiles * g.n_tiles : g.n_tiles;
+    const int64_t blocks = (groups + 7) / 8 * 8 * members;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (g.bplanes) {   // plain A, B from planes (forward and d(input) of a layer)
+        if constexpr (BM == 128) {
+            if (!tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, T, VEC, true>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, T, VEC, true>), grid, block, 0, s, g);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, T, VEC, false>), grid, block, 0, s, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, T, VEC, false>), grid, block, 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, T, VEC, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, T, VEC, false>), grid, block, 0, s, g);
     return hipGetLastError();
 }
 template <int T, bool VEC>
 hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStream_t s) {
     if (g.N <= 32) return launch_cfg<128, 32, 4, 1, T, VEC>(g, ta, tb, splits, s);
-    if (g.M <= 32) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, s);
+    if (g.M <= 32 && !g.bplanes) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, s);
     return launch_cfg<128, 128, 2, 2, T, VEC>(g, ta, tb, splits, s);
+}
+
+// One thread per element of a padded plane row: weights [N, K] f32 -> T planes [t][n_pad][k_pad] bf16 (truncation terms, or one
+// round-to-nearest term), zeros in the padding.
+struct PlaneJob { int64_t src_off, dst_off, first; int N, K, n_pad, k_pad; };
+struct PlaneJobs { PlaneJob j[2 * GEN_MAX_LAYERS]; int n; int64_t total; };
+template <int T>
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ params, uint16_t* __restrict__ planes, const PlaneJobs jobs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= jobs.total) return;
+    int q = 0;
+    for (int k = 1; k < jobs.n; k++) if (i >= jobs.j[k].first) q = k;
+    const PlaneJob& J = jobs.j[q];
+    const int64_t e = i - J.first;
+    const int n = (int)(e / J.k_pad), k = (int)(e % J.k_pad);
+    const float x = (n < J.N && k < J.K) ? params[J.src_off + (int64_t)n * J.K + k] : 0.0f;
+    const int64_t pe = (int64_t)J.n_pad * J.k_pad;
+    uint16_t* d = planes + J.dst_off + e;
+    if constexpr (T == 3) {
+        const uint32_t u0 = f2u(x);
+        const float r1 = x - u2f(u0 & 0xffff0000u);
+        const uint32_t u1 = f2u(r1);
+        const float r2 = r1 - u2f(u1 & 0xffff0000u);
+        d[0] = (uint16_t)(u0 >> 16); d[pe] = (uint16_t)(u1 >> 16); d[2 * pe] = (uint16_t)(f2u(r2) >> 16);
+    } else {
+        d[0] = (uint16_t)(pack_rne(x, 0.0f) & 0xffffu);
+    }
 }
 
 }  // namespace
@@ -402,7 +527,7 @@ hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStrea
 // into ranges of k_chunk (rounded up to a multiple of 32) and requires the plain epilogue.
 hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* c,
                          int64_t ldc, int epilogue, const float* aux, int64_t ld_aux, int precision, int splits, int64_t c_zstride, float* colsum,
-                         int64_t colsum_zstride, hipStream_t s) {
+                         int64_t colsum_zstride, const uint16_t* bplanes, int64_t bp_plane, int64_t bp_ld, hipStream_t s) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (M > 0x7fffffff || N > 0x7fffffff || K < 0 || splits < 1) return hipErrorInvalidValue;
     if (splits > 1 && epilogue != PPO_MM_EPI_NONE) return hipErrorInvalidValue;
@@ -416,8 +541,28 @@ hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64
     g.c_zstride = c_zstride;
     g.epi = epilogue; g.aux = aux; g.ld_aux = ld_aux;
     g.colsum = trans_a ? colsum : nullptr; g.colsum_zstride = colsum_zstride;
+    g.bplanes = (!trans_a && splits == 1) ? bplanes : nullptr; g.bp_plane = bp_plane; g.bp_ld = bp_ld;
     // contiguous extent of an operand: k (plain) or its row / column index (transposed)
-    const bool vec = ((trans_a ? M : K) % 4 == 0) && ((trans_b ? N : K) % 4 == 0);
+    const bool vec = ((trans_a ? M : K) % 4 == 0) && (g.bplanes != nullptr || (trans_b ? N : K) % 4 == 0);
     if (precision == PPO_MM_BF16) return vec ? launch_prec<1, true>(g, trans_a, trans_b, splits, s) : launch_prec<1, false>(g, trans_a, trans_b, splits, s);
     return vec ? launch_prec<3, true>(g, trans_a, trans_b, splits, s) : launch_prec<3, false>(g, trans_a, trans_b, splits, s);
+}
+
+// Pre-split weights of every layer of both nets (generic.hpp: GenericCtx::wplanes): one launch.
+hipError_t gen_weight_planes(const GenericCtx& g, const float* params, hipStream_t s) {
+    const GenLayout& L = g.L;
+    PlaneJobs jobs{};
+    int64_t first = 0;
+    for (int net = 0; net < 2; net++)
+        for (int l = 0; l < L.n_layers; l++) {
+            PlaneJob& J = jobs.j[jobs.n++];
+            J.src_off = L.w_off[net][l]; J.dst_off = g.wp_off[net][l]; J.first = first;
+            J.N = L.out_dim[net][l]; J.K = L.in_dim[l]; J.n_pad = g.wp_npad[net][l]; J.k_pad = g.wp_kpad[l];
+            first += (int64_t)J.n_pad * J.k_pad;
+        }
+    jobs.total = first;
+    const dim3 grid((unsigned)((first + 255) / 256)), block(256);
+    if (g.gemm_prec == PPO_MM_BF16) hipLaunchKernelGGL(weight_planes_kernel<1>, grid, block, 0, s, params, g.wplanes, jobs);
+    else hipLaunchKernelGGL(weight_planes_kernel<3>, grid, block, 0, s, params, g.wplanes, jobs);
+    return hipGetLastError();
 }

@@ -403,9 +403,11 @@ hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const 
         const int K = L.in_dim[l], N = L.out_dim[net][l];
         const bool last = l == L.n_layers - 1;
         float* dst = last ? out : (acts ? acts[l] : ((l & 1) ? scratch1 : scratch0));
-        if (g.gemm_backend == GEN_GEMM_MFMA) {   // one launch per layer: product, bias and tanh (kernels_gemm.hip)
+        if (g.gemm_backend == GEN_GEMM_MFMA) {   // one launch per layer: product, bias and tanh (kernels_gemm.hip); weights from their bf16 planes
+            if (g.use_planes && g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
             const hipError_t e = launch_matmul(false, false, rows, N, K, in, K, params + L.w_off[net][l], K, dst, N, last ? PPO_MM_EPI_BIAS : PPO_MM_EPI_BIAS_TANH,
-                                               params + L.b_off[net][l], 0, g.gemm_prec, 1, 0, nullptr, 0, s);
+                                               params + L.b_off[net][l], 0, g.gemm_prec, 1, 0, nullptr, 0, g.use_planes ? g.wplanes + g.wp_off[net][l] : nullptr,
+                                               (int64_t)g.wp_npad[net][l] * g.wp_kpad[l], g.wp_kpad[l], s);
             if (e != hipSuccess) return e;
             in = dst;
             continue;
@@ -492,7 +494,7 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
             S = (int)((rows + range - 1) / range);
             // ... and db beside it: the workgroups of the first column of tiles also sum their d tile over the rows (db_part[z][N])
             const hipError_t e = launch_matmul(true, true, N, K, rows, d, N, in, K, g.wslab, K, PPO_MM_EPI_NONE, nullptr, 0, g.gemm_prec, S, g.wslab_stride,
-                                               g.db_part, N, s);
+                                               g.db_part, N, nullptr, 0, 0, s);
             if (e != hipSuccess) return e;
         } else {
             const int64_t chunk = (rows + GEN_SPLIT - 1) / GEN_SPLIT;
@@ -517,8 +519,10 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
             float* nd = g.dz[(l & 1)];
             // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2): one launch on the matrix cores, two with the library
             if (g.gemm_backend == GEN_GEMM_MFMA) {
+                if (g.use_planes && g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
                 const hipError_t e = launch_matmul(false, true, rows, K, N, d, N, params + L.w_off[net][l], K, nd, K, PPO_MM_EPI_DTANH, g.acts[net][l - 1], K,
-                                                   g.gemm_prec, 1, 0, nullptr, 0, s);
+                                                   g.gemm_prec, 1, 0, nullptr, 0, g.use_planes ? g.wplanes + g.wp_off[net][l] : nullptr, (int64_t)g.wp_npad[net][l] * g.wp_kpad[l],
+                                                   g.wp_kpad[l], s);
                 if (e != hipSuccess) return e;
             } else {
                 RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_N, K, (int)rows, N, &one, params + L.w_off[net][l], K, d, N, &zero, nd, K));
