@@ -256,7 +256,8 @@ typedef struct ppo_profile {
     double fwd_bwd_ms, gae_ms, rollout_ms, optimizer_ms, reduce_ms;   /* summed over the launches since enable/read */
     double phase_cycles[24];  /* mode 3: [critic, actor][12 phases] shader cycles of one wave of the dominant kernel */
 } ppo_profile;
-/* on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fused forward/backward) and the GAE scan,
+/* on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fused forward/backward; ONE launch in 8 is bracketed: an
+ * event pair costs the stream ~3 us, 40 pairs per update were 8 % of the run) and the GAE scan,
  * 3 = in-kernel phase stamps of the dominant kernel (diagnostic kernel variant; read shares, not run time) */
 PPO_API ppo_status ppo_profile_enable(ppo_ctx* ctx, int32_t on);
 PPO_API ppo_status ppo_profile_read(ppo_ctx* ctx, ppo_profile* out);  /* synchronises; resets the accumulators */

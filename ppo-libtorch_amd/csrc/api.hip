@@ -128,6 +128,8 @@ struct ppo_ctx {
     bool state_in_alt = false;       // inside ppo_update: the committed params / moments live in alt_state (always false between updates)
     int last_n_blocks[2] = { 0, 0 };
     int mfma_prec = 1;               // 0: exact fp32 MFMA, 1: three-term bf16 split (env PPO_UPDATE_KERNEL=mfma_f32 selects 0)
+    int prof_every = 1;              // mode 2: bracket one update-kernel launch in prof_every (an event pair costs the stream ~3 us)
+    int64_t prof_count = 0;
     bool stamping = false;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
 
     // host-side training state
@@ -162,8 +164,8 @@ struct ProfScope {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    ProfScope(ppo_ctx* ctx, int k) : c(ctx), kind(k) {
-        if (!(c->profiling & (1u << kind))) return;
+    ProfScope(ppo_ctx* ctx, int k, bool sampled_in = true) : c(ctx), kind(k) {
+        if (!(c->profiling & (1u << kind)) || !sampled_in) return;
         a = get(c); b = get(c);
         if (a) (void)hipEventRecord(a, c->stream);
     }
@@ -1065,7 +1067,7 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     if (c->use_mfma) update_blocks_mfma((int)M, c->actor_share, c->mfma_prec, a.n_blocks);
     else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
-        ProfScope ps(c, PROF_FWD_BWD);
+        ProfScope ps(c, PROF_FWD_BWD, c->prof_every <= 1 || (c->prof_count++ % c->prof_every) == c->prof_every / 2);
         if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->mfma_prec, c->stream));
         else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
@@ -1286,9 +1288,11 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
     NEED(c, c != nullptr, "null ctx");
-    // on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fwd/bwd) and the GAE scan,
+    // on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fwd/bwd; one launch in 8) and the GAE scan,
     //     3 = in-kernel phase stamps of the dominant kernel (diagnostic variant: read its SHARES, never its run time)
     c->profiling = (on == 0 || on == 3) ? 0u : (on == 2 ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE)) : 0xffffffffu);
+    c->prof_every = on == 2 ? 8 : 1;   // mode 2 samples the update kernel: 1 launch in 8 (5 of an update's 40), every GAE launch
+    c->prof_count = 0;
     c->stamping = on == 3;
     if (c->stamping) HIPCHK(c, hipMemsetAsync(c->stamps, 0, 24 * sizeof(unsigned long long), c->stream));
     return PPO_OK;
