@@ -6,9 +6,10 @@
 //
 //   forward      h = tanh(x W^T + b)        A = x [rows, K]            B = W [N, K]              epilogue bias (+ tanh)
 //   d(input)     dz' = (dz W) (1 - h'^2)    A = dz [rows, N]           B = W read as [k = n][K]  epilogue tanh'
-//   d(weight)    dW = dz^T x                A = dz read as [k = row][N]  B = x read as [k = row][K]   split over rows (gridDim.z slabs)
+//   d(weight)    dW = dz^T x                A = dz read as [k = row][N]  B = x read as [k = row][K]   rows cut into ranges -> slabs
 //
-// Operands stay fp32 in HBM.  A workgroup (4 waves, 128 x 128 output tile, k step 32) loads its two operand tiles as fp32, cuts every
+// Activations stay fp32 in HBM (the weights also exist as pre-split bf16 planes, see PlaneStage).  A workgroup (4 waves, 128 x 128 output
+// tile, k step 32) loads its operand tiles as fp32, cuts every
 // value by truncation into three bf16 terms (x = t1 + t2 + t3 exactly; see kernels_update_mfma.hip) while staging them into LDS, and
 // issues each fp32 product as the six bf16 products a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 on v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation: fp32 accuracy at (1/6 of) the bf16 matrix rate, which on gfx950 is ~2.7x the rate of the fp32 MFMA a library sgemm
@@ -49,9 +50,9 @@ struct GemmArgs {
     float* c; int64_t ldc;
     int M, N;
     int64_t K;            // contraction length
-    int64_t k_chunk;      // contraction range of one blockIdx.z (a multiple of 2 BK); slab z is written at c + z * c_zstride
+    int64_t k_chunk;      // contraction range of one slab (a multiple of 2 BK); slab z is written at c + z * c_zstride
     int64_t c_zstride;
-    int m_tiles, n_tiles, splits;   // tile grid (the launch is 1-D: see tile_of_block)
+    int m_tiles, n_tiles, splits;   // tile grid; the launch is 1-D and XCD-aware (see the top of gemm_kernel)
     int epi;              // PPO_MM_EPI_*
     const float* aux;     // bias [N] or h [M, ld_aux]
     int64_t ld_aux;
@@ -291,8 +292,9 @@ struct PlaneStage {
     }
 };
 
-// BM x BN output tile, WM x WN waves (WM * WN = 4), each wave FM x FN blocks of 32 x 32.  VEC: the contiguous extent of BOTH operands is a
-// multiple of 4 (every layer product of a network whose widths are; heads and odd shapes take the 4-byte loads)
+// BM x BN output tile, WM x WN waves (WM * WN = 4), each wave FM x FN blocks of 32 x 32.  VEC: the contiguous extent of every operand that
+// is split on the fly is a multiple of 4 (every layer product of a network whose widths are; heads and odd shapes take the 4-byte loads).
+// BP: B comes as pre-split planes (PlaneStage).
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
@@ -302,9 +304,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Tiles that read the same
-    // operand rows -- the n tiles of one m tile (they share the A rows; with N = 256 every A row used to be fetched from HBM TWICE, by two
-    // XCDs, which alone put the 256-wide forward product within 25 % of the HBM roofline), or all tiles of one row range of a split
-    // product -- are therefore given ids that differ by multiples of 8: same XCD, consecutive dispatch slots, second reader hits L2.
+    // operand rows -- the n tiles of one m tile (they share the A rows: with N = 256 and the plain order every A row was fetched by two
+    // XCDs), or all tiles of one row range of a split product -- are therefore given ids that differ by multiples of 8: same XCD,
+    // consecutive dispatch slots, second reader hits L2.  (Measured neutral at 65 536 x 256: the 67 MB operand sits in the Infinity Cache.)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int members = g.splits > 1 ? g.m_tiles * g.n_tiles : g.n_tiles;
     const int member = slot % members, grp = (slot / members) * 8 + xcd;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     };
     float cs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    const bool do_cs = TA && g.colsum != nullptr && tn == 0;   // every blockIdx.x stages the same A tile: one of them sums it
+    const bool do_cs = TA && g.colsum != nullptr && tn == 0;   // every n tile stages the same A tile: the first one sums it
     auto pair = [&](auto guard) {   // stages and multiplies the two chunks in registers, fetches the two after them
         constexpr bool G = decltype(guard)::value;
         sa.template store<T, G>(va0, sA, tid, do_cs ? cs : nullptr);
