@@ -22,6 +22,7 @@
 // the next TWO chunks are in flight in registers during the current chunk's MFMAs.  Measured on the 65 536 x 256 x 1024 product
 // (rocprofv3 PMC): matrix pipe busy 60 % of the CU's cycles, no LDS bank conflicts, ~200 vector instructions per 48 MFMAs in the unguarded
 // loop; issue priority for one of the two workgroups, or starting it half a period late, changed nothing and is not in the code.
+#include <cstdlib>
 #include <type_traits>
 
 #include "ppo_internal.hpp"
@@ -217,7 +218,7 @@ struct Stage {
         k += BK;
     }
     template <int T, bool GUARD>
-    __device__ __forceinline__ void store(const Loaded<NV>& o, uint16_t* planes, int tid, float* cs = nullptr) const {
+    __device__ __forceinline__ void store(const Loaded<NV>& o, uint16_t* planes, int tid, float (&cs)[4], bool do_cs) const {
         constexpr int PE = tile_elems(BX, TRANS);
         if constexpr (!TRANS) {
             const int kq = tid & 7;
@@ -231,7 +232,7 @@ struct Stage {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float4 q = pin_and_zero(o.v[j], GUARD ? (j < o.kvalid ? xvalid[j] : 0) : 4);
-                    if (cs) { cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w; }   // running sums of the thread's four columns over k
+                    if (do_cs) { cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w; }   // running sums of the thread's four columns over k
                     split_store<T>(planes, PE, (4 * kq + j) * STR + 4 * mq, q);
                 }
             }
@@ -295,12 +296,20 @@ struct PlaneStage {
 // BM x BN output tile, WM x WN waves (WM * WN = 4), each wave FM x FN blocks of 32 x 32.  VEC: the contiguous extent of every operand that
 // is split on the fly is a multiple of 4 (every layer product of a network whose widths are; heads and odd shapes take the 4-byte loads).
 // BP: B comes as pre-split planes (PlaneStage).
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+// DB (PPO_GEMM_DB=1, an experiment kept selectable): ONE workgroup per CU with two LDS tile sets: chunk c + 1 is staged into the other set
+// while chunk c is multiplied, one barrier per chunk, the staging's vector instructions and LDS writes in the same instruction stream as
+// the MFMAs (the compiler does interleave them: 1 MFMA / 7 VALU runs).  Measured: fp32-accurate forward 256 -> 256 82 us against 62 with
+// two workgroups per CU (one wave per SIMD issues a vector instruction every ~5 cycles, two waves one every ~2.4: the staging needs the
+// second wave); plain bf16, which stages little, gains 3-8 %.  Default stays two workgroups per CU.
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB>
+__global__ __launch_bounds__(256, DB ? 1 : 2) void gemm_kernel(const GemmArgs g) {
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     constexpr int EA = tile_elems(BM, TA), EB = tile_elems(BN, TB);
-    __shared__ __attribute__((aligned(16))) uint16_t sA[T * EA];
-    __shared__ __attribute__((aligned(16))) uint16_t sB[T * EB];
+    extern __shared__ __attribute__((aligned(16))) uint16_t dyn_lds[];   // (DB ? 2 : 1) x (T EA + T EB) bf16
+    uint16_t* const sA = dyn_lds;
+    uint16_t* const sB = dyn_lds + T * EA;
+    uint16_t* const sA1 = dyn_lds + (DB ? T * (EA + EB) : 0);            // second tile set (DB)
+    uint16_t* const sB1 = sA1 + T * EA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Tiles that read the same
@@ -340,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         if constexpr (BP) sb.load(set);
         else sb.template load<decltype(guard)::value>(set, kend);
     };
-    auto store_b = [&](const auto& set, auto guard) {
-        if constexpr (BP) sb.store(set, sB);
-        else sb.template store<T, decltype(guard)::value>(set, sB, tid);
+    auto store_b = [&](const auto& set, uint16_t* dst, auto guard) {
+        if constexpr (BP) sb.store(set, dst);
+        else { float none[4] = { 0.0f, 0.0f, 0.0f, 0.0f }; sb.template store<T, decltype(guard)::value>(set, dst, tid, none, false); }
     };
     // Plane loads (BP) hit L2 and are fetched ONE chunk ahead into a single register set (two sets of six 16-byte registers on top of A's
     // spilled); within a slot they are issued BEFORE A's loads, so that waiting for them leaves A's newer set in flight.
@@ -351,18 +360,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     if constexpr (!BP) load_b(vb1, std::true_type{});
     sa.template load<true>(va1, kend);
     __builtin_amdgcn_sched_barrier(0);
-    auto compute = [&]() {
+    auto compute = [&](const uint16_t* cA, const uint16_t* cB) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ks++) {
             u32x4 af[FM][T], bf[FN][T];
 #pragma unroll
             for (int i = 0; i < FM; i++)
 #pragma unroll
-                for (int t = 0; t < T; t++) af[i][t] = frag<TA, BM>(sA + t * EA, (wm * FM + i) * 32, ks, lane);
+                for (int t = 0; t < T; t++) af[i][t] = frag<TA, BM>(cA + t * EA, (wm * FM + i) * 32, ks, lane);
 #pragma unroll
             for (int j = 0; j < FN; j++)
 #pragma unroll
-                for (int t = 0; t < T; t++) bf[j][t] = frag<TB, BN>(sB + t * EB, (wn * FN + j) * 32, ks, lane);
+                for (int t = 0; t < T; t++) bf[j][t] = frag<TB, BN>(cB + t * EB, (wn * FN + j) * 32, ks, lane);
             // small terms first; the FM x FN accumulators of one product are independent MFMAs
             constexpr int NP = T == 3 ? 6 : 1;
             constexpr int pa[6] = { T == 3 ? 2 : 0, 0, 1, 1, 0, 0 }, pb[6] = { 0, 2, 1, 0, 1, 0 };
@@ -378,29 +387,52 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const bool do_cs = TA && g.colsum != nullptr && tn == 0;   // every n tile stages the same A tile: the first one sums it
     auto pair = [&](auto guard) {   // stages and multiplies the two chunks in registers, fetches the two after them
         constexpr bool G = decltype(guard)::value;
-        sa.template store<T, G>(va0, sA, tid, do_cs ? cs : nullptr);
-        store_b(vb0, guard);
-        __syncthreads();
-        load_b(vb0, guard);
-        __builtin_amdgcn_sched_barrier(0);
-        sa.template load<G>(va0, kend);
-        __builtin_amdgcn_sched_barrier(0);   // the loads go out BEFORE the MFMAs they are meant to hide behind (the scheduler sinks them otherwise)
-        compute();
-        __syncthreads();
-        sa.template store<T, G>(va1, sA, tid, do_cs ? cs : nullptr);
-        if constexpr (BP) store_b(vb0, guard); else store_b(vb1, guard);
-        __syncthreads();
-        if constexpr (BP) load_b(vb0, guard); else load_b(vb1, guard);
-        __builtin_amdgcn_sched_barrier(0);
-        sa.template load<G>(va1, kend);
-        __builtin_amdgcn_sched_barrier(0);
-        compute();
-        __syncthreads();
+        if constexpr (!DB) {
+            sa.template store<T, G>(va0, sA, tid, cs, do_cs);
+            store_b(vb0, sB, guard);
+            __syncthreads();
+            load_b(vb0, guard);
+            __builtin_amdgcn_sched_barrier(0);
+            sa.template load<G>(va0, kend);
+            __builtin_amdgcn_sched_barrier(0);   // the loads go out BEFORE the MFMAs they are meant to hide behind (the scheduler sinks them otherwise)
+            compute(sA, sB);
+            __syncthreads();
+            sa.template store<T, G>(va1, sA, tid, cs, do_cs);
+            if constexpr (BP) store_b(vb0, sB, guard); else store_b(vb1, sB, guard);
+            __syncthreads();
+            if constexpr (BP) load_b(vb0, guard); else load_b(vb1, guard);
+            __builtin_amdgcn_sched_barrier(0);
+            sa.template load<G>(va1, kend);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(sA, sB);
+            __syncthreads();
+        } else {
+            // on entry: tile set 0 holds chunk c; va1 (and vb1 / vb0) chunk c + 1, va0 chunk c + 2
+            sa.template store<T, G>(va1, sA1, tid, cs, do_cs);
+            if constexpr (BP) store_b(vb0, sB1, guard); else store_b(vb1, sB1, guard);
+            if constexpr (BP) load_b(vb0, guard); else load_b(vb1, guard);
+            sa.template load<G>(va1, kend);
+            compute(sA, sB);
+            __syncthreads();
+            sa.template store<T, G>(va0, sA, tid, cs, do_cs);
+            store_b(vb0, sB, guard);
+            load_b(vb0, guard);
+            sa.template load<G>(va0, kend);
+            compute(sA1, sB1);
+            __syncthreads();
+        }
     };
+    if constexpr (DB) {   // chunk 0 into tile set 0; its register set goes on to chunk 2
+        sa.template store<T, true>(va0, sA, tid, cs, do_cs);
+        store_b(vb0, sB, std::true_type{});
+        load_b(vb0, std::true_type{});
+        sa.template load<true>(va0, kend);
+        __syncthreads();
+    }
     int64_t kc = kbeg;
     if (m0 + BM <= g.M && (BP || n0 + BN <= g.N)) {
         // interior tile: while this pair AND the pair fetched during it lie inside the range, nothing needs a guard
-        for (; kc + 4 * BK <= kend; kc += 2 * BK) pair(std::false_type{});
+        for (; kc + (DB ? 6 : 4) * BK <= kend; kc += 2 * BK) pair(std::false_type{});   // DB fetches one chunk further ahead
     }
     for (; kc < kend; kc += 2 * BK) pair(std::true_type{});
 
@@ -466,34 +498,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// one instantiation: LDS size, (for the double-buffered variant) the attribute that allows more than 64 KB, launch
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB>
+hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)(DB ? 2 : 1) * T * (tile_elems(BM, TA) + tile_elems(BN, TB)) * sizeof(uint16_t);
+    auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, T, VEC, BP, DB>;
+    if constexpr (DB) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);
+    return hipGetLastError();
+}
 template <int BM, int BN, int WM, int WN, int T, bool VEC>
-hipError_t launch_cfg(const GemmArgs& g_in, bool ta, bool tb, int splits, hipStream_t s) {
+hipError_t launch_cfg(const GemmArgs& g_in, bool ta, bool tb, int splits, bool db, hipStream_t s) {
     GemmArgs g = g_in;
     g.m_tiles = (g.M + BM - 1) / BM; g.n_tiles = (g.N + BN - 1) / BN; g.splits = splits;
     const int64_t groups = splits > 1 ? splits : g.m_tiles, members = splits > 1 ? (int64_t)g.m_tiles * g.n_tiles : g.n_tiles;
     const int64_t blocks = (groups + 7) / 8 * 8 * members;
     if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)blocks), block(256);
-    if (g.bplanes) {   // plain A, B from planes (forward and d(input) of a layer)
-        if constexpr (BM == 128) {
-            if (!tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, T, VEC, true>), grid, block, 0, s, g);
-            else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, T, VEC, true>), grid, block, 0, s, g);
-            return hipGetLastError();
-        } else {
-            return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
+    if constexpr (BM == 128 && BN == 128) {
+        if (db) {   // double-buffered variant: the big tile only, the orientations the layer products use
+            if (g.bplanes) return tb ? launch_one<BM, BN, WM, WN, false, true, T, VEC, true, true>(g, grid, s) : launch_one<BM, BN, WM, WN, false, false, T, VEC, true, true>(g, grid, s);
+            if (ta && tb) return launch_one<BM, BN, WM, WN, true, true, T, VEC, false, true>(g, grid, s);
+            if (!ta && !tb) return launch_one<BM, BN, WM, WN, false, false, T, VEC, false, true>(g, grid, s);
+            if (!ta && tb) return launch_one<BM, BN, WM, WN, false, true, T, VEC, false, true>(g, grid, s);
         }
     }
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, T, VEC, false>), grid, block, 0, s, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, T, VEC, false>), grid, block, 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, T, VEC, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, T, VEC, false>), grid, block, 0, s, g);
-    return hipGetLastError();
+    if (g.bplanes) {   // plain A, B from planes (forward and d(input) of a layer)
+        if constexpr (BM == 128) return tb ? launch_one<BM, BN, WM, WN, false, true, T, VEC, true, false>(g, grid, s) : launch_one<BM, BN, WM, WN, false, false, T, VEC, true, false>(g, grid, s);
+        else return hipErrorInvalidValue;
+    }
+    if (!ta && !tb) return launch_one<BM, BN, WM, WN, false, false, T, VEC, false, false>(g, grid, s);
+    if (!ta && tb) return launch_one<BM, BN, WM, WN, false, true, T, VEC, false, false>(g, grid, s);
+    if (ta && !tb) return launch_one<BM, BN, WM, WN, true, false, T, VEC, false, false>(g, grid, s);
+    return launch_one<BM, BN, WM, WN, true, true, T, VEC, false, false>(g, grid, s);
 }
 template <int T, bool VEC>
 hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStream_t s) {
-    if (g.N <= 32) return launch_cfg<128, 32, 4, 1, T, VEC>(g, ta, tb, splits, s);
-    if (g.M <= 32 && !g.bplanes) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, s);
-    return launch_cfg<128, 128, 2, 2, T, VEC>(g, ta, tb, splits, s);
+    const char* dbe = getenv("PPO_GEMM_DB");   // experiment switch, read per launch (tests toggle it)
+    const bool db = dbe && dbe[0] == '1';
+    if (g.N <= 32) return launch_cfg<128, 32, 4, 1, T, VEC>(g, ta, tb, splits, false, s);
+    if (g.M <= 32 && !g.bplanes) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, false, s);
+    return launch_cfg<128, 128, 2, 2, T, VEC>(g, ta, tb, splits, db, s);
 }
 
 // One thread per element of a padded plane row: weights [N, K] f32 -> T planes [t][n_pad][k_pad] bf16 (truncation terms, or one

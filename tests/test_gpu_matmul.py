@@ -82,3 +82,20 @@ def test_matmul_epilogues(P, ctx):
     got = B_.matmul(ctx, dz, Wn, False, True, epilogue=B_.MM_EPI_DTANH, aux=h)
     ref = (dz.astype(np.float64) @ Wn.astype(np.float64)) * (1.0 - h.astype(np.float64) ** 2)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_matmul_double_buffered_variant(P, ctx, monkeypatch, ta, tb):
+    """PPO_GEMM_DB=1: the one-workgroup-per-CU variant with two LDS tile sets (an experiment kept selectable, kernels_gemm.hip): same results
+    to the same bound, on shapes with an odd number of chunk pairs, ragged edges and a contraction shorter than its prefetch distance."""
+    monkeypatch.setenv("PPO_GEMM_DB", "1")
+    for M, N, K in [(300, 256, 376), (256, 256, 256), (130, 130, 40), (512, 384, 1000)]:
+        rng = np.random.default_rng(M + N + K)
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = (rng.standard_normal((N, K)) * 0.3).astype(np.float32)
+        a = np.ascontiguousarray(A.T) if ta else A
+        b = np.ascontiguousarray(B.T) if tb else B
+        c = P.binding.matmul(ctx, a, b, ta, tb)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+        assert np.all(np.abs(c - ref) <= 2e-6 * bound + 1e-30), (M, N, K)
