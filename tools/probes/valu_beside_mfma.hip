@@ -1,6 +1,9 @@
 // Probe: which vector instructions of the split / staging code co-execute with bf16 MFMAs issued by the SIMD's other wave?
 // Waves 0-3 of a 512-thread workgroup issue 16 dependent v_mfma_f32_32x32x16_bf16 per iteration, waves 4-7 (their SIMD partners) 256 of the
 // instruction under test.  Prints cycles per iteration of both, alone and together.
+// Reading the output: the inline asm carries a vcc clobber, so the compiler puts an s_nop behind every instruction under test -- absolute
+// cycles per instruction are ~2x the real ones; what the probe answers is the COMPARISON: and / sub / perm / cmp / lshl_add_u64 / f64 add all
+// behave like v_fma_f32 beside MFMAs (none of them blocks or is blocked), transcendentals cost twice a plain instruction.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_beside_mfma valu_beside_mfma.hip && ./valu_beside_mfma
 #include <hip/hip_runtime.h>
 #include <cstdio>
