@@ -127,6 +127,17 @@ def test_plain_categorical_one_layer(P):
     _check_shape(P, obs_dim=7, hidden=48, n_hidden=1, heads=(4,), N=32, T=12, nmb=3, masked=False, seed=9)
 
 
+def test_widths_that_are_not_multiples_of_four(P):
+    """hidden 30, obs 5, 40 envs x 10 steps: every operand of every layer product has a ragged contiguous extent (4-byte loads, zero-filled
+    tails), every tile is an edge tile, the weight planes are mostly padding, and the minibatch (200 rows) is not a multiple of a chunk."""
+    _check_shape(P, obs_dim=5, hidden=30, n_hidden=2, heads=(3,), N=40, T=10, nmb=2, masked=False, seed=11)
+
+
+def test_hidden_wider_than_one_tile(P):
+    """hidden 160: two n tiles of which the second is ragged (XCD-aware tile order with an odd tile count, plane rows beyond the width)."""
+    _check_shape(P, obs_dim=20, hidden=160, n_hidden=2, heads=(2, 3), N=48, T=12, nmb=2, masked=True, seed=13)
+
+
 def test_config4_shape_obs376_4x256_heads_3332(P):
     """BASELINE configs[4]'s network and head list on a batch the scalar oracle can still check (256 envs x 32 steps)."""
     _check_shape(P, obs_dim=376, hidden=256, n_hidden=4, heads=(3, 3, 3, 2), N=256, T=32, nmb=4, masked=True, seed=3, max_steps=25)
