@@ -154,11 +154,14 @@ __device__ __forceinline__ int stage_row(int tid) {
 template <int NV>
 struct Loaded {
     f32x4 v[NV];
-    int kvalid;   // !TRANS: leading contraction elements of every quad that exist;  TRANS: leading k rows (of the thread's four) that exist
+    int kvalid;   // !TRANS: leading contraction elements of every quad that exist;  TRANS: leading k rows (of the thread's KR) that exist
 };
-template <int BX, bool TRANS, bool VEC>
+// NT: threads of the workgroup (256, or 512 for the two-waves-per-SIMD double-buffered variant)
+template <int BX, bool TRANS, bool VEC, int NT = 256>
 struct Stage {
-    static constexpr int NV = TRANS ? 4 : BX / 32;
+    static constexpr int RP = NT / 8;                                   // plain: tile rows covered per pass of the workgroup
+    static constexpr int KR = BX == 128 ? 32 * (BX / 4) / NT : 4;       // as-it-comes: k rows per thread
+    static constexpr int NV = TRANS ? KR : (BX / RP > 0 ? BX / RP : 1);
     const float* ptr[NV];     // next chunk's address of quad p (its first element)
     int xvalid[NV];           // !TRANS: 4 if the row exists else 0;  TRANS: valid columns of the quad (0 .. 4), same for every p
     int64_t k;                // contraction index of the thread's first element in the next chunk
@@ -173,7 +176,7 @@ struct Stage {
             step = BK;
 #pragma unroll
             for (int p = 0; p < NV; p++) {
-                const int row = x0 + stage_row(tid) + 32 * p;
+                const int row = x0 + stage_row(tid) + RP * p;
                 xvalid[p] = row < X ? 4 : 0;
                 ptr[p] = src + (int64_t)(row < X ? row : 0) * ld + k;
             }
@@ -183,10 +186,10 @@ struct Stage {
             active = BX >= 128 || kq < 8;   // BX = 32: whole waves are idle
             const int col = x0 + 4 * mq;
             const int cleft = X - col;
-            k = k0 + 4 * kq;
+            k = k0 + KR * kq;
             step = BK * ld;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < KR; j++) {
                 xvalid[j] = cleft >= 4 ? 4 : (cleft > 0 ? cleft : 0);
                 ptr[j] = src + (k + j) * ld + (cleft > 0 ? col : 0);
             }
@@ -198,7 +201,8 @@ struct Stage {
     __device__ __forceinline__ void load(Loaded<NV>& o, int64_t kend) {
         if constexpr (GUARD) {
             const int64_t left = kend - k;
-            o.kvalid = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+            constexpr int W = TRANS ? KR : 4;   // elements (plain) or k rows (as-it-comes) the thread covers along k
+            o.kvalid = left >= W ? W : (left > 0 ? (int)left : 0);
         }
         if constexpr (!TRANS) {
 #pragma unroll
@@ -209,7 +213,7 @@ struct Stage {
         } else {
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < KR; j++) {
                     o.v[j] = load4<VEC>(ptr[j], safe, GUARD ? (j < o.kvalid ? xvalid[j] : 0) : 4);
                     ptr[j] += step;
                 }
@@ -224,16 +228,16 @@ struct Stage {
             const int kq = tid & 7;
 #pragma unroll
             for (int p = 0; p < NV; p++)
-                split_store<T>(planes, PE, (stage_row(tid) + 32 * p) * KS + 4 * kq, pin_and_zero(o.v[p], GUARD ? (xvalid[p] ? o.kvalid : 0) : 4));
+                split_store<T>(planes, PE, (stage_row(tid) + RP * p) * KS + 4 * kq, pin_and_zero(o.v[p], GUARD ? (xvalid[p] ? o.kvalid : 0) : 4));
         } else {
             constexpr int MQ = BX / 4, STR = tr_stride(BX);
             const int mq = tid % MQ, kq = tid / MQ;
             if (active) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < KR; j++) {
                     const float4 q = pin_and_zero(o.v[j], GUARD ? (j < o.kvalid ? xvalid[j] : 0) : 4);
                     if (do_cs) { cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w; }   // running sums of the thread's four columns over k
-                    split_store<T>(planes, PE, (4 * kq + j) * STR + 4 * mq, q);
+                    split_store<T>(planes, PE, (KR * kq + j) * STR + 4 * mq, q);
                 }
             }
         }
@@ -246,9 +250,10 @@ struct Stage {
 //   plain  (rows = n, k contiguous): thread (row = 4 ((l >> 2) & 3) + (l >> 4) + 16 w + 64 p, 8 k at 8 (l & 3)): the four rows a
 //          256-byte LDS cycle writes are r, r + 4, r + 8, r + 12 (disjoint banks at the 80-byte pitch)
 //   as-it-comes (rows = k, n contiguous): thread (k row = tid / 16 + 16 p, 8 columns at 8 (tid & 15))
-template <int BX, bool TRANS, int T>
+template <int BX, bool TRANS, int T, int NT = 256>
 struct PlaneStage {
-    static constexpr int NVP = BX == 128 ? 2 : 1;
+    static constexpr int ROWS = TRANS ? NT / (BX / 8) : NT / 4;          // tile rows (plain) or k rows (as-it-comes) covered per pass
+    static constexpr int NVP = TRANS ? (32 / ROWS > 0 ? 32 / ROWS : 1) : (BX / ROWS > 0 ? BX / ROWS : 1);
     struct Set { u32x4 v[T][NVP]; };
     const uint16_t* ptr;    // plane 0, this thread's first element of the next chunk
     int64_t plane, step, pstep;
@@ -259,21 +264,21 @@ struct PlaneStage {
         const int l = tid & 63, w = tid >> 6;
         if constexpr (!TRANS) {
             const int row = 4 * ((l >> 2) & 3) + (l >> 4) + 16 * w;
-            active = BX == 128 || row < 32;
+            active = row < BX;
             ptr = planes + (int64_t)(x0 + (active ? row : 0)) * ld + k0 + 8 * (l & 3);
-            step = BK; pstep = 64 * ld;
+            step = BK; pstep = ROWS * ld;
             lds_off = row * KS + 8 * (l & 3);
         } else {
             constexpr int C8 = BX / 8;   // 16-byte pieces per k row
             const int c8 = tid % C8, krow = tid / C8;
-            active = krow < (BX == 128 ? 16 : 32);
+            active = krow < 32;
             ptr = planes + (k0 + (active ? krow : 0)) * ld + x0 + 8 * c8;
-            step = BK * ld; pstep = 16 * ld;
+            step = BK * ld; pstep = ROWS * ld;
             lds_off = krow * tr_stride(BX) + 8 * c8;
         }
     }
     __device__ __forceinline__ void load(Set& o) {
-        if (BX == 128 || active) {
+        if ((BX == 128 && NT <= 512) || active) {
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
@@ -283,8 +288,8 @@ struct PlaneStage {
     }
     __device__ __forceinline__ void store(const Set& o, uint16_t* tiles) const {
         constexpr int PE = tile_elems(BX, TRANS);
-        constexpr int LP = TRANS ? 16 * tr_stride(BX) : 64 * KS;   // LDS distance of the thread's second piece
-        if (BX == 128 || active) {
+        constexpr int LP = ROWS * (TRANS ? tr_stride(BX) : KS);   // LDS distance of the thread's second piece
+        if ((BX == 128 && NT <= 512) || active) {
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
@@ -296,13 +301,14 @@ struct PlaneStage {
 // BM x BN output tile, WM x WN waves (WM * WN = 4), each wave FM x FN blocks of 32 x 32.  VEC: the contiguous extent of every operand that
 // is split on the fly is a multiple of 4 (every layer product of a network whose widths are; heads and odd shapes take the 4-byte loads).
 // BP: B comes as pre-split planes (PlaneStage).
-// DB (PPO_GEMM_DB=1, an experiment kept selectable): ONE workgroup per CU with two LDS tile sets: chunk c + 1 is staged into the other set
-// while chunk c is multiplied, one barrier per chunk, the staging's vector instructions and LDS writes in the same instruction stream as
-// the MFMAs (the compiler does interleave them: 1 MFMA / 7 VALU runs).  Measured: fp32-accurate forward 256 -> 256 82 us against 62 with
-// two workgroups per CU (one wave per SIMD issues a vector instruction every ~5 cycles, two waves one every ~2.4: the staging needs the
-// second wave); plain bf16, which stages little, gains 3-8 %.  Default stays two workgroups per CU.
+// DB: ONE eight-wave workgroup per CU (two waves per SIMD) with two LDS tile sets: chunk c + 1 is staged into the other set while chunk c
+// is multiplied, one barrier per chunk, the staging's vector instructions and LDS writes in the same instruction stream as the MFMAs (the
+// compiler does interleave them: 1 MFMA / 7 VALU runs).  Used where it measured faster (small batches, plain bf16; see launch_prec); the
+// fp32-accurate product at minibatch size stays on two four-wave workgroups per CU.  (A four-wave version of DB -- one wave per SIMD --
+// was 30 % slower than either: one wave issues a vector instruction every ~5 cycles, two waves one every ~2.4.)
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB>
-__global__ __launch_bounds__(256, DB ? 1 : 2) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int NT = 64 * WM * WN;   // 256 threads; 512 (two waves per SIMD of ONE workgroup) for the double-buffered variant
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     constexpr int EA = tile_elems(BM, TA), EB = tile_elems(BN, TB);
     extern __shared__ __attribute__((aligned(16))) uint16_t dyn_lds[];   // (DB ? 2 : 1) x (T EA + T EB) bf16
@@ -337,12 +343,12 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void gemm_kernel(const GemmArgs g)
     // Two chunks of operands are in flight in registers: the loads of chunk c + 2 are issued when chunk c has been staged, so a load has two
     // chunks of MFMAs (not one) to cover its trip to HBM.  The contraction range is walked in PAIRS of chunks (the host rounds k_chunk
     // to a multiple of 64; chunks past the end load zeros) so that the loop body has no branch around a load.
-    Stage<BM, TA, VEC> sa;
+    Stage<BM, TA, VEC, NT> sa;
     sa.init(g.a, g.lda, m0, g.M, kbeg, tid);
-    Loaded<Stage<BM, TA, VEC>::NV> va0, va1;
+    Loaded<Stage<BM, TA, VEC, NT>::NV> va0, va1;
     // B: split on the fly like A, or (BP) fetched as ready-made bf16 planes
-    typename std::conditional<BP, PlaneStage<BN, TB, T>, Stage<BN, TB, VEC>>::type sb;
-    typename std::conditional<BP, typename PlaneStage<BN, TB, T>::Set, Loaded<Stage<BN, TB, VEC>::NV>>::type vb0, vb1;
+    typename std::conditional<BP, PlaneStage<BN, TB, T, NT>, Stage<BN, TB, VEC, NT>>::type sb;
+    typename std::conditional<BP, typename PlaneStage<BN, TB, T, NT>::Set, Loaded<Stage<BN, TB, VEC, NT>::NV>>::type vb0, vb1;
     if constexpr (BP) sb.init(g.bplanes, g.bp_plane, g.bp_ld, n0, kbeg, tid);
     else sb.init(g.b, g.ldb, n0, g.N, kbeg, tid);
     auto load_b = [&](auto& set, auto guard) {
@@ -437,11 +443,11 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void gemm_kernel(const GemmArgs g)
     for (; kc < kend; kc += 2 * BK) pair(std::true_type{});
 
     if constexpr (TA) {
-        if (do_cs) {   // the eight k-row groups of threads that share a column quad are added in a fixed order through LDS (the tiles are dead)
-            constexpr int MQ = BM / 4;
-            float* red = reinterpret_cast<float*>(sA);   // [8][BM]
+        if (do_cs) {   // the k-row groups of threads that share a column quad are added in a fixed order through LDS (the tiles are dead)
+            constexpr int MQ = BM / 4, NG = BM == 128 ? NT / MQ : 8;
+            float* red = reinterpret_cast<float*>(sA);   // [NG][BM]
             const int mq = tid % MQ, kq = tid / MQ;
-            if (kq < 8) {
+            if (kq < NG) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) red[kq * BM + 4 * mq + e] = cs[e];
             }
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void gemm_kernel(const GemmArgs g)
             if (tid < BM && m0 + tid < g.M) {
                 float t = red[tid];
 #pragma unroll
-                for (int q = 1; q < 8; q++) t += red[q * BM + tid];
+                for (int q = 1; q < NG; q++) t += red[q * BM + tid];
                 g.colsum[(int64_t)tz * g.colsum_zstride + m0 + tid] = t;
             }
         }
@@ -507,7 +513,7 @@ hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);
     return hipGetLastError();
 }
 template <int BM, int BN, int WM, int WN, int T, bool VEC>
@@ -520,10 +526,11 @@ hipError_t launch_cfg(const GemmArgs& g_in, bool ta, bool tb, int splits, bool d
     const dim3 grid((unsigned)blocks);
     if constexpr (BM == 128 && BN == 128) {
         if (db) {   // double-buffered variant: the big tile only, the orientations the layer products use
-            if (g.bplanes) return tb ? launch_one<BM, BN, WM, WN, false, true, T, VEC, true, true>(g, grid, s) : launch_one<BM, BN, WM, WN, false, false, T, VEC, true, true>(g, grid, s);
-            if (ta && tb) return launch_one<BM, BN, WM, WN, true, true, T, VEC, false, true>(g, grid, s);
-            if (!ta && !tb) return launch_one<BM, BN, WM, WN, false, false, T, VEC, false, true>(g, grid, s);
-            if (!ta && tb) return launch_one<BM, BN, WM, WN, false, true, T, VEC, false, true>(g, grid, s);
+            // eight waves (4 x 2, each 32 x 64): two per SIMD, all of ONE workgroup
+            if (g.bplanes) return tb ? launch_one<BM, BN, 4, 2, false, true, T, VEC, true, true>(g, grid, s) : launch_one<BM, BN, 4, 2, false, false, T, VEC, true, true>(g, grid, s);
+            if (ta && tb) return launch_one<BM, BN, 4, 2, true, true, T, VEC, false, true>(g, grid, s);
+            if (!ta && !tb) return launch_one<BM, BN, 4, 2, false, false, T, VEC, false, true>(g, grid, s);
+            if (!ta && tb) return launch_one<BM, BN, 4, 2, false, true, T, VEC, false, true>(g, grid, s);
         }
     }
     if (g.bplanes) {   // plain A, B from planes (forward and d(input) of a layer)
@@ -537,8 +544,12 @@ hipError_t launch_cfg(const GemmArgs& g_in, bool ta, bool tb, int splits, bool d
 }
 template <int T, bool VEC>
 hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStream_t s) {
-    const char* dbe = getenv("PPO_GEMM_DB");   // experiment switch, read per launch (tests toggle it)
-    const bool db = dbe && dbe[0] == '1';
+    // Which main loop: two workgroups per CU with one tile set each, or ONE eight-wave workgroup with two tile sets (DB)?  Measured on
+    // configs[4] (A/B in one call): the fp32-accurate product at minibatch size is 7 % faster with two workgroups (1.87 against 2.00 ms per
+    // step); the same product on a rollout step's 2048 rows -- few workgroups, nothing to overlap with but itself -- is 11 % faster double-
+    // buffered (13.1 against 14.8 ms per rollout), and so is plain bf16, which stages little (3 %).  PPO_GEMM_DB=0 / 1 forces one (tests).
+    const char* dbe = getenv("PPO_GEMM_DB");
+    const bool db = dbe ? dbe[0] == '1' : (T == 1 || (g.M <= 8192 && splits == 1));
     if (g.N <= 32) return launch_cfg<128, 32, 4, 1, T, VEC>(g, ta, tb, splits, false, s);
     if (g.M <= 32 && !g.bplanes) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, false, s);
     return launch_cfg<128, 128, 2, 2, T, VEC>(g, ta, tb, splits, db, s);
