@@ -104,3 +104,23 @@ def test_matmul_double_buffered_variant(P, ctx, monkeypatch, ta, tb):
         c0 = P.binding.matmul(ctx, a, b, ta, tb)
         monkeypatch.setenv("PPO_GEMM_DB", "1")
         assert np.all(np.abs(c0 - ref) <= 2e-6 * bound + 1e-30), (M, N, K)
+
+
+def test_matmul_degenerate_sizes_and_bad_arguments(P, ctx):
+    B_ = P.binding
+    # K = 0: the product is empty, the epilogue still applies
+    bias = np.arange(5, dtype=np.float32)
+    d_a, d_b, d_c, d_x = ctx.dev(np.zeros((3, 1), np.float32)), ctx.dev(np.zeros((5, 1), np.float32)), ctx.dev(np.full((3, 5), 7.0, np.float32)), ctx.dev(bias)
+    B_.matmul_launch(ctx, False, False, 3, 5, 0, d_a, 1, d_b, 1, d_c, 5, B_.MM_EPI_BIAS, d_x, 0)
+    ctx.sync()
+    assert np.array_equal(d_c.download(), np.tile(bias, (3, 1)))
+    # M = 0 / N = 0: nothing is written, status OK
+    d_c.upload(np.full((3, 5), 7.0, np.float32))
+    B_.matmul_launch(ctx, False, False, 0, 5, 1, d_a, 1, d_b, 1, d_c, 5)
+    B_.matmul_launch(ctx, False, False, 3, 0, 1, d_a, 1, d_b, 1, d_c, 5)
+    ctx.sync()
+    assert np.all(d_c.download() == 7.0)
+    # an epilogue without its operand, an unknown epilogue / precision: PPO_ERR_INVALID, not a launch
+    for kw in (dict(epilogue=B_.MM_EPI_BIAS), dict(epilogue=9, d_aux=d_x), dict(precision=5)):
+        with pytest.raises(B_.PPOError):
+            B_.matmul_launch(ctx, False, False, 3, 5, 1, d_a, 1, d_b, 1, d_c, 5, **kw)
