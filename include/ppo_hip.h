@@ -28,7 +28,7 @@ extern "C" {
 
 #define PPO_MAX_HEADS 8
 #define PPO_API __attribute__((visibility("default")))
-#define PPO_ABI_VERSION 1
+#define PPO_ABI_VERSION 2
 
 typedef int32_t ppo_status;
 enum { PPO_OK = 0, PPO_ERR_INVALID = 1, PPO_ERR_HIP = 2, PPO_ERR_STATE = 3, PPO_ERR_COMM = 4, PPO_ERR_UNSUPPORTED = 5 };
@@ -39,6 +39,10 @@ enum { PPO_ENV_CARTPOLE = 0, PPO_ENV_MOUNTAINCAR = 1, PPO_ENV_SYNTHETIC = 2 };
 /* PPO_DIST_CATEGORICAL reproduces Distributions/Categorical.cpp including its entropy clamp (:112-119);
  * PPO_DIST_MASKED reproduces Distributions/CategoricalMasked.cpp (true entropy, -1e8 masking). */
 enum { PPO_DIST_CATEGORICAL = 0, PPO_DIST_MASKED = 1 };
+/* PPO_DTYPE_F32: every product carries f32 accuracy (on the matrix cores: f32 operands as three exact bf16 terms, f32 accumulation).
+ * PPO_DTYPE_BF16: "bf16 with MFMA GEMMs" of BASELINE configs[4] -- operands and stored activations rounded to bf16 (nearest even),
+ * f32 accumulation, f32 master weights, gradients and optimizer state. */
+enum { PPO_DTYPE_F32 = 0, PPO_DTYPE_BF16 = 1 };
 
 /* Hyper-parameters: the m_* fields of PPO_Discrete (PPO_Discrete.h:52-85) / the TOML keys (PPO_Discrete.cpp:107-255). */
 typedef struct ppo_config {
@@ -62,6 +66,7 @@ typedef struct ppo_config {
     int64_t env_offset;         /* global index of this shard's env 0 */
     int64_t global_num_envs;    /* 0 or num_envs when not sharded */
     float learning_rate, gamma, gae_lambda, clip_coef, ent_coef, vf_coef, max_grad_norm;
+    int32_t compute_dtype;      /* PPO_DTYPE_*: arithmetic of the layer GEMMs of a PPO_ENV_SYNTHETIC network; the 2 x 64 paths are always f32 */
 } ppo_config;
 
 /* Scalars the reference prints per update (PPO_Discrete.cpp:700-774) plus per-step diagnostics. */

@@ -611,7 +611,7 @@ void orc_minibatch_grads_shard(const orc_net* c, const orc_hparams* hp, const fl
             double mean = adv_sums[0] / (double)global_M;
             double var = (adv_sums[1] - adv_sums[0] * mean) / (double)(global_M - 1);
             mean_f = (float)mean;
-            std_f = (float)sqrt(var > 0.0 ? var : 0.0);
+            std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
         } else {
             double s = 0.0;
             for (int64_t j = 0; j < M; j++) s += b_advantages[idx[j]];

@@ -17,6 +17,8 @@ ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_SYNTHETIC = 0, 1, 2
 MM_EPI_NONE, MM_EPI_BIAS, MM_EPI_BIAS_TANH, MM_EPI_DTANH = 0, 1, 2, 3
 MM_F32X3, MM_BF16 = 0, 1
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
+ABI_VERSION = 2
 COMM_ID_BYTES = 128
 
 BUF = dict(OBS=0, ACTIONS=1, LOGPROBS=2, REWARDS=3, DONES=4, VALUES=5, MASKS=6, ADVANTAGES=7, RETURNS=8, NEXT_OBS=9,
@@ -51,7 +53,7 @@ class Config(C.Structure):
                 ("clip_vloss", C.c_int32), ("anneal_lr", C.c_int32), ("seed", C.c_int64), ("total_timesteps", C.c_int64),
                 ("env_offset", C.c_int64), ("global_num_envs", C.c_int64), ("learning_rate", C.c_float), ("gamma", C.c_float),
                 ("gae_lambda", C.c_float), ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float),
-                ("max_grad_norm", C.c_float)]
+                ("max_grad_norm", C.c_float), ("compute_dtype", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -79,7 +81,8 @@ class Profile(C.Structure):
 def make_config(env_kind=ENV_CARTPOLE, dist_kind=DIST_CATEGORICAL, obs_size=4, head_dims=(2,), num_envs=8, num_steps=32,
                 num_minibatches=4, update_epochs=10, max_episode_steps=500, use_gae=True, norm_adv=True, clip_vloss=True,
                 anneal_lr=True, seed=2, total_timesteps=100000, env_offset=0, global_num_envs=0, learning_rate=1e-3, gamma=0.98,
-                gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, device=0, hidden=64, n_hidden=2):
+                gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, device=0, hidden=64, n_hidden=2,
+                compute_dtype=0):
     """Defaults = Environments/CartPoleRecommendedSettings.toml of the reference with action_size = 2."""
     c = Config()
     c.struct_size = C.sizeof(Config)
@@ -94,6 +97,7 @@ def make_config(env_kind=ENV_CARTPOLE, dist_kind=DIST_CATEGORICAL, obs_size=4, h
     c.seed, c.total_timesteps, c.env_offset, c.global_num_envs = seed, total_timesteps, env_offset, global_num_envs
     c.learning_rate, c.gamma, c.gae_lambda, c.clip_coef = learning_rate, gamma, gae_lambda, clip_coef
     c.ent_coef, c.vf_coef, c.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+    c.compute_dtype = compute_dtype
     return c
 
 
@@ -115,7 +119,7 @@ def lib():
         L.ppo_ctx_destroy.restype = None
         for name in ABI_SYMBOLS:
             getattr(L, name)  # AttributeError if the build lacks a declared symbol
-        if L.ppo_abi_version() != 1:
+        if L.ppo_abi_version() != ABI_VERSION:
             raise RuntimeError("libppo_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -107,30 +107,23 @@ struct ppo_ctx {
     double* clipfrac_accum = nullptr;   // {sum, count}
     double* norm2 = nullptr;            // [12] per-tensor squared gradient norms of the current step
     double* ev_sums = nullptr;          // [PPO_EV_BLOCKS][4]
+    float* rec_critic = nullptr;        // [B][8] packed sample records the matrix-core update kernel gathers from (launch_pack_records)
+    float* rec_actor = nullptr;         // [B][8]
     int32_t* row_counts = nullptr;      // [T]
     uint64_t* group_bits = nullptr;     // [T, ceil(N/64)] ballots of finished episodes
     EpisodeRing* ring = nullptr;
     float* scratch_obs = nullptr;       // [N,O] staging for AoS<->SoA conversions
     int max_blocks_per_net = 0;
     bool use_mfma = true;
-    double actor_share = 0.5;       // share of the fwd/bwd workgroups given to the actor (measured: with 4 tiles per wave an uneven
-                                    // split only moves the integer tile count of the slower side up; kept as a tuning knob)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
     GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
     uint8_t* cur_mask = nullptr;     // generic path: action mask of the observation in NEXT_OBS, [N, A]
     bool force_collectives = false;  // PPO_COMM_SELFTEST: world == 1 but the multi-rank path (RCCL included) is taken
-    bool fused_opt = true;           // single-rank contexts: optimizer step in two launches instead of three (env PPO_FUSED_OPT=0 disables)
     double* fused_partial = nullptr; // [fused_opt_blocks][12] per-workgroup sums of squares of the gradient
-    bool defer_opt = false;          // PPO_DEFER_OPT=1: clip + AdamW of step k applied by step k + 1's update kernel while it loads its weights.  Bit-identical,
-                                     // measured SLOWER (the update kernel grows by 5.8 us, the launch it replaces took 5.0): off by default, kept as a tested experiment
-    float* alt_state[3] = { nullptr, nullptr, nullptr };   // second set of params / exp_avg / exp_avg_sq the deferred steps alternate with
-    DeferredOpt pending_opt{};       // consumed by the next fwd_bwd()
-    bool state_in_alt = false;       // inside ppo_update: the committed params / moments live in alt_state (always false between updates)
     int last_n_blocks[2] = { 0, 0 };
-    int mfma_prec = 1;               // 0: exact fp32 MFMA, 1: three-term bf16 split (env PPO_UPDATE_KERNEL=mfma_f32 selects 0)
     int prof_every = 1;              // mode 2: bracket one update-kernel launch in prof_every (an event pair costs the stream ~3 us)
     int64_t prof_count = 0;
-    bool stamping = false;           // fwd/bwd kernel flavour (env PPO_UPDATE_KERNEL=valu selects the VALU kernel)
+    bool stamping = false;           // diagnostic flavour of the update kernel (in-kernel phase stamps)
 
     // host-side training state
     double lr = 0.0;
@@ -307,7 +300,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (c->lg_ready) (void)hipEventDestroy(c->lg_ready);
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->gen) { gen_blas_destroy(c->gen->blas); delete c->gen; c->gen = nullptr; }
+    if (c->gen) { delete c->gen; c->gen = nullptr; }
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->adam_coefs_h) (void)hipHostFree(c->adam_coefs_h);
     for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
@@ -329,6 +322,10 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     if (cfg->env_kind != PPO_ENV_CARTPOLE && cfg->env_kind != PPO_ENV_MOUNTAINCAR && cfg->env_kind != PPO_ENV_SYNTHETIC)
         return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     if (cfg->dist_kind != PPO_DIST_CATEGORICAL && cfg->dist_kind != PPO_DIST_MASKED) return fail(nullptr, PPO_ERR_INVALID, "unknown dist_kind %d", cfg->dist_kind);
+    if (cfg->compute_dtype != PPO_DTYPE_F32 && cfg->compute_dtype != PPO_DTYPE_BF16) return fail(nullptr, PPO_ERR_INVALID, "unknown compute_dtype %d", cfg->compute_dtype);
+    if (cfg->compute_dtype == PPO_DTYPE_BF16 && !generic)
+        return fail(nullptr, PPO_ERR_UNSUPPORTED, "compute_dtype = PPO_DTYPE_BF16 applies to networks whose layers are GEMMs (env_kind = PPO_ENV_SYNTHETIC); the reference's "
+                    "2 x 64 networks always compute in f32");
     const int env_obs = cfg->env_kind == PPO_ENV_CARTPOLE ? 4 : (cfg->env_kind == PPO_ENV_MOUNTAINCAR ? 2 : cfg->obs_size);
     if (cfg->obs_size != env_obs) {
         // the reference's runtime check in initEnvs (PPO_Discrete.cpp:370-375), same wording
@@ -409,18 +406,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc_buf<int32_t>(c, PPO_BUF_FIN_LEN, TN));
     CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
     CK(dalloc(c, &c->error_flag, 1));
-    {
-        const char* k = getenv("PPO_UPDATE_KERNEL");
-        c->use_mfma = (A <= 4) && !(k && std::strcmp(k, "valu") == 0);
-        c->mfma_prec = (k && std::strcmp(k, "mfma_f32") == 0) ? 0 : 1;
-        const char* fo = getenv("PPO_FUSED_OPT");
-        if (fo && std::strcmp(fo, "0") == 0) c->fused_opt = false;
-        const char* dfo = getenv("PPO_DEFER_OPT");
-        if (dfo && std::strcmp(dfo, "1") == 0) c->defer_opt = true;
-        const char* sh = getenv("PPO_ACTOR_SHARE");
-        if (sh) c->actor_share = atof(sh);
-
-    }
+    c->use_mfma = A <= 4;   // the matrix-core update kernel folds heads of up to 4 logits; wider policies (2 x 64 nets) run the vector kernel
     c->max_blocks_per_net = 512;
     const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
     CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));
@@ -435,8 +421,11 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->clipfrac_accum, 2));
     CK(dalloc(c, &c->norm2, 4 * GEN_MAX_LAYERS * GEN_NORM_PARTS));
     CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
-    for (int i = 0; i < 3; i++) CK(dalloc(c, &c->alt_state[i], (size_t)c->L.P + 8));
     CK(dalloc(c, &c->ev_sums, PPO_EV_BLOCKS * 4));
+    if (c->use_mfma && !generic) {
+        CK(dalloc(c, &c->rec_critic, (size_t)B * 8));
+        CK(dalloc(c, &c->rec_actor, (size_t)B * 8));
+    }
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
     CK(dalloc(c, &c->group_bits, (size_t)c->T * ((N + 63) / 64)));
     CK(dalloc(c, &c->ring, 1));
@@ -464,7 +453,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             int64_t mx = 0;
             for (int l = 0; l < GL.n_layers; l++) mx = std::max<int64_t>(mx, (int64_t)std::max(GL.out_dim[0][l], GL.out_dim[1][l]) * (GL.in_dim[l] + 1));
             g.wslab_stride = (mx + 3) & ~3ll;
-            CK(dalloc(c, &g.wslab, (size_t)(std::max(GEN_SPLIT, GEN_SPLIT_MFMA) + 1) * g.wslab_stride));
+            CK(dalloc(c, &g.wslab, (size_t)(GEN_SPLIT_MFMA + 1) * g.wslab_stride));
             CK(dalloc(c, &g.db_part, (size_t)GEN_DB_CHUNKS * std::max(GL.hidden, GL.act)));
         }
         {   // bf16 planes of every layer's weights, padded to tile multiples (kernels_gemm.hip: PlaneStage)
@@ -486,22 +475,8 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         // the zero-fills above ran on the null stream, which a non-blocking stream does not wait for: drain them before the first write
         CK(hipDeviceSynchronize());
         CK(gen_fill(g.row_f[4] + 2, (int64_t)R, 1.0f, c->stream));   // the ones vector of the bias-gradient gemv
-        // layer products: hand-written matrix-core kernels (kernels_gemm.hip) unless the library yardstick is asked for
-        const char* gb = getenv("PPO_GENERIC_GEMM");
-        const char* gp = getenv("PPO_GENERIC_PREC");
-        g.gemm_backend = (gb && !strcmp(gb, "rocblas")) ? GEN_GEMM_ROCBLAS : GEN_GEMM_MFMA;
-        g.gemm_prec = (gp && !strcmp(gp, "bf16")) ? PPO_MM_BF16 : PPO_MM_F32X3;
-        { const char* wp = getenv("PPO_GENERIC_WPLANES"); g.use_planes = !(wp && !strcmp(wp, "0")); }
-        if ((gb && strcmp(gb, "rocblas") && strcmp(gb, "mfma")) || (gp && strcmp(gp, "bf16") && strcmp(gp, "f32x3"))) {
-            fail(nullptr, PPO_ERR_INVALID, "PPO_GENERIC_GEMM must be mfma|rocblas and PPO_GENERIC_PREC f32x3|bf16");
-            ppo_ctx_destroy(c);
-            return PPO_ERR_INVALID;
-        }
-        if (g.gemm_backend == GEN_GEMM_ROCBLAS) {
-            std::string berr;
-            hipError_t be = gen_blas_create(&g.blas, c->stream, berr);
-            if (be != hipSuccess) { fail(nullptr, PPO_ERR_UNSUPPORTED, "%s", berr.c_str()); ppo_ctx_destroy(c); return PPO_ERR_UNSUPPORTED; }
-        }
+        // arithmetic of the layer products (kernels_gemm.hip): fp32 carried as three bf16 terms, or plain bf16 operands (configs[4])
+        g.gemm_prec = cfg->compute_dtype == PPO_DTYPE_BF16 ? PPO_MM_BF16 : PPO_MM_F32X3;
     }
 #undef CK
     // every env can reset at most once per step: steps per env over the whole run bounds the shared reset stream
@@ -1039,13 +1014,21 @@ static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced) {
     return PPO_OK;
 }
 
+// The matrix-core update kernel gathers from one packed record per sample and net: (re)build them from the flattened rollout buffers
+// (PPO_Discrete.cpp:557-562).  Also leaves the explained-variance partial sums (:647-648), which read the same returns / values.
+static ppo_status pack_records(ppo_ctx* c) {
+    if (!c->use_mfma || c->gen) return PPO_OK;
+    HIPCHK(c, launch_pack_records(c->L, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS),
+                                  c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
+                                  B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->rec_critic,
+                                  c->rec_actor, c->ev_sums, c->stream));
+    return PPO_OK;
+}
+
 static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, bool reduce = true) {
     if (c->gen) return gen_fwd_bwd(c, idx, M, slot);
     UpdateArgs a{};
-    a.params = c->state_in_alt ? c->alt_state[0] : B_<float>(c, PPO_BUF_PARAMS);
-    a.opt = c->pending_opt;          // a deferred optimizer step rides on this launch (ppo_update) ...
-    c->pending_opt = DeferredOpt{};  // ... exactly once;
-    if (a.opt.pending) c->state_in_alt = !c->state_in_alt;   // ... and moves the committed state to the other set of buffers
+    a.params = B_<float>(c, PPO_BUF_PARAMS);
     a.L = c->L;
     a.hp = c->hp;
     a.obs = B_<float>(c, PPO_BUF_OBS);
@@ -1055,6 +1038,8 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     a.advantages = B_<float>(c, PPO_BUF_ADVANTAGES);
     a.returns = B_<float>(c, PPO_BUF_RETURNS);
     a.values = B_<float>(c, PPO_BUF_VALUES);
+    a.rec_critic = c->rec_critic;
+    a.rec_actor = c->rec_actor;
     a.idx = idx;
     a.M = (int)M;
     a.global_M = (double)M * c->world;
@@ -1064,11 +1049,11 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     a.slab = c->slab;
     a.stat_slab = c->stat_slab;
     a.stamps = c->stamping ? c->stamps : nullptr;
-    if (c->use_mfma) update_blocks_mfma((int)M, c->actor_share, c->mfma_prec, a.n_blocks);
+    if (c->use_mfma) update_blocks_mfma((int)M, a.n_blocks);
     else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
         ProfScope ps(c, PROF_FWD_BWD, c->prof_every <= 1 || (c->prof_count++ % c->prof_every) == c->prof_every / 2);
-        if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->mfma_prec, c->stream));
+        if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
         else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
     c->last_n_blocks[0] = a.n_blocks[0]; c->last_n_blocks[1] = a.n_blocks[1];
@@ -1096,6 +1081,10 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
     NEED(c, c && idx, "null argument");
     NEED(c, M >= 1 && M <= c->B, "minibatch size out of range");
     const int slot = c->steps_per_update;  // scratch slot
+    {   // stand-alone call: the caller may have rewritten any rollout buffer since the last pack
+        const ppo_status ps = pack_records(c);
+        if (ps != PPO_OK) return ps;
+    }
     if (c->cfg.norm_adv) {
         HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), idx, M, M, 1, c->adv_stats + (size_t)slot * PPO_ADV_PARTS, c->stream));
         ppo_status s = allreduce_sum(c, c->adv_stats + (size_t)slot * PPO_ADV_PARTS, 2 * PPO_ADV_PARTS, true);
@@ -1148,16 +1137,21 @@ extern "C" ppo_status ppo_set_learning_rate(ppo_ctx* c, double lr) {
 extern "C" ppo_status ppo_update(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
     const int E = c->cfg.update_epochs, nmb = c->n_mb;
-    ppo_status s = ppo_generate_permutations(c);
-    if (s != PPO_OK) return s;
+    ppo_status s = PPO_OK;
     const int32_t* perm = B_<int32_t>(c, PPO_BUF_PERM);
     if (c->cfg.norm_adv) {
-        // the advantages and the permutations are fixed for the whole update: statistics of ALL minibatches in one launch
-        // (and, when sharded, one small all-reduce) instead of a reduction inside every optimizer step
-        HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), perm, c->B, c->MB, E * nmb, c->adv_stats, c->stream));
+        // the advantages and the permutations are fixed for the whole update: the permutations of all epochs and the statistics of ALL
+        // minibatches in one launch (and, when sharded, one small all-reduce) instead of a reduction inside every optimizer step
+        HIPCHK(c, launch_permutations_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), B_<int32_t>(c, PPO_BUF_PERM), c->B, E, c->MB, c->cfg.seed, c->updates,
+                                                c->rank, c->adv_stats, c->stream));
         s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
+    } else {
+        s = ppo_generate_permutations(c);
+        if (s != PPO_OK) return s;
     }
+    s = pack_records(c);
+    if (s != PPO_OK) return s;
     // AdamW scalars of every step of this update, one async copy.  The pinned mirror has two halves used alternately; a half is
     // rewritten only once its previous copy has completed (normally long ago: no stall, and no stream-wide synchronisation).
     {
@@ -1175,41 +1169,16 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         for (int mbi = 0; mbi < nmb; mbi++, k++) {
             const int64_t start = (int64_t)mbi * c->MB;
             const int64_t M = std::min<int64_t>(c->MB, c->B - start);
-            const bool fused = c->fused_opt && c->world == 1 && !c->force_collectives && !c->gen;
-            // deferred: step k's clip + AdamW is applied by step k + 1's update kernel (DeferredOpt); the state alternates between the
-            // context's buffers and alt_state, and the last step of the update runs the stand-alone kernel INTO the context's buffers
-            const bool defer = fused && c->defer_opt && c->use_mfma && !c->stamping;
+            const bool fused = c->world == 1 && !c->force_collectives && !c->gen;
             s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !fused);
             if (s != PPO_OK) return s;
             if (fused) {
+                // single rank: two launches (slab reduction + sums of squares, then norm + clip + AdamW) instead of three
                 c->opt_step += 1;
                 ProfScope ps(c, PROF_OPT);
-                float* canon[3] = { B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ) };
-                if (!defer) {
-                    // single rank: two launches (reduction + sums of squares, clip + AdamW) instead of three
-                    HIPCHK(c, launch_reduce_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, canon[0], canon[1],
-                                                       canon[2], c->cfg.max_grad_norm, c->adam_coefs + k, (double)M, c->hp, c->step_stats + k,
-                                                       c->clipfrac_accum, c->fused_partial, c->stream));
-                } else {
-                    HIPCHK(c, launch_reduce_grads_sumsq(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, c->fused_partial,
-                                                        c->stream));
-                    float* const* src = c->state_in_alt ? c->alt_state : canon;   // the state before this step
-                    if (k + 1 < E * nmb) {
-                        float* const* dst = c->state_in_alt ? canon : c->alt_state;
-                        DeferredOpt& o = c->pending_opt;
-                        o.pending = 1;
-                        o.grads = B_<float>(c, PPO_BUF_GRADS);
-                        o.p_src = src[0]; o.m_src = src[1]; o.v_src = src[2];
-                        o.p_dst = dst[0]; o.m_dst = dst[1]; o.v_dst = dst[2];
-                        o.coef = c->adam_coefs + k; o.partial = c->fused_partial; o.max_norm = c->cfg.max_grad_norm;
-                        o.sums = c->loss_sums; o.global_M = (double)M; o.hp = c->hp; o.stats_out = c->step_stats + k; o.clipfrac_accum = c->clipfrac_accum;
-                    } else {
-                        HIPCHK(c, launch_clip_adamw_sumsq(c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, src[0], src[1], src[2], canon[0], canon[1], canon[2],
-                                                          c->cfg.max_grad_norm, c->adam_coefs + k, (double)M, c->hp, c->step_stats + k, c->clipfrac_accum,
-                                                          c->fused_partial, c->stream));
-                        c->state_in_alt = false;
-                    }
-                }
+                HIPCHK(c, launch_reduce_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, B_<float>(c, PPO_BUF_PARAMS),
+                                                   B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ), c->cfg.max_grad_norm, c->adam_coefs + k, (double)M,
+                                                   c->hp, c->step_stats + k, c->clipfrac_accum, c->fused_partial, c->stream));
                 c->last_stat_slot = k;
                 continue;
             }
@@ -1219,7 +1188,8 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
             if (s != PPO_OK) return s;
         }
     }
-    HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
+    if (!c->use_mfma || c->gen)   // otherwise pack_records left the sums
+        HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
     c->have_ev = true;
     c->updates += 1;
     return PPO_OK;

@@ -2,9 +2,9 @@
 // [3,3,3,2]; SURVEY 8(a) a6 "hidden width / depth configurable", cf. the commented 256-wide third layer of Agent.cpp:27,32,45-46).
 //
 // Same contract and the same C-ABI as the specialised path; different machine mapping: at these widths every layer is a real GEMM
-// (M = rows of the step or of the minibatch, N = K = hidden), so layers are plain library GEMMs (rocBLAS sgemm, fp32, atomics off:
-// deterministic) glued by small hand-written kernels for what is not a GEMM -- bias + tanh, the categorical heads, the PPO loss
-// and its gradient, tanh', column sums for the bias gradients, the gather, clip + AdamW over an arbitrary tensor list.
+// (M = rows of the step or of the minibatch, N = K = hidden), so layers are the hand-written matrix-core products of kernels_gemm.hip
+// (bias, tanh, tanh' and the bias gradient fused into them) glued by small kernels for what is not a GEMM -- the categorical heads,
+// the PPO loss and its gradient, the gather, clip + AdamW over an arbitrary tensor list.
 // Parameter order is the reference's generalised: critic layers (W [out][in] row-major, b) then actor layers (Agent.cpp:65-66).
 #pragma once
 #include <cstdint>
@@ -51,8 +51,6 @@ inline GenLayout make_gen_layout(int obs, int hidden, int n_hidden, int n_heads,
 // Device workspace and library handle of one generic context (owned by ppo_ctx; see api.hip).
 struct GenericCtx {
     GenLayout L{};
-    void* blas = nullptr;          // rocblas_handle (only with PPO_GENERIC_GEMM=rocblas)
-    int gemm_backend = 0;          // GEN_GEMM_MFMA (kernels_gemm.hip, default) or GEN_GEMM_ROCBLAS (library sgemm: the yardstick)
     int gemm_prec = 0;             // PPO_MM_F32X3 (default) or PPO_MM_BF16 (PPO_GENERIC_PREC=bf16)
     // weights of every layer pre-split into bf16 planes [t][n_pad][k_pad] (n_pad, k_pad: multiples of 128, zero padded) for the B operand of
     // the forward and d(input) products; rewritten (one launch) when the parameters have changed since the last use
@@ -60,7 +58,6 @@ struct GenericCtx {
     int64_t wp_off[2][GEN_MAX_LAYERS] = {};
     int wp_npad[2][GEN_MAX_LAYERS] = {}, wp_kpad[GEN_MAX_LAYERS] = {};
     mutable bool planes_dirty = true;
-    bool use_planes = true;        // PPO_GENERIC_WPLANES=0: split the weights on the fly in every workgroup instead (A/B switch)
     int64_t rows_max = 0;          // rows the workspaces are sized for: max(minibatch, T*N + N for the critic batch is chunked to it)
     float* acts[2][GEN_MAX_LAYERS] = {};   // [net][l]: post-tanh activations of hidden layer l, [rows_max, hidden]
     float* dz[2] = {};             // ping-pong d(pre-activation), [rows_max, hidden]
@@ -82,9 +79,7 @@ struct GenericCtx {
 };
 constexpr int GEN_LOSS_BLOCKS = 256;
 constexpr int GEN_DB_CHUNKS = 256, GEN_NORM_PARTS = 16;
-constexpr int GEN_GEMM_MFMA = 0, GEN_GEMM_ROCBLAS = 1;
 constexpr int GEN_SPLIT_MFMA = 128;   // row ranges of a weight-gradient product on the matrix cores: (out / 128)(in / 128) tiles x ranges >= 2 workgroups per CU
-constexpr int GEN_SPLIT = 32;   // row chunks of a weight-gradient GEMM (the contraction runs over the minibatch rows; see gen_backward)
 
 // kernels_gemm.hip: c[z][M, N] (z < splits, slabs c_zstride floats apart) = epilogue(sum over the z-th range of k of A(m, k) B(n, k));
 // see ppo_matmul in ppo_hip.h.  splits > 1 cuts the contraction into equal ranges (multiples of 64) and requires PPO_MM_EPI_NONE.
@@ -97,8 +92,6 @@ hipError_t gen_weight_planes(const GenericCtx& g, const float* params, hipStream
 
 // kernels_generic.hip
 struct ppo_ctx;
-hipError_t gen_blas_create(void** handle, hipStream_t s, std::string& err);
-void gen_blas_destroy(void* handle);
 // out[rows, out_dim(last)] = net(x[rows, obs]); acts != nullptr keeps every hidden layer's activations (for the backward pass)
 hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, float* const* acts, float* scratch0,
                        float* scratch1, float* out, hipStream_t s);

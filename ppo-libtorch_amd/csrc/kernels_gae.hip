@@ -196,8 +196,7 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     // Strip width: wide strips coalesce better (EPB*4-byte rows), narrow strips give more workgroups.  Keep >= ~2 per CU.
     // Strip width, measured on MI355X (tools/gae_sweep.py): 32 columns (48 KB of LDS, three workgroups per CU overlapping their
     // load / walk / store phases) is best from 32 768 envs up (4.5 TB/s); below ~8 192 envs 16 columns give every CU a workgroup.
-    int epb = N >= 8192 ? 32 : 16;
-    if (const char* e = getenv("PPO_GAE_EPB")) epb = atoi(e);   // tuning knob
+    const int epb = N >= 8192 ? 32 : 16;
 #define PPO_GAE_LAUNCH(EPB)                                                                                                   \
     do {                                                                                                                      \
         const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \

@@ -547,9 +547,8 @@ hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStrea
     // Which main loop: two workgroups per CU with one tile set each, or ONE eight-wave workgroup with two tile sets (DB)?  Measured on
     // configs[4] (A/B in one call): the fp32-accurate product at minibatch size is 7 % faster with two workgroups (1.87 against 2.00 ms per
     // step); the same product on a rollout step's 2048 rows -- few workgroups, nothing to overlap with but itself -- is 11 % faster double-
-    // buffered (13.1 against 14.8 ms per rollout), and so is plain bf16, which stages little (3 %).  PPO_GEMM_DB=0 / 1 forces one (tests).
-    const char* dbe = getenv("PPO_GEMM_DB");
-    const bool db = dbe ? dbe[0] == '1' : (T == 1 || (g.M <= 8192 && splits == 1));
+    // buffered (13.1 against 14.8 ms per rollout), and so is plain bf16, which stages little (3 %).
+    const bool db = T == 1 || (g.M <= 8192 && splits == 1);
     if (g.N <= 32) return launch_cfg<128, 32, 4, 1, T, VEC>(g, ta, tb, splits, false, s);
     if (g.M <= 32 && !g.bplanes) return launch_cfg<32, 128, 1, 4, T, VEC>(g, ta, tb, splits, false, s);
     return launch_cfg<128, 128, 2, 2, T, VEC>(g, ta, tb, splits, db, s);

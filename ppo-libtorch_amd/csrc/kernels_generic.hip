@@ -1,77 +1,14 @@
 // ppo-libtorch_amd/csrc/kernels_generic.hip -- networks other than the reference's 2 x 64 (see generic.hpp).
 //
-// Layers are rocBLAS sgemm calls (fp32, atomics off: bit-reproducible); this file holds the glue that is not a GEMM, written for
-// wave64: bias + tanh, categorical heads (one thread per row), the PPO loss and its gradient, tanh', the gather, clip + AdamW
-// over an arbitrary tensor list, and the synthetic environment of BASELINE configs[4].
-// Row-major X[rows, K] is column-major X^T[K, rows] with leading dimension K, so  Y = X W^T  is  sgemm(T, N, N, rows, K, W, X).
-#include <dlfcn.h>
-
-#include <mutex>
+// Layers are the hand-written matrix-core products of kernels_gemm.hip (bias / tanh / tanh' fused into their epilogues); this file holds
+// the glue that is not a GEMM, written for wave64: categorical heads (one thread per row), the PPO loss and its gradient, the gather,
+// clip + AdamW over an arbitrary tensor list, and the synthetic environment of BASELINE configs[4].
 #include <string>
 
 #include "generic.hpp"
 
-namespace rb {
-typedef int (*create_t)(void**);
-typedef int (*destroy_t)(void*);
-typedef int (*set_stream_t)(void*, hipStream_t);
-typedef int (*set_atomics_t)(void*, int);
-typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
-typedef int (*sgemv_t)(void*, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
-typedef int (*sgemm_sb_t)(void*, int, int, int, int, int, const float*, const float*, int, int64_t, const float*, int, int64_t, const float*, float*, int,
-                          int64_t, int);
-static create_t create;
-static destroy_t destroy;
-static set_stream_t set_stream;
-static set_atomics_t set_atomics;
-static sgemm_t sgemm;
-static sgemv_t sgemv;
-static sgemm_sb_t sgemm_sb;
-constexpr int OP_N = 111, OP_T = 112, ATOMICS_NOT_ALLOWED = 0;
-static bool load(std::string& err) {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> g(mu);
-    if (sgemm) return true;
-    void* h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { err = std::string("cannot load librocblas (needed for networks other than 2 x 64): ") + dlerror(); return false; }
-    create = (create_t)dlsym(h, "rocblas_create_handle");
-    destroy = (destroy_t)dlsym(h, "rocblas_destroy_handle");
-    set_stream = (set_stream_t)dlsym(h, "rocblas_set_stream");
-    set_atomics = (set_atomics_t)dlsym(h, "rocblas_set_atomics_mode");
-    sgemm = (sgemm_t)dlsym(h, "rocblas_sgemm");
-    sgemv = (sgemv_t)dlsym(h, "rocblas_sgemv");
-    sgemm_sb = (sgemm_sb_t)dlsym(h, "rocblas_sgemm_strided_batched");
-    if (!create || !destroy || !set_stream || !set_atomics || !sgemm || !sgemv || !sgemm_sb) { err = "librocblas lacks rocblas_* symbols"; sgemm = nullptr; return false; }
-    return true;
-}
-}  // namespace rb
-
-hipError_t gen_blas_create(void** handle, hipStream_t s, std::string& err) {
-    if (!rb::load(err)) return hipErrorNotSupported;
-    if (rb::create(handle) != 0) { err = "rocblas_create_handle failed"; return hipErrorUnknown; }
-    if (rb::set_stream(*handle, s) != 0 || rb::set_atomics(*handle, rb::ATOMICS_NOT_ALLOWED) != 0) { err = "rocblas handle setup failed"; return hipErrorUnknown; }
-    return hipSuccess;
-}
-void gen_blas_destroy(void* handle) { if (handle && rb::destroy) rb::destroy(handle); }
-
 namespace {
 
-// h[r][n] = tanh(z[r][n] + b[n])   (ACT) or z + b (last layer).  Library tanhf: this path is the yardstick-accurate one.
-template <bool ACT>
-__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ z, const float* __restrict__ b, int64_t rows, int n) {
-    const int64_t total = rows * n;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const float v = z[i] + b[i % n];
-        z[i] = ACT ? tanhf(v) : v;
-    }
-}
-// d[r][n] *= 1 - h[r][n]^2
-__global__ __launch_bounds__(256) void dtanh_kernel(float* __restrict__ d, const float* __restrict__ h, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) d[i] = d[i] * (1.0f - h[i] * h[i]);
-}
 __global__ void fill_kernel(float* p, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -345,17 +282,6 @@ __global__ __launch_bounds__(256) void store_step_kernel(GenLayout L, int N, con
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) { lp_t[i] = lp[i]; dones_t[i] = (float)done_prev[i]; }
 }
 
-// column sums of d[rows, n] over the row chunk blockIdx.y (rows [y * chunk, min(rows, (y + 1) * chunk))): 64 columns x 4 row lanes per block
-__global__ __launch_bounds__(256) void colsum_chunk_kernel(const float* __restrict__ d, int64_t rows, int n, int64_t chunk, float* __restrict__ part) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
-    float acc = 0.0f;
-    if (col < n) for (int64_t r = r0 + rl; r < r1; r += 4) acc += d[r * n + col];
-    red[rl][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (rl == 0 && col < n) part[(size_t)blockIdx.y * n + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-}
 // out[i] = sum over the S partial slabs in a fixed order: 64 elements per block, four lanes per element each adding a quarter of the slabs
 // (eight loads in flight at a time), then ((q0 + q1) + q2) + q3
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int S, int64_t n_w, const float* __restrict__ db_part,
@@ -392,29 +318,20 @@ inline unsigned grid_for(int64_t n, int per_block) { const int64_t g = (n + per_
 
 }  // namespace
 
-#define RBCHK(x) do { if ((x) != 0) return hipErrorUnknown; } while (0)
-
 hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, float* const* acts, float* scratch0,
                        float* scratch1, float* out, hipStream_t s) {
     const GenLayout& L = g.L;
-    const float one = 1.0f, zero = 0.0f;
     const float* in = x;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
     for (int l = 0; l < L.n_layers; l++) {
         const int K = L.in_dim[l], N = L.out_dim[net][l];
         const bool last = l == L.n_layers - 1;
         float* dst = last ? out : (acts ? acts[l] : ((l & 1) ? scratch1 : scratch0));
-        if (g.gemm_backend == GEN_GEMM_MFMA) {   // one launch per layer: product, bias and tanh (kernels_gemm.hip); weights from their bf16 planes
-            if (g.use_planes && g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
-            const hipError_t e = launch_matmul(false, false, rows, N, K, in, K, params + L.w_off[net][l], K, dst, N, last ? PPO_MM_EPI_BIAS : PPO_MM_EPI_BIAS_TANH,
-                                               params + L.b_off[net][l], 0, g.gemm_prec, 1, 0, nullptr, 0, g.use_planes ? g.wplanes + g.wp_off[net][l] : nullptr,
-                                               (int64_t)g.wp_npad[net][l] * g.wp_kpad[l], g.wp_kpad[l], s);
-            if (e != hipSuccess) return e;
-            in = dst;
-            continue;
-        }
-        RBCHK(rb::sgemm(g.blas, rb::OP_T, rb::OP_N, N, (int)rows, K, &one, params + L.w_off[net][l], K, in, K, &zero, dst, N));
-        if (last) hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid_for(rows * N, 256)), dim3(256), 0, s, dst, params + L.b_off[net][l], rows, N);
-        else hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid_for(rows * N, 256)), dim3(256), 0, s, dst, params + L.b_off[net][l], rows, N);
+        // one launch per layer: product, bias and tanh (kernels_gemm.hip); weights from their bf16 planes
+        const hipError_t e = launch_matmul(false, false, rows, N, K, in, K, params + L.w_off[net][l], K, dst, N, last ? PPO_MM_EPI_BIAS : PPO_MM_EPI_BIAS_TANH,
+                                           params + L.b_off[net][l], 0, g.gemm_prec, 1, 0, nullptr, 0, g.wplanes + g.wp_off[net][l],
+                                           (int64_t)g.wp_npad[net][l] * g.wp_kpad[l], g.wp_kpad[l], s);
+        if (e != hipSuccess) return e;
         in = dst;
     }
     return hipGetLastError();
@@ -449,7 +366,7 @@ __global__ void adv_finish_kernel(const AdvStat* adv_stat, double global_M, int 
         const double mean = t1 / global_M;
         const double var = (t2 - t1 * mean) / (global_M - 1.0);
         mean_f = (float)mean;
-        std_f = (float)sqrt(var > 0.0 ? var : 0.0);
+        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
     }
     out2[0] = mean_f;
     out2[1] = 1.0f / (std_f + 1e-8f);
@@ -475,59 +392,34 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
                         hipStream_t s) {
     const GenLayout& L = g.L;
-    const float one = 1.0f, zero = 0.0f;
     const float* d = dout;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
     for (int l = L.n_layers - 1; l >= 0; l--) {
         const int K = L.in_dim[l], N = L.out_dim[net][l];
         const float* in = l == 0 ? x : g.acts[net][l - 1];
-        // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single GEMM would have N K / tile
-        // workgroups walking all rows (and rocBLAS may not split the contraction without atomics), so the rows are cut into GEN_SPLIT
-        // chunks -- one strided-batched GEMM, every chunk its own partial slab -- and the slabs are added in a fixed order.
+        // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single product would have N K / tile
+        // workgroups walking all rows, so the rows are cut into ranges -- every range its own partial slab, enough of them for two workgroups
+        // per CU, each a multiple of 64 rows -- and the slabs are added in a fixed order.
         const int64_t n_w = (int64_t)N * K;
-        int S;
-        if (g.gemm_backend == GEN_GEMM_MFMA) {
-            // dW = d^T in on the matrix cores: row ranges -> slabs, enough of them for two workgroups per CU, each a multiple of 64 rows
-            const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 127) / 128);
-            int64_t want = (512 + tiles - 1) / tiles;
-            if (want > GEN_SPLIT_MFMA) want = GEN_SPLIT_MFMA;
-            int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;
-            S = (int)((rows + range - 1) / range);
-            // ... and db beside it: the workgroups of the first column of tiles also sum their d tile over the rows (db_part[z][N])
+        const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 127) / 128);
+        int64_t want = (512 + tiles - 1) / tiles;
+        if (want > GEN_SPLIT_MFMA) want = GEN_SPLIT_MFMA;
+        const int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;
+        const int S = (int)((rows + range - 1) / range);
+        {   // ... and db beside it: the workgroups of the first column of tiles also sum their d tile over the rows (db_part[z][N])
             const hipError_t e = launch_matmul(true, true, N, K, rows, d, N, in, K, g.wslab, K, PPO_MM_EPI_NONE, nullptr, 0, g.gemm_prec, S, g.wslab_stride,
                                                g.db_part, N, nullptr, 0, 0, s);
             if (e != hipSuccess) return e;
-        } else {
-            const int64_t chunk = (rows + GEN_SPLIT - 1) / GEN_SPLIT;
-            const int full = (int)(rows / chunk);            // chunks of exactly `chunk` rows
-            const int64_t rem = rows - (int64_t)full * chunk;
-            S = full + (rem > 0 ? 1 : 0);
-            if (full > 0)
-                RBCHK(rb::sgemm_sb(g.blas, rb::OP_N, rb::OP_T, K, N, (int)chunk, &one, in, K, chunk * K, d, N, chunk * N, &zero, g.wslab, K, g.wslab_stride, full));
-            if (rem > 0)
-                RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_T, K, N, (int)rem, &one, in + (size_t)full * chunk * K, K, d + (size_t)full * chunk * N, N, &zero,
-                                g.wslab + (size_t)full * g.wslab_stride, K));
         }
-        int n_dbc = S;
-        if (g.gemm_backend != GEN_GEMM_MFMA) {
-            const int64_t dbc = (rows + GEN_DB_CHUNKS - 1) / GEN_DB_CHUNKS;
-            n_dbc = (int)((rows + dbc - 1) / dbc);
-            hipLaunchKernelGGL(colsum_chunk_kernel, dim3((N + 63) / 64, n_dbc), dim3(256), 0, s, d, rows, N, dbc, g.db_part);
-        }
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, n_dbc, (int64_t)N,
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, S, (int64_t)N,
                            grads + L.w_off[net][l], grads + L.b_off[net][l]);
         if (l > 0) {
             float* nd = g.dz[(l & 1)];
-            // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2): one launch on the matrix cores, two with the library
-            if (g.gemm_backend == GEN_GEMM_MFMA) {
-                if (g.use_planes && g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
-                const hipError_t e = launch_matmul(false, true, rows, K, N, d, N, params + L.w_off[net][l], K, nd, K, PPO_MM_EPI_DTANH, g.acts[net][l - 1], K,
-                                                   g.gemm_prec, 1, 0, nullptr, 0, g.use_planes ? g.wplanes + g.wp_off[net][l] : nullptr, (int64_t)g.wp_npad[net][l] * g.wp_kpad[l],
-                                                   g.wp_kpad[l], s);
-                if (e != hipSuccess) return e;
-            } else {
-                RBCHK(rb::sgemm(g.blas, rb::OP_N, rb::OP_N, K, (int)rows, N, &one, params + L.w_off[net][l], K, d, N, &zero, nd, K));
-                hipLaunchKernelGGL(dtanh_kernel, dim3(grid_for(rows * K, 256)), dim3(256), 0, s, nd, g.acts[net][l - 1], rows * K);
-            }
+            // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2): one launch
+            const hipError_t e = launch_matmul(false, true, rows, K, N, d, N, params + L.w_off[net][l], K, nd, K, PPO_MM_EPI_DTANH, g.acts[net][l - 1], K,
+                                               g.gemm_prec, 1, 0, nullptr, 0, g.wplanes + g.wp_off[net][l], (int64_t)g.wp_npad[net][l] * g.wp_kpad[l],
+                                               g.wp_kpad[l], s);
+            if (e != hipSuccess) return e;
             d = nd;
         }
     }

@@ -653,14 +653,11 @@ __global__ void categorical_sample_kernel(const float* __restrict__ probs, int64
 // ---------------------------------------------------------------------------------------------------------
 hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.N), block(64);
-    static const bool two_per_wave = [] { const char* e = getenv("PPO_ROLLOUT_2PW"); return !(e && e[0] == '0'); }();
     const dim3 grid2((unsigned)((a.N + 1) / 2));
 #define PPO_LAUNCH_ROLLOUT(ENV, DIST, OBS)                                                                       \
     do {                                                                                                         \
-        if (two_per_wave && a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 2>), grid2, block, 0, s, a);      \
-        else if (two_per_wave && a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 3>), grid2, block, 0, s, a); \
-        else if (a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 2>), grid, block, 0, s, a);      \
-        else if (a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 3>), grid, block, 0, s, a); \
+        if (a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 2>), grid2, block, 0, s, a);      \
+        else if (a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 3>), grid2, block, 0, s, a); \
         else if (a.L.act <= 4) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 0>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, PPO_MAX_ACT, 0>), grid, block, 0, s, a);         \
     } while (0)

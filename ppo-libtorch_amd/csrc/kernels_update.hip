@@ -111,7 +111,7 @@ __device__ __forceinline__ void fwd_bwd_body(const UpdateArgs& a, float* smem) {
         const double mean = t1 / a.global_M;
         const double var = (t2 - t1 * mean) / (a.global_M - 1.0);
         mean_f = (float)mean;
-        std_f = (float)sqrt(var > 0.0 ? var : 0.0);
+        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
     }
     __syncthreads();
 
@@ -754,6 +754,59 @@ __global__ void permutation_kernel(int32_t* perm, int64_t B, int E, int64_t seed
     perm[(size_t)e * B + i] = (int32_t)x;
 }
 
+// permutation_kernel and adv_stats_kernel in ONE pass over the update's E x B index space: a workgroup forms its slice of one minibatch's
+// permutation (same bijection, same keys), stores it, and sums the advantages it selects -- the indices never make a round trip
+// through memory between the two.  Grid (minibatch of the update, part), as adv_stats_kernel.
+__global__ __launch_bounds__(256) void perm_adv_stats_kernel(const float* __restrict__ adv, int32_t* __restrict__ perm, int64_t B, int64_t MB,
+                                                             int n_mb_per_epoch, int64_t seed, int64_t update_index, int64_t rank_salt,
+                                                             AdvStat* out) {
+    __shared__ double r1[4], r2[4];
+    __shared__ uint4 s_key;
+    const int mb = blockIdx.x, part = blockIdx.y;
+    const int e = mb / n_mb_per_epoch, m = mb % n_mb_per_epoch;
+    if (threadIdx.x == 0) s_key = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)update_index, (uint32_t)e, (uint32_t)rank_salt, 2u);
+    int bits = 1;
+    while ((1ll << bits) < B) bits++;
+    const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    __syncthreads();
+    const uint4 k = s_key;
+    const int64_t start = (int64_t)m * MB;
+    const int64_t end = start + MB < B ? start + MB : B;
+    const int64_t len = end - start;
+    const int64_t p0 = start + (len * part) / PPO_ADV_PARTS, p1 = start + (len * (part + 1)) / PPO_ADV_PARTS;
+    int32_t* idx = perm + (size_t)e * B;
+    double s1 = 0.0, s2 = 0.0;
+    int64_t j = p0 + threadIdx.x;
+    for (; j + 7 * 256 < p1; j += 8 * 256) {
+        uint32_t x[8];
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            x[i] = (uint32_t)(j + i * 256);
+            do { x[i] = mix_bits(x[i], mask, bits, k); } while (x[i] >= (uint64_t)B);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = adv[x[i]];
+#pragma unroll
+        for (int i = 0; i < 8; i++) idx[j + i * 256] = (int32_t)x[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const double t = v[i]; s1 += t; s2 += t * t; }
+    }
+    for (; j < p1; j += 256) {
+        uint32_t x = (uint32_t)j;
+        do { x = mix_bits(x, mask, bits, k); } while (x >= (uint64_t)B);
+        idx[j] = (int32_t)x;
+        const double t = adv[x]; s1 += t; s2 += t * t;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[mb * PPO_ADV_PARTS + part].s1 = ((r1[0] + r1[1]) + r1[2]) + r1[3];
+        out[mb * PPO_ADV_PARTS + part].s2 = ((r2[0] + r2[1]) + r2[2]) + r2[3];
+    }
+}
+
 // In-process all-reduce: out[i] = bufs[0][i] + bufs[1][i] + ... (rank order), written back to every rank's buffer.
 struct PtrPack8 { void* p[8]; };
 template <class Tp>
@@ -850,25 +903,6 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_reduce_grads_sumsq(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
-                                     double* sums_out, double* partial, hipStream_t s) {
-    FusedOptArgs a{};
-    a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out; a.partial = partial;
-    hipLaunchKernelGGL(reduce_grads_sumsq_kernel, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
-    return hipGetLastError();
-}
-hipError_t launch_clip_adamw_sumsq(const NetLayout& L, const float* grads, const double* sums, const float* p_src, const float* m_src,
-                                   const float* v_src, float* p_dst, float* m_dst, float* v_dst, float max_grad_norm, const AdamCoef* coef,
-                                   double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum, const double* partial, hipStream_t s) {
-    FusedOptArgs a{};
-    a.L = L; a.grads = const_cast<float*>(grads); a.sums_out = const_cast<double*>(sums);
-    a.p_src = p_src; a.m_src = m_src; a.v_src = v_src; a.params = p_dst; a.exp_avg = m_dst; a.exp_avg_sq = v_dst;
-    a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M; a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum;
-    a.partial = const_cast<double*>(partial);
-    hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
-    return hipGetLastError();
-}
-
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s) {
     const int per_epoch = (int)((B + MB - 1) / MB);
@@ -878,6 +912,13 @@ hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_
 
 hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s) {
     hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)E), dim3(256), 0, s, perm, B, E, seed, update_index, rank_salt);
+    return hipGetLastError();
+}
+
+hipError_t launch_permutations_adv_stats(const float* advantages, int32_t* perm, int64_t B, int E, int64_t MB, int64_t seed, int64_t update_index,
+                                         int64_t rank_salt, AdvStat* out, hipStream_t s) {
+    const int per_epoch = (int)((B + MB - 1) / MB);
+    hipLaunchKernelGGL(perm_adv_stats_kernel, dim3(E * per_epoch, PPO_ADV_PARTS), dim3(256), 0, s, advantages, perm, B, MB, per_epoch, seed, update_index, rank_salt, out);
     return hipGetLastError();
 }
 

@@ -457,27 +457,8 @@ hipError_t launch_gae(const float* rewards, const float* values, const float* do
 hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
                         const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s);
 
-// An optimizer step whose clip + AdamW is applied by the NEXT update kernel while it loads its weights (single-rank fused loop, api.hip:
-// ppo_update): every workgroup forms the updated weights of its net for its own use, workgroup 0 of each net also writes the new
-// parameters and moments to the other set of buffers (p/m/v_dst != _src: no workgroup reads what another writes).
-struct DeferredOpt {
-    int pending;
-    const float* grads;                                          // reduced gradient of that step (reduce_grads_sumsq_kernel)
-    const float* p_src; const float* m_src; const float* v_src;  // state before the step
-    float* p_dst; float* m_dst; float* v_dst;                    // state after it
-    const AdamCoef* coef;
-    const double* partial;                                       // [reduce workgroups][12] sums of squares of the gradient
-    float max_norm;
-    const double* sums;                                          // loss sums of that step
-    double global_M;
-    LossParams hp;
-    StepStats* stats_out;
-    double* clipfrac_accum;
-};
-
 struct UpdateArgs {
     const float* params;
-    DeferredOpt opt;
     NetLayout L;
     LossParams hp;
     // flattened batch views [B,...]
@@ -488,6 +469,8 @@ struct UpdateArgs {
     const float* advantages;
     const float* returns;
     const float* values;
+    const float* rec_critic; // [B][8] packed sample records of the matrix-core kernel (launch_pack_records); the vector kernel reads the views above
+    const float* rec_actor;  // [B][8]
     const int32_t* idx;      // [M]
     int M;                   // local minibatch rows
     double inv_global_M;     // 1 / (rows of the global minibatch)
@@ -500,10 +483,13 @@ struct UpdateArgs {
 };
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
-// matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}.  prec 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
-// prec 1: fp32 carried as three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product (fp32 accuracy)
-void update_blocks_mfma(int M, double actor_share, int prec, int n_blocks[2]);
-hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, int prec, hipStream_t s);
+// matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}: fp32 carried as three bf16 terms, six
+// v_mfma_f32_32x32x16_bf16 products per fp32 product (fp32 accuracy).  Gathers from the packed records.
+void update_blocks_mfma(int M, int n_blocks[2]);
+hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
+hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
+                               const float* advantages, const float* returns, const float* values, int64_t B, float* rec_critic, float* rec_actor,
+                               double* ev_sums, hipStream_t s);
 // grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s);
@@ -519,14 +505,6 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
                                     double* partial, hipStream_t s);
-// the two halves on their own: the reduction (gradient, loss sums, per-workgroup sums of squares), and clip + AdamW reading the state at
-// p/m/v_src and writing it at p/m/v_dst (equal pointers: in place)
-hipError_t launch_reduce_grads_sumsq(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
-                                     double* sums_out, double* partial, hipStream_t s);
-hipError_t launch_clip_adamw_sumsq(const NetLayout& L, const float* grads, const double* sums, const float* p_src, const float* m_src,
-                                   const float* v_src, float* p_dst, float* m_dst, float* v_dst, float max_grad_norm, const AdamCoef* coef,
-                                   double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum, const double* partial, hipStream_t s);
-
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
 struct EpisodeRing {
     float rew[100];
@@ -539,5 +517,8 @@ hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_r
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s);
 hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s);
+// the two above in one pass (ppo_update with norm_adv): perm[e][j] and the advantage sums of every minibatch of the update
+hipError_t launch_permutations_adv_stats(const float* advantages, int32_t* perm, int64_t B, int E, int64_t MB, int64_t seed, int64_t update_index,
+                                         int64_t rank_salt, AdvStat* out, hipStream_t s);
 hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s);
 hipError_t launch_orthogonal_init(float* params, const NetLayout& L, int64_t seed, hipStream_t s);

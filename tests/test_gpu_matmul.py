@@ -85,12 +85,12 @@ def test_matmul_epilogues(P, ctx):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
-def test_matmul_double_buffered_variant(P, ctx, monkeypatch, ta, tb):
-    """Both main loops of the layer product on the same shapes (kernels_gemm.hip picks one by batch size and precision; PPO_GEMM_DB forces
-    it): the eight-wave double-buffered one and the two-workgroups-per-CU one give results within the same bound -- shapes with an odd
-    number of chunk pairs, ragged edges, and a contraction shorter than the prefetch distance."""
-    monkeypatch.setenv("PPO_GEMM_DB", "1")
-    for M, N, K in [(300, 256, 376), (256, 256, 256), (130, 130, 40), (512, 384, 1000)]:
+def test_matmul_both_main_loops(P, ctx, ta, tb):
+    """Both main loops of the layer product (kernels_gemm.hip picks one by batch size and precision): the eight-wave double-buffered
+    one (up to 8192 rows, and every plain-bf16 product) and the two-workgroups-per-CU one (larger fp32-accurate products) give results
+    within the same bound -- shapes with an odd number of chunk pairs, ragged edges, a contraction shorter than the prefetch distance,
+    and one shape on the far side of the row threshold."""
+    for M, N, K in [(300, 256, 376), (256, 256, 256), (130, 130, 40), (512, 384, 1000), (8200, 256, 136)]:
         rng = np.random.default_rng(M + N + K)
         A = rng.standard_normal((M, K)).astype(np.float32)
         B = (rng.standard_normal((N, K)) * 0.3).astype(np.float32)
@@ -100,10 +100,6 @@ def test_matmul_double_buffered_variant(P, ctx, monkeypatch, ta, tb):
         ref = A.astype(np.float64) @ B.astype(np.float64).T
         bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
         assert np.all(np.abs(c - ref) <= 2e-6 * bound + 1e-30), (M, N, K)
-        monkeypatch.setenv("PPO_GEMM_DB", "0")
-        c0 = P.binding.matmul(ctx, a, b, ta, tb)
-        monkeypatch.setenv("PPO_GEMM_DB", "1")
-        assert np.all(np.abs(c0 - ref) <= 2e-6 * bound + 1e-30), (M, N, K)
 
 
 def test_matmul_degenerate_sizes_and_bad_arguments(P, ctx):
