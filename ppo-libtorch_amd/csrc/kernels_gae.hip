@@ -16,8 +16,11 @@
 //   (iv) all threads then stream A_t and R_t = A_t + v_t to HBM with coalesced 16-byte stores.
 // A done flag cuts the chain (c_t = 0 => A_t = delta_t exactly): that is the "segmented" part; it needs no special
 // handling in the serial walk and costs nothing.
-// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done).  v_{t+1} is read
-// a second time by the thread that forms delta_t, but that row is being loaded as v_t by a neighbour: an L1/L2 hit.
+// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done).  v_{t+1} and
+// dones_{t+1} are requested a second time by the thread that forms delta_t while a neighbour's request for the same row (as its v_t) is
+// still in flight, so the memory side sees ~1.6x the algorithmic reads (PMC).  Fetching every row once and handing row t + 1 over through
+// LDS (one more barrier and LDS pass before the walk) was built and measured in round 2, A/B in one call: SLOWER at every size (4 096 envs
+// 5.6 against 4.9 us, 8 192: 6.9 against 6.3, 32 768: 21.2 against 18.7) -- the duplicate requests are cheaper than the extra phase.
 #include <cstdlib>
 
 #include "ppo_internal.hpp"
