@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec (rollout + GAE + update) of the MI355X-native PPO hot path, BASELINE.json's metric.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload cartpole|mountaincar|config4]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
 
 A "step" is one pass of the hot path over one batch: one iteration of PPO_Discrete::train()'s loop (reference
 PPO/PPO_Discrete.cpp:511-659) = rollout of num_steps x num_envs env-steps, GAE scan, update_epochs x num_minibatches optimizer
-steps.  Workload at N = 1: BASELINE.json configs[1] (CartPole-v1, 4096 envs x 128 steps, 2x64 MLP, 4 minibatches x 10 epochs,
-hyper-parameters of the reference's CartPoleRecommendedSettings.toml with action_size = 2).  N > 1: every rank owns 4096 envs
-(weak scaling, configs[2] at N = 8) and ONE RCCL all-reduce of the flat gradient per optimizer step crosses xGMI.
+steps.  Default workload (the one BASELINE.json's metric is quoted on): configs[1] at N = 1 (CartPole-v1, 4096 envs x 128 steps,
+2x64 MLP, 4 minibatches x 10 epochs, hyper-parameters of the reference's CartPoleRecommendedSettings.toml with action_size = 2);
+N > 1: every rank owns 4096 envs (weak scaling, configs[2] at N = 8) and ONE gradient all-reduce per optimizer step crosses xGMI.
+--workload mountaincar = configs[3] (8192 envs, CategoricalMasked); --workload config4 = one GPU's share of configs[4] (synthetic env,
+obs 376, heads [3,3,3,2], 4x256 MLP, bf16 MFMA GEMMs, 2048 envs per GPU).
 value = env-steps of all ranks / max-over-ranks wall time of the K timed steps; the reference prints the same quantity as `fps`
 (PPO_Discrete.cpp:650-652,718).  Everything is resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (fused gather+forward+loss+backward): algorithmic FLOPs per launch / its average launch
                 duration measured with HIP events on the kernel's own stream inside the timed region
-  gae_roofline  the GAE scan (the kernel BASELINE.json's HBM-roofline target names), algorithmic bytes / event time
+  gae_roofline  the GAE scan (the kernel BASELINE.json's HBM-roofline target names), algorithmic bytes / time, at this workload's size
+                and back to back at 4096 / 8192 / 32768 envs, beside the committed rocprofv3 kernel time and the floor probe
   cpu_baseline  the reference's own CPU ThreadPool path (oracle/_ref/ref_harness = the unmodified reference compiled against
                 LibTorch CPU) timed on this host, or the C port when that binary is absent -- a reported baseline
 """
 import argparse
+import csv
+import glob
 import json
 import os
 import re
@@ -35,52 +40,93 @@ BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
 HBM_PEAK_GBS = 8000.0     # HBM3E spec peak
 
 
-def flops_per_sample(obs, act):
+def flops_per_sample(obs, act, hidden=64, n_hidden=2):
     """Algorithmic FLOPs of forward + backward of both MLPs for one sample (2 FLOP per MAC; backward = 2 x forward)."""
     macs = 0
     for out in (1, act):
-        macs += obs * 64 + 64 * 64 + 64 * out
+        macs += obs * hidden + (n_hidden - 1) * hidden * hidden + hidden * out
     return 3 * 2 * macs
 
 
+def newest_profile(suffix):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
+    return files[-1] if files else None
+
+
 def pmc_traffic(prefix):
-    """HBM bytes per launch of the kernel whose name starts with `prefix`, from the newest committed rocprofv3 --pmc summary
-    (profiles/*_pmc_per_dispatch.json, written by tools/collect_profiles.sh: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate
-    passes).  Counters cannot be read from inside the timed run, so this is the committed measurement of the same command, or None."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_dispatch.json")))
-    if not files:
+    """HBM-side bytes per launch of the kernel whose name starts with `prefix`, from the newest committed rocprofv3 --pmc summary
+    (profiles/*_pmc_per_dispatch.json, written by tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate passes, corrected
+    as MI355X_MICROARCH.md prescribes -- see tools/pmc_summary.py).  Counters cannot be read from inside the timed run, so this is the
+    committed measurement of the same command, or None."""
+    f = newest_profile("_pmc_per_dispatch.json")
+    if not f:
         return None
     try:
-        with open(files[-1]) as fh:
+        with open(f) as fh:
             d = json.load(fh)
         for k, v in d.items():
             if k.startswith(prefix) and "hbm_read_bytes" in v and "hbm_write_bytes" in v:
                 return {"bytes": v["hbm_read_bytes"] + v["hbm_write_bytes"], "read": v["hbm_read_bytes"], "write": v["hbm_write_bytes"],
-                        "source": "profiles/" + os.path.basename(files[-1])}
+                        "source": "profiles/" + os.path.basename(f)}
     except Exception:
         return None
     return None
 
 
-def cpu_baseline(num_envs, num_steps, obs, act):
+def rocprof_kernel_us(prefix):
+    """Average in-trace duration (us) of a kernel from the newest committed rocprofv3 --kernel-trace --stats summary."""
+    f = newest_profile("_kernel_stats.csv")
+    if not f:
+        return None
+    try:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if prefix in row["Name"]:
+                    return {"avg_us": float(row["AverageNs"]) / 1e3, "calls": int(row["Calls"]), "source": "profiles/" + os.path.basename(f)}
+    except Exception:
+        return None
+    return None
+
+
+def committed_jsonl(suffix):
+    f = newest_profile(suffix)
+    if not f:
+        return None
+    try:
+        with open(f) as fh:
+            return {"rows": [json.loads(l) for l in fh if l.strip().startswith("{")], "source": "profiles/" + os.path.basename(f)}
+    except Exception:
+        return None
+
+
+def run_reference(num_envs, num_steps, updates, timeout=900):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    cores = os.cpu_count() or 1
-    if os.path.exists(ref):
-        try:
-            # bounded sample (~20 s on the GPU box's host cores): one full update iteration on a quarter of the envs; env-steps/s of the
-            # reference's ThreadPool path is per-env-step work, so the rate carries to the full workload (measured 7.0k at 4096 envs x 2)
-            updates = 1
-            num_envs = min(num_envs, 1024)
-            out = subprocess.run([ref, "bench", str(num_envs), str(num_steps), str(updates)], capture_output=True, text=True, timeout=900).stdout
-            m = re.search(r"REF_BENCH (\{.*\})", out)
-            if m:
-                r = json.loads(m.group(1))
-                return {"value": r["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(r["threads"]), "kind": "reference",
-                        "sample": "%d full update iteration(s) (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch "
-                                  "CPU, ThreadPool(hardware_concurrency), %d envs x %d steps" % (updates, num_envs, num_steps)}
-        except Exception as ex:  # fall through to the port
-            sys.stderr.write("reference harness failed: %r\n" % (ex,))
+    if not os.path.exists(ref):
+        return None
+    try:
+        out = subprocess.run([ref, "bench", str(num_envs), str(num_steps), str(updates)], capture_output=True, text=True, timeout=timeout).stdout
+        m = re.search(r"REF_BENCH (\{.*\})", out)
+        return json.loads(m.group(1)) if m else None
+    except Exception as ex:
+        sys.stderr.write("reference harness failed: %r\n" % (ex,))
+        return None
+
+
+def cpu_baseline(num_envs, num_steps, obs, act):
+    # bounded sample (~15 s on the GPU box's host cores): ONE full update iteration of the headline workload on a quarter of its envs
+    # (1024 of 4096); the ThreadPool path's cost is per env-step, so the rate carries to the full workload (measured 7.0k at 4096 x 2)
+    sample_envs = min(num_envs, 1024)
+    r = run_reference(sample_envs, num_steps, 1)
+    if r:
+        out = {"value": r["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(r["threads"]), "kind": "reference",
+               "sample": "1 full update iteration (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch CPU, "
+                         "ThreadPool(hardware_concurrency), %d envs x %d steps (the headline workload has %d envs: bounded sample)" % (sample_envs, num_steps, num_envs)}
+        # BASELINE.json configs[0]: the reference's own CPU-runnable case, 8 envs x 128 steps
+        c1 = run_reference(8, 128, 20)
+        if c1:
+            out["configs0"] = {"value": c1["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(c1["threads"]),
+                               "workload": "BASELINE.json configs[0]: CartPole-v1, PPO_Discrete, 8 envs x 128 steps, 20 update iterations, reference CPU ThreadPool path"}
+        return out
     # C port (scalar, single thread): one rollout of a bounded env count + one minibatch of the update, scaled per env-step
     import numpy as np
     import oracle as O
@@ -106,18 +152,31 @@ def cpu_baseline(num_envs, num_steps, obs, act):
             "sample": "scalar C restatement, 1 thread: %d envs x %d steps rollout + 10 epochs of forward/backward over that batch" % (n, num_steps)}
 
 
+WORKLOADS = {
+    # name: (BASELINE.json configs index at N = 1, at N = 8)
+    "cartpole": dict(envs=4096, obs=4, heads=(2,), hidden=64, n_hidden=2, max_steps=500, cfg1=1, cfg8=2,
+                     label="CartPole-v1 PPO_Discrete, %d envs x %d steps per GPU, 2x64 MLP, 4 minibatches x 10 epochs"),
+    "mountaincar": dict(envs=8192, obs=2, heads=(3,), hidden=64, n_hidden=2, max_steps=200, cfg1=3, cfg8=3,
+                        label="MountainCar PPO_MultiDiscrete (CategoricalMasked), %d envs x %d steps per GPU, 2x64 MLP, 4 minibatches x 10 epochs"),
+    "config4": dict(envs=2048, obs=376, heads=(3, 3, 3, 2), hidden=256, n_hidden=4, max_steps=1000, cfg1=4, cfg8=4,
+                    label="PPO_MultiDiscrete synthetic env obs 376 heads [3,3,3,2], %d envs x %d steps per GPU (16384 / 8), 4x256 MLP bf16 MFMA GEMMs, 4 minibatches x 10 epochs"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cartpole")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-selftest", action="store_true", help="N = 1 only: drive the multi-rank code path (RCCL all-reduces over a one-rank communicator, "
                     "three-kernel optimizer step) to see its per-step cost on one GPU; not a valid headline number")
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel + GAE")
     args = ap.parse_args()
+    W = WORKLOADS[args.workload]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -132,13 +191,16 @@ def main():
     dist = None
     if world > 1:
         dist, rank, world = P.dist.init_process_group("gloo")  # plumbing only: rendezvous, id broadcast, barrier, max over ranks
-    obs, act = 4, 2
-    N, T = args.envs, args.num_steps
+    obs, heads = W["obs"], W["heads"]
+    act = sum(heads)
+    N, T = args.envs or W["envs"], args.num_steps
     total_updates = args.steps + args.warmup
-    cfg = P.dist.shard_config(P.make_config, rank, world, N * world, env_kind=P.ENV_CARTPOLE, dist_kind=P.DIST_CATEGORICAL, obs_size=obs,
-                              head_dims=(act,), num_steps=T, num_minibatches=4, update_epochs=10, max_episode_steps=500, seed=2,
-                              total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98, gae_lambda=0.95, clip_coef=0.2,
-                              ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank)
+    kind = dict(cartpole=(P.ENV_CARTPOLE, P.DIST_CATEGORICAL), mountaincar=(P.ENV_MOUNTAINCAR, P.DIST_MASKED), config4=(P.ENV_SYNTHETIC, P.DIST_MASKED))[args.workload]
+    cfg = P.dist.shard_config(P.make_config, rank, world, N * world, env_kind=kind[0], dist_kind=kind[1], obs_size=obs,
+                              head_dims=heads, hidden=W["hidden"], n_hidden=W["n_hidden"], num_steps=T, num_minibatches=4, update_epochs=10,
+                              max_episode_steps=W["max_steps"], seed=2, total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98,
+                              gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank,
+                              compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32)
     ctx = P.Context(cfg)
     if args.comm_selftest and world == 1:
         os.environ["PPO_COMM_SELFTEST"] = "1"
@@ -165,62 +227,97 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile_enable(0)
-    # GAE scan back to back on the context's own buffers, outside the timed region (same inputs -> same outputs): the kernel's time without
-    # the ~3 us an event pair adds to a 5 us launch and without a foreign kernel in front of it (kernel-only time)
-    class _Ptr:
-        def __init__(self, p):
-            self.ptr = p
-    gb = [_Ptr(ctx.buffer_ptr(n)[0]) for n in ("REWARDS", "VALUES", "DONES", "NEXT_VALUE", "NEXT_DONE", "ADVANTAGES", "RETURNS")]
-    reps = 200
-    for _ in range(3):
-        P.gae_launch(ctx, gb[0], gb[1], gb[2], gb[3], gb[4], args.num_steps, args.envs, 0.98, 0.95, gb[5], gb[6])
-    ctx.sync()
-    tg = time.perf_counter()
-    for _ in range(reps):
-        P.gae_launch(ctx, gb[0], gb[1], gb[2], gb[3], gb[4], args.num_steps, args.envs, 0.98, 0.95, gb[5], gb[6])
-    ctx.sync()
-    gae_b2b_ms = 1e3 * (time.perf_counter() - tg) / reps
     if dist is not None:
         dt = P.dist.max_over_ranks(dist, dt)
     st = ctx.stats()
 
+    # GAE scan back to back, outside the timed region: on the context's own buffers (this workload's size) and on fresh buffers of the three
+    # sizes the roofline is quoted at -- wall time of 200 launches / 200: no event pair (~3 us on a 5 us launch), no foreign kernel in front
+    def gae_b2b(n_envs, bufs=None):
+        import numpy as np
+        if bufs is None:
+            rng = np.random.default_rng(n_envs)
+            bufs = [ctx.dev(np.where(rng.random((T, n_envs), dtype=np.float32) < 0.05, -1.0, 1.0).astype(np.float32)),
+                    ctx.dev(rng.standard_normal((T, n_envs), dtype=np.float32)), ctx.dev((rng.random((T, n_envs), dtype=np.float32) < 0.05).astype(np.float32)),
+                    ctx.dev(rng.standard_normal(n_envs, dtype=np.float32)), ctx.dev((rng.random(n_envs) < 0.05).astype(np.int32)),
+                    ctx.empty((T, n_envs), np.float32), ctx.empty((T, n_envs), np.float32)]
+        reps = 200
+        for _ in range(3):
+            P.gae_launch(ctx, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], T, n_envs, 0.98, 0.95, bufs[5], bufs[6])
+        ctx.sync()
+        tg = time.perf_counter()
+        for _ in range(reps):
+            P.gae_launch(ctx, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], T, n_envs, 0.98, 0.95, bufs[5], bufs[6])
+        ctx.sync()
+        ms = 1e3 * (time.perf_counter() - tg) / reps
+        nbytes = 20 * n_envs * T + 8 * n_envs
+        return {"envs": n_envs, "bytes_per_launch": nbytes, "avg_launch_ms": ms, "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    class _Ptr:
+        def __init__(self, p):
+            self.ptr = p
+    gae_rows = []
+    if rank == 0:
+        own = [_Ptr(ctx.buffer_ptr(n)[0]) for n in ("REWARDS", "VALUES", "DONES", "NEXT_VALUE", "NEXT_DONE", "ADVANTAGES", "RETURNS")]
+        gae_own = gae_b2b(N, own)
+        gae_rows = [gae_b2b(n) for n in (4096, 8192, 32768)]
+
     if rank == 0:
         env_steps = args.steps * N * T * world
         M = (N * T) // 4
-        fl = flops_per_sample(obs, act) * M
-        bf16_fl = 2 * ((M + 31) // 32) * 144 * (2 * 32 * 32 * 16)
-        fb_ms = prof["fwd_bwd_ms"] / max(prof["fwd_bwd_launches"], 1) or float("nan")
-        gae_ms = prof["gae_ms"] / max(prof["gae_launches"], 1) or float("nan")
+        fl = flops_per_sample(obs, act, W["hidden"], W["n_hidden"]) * M
+
+        def per_launch(kind_):
+            n = prof[kind_ + "_launches"]
+            return prof[kind_ + "_ms"] / n if n > 0 else None
+        fb_ms, gae_ms = per_launch("fwd_bwd"), per_launch("gae")
         gae_bytes = 20 * N * T + 8 * N
-        fb_tr, gae_tr = pmc_traffic("fwd_bwd_mfma_kernel"), pmc_traffic("gae_kernel")
+        generic = args.workload == "config4"
+        fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma_kernel"
+        fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, pmc_traffic("gae_kernel") if args.workload == "cartpole" else None
+        if generic:
+            roof = {"kernel": "one minibatch step of the generic path (gather, 10 forward + 18 backward layer products on gemm_kernel with fused bias / tanh / tanh' / "
+                              "bias-gradient epilogues, heads + PPO loss): bf16 operands and activations, f32 accumulation", "bound": "mfma",
+                    "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None, "traffic": None}
+        else:
+            bf16_fl = 2 * ((M + 31) // 32) * 144 * (2 * 32 * 32 * 16)
+            roof = {"kernel": "fwd_bwd_mfma_kernel (gather+forward+PPO loss+backward; fp32 via 3-term bf16 splits)", "bound": "mfma",
+                    "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if fb_ms else None,
+                    "traffic": (fb_tr or {}).get("bytes"), "traffic_detail": fb_tr,
+                    # what the matrix cores actually execute: per 32-sample tile and net 144 v_mfma_f32_32x32x16_bf16 (fp32 products as
+                    # six bf16 products over exact three-term splits) -- reported beside the algorithmic fp32 rate
+                    "executed": {"unit": "TFLOP/s bf16", "achieved": bf16_fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS,
+                                 "frac": bf16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None},
+                    "rocprof": rocprof_kernel_us("fwd_bwd_mfma_kernel") if args.workload == "cartpole" else None}
+        roof.update({"flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
+                     "sampling": "HIP events on the context's stream around 1 launch in 8 (--profile 2), every launch with --profile 1"})
+        phases = {"rollout": "rollout", "gae": "gae", "grad_reduce": "reduce", "clip_adamw": "optimizer"}
         out = {
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (fixed-seed CartPole-v1, random-init 2x64 actor/critic)",
-            "config": {"workload": "CartPole-v1 PPO_Discrete, %d envs x %d steps per GPU, 2x64 MLP, 4 minibatches x 10 epochs (BASELINE.json configs[%d])"
-                                   % (N, T, 1 if world == 1 else 2), "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
-                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 RCCL grad all-reduce per optimizer step)" % world + (" [comm self-test]" if args.comm_selftest else "")},
-            "roofline": {"kernel": "fwd_bwd_mfma_kernel (gather+forward+PPO loss+backward; fp32 via 3-term bf16 splits)", "bound": "mfma", "achieved": fl / (fb_ms * 1e-3) / 1e12,
-                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS,
-                         "traffic": (fb_tr or {}).get("bytes"), "traffic_detail": fb_tr,
-                         "flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
-                         "sampling": "HIP events around 1 launch in 8 (--profile 2), every launch with --profile 1",
-                         # what the matrix cores actually execute: per 32-sample tile and net 144 v_mfma_f32_32x32x16_bf16 (fp32 products as
-                         # six bf16 products over exact three-term splits) -- reported beside the algorithmic fp32 rate
-                         "executed": {"unit": "TFLOP/s bf16", "achieved": bf16_fl / (fb_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS,
-                                      "frac": bf16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS}},
-            "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_bytes / (gae_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if generic else "f32",
+            "data": "synthetic (counter-based env, random-init 4x256 actor/critic)" if generic else "synthetic (fixed-seed %s, random-init 2x64 actor/critic)" % ("CartPole-v1" if args.workload == "cartpole" else "MountainCar"),
+            "config": {"workload": (W["label"] % (N, T)) + " (BASELINE.json configs[%d]%s)" % (W["cfg1"] if world == 1 else W["cfg8"], ", one GPU's share" if generic and world == 1 else ""),
+                       "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
+                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 gradient all-reduce per optimizer step)" % world + (" [comm self-test]" if args.comm_selftest else "")},
+            "roofline": roof,
+            "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_bytes / (gae_ms * 1e-3) / 1e9 if gae_ms else None, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gae_ms else None,
                              "traffic": (gae_tr or {}).get("bytes"), "traffic_detail": gae_tr, "bytes_per_launch": gae_bytes,
                              "avg_launch_ms": gae_ms, "launches": prof["gae_launches"],
-                             "back_to_back": {"avg_launch_ms": gae_b2b_ms, "launches": reps, "achieved": gae_bytes / (gae_b2b_ms * 1e-3) / 1e9,
-                                              "frac": gae_bytes / (gae_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                              "note": "same kernel, same buffers, 200 launches in a row after the timed region (wall time / 200): no event pair, no foreign kernel in front"}},
-            "phase_ms_per_step": {"rollout": prof["rollout_ms"] / args.steps, "gae": prof["gae_ms"] / args.steps, "fwd_bwd": 40 * fb_ms,
-                                  "grad_reduce": prof["reduce_ms"] / args.steps, "clip_adamw": prof["optimizer_ms"] / args.steps},
+                             "timing": "HIP events around the launch inside the iteration (an event pair adds ~3 us to a ~5 us launch); kernel-only numbers follow",
+                             "back_to_back": dict(gae_own, note="same kernel, this workload's buffers, 200 launches in a row after the timed region (wall time / 200)"),
+                             "back_to_back_sizes": gae_rows,
+                             "rocprof": rocprof_kernel_us("gae_kernel<16") if args.workload == "cartpole" else None,
+                             "floor_probe": committed_jsonl("_gae_floor.jsonl")},
+            # HIP-event time per iteration of the phases that were bracketed (--profile 1 brackets all of them); null = not sampled in this run
+            "phase_ms_per_step": dict({k: (prof[v + "_ms"] / args.steps if prof[v + "_launches"] > 0 else None) for k, v in phases.items()},
+                                      fwd_bwd=40 * fb_ms if fb_ms else None),
             "train_stats": {k: st[k] for k in ("loss", "ep_len_mean", "ep_rew_mean", "explained_variance", "global_step")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cartpole":
             out["cpu_baseline"] = cpu_baseline(N, T, obs, act)
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -239,7 +239,7 @@ class Context:
         _check(lib().ppo_params_init_orthogonal(self.h, C.c_int64(seed)), self.h)
 
     def param_shapes(self):
-        shapes = np.empty((12, 2), np.int64)
+        shapes = np.empty((32, 2), np.int64)   # up to 2 nets x 8 layers x {weight, bias}
         n = C.c_int32()
         _check(lib().ppo_param_shapes(self.h, shapes.ctypes.data_as(C.c_void_p), C.byref(n)), self.h)
         return shapes[:n.value]

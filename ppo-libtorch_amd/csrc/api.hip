@@ -1264,6 +1264,13 @@ extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
     c->prof_every = on == 2 ? 8 : 1;   // mode 2 samples the update kernel: 1 launch in 8 (5 of an update's 40), every GAE launch
     c->prof_count = 0;
     c->stamping = on == 3;
+    if (c->profiling) {   // events are created here, not inside the region being timed
+        while (c->event_pool.size() < 256) {
+            hipEvent_t e = nullptr;
+            HIPCHK(c, hipEventCreate(&e));
+            c->event_pool.push_back(e);
+        }
+    }
     if (c->stamping) HIPCHK(c, hipMemsetAsync(c->stamps, 0, 24 * sizeof(unsigned long long), c->stream));
     return PPO_OK;
 }

@@ -5,8 +5,13 @@
 
 Kernel names are reduced to the bare function name (template arguments kept).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3
 in KiB; `hbm_read_bytes` applies the gfx950 correction of MI355X_MICROARCH.md "HBM" (wide coalesced reads are tallied at half
-their size: x2), `hbm_write_bytes` is WRITE_SIZE as read.
+their size: x2), `hbm_write_bytes` is WRITE_SIZE as read.  That guide calls other access widths uncalibrated, so the one kernel of this
+build whose reads are a random gather of 32-byte records (fwd_bwd_mfma_kernel) is calibrated with tools/probes/fetch_calib.hip: a
+coalesced 64 MiB stream reports exactly half (x2 confirmed), the gather reports 15.8 MB for 262 144 records that occupy 16.8 MB of
+64-byte sectors (8.4 MB useful) -- one 64-byte request per record, counted at its size -- so gather kernels get x1, and both
+readings are kept in the JSON (`hbm_read_bytes_x1`, `hbm_read_bytes_x2`).
 """
+GATHER_KERNELS = ("fwd_bwd_mfma_kernel", "gather_read")
 import csv
 import glob
 import json
@@ -53,7 +58,9 @@ def main():
             o[c] = tot / n
             o.setdefault("dispatches", n)
         if "FETCH_SIZE" in o:
-            o["hbm_read_bytes"] = o["FETCH_SIZE"] * 1024.0 * 2.0
+            o["hbm_read_bytes_x1"] = o["FETCH_SIZE"] * 1024.0
+            o["hbm_read_bytes_x2"] = o["FETCH_SIZE"] * 1024.0 * 2.0
+            o["hbm_read_bytes"] = o["hbm_read_bytes_x1"] if k.startswith(GATHER_KERNELS) else o["hbm_read_bytes_x2"]
         if "WRITE_SIZE" in o:
             o["hbm_write_bytes"] = o["WRITE_SIZE"] * 1024.0
         res[k] = o
