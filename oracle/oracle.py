@@ -16,6 +16,7 @@ REF_BIN = os.path.join(_HERE, "_ref", "ref_harness")
 
 MAX_HEADS = 8
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
 ENV_CARTPOLE, ENV_MOUNTAINCAR = 0, 1
 
 
@@ -30,12 +31,13 @@ def build(force=False):
 
 class Net(C.Structure):
     _fields_ = [("obs_size", C.c_int32), ("n_heads", C.c_int32), ("head_dims", C.c_int32 * MAX_HEADS),
-                ("hidden", C.c_int32), ("n_hidden", C.c_int32), ("dist_kind", C.c_int32)]
+                ("hidden", C.c_int32), ("n_hidden", C.c_int32), ("dist_kind", C.c_int32), ("dtype", C.c_int32)]
 
     @staticmethod
-    def make(obs_size, head_dims, hidden=64, n_hidden=2, dist_kind=DIST_CATEGORICAL):
+    def make(obs_size, head_dims, hidden=64, n_hidden=2, dist_kind=DIST_CATEGORICAL, dtype=0):
         n = Net()
         n.obs_size, n.n_heads, n.hidden, n.n_hidden, n.dist_kind = obs_size, len(head_dims), hidden, n_hidden, dist_kind
+        n.dtype = dtype
         for i, d in enumerate(head_dims):
             n.head_dims[i] = d
         return n

@@ -357,9 +357,19 @@ void orc_param_shapes(const orc_net* c, int64_t* shapes) {
 
 /* Forward of one net for one sample.  acts (optional) receives the post-tanh activations of every hidden
  * layer, [n_hidden][hidden].  out[layer_out(last)]. */
+/* round to nearest even to bf16, returned as float (NaN stays NaN) */
+static inline float bf16r(float x) {
+    uint32_t u = f2u(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    float r; memcpy(&r, &u, 4); return r;
+}
+static inline float opnd(const orc_net* c, float x) { return c->dtype == ORC_DTYPE_BF16 ? bf16r(x) : x; }
+
 static void mlp_forward1(const orc_net* c, int net, const float* p, const float* x, float* acts, float* out) {
-    float bufA[1024], bufB[1024];
+    float bufA[1024], bufB[1024], bufX[8192];
     const float* in = x;
+    if (c->dtype == ORC_DTYPE_BF16) { for (int k = 0; k < c->obs_size; k++) bufX[k] = bf16r(x[k]); in = bufX; }
     float* cur = bufA;
     for (int l = 0; l <= c->n_hidden; l++) {
         int ni = layer_in(c, l), no = layer_out(c, net, l);
@@ -368,8 +378,8 @@ static void mlp_forward1(const orc_net* c, int net, const float* p, const float*
         float* dst = (l == c->n_hidden) ? out : cur;
         for (int j = 0; j < no; j++) {
             float acc = b[j];
-            for (int k = 0; k < ni; k++) acc += in[k] * W[(size_t)j * ni + k];
-            dst[j] = (l == c->n_hidden) ? acc : tanhf(acc);
+            for (int k = 0; k < ni; k++) acc += in[k] * opnd(c, W[(size_t)j * ni + k]);
+            dst[j] = (l == c->n_hidden) ? acc : opnd(c, tanhf(acc));   /* a hidden activation is stored in the compute dtype */
         }
         if (l < c->n_hidden) {
             if (acts) memcpy(acts + (size_t)l * c->hidden, dst, (size_t)no * sizeof(float));
@@ -545,23 +555,24 @@ static void mlp_backward1(const orc_net* c, int net, const float* p, const float
     size_t off[16];
     size_t o = 0;
     for (int l = 0; l <= c->n_hidden; l++) { off[l] = o; o += (size_t)layer_out(c, net, l) * layer_in(c, l) + layer_out(c, net, l); }
-    float dz[1024], dh[1024];
+    float dz[1024], dh[1024], xq[8192];
     int no = layer_out(c, net, c->n_hidden);
     for (int j = 0; j < no; j++) dz[j] = dout[j];
+    if (c->dtype == ORC_DTYPE_BF16) { for (int k = 0; k < c->obs_size; k++) xq[k] = bf16r(x[k]); x = xq; }
     for (int l = c->n_hidden; l >= 0; l--) {
         int ni = layer_in(c, l);
         no = layer_out(c, net, l);
         const float* W = p + off[l];
         double* gW = g + off[l];
         double* gb = gW + (size_t)no * ni;
-        const float* in = (l == 0) ? x : acts + (size_t)(l - 1) * c->hidden;
+        const float* in = (l == 0) ? x : acts + (size_t)(l - 1) * c->hidden;   /* stored (rounded) activations */
         for (int k = 0; k < ni; k++) dh[k] = 0.0f;
         for (int j = 0; j < no; j++) {
-            float d = dz[j];
-            gb[j] += d;
+            gb[j] += dz[j];                        /* bias gradient: the f32 d(pre-activation) */
+            float d = opnd(c, dz[j]);              /* as an operand of the two products: the compute dtype */
             for (int k = 0; k < ni; k++) {
                 gW[(size_t)j * ni + k] += (double)(d * in[k]);
-                dh[k] += d * W[(size_t)j * ni + k];
+                dh[k] += d * opnd(c, W[(size_t)j * ni + k]);
             }
         }
         if (l > 0)

@@ -25,6 +25,13 @@ extern "C" {
 
 enum { ORC_DIST_CATEGORICAL = 0, ORC_DIST_MASKED = 1 };
 enum { ORC_ENV_CARTPOLE = 0, ORC_ENV_MOUNTAINCAR = 1 };
+/* ORC_DTYPE_F32: the reference's arithmetic.  ORC_DTYPE_BF16: "bf16 with MFMA GEMMs" of BASELINE.json configs[4] (no reference
+ * counterpart: the reference has no reduced-precision mode) -- the mixed-precision scheme the HIP path implements with
+ * ppo_config.compute_dtype = PPO_DTYPE_BF16, restated in scalar C so that it can be checked:
+ *   every operand of a Linear product (weights, layer inputs, back-propagated d(pre-activation)) is rounded to bf16, round to nearest
+ *   even; products are exact and accumulated in f32; biases, tanh, the loss, bias gradients and the optimizer stay f32; a hidden
+ *   activation is STORED as bf16, so tanh' in the backward pass sees the rounded value. */
+enum { ORC_DTYPE_F32 = 0, ORC_DTYPE_BF16 = 1 };
 
 typedef struct orc_net {
     int32_t obs_size;
@@ -33,6 +40,7 @@ typedef struct orc_net {
     int32_t hidden;    /* width of every hidden layer (reference: 64, Agent.cpp:25-32) */
     int32_t n_hidden;  /* number of tanh hidden layers (reference: 2) */
     int32_t dist_kind; /* ORC_DIST_* */
+    int32_t dtype;     /* ORC_DTYPE_*: arithmetic of the Linear layers */
 } orc_net;
 
 typedef struct orc_hparams {

@@ -434,16 +434,35 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     if (c->gen) {
         GenericCtx& g = *c->gen;
         const GenLayout& GL = g.L;
-        g.rows_max = std::max<int64_t>(c->MB, c->N);
+        g.rows_max = (std::max<int64_t>(c->MB, c->N) + 127) / 128 * 128;
         const size_t R = (size_t)g.rows_max;
-        for (int net = 0; net < 2; net++)
-            for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts[net][l], R * GL.hidden));
-        for (int i = 0; i < 2; i++) CK(dalloc(c, &g.dz[i], R * GL.hidden));
-        CK(dalloc(c, &g.xin, R * GL.obs));
+        g.bf16 = cfg->compute_dtype == PPO_DTYPE_BF16;
+        if (g.bf16) {
+            // every bf16 buffer: 128 extra rows (the unguarded staging prefetches up to three chunks past the last one it uses), pitches padded
+            // to 128 columns, zero-filled once -- nothing ever writes the padding
+            g.ld_in0 = (GL.obs + 127) / 128 * 128;
+            g.ld_h = (GL.hidden + 127) / 128 * 128;
+            const size_t RB = R + 128;
+            CK(dalloc(c, &g.xin_bf, RB * g.ld_in0));
+            for (int net = 0; net < 2; net++)
+                for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts_bf[net][l], RB * g.ld_h));
+            for (int i = 0; i < 2; i++) {
+                CK(dalloc(c, &g.tmp_bf[i], RB * g.ld_h));
+                CK(dalloc(c, &g.dz_bf[i], RB * g.ld_h));
+                CK(dalloc(c, &g.dout_bf[i], RB * 128));
+            }
+            CK(dalloc(c, &g.cs_part, (R / 128 + 1) * g.ld_h));
+            CK(dalloc(c, &g.head_db_part, (size_t)GEN_LOSS_BLOCKS * (GL.act + 1)));
+        } else {
+            for (int net = 0; net < 2; net++)
+                for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts[net][l], R * GL.hidden));
+            for (int i = 0; i < 2; i++) CK(dalloc(c, &g.dz[i], R * GL.hidden));
+            CK(dalloc(c, &g.xin, R * GL.obs));
+            CK(dalloc(c, &g.dlogits, R * GL.act));
+            CK(dalloc(c, &g.dval, R));
+        }
         CK(dalloc(c, &g.logits, R * GL.act));
-        CK(dalloc(c, &g.dlogits, R * GL.act));
         CK(dalloc(c, &g.val, R));
-        CK(dalloc(c, &g.dval, R));
         for (int i = 0; i < 4; i++) CK(dalloc(c, &g.row_f[i], R));
         CK(dalloc(c, &g.row_f[4], R + 2));
         CK(dalloc(c, &g.row_act, R * GL.n_heads));
@@ -465,7 +484,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
                     g.wp_off[net][l] = off;
                     off += 3ll * g.wp_npad[net][l] * g.wp_kpad[l];
                 }
-            CK(dalloc(c, &g.wplanes, (size_t)off));
+            CK(dalloc(c, &g.wplanes, (size_t)off + 128 * 256));   // + slack for the staging's prefetch past the last chunk
             g.planes_dirty = true;
         }
         CK(dalloc(c, &g.act64, N * GL.n_heads));

@@ -73,6 +73,17 @@ struct GenericCtx {
     float* wslab = nullptr;        // [GEN_SPLIT + 1][max over layers of out * in + out]: row-chunk partials of one layer's dW | db
     int64_t wslab_stride = 0;
     float* db_part = nullptr;      // [GEN_DB_CHUNKS][max out]: row-chunk partials of one layer's bias gradient
+    // ---- bf16 storage (ppo_config.compute_dtype = PPO_DTYPE_BF16): layer inputs, hidden activations and back-propagated gradients live in HBM
+    //      as bf16, every buffer [rows_max + 128][pitch] with pitch a multiple of 128 and zeros in the padding (launch_matmul_bf16 has no guards)
+    bool bf16 = false;
+    int ld_in0 = 0, ld_h = 0;      // pitches of the network input (pad128(obs)) and of a hidden vector (pad128(hidden))
+    uint16_t* xin_bf = nullptr;    // [.][ld_in0] layer-0 input: the gathered (or converted) observations
+    uint16_t* acts_bf[2][GEN_MAX_LAYERS] = {};   // [net][l] [.][ld_h] kept activations of a minibatch step
+    uint16_t* tmp_bf[2] = {};      // [.][ld_h] ping-pong activations of a forward pass that keeps nothing (rollout step, critic batch)
+    uint16_t* dz_bf[2] = {};       // [.][ld_h] ping-pong d(pre-activation)
+    uint16_t* dout_bf[2] = {};     // [net] [.][128] d(loss)/d(value), d(loss)/d(logits); zero beyond the head's width
+    float* cs_part = nullptr;      // [rows_max / 128][ld_h] per-m-tile column sums of a d(pre-activation) (the next bias gradient)
+    float* head_db_part = nullptr; // [GEN_LOSS_BLOCKS][act + 1] block sums of d(loss)/d(logits) | d(value) (the head layers' bias gradients)
     int64_t* act64 = nullptr;      // [N, n_heads] actions of the current rollout step (int64, the stand-alone API's type)
     float* step_lp = nullptr;      // [N] log-prob / entropy of the current rollout step
     float* step_en = nullptr;
@@ -89,10 +100,16 @@ hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64
                          int64_t colsum_zstride, const uint16_t* bplanes, int64_t bp_plane, int64_t bp_ld, hipStream_t s);
 struct GenericCtx;
 hipError_t gen_weight_planes(const GenericCtx& g, const float* params, hipStream_t s);
+// bf16-storage variant of launch_matmul and the f32 -> padded bf16 converter (kernels_gemm.hip)
+hipError_t launch_matmul_bf16(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
+                              void* c, int64_t ldc, bool c_bf16, int epilogue, const void* aux, int64_t ld_aux, int splits, int64_t c_zstride,
+                              float* colsum, int64_t colsum_stride, hipStream_t s);
+hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s);
 
 // kernels_generic.hip
 struct ppo_ctx;
-// out[rows, out_dim(last)] = net(x[rows, obs]); acts != nullptr keeps every hidden layer's activations (for the backward pass)
+// out[rows, out_dim(last)] = net(x[rows, obs]); acts != nullptr keeps every hidden layer's activations (for the backward pass).
+// bf16 storage: x == nullptr means the input already sits in g.xin_bf (gen_gather put it there); acts != nullptr keeps g.acts_bf[net]
 hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, float* const* acts, float* scratch0,
                        float* scratch1, float* out, hipStream_t s);
 hipError_t gen_heads(const GenLayout& L, int dist_kind, const float* logits, const uint8_t* mask, const int64_t* forced, int64_t n, int64_t seed,

@@ -59,9 +59,14 @@ struct GemmArgs {
     int64_t ld_aux;
     const uint16_t* bplanes;   // BP kernels: B pre-split into T bf16 planes [t][rows_pad][bp_ld] (gen_weight_planes), zero padded to tile multiples
     int64_t bp_plane, bp_ld;   // elements per plane, elements per plane row
-    float* colsum;        // TA only, may be null: colsum[z * colsum_zstride + m] = sum over the z-th k range of A(m, k) (the bias gradient beside dW)
+    float* colsum;        // may be null.  TA (f32 A): colsum[z * colsum_zstride + m] = sum over the z-th k range of A(m, k) (the bias gradient beside dW).
+                          // !TA with PPO_MM_EPI_DTANH: colsum[tm * colsum_zstride + n] = sum over the rows of m tile tm of the f32 result (the NEXT layer
+                          // down's bias gradient, formed where d(pre-activation) is produced, before it is rounded for storage)
     int64_t colsum_zstride;
 };
+// ABF kernels: A is bf16 in memory (`a` really points at uint16_t, lda in elements), rows padded to the tile and the contraction padded with
+// zeros to a multiple of 64 (+ slack for the prefetch): staged by PlaneStage, no guards, no vector work.  CBF kernels: the result is stored as
+// bf16 (`c` really points at uint16_t, ldc in elements; round to nearest even) -- a layer then moves 2 bytes per activation element.
 
 // Four consecutive floats from global memory, branch-free (a load inside a branch makes the compiler wait for every outstanding load at the
 // join, which serialises the eight loads of a chunk into eight memory round trips): elements that do not exist are read from `safe` (any
@@ -306,8 +311,9 @@ struct PlaneStage {
 // compiler does interleave them: 1 MFMA / 7 VALU runs).  Used where it measured faster (small batches, plain bf16; see launch_prec); the
 // fp32-accurate product at minibatch size stays on two four-wave workgroups per CU.  (A four-wave version of DB -- one wave per SIMD --
 // was 30 % slower than either: one wave issues a vector instruction every ~5 cycles, two waves one every ~2.4.)
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB, bool ABF = false, bool CBF = false>
 __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const GemmArgs g) {
+    static_assert(!ABF || (T == 1 && BP), "bf16 activations come with the plain-bf16 arithmetic and plane-staged B");
     constexpr int NT = 64 * WM * WN;   // 256 threads; 512 (two waves per SIMD of ONE workgroup) for the double-buffered variant
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
     constexpr int EA = tile_elems(BM, TA), EB = tile_elems(BN, TB);
@@ -343,9 +349,20 @@ __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const Ge
     // Two chunks of operands are in flight in registers: the loads of chunk c + 2 are issued when chunk c has been staged, so a load has two
     // chunks of MFMAs (not one) to cover its trip to HBM.  The contraction range is walked in PAIRS of chunks (the host rounds k_chunk
     // to a multiple of 64; chunks past the end load zeros) so that the loop body has no branch around a load.
-    Stage<BM, TA, VEC, NT> sa;
-    sa.init(g.a, g.lda, m0, g.M, kbeg, tid);
-    Loaded<Stage<BM, TA, VEC, NT>::NV> va0, va1;
+    typename std::conditional<ABF, PlaneStage<BM, TA, T, NT>, Stage<BM, TA, VEC, NT>>::type sa;
+    typename std::conditional<ABF, typename PlaneStage<BM, TA, T, NT>::Set, Loaded<Stage<BM, TA, VEC, NT>::NV>>::type va0, va1;
+    if constexpr (ABF) sa.init(reinterpret_cast<const uint16_t*>(g.a), 0, g.lda, m0, kbeg, tid);
+    else sa.init(g.a, g.lda, m0, g.M, kbeg, tid);
+    float cs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const bool do_cs = !ABF && TA && g.colsum != nullptr && tn == 0;   // every n tile stages the same A tile: the first one sums it
+    auto load_a = [&](auto& set, auto guard) {
+        if constexpr (ABF) sa.load(set);
+        else sa.template load<decltype(guard)::value>(set, kend);
+    };
+    auto store_a = [&](const auto& set, uint16_t* dst, auto guard) {
+        if constexpr (ABF) sa.store(set, dst);
+        else sa.template store<T, decltype(guard)::value>(set, dst, tid, cs, do_cs);
+    };
     // B: split on the fly like A, or (BP) fetched as ready-made bf16 planes
     typename std::conditional<BP, PlaneStage<BN, TB, T, NT>, Stage<BN, TB, VEC, NT>>::type sb;
     typename std::conditional<BP, typename PlaneStage<BN, TB, T, NT>::Set, Loaded<Stage<BN, TB, VEC, NT>::NV>>::type vb0, vb1;
@@ -361,10 +378,10 @@ __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const Ge
     };
     // Plane loads (BP) hit L2 and are fetched ONE chunk ahead into a single register set (two sets of six 16-byte registers on top of A's
     // spilled); within a slot they are issued BEFORE A's loads, so that waiting for them leaves A's newer set in flight.
-    load_b(vb0, std::true_type{}); sa.template load<true>(va0, kend);
+    load_b(vb0, std::true_type{}); load_a(va0, std::true_type{});
     __builtin_amdgcn_sched_barrier(0);   // set 0 strictly before set 1: the in-order load counter then lets the loop wait for set 0 alone
     if constexpr (!BP) load_b(vb1, std::true_type{});
-    sa.template load<true>(va1, kend);
+    load_a(va1, std::true_type{});
     __builtin_amdgcn_sched_barrier(0);
     auto compute = [&](const uint16_t* cA, const uint16_t* cB) {
 #pragma unroll
@@ -389,60 +406,57 @@ __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const Ge
                     for (int j = 0; j < FN; j++) acc[i][j] = mfma_bf16(af[i][pa[p]], bf[j][pb[p]], acc[i][j]);
         }
     };
-    float cs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    const bool do_cs = TA && g.colsum != nullptr && tn == 0;   // every n tile stages the same A tile: the first one sums it
     auto pair = [&](auto guard) {   // stages and multiplies the two chunks in registers, fetches the two after them
-        constexpr bool G = decltype(guard)::value;
         if constexpr (!DB) {
-            sa.template store<T, G>(va0, sA, tid, cs, do_cs);
+            store_a(va0, sA, guard);
             store_b(vb0, sB, guard);
             __syncthreads();
             load_b(vb0, guard);
             __builtin_amdgcn_sched_barrier(0);
-            sa.template load<G>(va0, kend);
+            load_a(va0, guard);
             __builtin_amdgcn_sched_barrier(0);   // the loads go out BEFORE the MFMAs they are meant to hide behind (the scheduler sinks them otherwise)
             compute(sA, sB);
             __syncthreads();
-            sa.template store<T, G>(va1, sA, tid, cs, do_cs);
+            store_a(va1, sA, guard);
             if constexpr (BP) store_b(vb0, sB, guard); else store_b(vb1, sB, guard);
             __syncthreads();
             if constexpr (BP) load_b(vb0, guard); else load_b(vb1, guard);
             __builtin_amdgcn_sched_barrier(0);
-            sa.template load<G>(va1, kend);
+            load_a(va1, guard);
             __builtin_amdgcn_sched_barrier(0);
             compute(sA, sB);
             __syncthreads();
         } else {
             // on entry: tile set 0 holds chunk c; va1 (and vb1 / vb0) chunk c + 1, va0 chunk c + 2
-            sa.template store<T, G>(va1, sA1, tid, cs, do_cs);
+            store_a(va1, sA1, guard);
             if constexpr (BP) store_b(vb0, sB1, guard); else store_b(vb1, sB1, guard);
             if constexpr (BP) load_b(vb0, guard); else load_b(vb1, guard);
-            sa.template load<G>(va1, kend);
+            load_a(va1, guard);
             compute(sA, sB);
             __syncthreads();
-            sa.template store<T, G>(va0, sA, tid, cs, do_cs);
+            store_a(va0, sA, guard);
             store_b(vb0, sB, guard);
             load_b(vb0, guard);
-            sa.template load<G>(va0, kend);
+            load_a(va0, guard);
             compute(sA1, sB1);
             __syncthreads();
         }
     };
     if constexpr (DB) {   // chunk 0 into tile set 0; its register set goes on to chunk 2
-        sa.template store<T, true>(va0, sA, tid, cs, do_cs);
+        store_a(va0, sA, std::true_type{});
         store_b(vb0, sB, std::true_type{});
         load_b(vb0, std::true_type{});
-        sa.template load<true>(va0, kend);
+        load_a(va0, std::true_type{});
         __syncthreads();
     }
     int64_t kc = kbeg;
-    if (m0 + BM <= g.M && (BP || n0 + BN <= g.N)) {
+    if ((ABF || m0 + BM <= g.M) && (BP || n0 + BN <= g.N)) {
         // interior tile: while this pair AND the pair fetched during it lie inside the range, nothing needs a guard
         for (; kc + (DB ? 6 : 4) * BK <= kend; kc += 2 * BK) pair(std::false_type{});   // DB fetches one chunk further ahead
     }
     for (; kc < kend; kc += 2 * BK) pair(std::true_type{});
 
-    if constexpr (TA) {
+    if constexpr (TA && !ABF) {
         if (do_cs) {   // the k-row groups of threads that share a column quad are added in a fixed order through LDS (the tiles are dead)
             constexpr int MQ = BM / 4, NG = BM == 128 ? NT / MQ : 8;
             float* red = reinterpret_cast<float*>(sA);   // [NG][BM]
@@ -465,14 +479,24 @@ __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const Ge
     float* __restrict__ c = g.c + (int64_t)tz * g.c_zstride;
     const int hi = lane >> 5;
     const bool interior = m0 + BM <= g.M && n0 + BN <= g.N;
+    const bool want_cs = !TA && g.epi == PPO_MM_EPI_DTANH && g.colsum != nullptr;
+    // CBF: the tile is gathered in LDS as bf16 [BM][BN + 8] (the operand tiles are dead) and leaves in 16-byte row pieces
+    constexpr int CS = BN + 8;
+    uint16_t* const sC = dyn_lds;
+    float* const sRed = reinterpret_cast<float*>(dyn_lds + (CBF ? BM * CS : 0));   // [WM][BN] column sums of the waves along m
+    static_assert(!CBF || (size_t)BM * CS * 2 + (size_t)WM * BN * 4 <= (size_t)(DB ? 2 : 1) * T * (EA + EB) * 2, "the C tile must fit the operand tiles' LDS");
+    if (CBF || want_cs) __syncthreads();   // every wave is done reading the operand tiles
 #pragma unroll
     for (int j = 0; j < FN; j++) {
-        const int n = n0 + (wn * FN + j) * 32 + (lane & 31);
+        const int nl = (wn * FN + j) * 32 + (lane & 31);
+        const int n = n0 + nl;
         const bool n_ok = n < g.N;
         const float bias = ((g.epi == PPO_MM_EPI_BIAS || g.epi == PPO_MM_EPI_BIAS_TANH) && n_ok) ? g.aux[n] : 0.0f;
+        float csum = 0.0f;
 #pragma unroll
         for (int i = 0; i < FM; i++) {
-            const int mb = m0 + (wm * FM + i) * 32 + 4 * hi;
+            const int ml = (wm * FM + i) * 32 + 4 * hi;
+            const int mb = m0 + ml;
             float v[16];
             if (g.epi == PPO_MM_EPI_BIAS_TANH) {
 #pragma unroll
@@ -482,15 +506,24 @@ __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const Ge
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    h[r] = g.aux[(n_ok && m < g.M) ? (int64_t)m * g.ld_aux + n : 0];
+                    const int64_t at = (n_ok && m < g.M) ? (int64_t)m * g.ld_aux + n : 0;
+                    if constexpr (ABF) h[r] = u2f((uint32_t)reinterpret_cast<const uint16_t*>(g.aux)[at] << 16);   // the stored (bf16) activation
+                    else h[r] = g.aux[at];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = acc[i][j][r] * (1.0f - h[r] * h[r]);
+                if (want_cs) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) csum += (mb + (r & 3) + 8 * (r >> 2) < g.M) ? v[r] : 0.0f;
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = acc[i][j][r] + bias;
             }
-            if (interior) {
+            if constexpr (CBF) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) sC[(ml + (r & 3) + 8 * (r >> 2)) * CS + nl] = (uint16_t)(pack_rne(v[r], 0.0f) & 0xffffu);
+            } else if (interior) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) c[(int64_t)(mb + (r & 3) + 8 * (r >> 2)) * g.ldc + n] = v[r];
             } else {
@@ -501,14 +534,36 @@ __global__ __launch_bounds__(64 * WM * WN, DB ? 1 : 2) void gemm_kernel(const Ge
                 }
             }
         }
+        if (want_cs) {
+            csum += __shfl_xor(csum, 32, 64);
+            if (hi == 0) sRed[wm * BN + nl] = csum;
+        }
+    }
+    if constexpr (CBF) {
+        __syncthreads();
+        // rows of the tile that exist, all BN columns (the destination's row pitch covers the padded width): 16 bytes per thread and pass
+        uint16_t* __restrict__ cb = reinterpret_cast<uint16_t*>(g.c);
+        constexpr int P8 = BN / 8;
+        for (int e = tid; e < BM * P8; e += NT) {
+            const int row = e / P8, c8 = e % P8;
+            if (m0 + row < g.M) *reinterpret_cast<u32x4*>(cb + (int64_t)(m0 + row) * g.ldc + n0 + 8 * c8) = *reinterpret_cast<const u32x4*>(sC + row * CS + 8 * c8);
+        }
+    } else if (want_cs) {
+        __syncthreads();
+    }
+    if (want_cs && tid < BN && n0 + tid < g.N) {
+        float t = sRed[tid];
+#pragma unroll
+        for (int q = 1; q < WM; q++) t += sRed[q * BN + tid];   // fixed order
+        g.colsum[(int64_t)tm * g.colsum_zstride + n0 + tid] = t;
     }
 }
 
 // one instantiation: LDS size, (for the double-buffered variant) the attribute that allows more than 64 KB, launch
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int T, bool VEC, bool BP, bool DB, bool ABF = false, bool CBF = false>
 hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(DB ? 2 : 1) * T * (tile_elems(BM, TA) + tile_elems(BN, TB)) * sizeof(uint16_t);
-    auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, T, VEC, BP, DB>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, T, VEC, BP, DB, ABF, CBF>;
     if constexpr (DB) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return attr;
@@ -600,12 +655,62 @@ hipError_t launch_matmul(bool trans_a, bool trans_b, int64_t M, int64_t N, int64
     g.k_chunk = kc;
     g.c_zstride = c_zstride;
     g.epi = epilogue; g.aux = aux; g.ld_aux = ld_aux;
-    g.colsum = trans_a ? colsum : nullptr; g.colsum_zstride = colsum_zstride;
+    g.colsum = colsum; g.colsum_zstride = colsum_zstride;   // TA: sums of A over each k range; plain A with PPO_MM_EPI_DTANH: column sums of the result per m tile
     g.bplanes = (!trans_a && splits == 1) ? bplanes : nullptr; g.bp_plane = bp_plane; g.bp_ld = bp_ld;
     // contiguous extent of an operand: k (plain) or its row / column index (transposed)
     const bool vec = ((trans_a ? M : K) % 4 == 0) && (g.bplanes != nullptr || (trans_b ? N : K) % 4 == 0);
     if (precision == PPO_MM_BF16) return vec ? launch_prec<1, true>(g, trans_a, trans_b, splits, s) : launch_prec<1, false>(g, trans_a, trans_b, splits, s);
     return vec ? launch_prec<3, true>(g, trans_a, trans_b, splits, s) : launch_prec<3, false>(g, trans_a, trans_b, splits, s);
+}
+
+// The same products with bf16 STORAGE (ppo_config.compute_dtype = PPO_DTYPE_BF16): both operands are bf16 in memory -- A(m, k) and B(n, k)
+// read plain or transposed like launch_matmul's, rows padded to 128 and the contraction zero-padded to a multiple of 64 by the caller's
+// buffers (PlaneStage has no guards) -- products on v_mfma_f32_32x32x16_bf16 with f32 accumulation, the result f32 or (c_bf16) bf16 rounded
+// to nearest even.  One tile shape: 128 x 128, eight waves, double-buffered.  colsum: see GemmArgs.
+hipError_t launch_matmul_bf16(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
+                              void* c, int64_t ldc, bool c_bf16, int epilogue, const void* aux, int64_t ld_aux, int splits, int64_t c_zstride,
+                              float* colsum, int64_t colsum_stride, hipStream_t s) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (M > 0x7fffffff || N > 0x7fffffff || K < 0 || splits < 1) return hipErrorInvalidValue;
+    if (splits > 1 && (epilogue != PPO_MM_EPI_NONE || c_bf16)) return hipErrorInvalidValue;
+    GemmArgs g{};
+    g.a = reinterpret_cast<const float*>(a); g.lda = lda; g.b = nullptr; g.ldb = ldb; g.c = reinterpret_cast<float*>(c); g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = K;
+    int64_t kc = (K + splits - 1) / splits;
+    kc = (kc + 2 * BK - 1) / (2 * BK) * (2 * BK);
+    if (kc < 2 * BK) kc = 2 * BK;
+    g.k_chunk = kc; g.c_zstride = c_zstride;
+    g.epi = epilogue; g.aux = reinterpret_cast<const float*>(aux); g.ld_aux = ld_aux;
+    g.colsum = colsum; g.colsum_zstride = colsum_stride;
+    g.bplanes = b; g.bp_plane = 0; g.bp_ld = ldb;
+    g.m_tiles = (g.M + 127) / 128; g.n_tiles = (g.N + 127) / 128; g.splits = splits;
+    const int64_t groups = splits > 1 ? splits : g.m_tiles, members = splits > 1 ? (int64_t)g.m_tiles * g.n_tiles : g.n_tiles;
+    const int64_t blocks = (groups + 7) / 8 * 8 * members;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
+    if (!trans_a && !trans_b) return c_bf16 ? launch_one<128, 128, 4, 2, false, false, 1, true, true, true, true, true>(g, grid, s)
+                                            : launch_one<128, 128, 4, 2, false, false, 1, true, true, true, true, false>(g, grid, s);
+    if (!trans_a && trans_b && c_bf16) return launch_one<128, 128, 4, 2, false, true, 1, true, true, true, true, true>(g, grid, s);
+    if (trans_a && trans_b && !c_bf16) return launch_one<128, 128, 4, 2, true, true, 1, true, true, true, true, false>(g, grid, s);
+    return hipErrorNotSupported;
+}
+
+// f32 [rows, K] -> bf16 [rows, ld] (round to nearest even), columns K .. ld - 1 zero: the layer input of a bf16 network
+__global__ __launch_bounds__(256) void to_bf16_pad_kernel(const float* __restrict__ src, int64_t rows, int K, uint16_t* __restrict__ dst, int ld) {
+    const int64_t total = rows * (ld / 2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (ld / 2);
+        const int k = 2 * (int)(i % (ld / 2));
+        const float x0 = k < K ? src[r * K + k] : 0.0f, x1 = k + 1 < K ? src[r * K + k + 1] : 0.0f;
+        reinterpret_cast<uint32_t*>(dst)[i] = pack_rne(x0, x1);
+    }
+}
+hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t total = rows * (ld / 2);
+    const int64_t gb = (total + 255) / 256;
+    hipLaunchKernelGGL(to_bf16_pad_kernel, dim3((unsigned)(gb < 4096 ? gb : 4096)), dim3(256), 0, s, src, rows, K, dst, ld);
+    return hipGetLastError();
 }
 
 // Pre-split weights of every layer of both nets (generic.hpp: GenericCtx::wplanes): one launch.

@@ -51,12 +51,17 @@ __global__ __launch_bounds__(128) void heads_kernel(GenLayout L, const float* __
 __global__ __launch_bounds__(256) void gather_kernel(GenLayout L, const float* __restrict__ obs, const int32_t* __restrict__ actions,
                                                      const uint8_t* __restrict__ masks, const float* __restrict__ logprobs, const float* __restrict__ adv,
                                                      const float* __restrict__ ret, const float* __restrict__ values, const int32_t* __restrict__ idx,
-                                                     int64_t M, float* xin, int32_t* row_act, uint8_t* row_mask, float* f0, float* f1, float* f2, float* f3) {
+                                                     int64_t M, float* xin, uint16_t* xin_bf, int ld_bf, int32_t* row_act, uint8_t* row_mask, float* f0, float* f1,
+                                                     float* f2, float* f3) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per row
     if (r >= M) return;
     const int64_t src = idx[r];
-    for (int o = lane; o < L.obs; o += 64) xin[r * L.obs + o] = obs[src * L.obs + o];
+    if (xin_bf) {   // bf16 storage: rounded to nearest even, the row's padding stays zero
+        for (int o = lane; o < L.obs; o += 64) { const __bf16 b = (__bf16)obs[src * L.obs + o]; xin_bf[r * ld_bf + o] = __builtin_bit_cast(uint16_t, b); }
+    } else {
+        for (int o = lane; o < L.obs; o += 64) xin[r * L.obs + o] = obs[src * L.obs + o];
+    }
     if (lane < L.n_heads) row_act[r * L.n_heads + lane] = actions[src * L.n_heads + lane];
     if (masks && lane < L.act) row_mask[r * L.act + lane] = masks[src * L.act + lane];
     if (lane == 0) { f0[r] = logprobs[src]; f1[r] = adv[src]; f2[r] = ret[src]; f3[r] = values[src]; }
@@ -69,8 +74,14 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
                                                    const int32_t* __restrict__ row_act, const uint8_t* __restrict__ row_mask,
                                                    const float* __restrict__ oldlp, const float* __restrict__ advs, const float* __restrict__ rets,
                                                    const float* __restrict__ oldv, int64_t M, float invM, const float* __restrict__ stat2,
-                                                   float* dlogits, float* dval, double* loss_part) {
+                                                   float* dlogits, float* dval, double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf,
+                                                   float* head_db_part) {
+    // bf16 storage (dlogits_bf != nullptr): the two head gradients leave as bf16 rows of pitch 128 (the operand of the head layers' backward
+    // products), and the block's f32 column sums of them -- the head layers' bias gradients -- as head_db_part[block][act + 1]
     __shared__ double red[5][4];
+    __shared__ float sdb[4][PPO_MAX_ACT + 1];
+    float dbs[PPO_MAX_ACT + 1];
+    for (int k = 0; k <= PPO_MAX_ACT; k++) dbs[k] = 0.0f;
     double s[5] = { 0, 0, 0, 0, 0 };
     const float mean_f = stat2[0], inv_std = stat2[1];   // advantage mean and 1 / (std + 1e-8) of the (global) minibatch
     const float clip = hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip;
@@ -110,7 +121,9 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
                 const bool ok = !(DIST == PPO_DIST_MASKED && row_mask) || row_mask[r * L.act + off + k] != 0;
                 float d = g_nlp * ((k == a ? 1.0f : 0.0f) - p[off + k]);
                 if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[off + k] * (z[off + k] + headH[h]));
-                dlogits[r * L.act + off + k] = ok ? d : 0.0f;
+                d = ok ? d : 0.0f;
+                if (dlogits_bf) { const __bf16 b = (__bf16)d; dlogits_bf[r * 128 + off + k] = __builtin_bit_cast(uint16_t, b); dbs[off + k] += d; }
+                else dlogits[r * L.act + off + k] = d;
             }
             off += A;
         }
@@ -136,8 +149,15 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
             lossv = un;
             g_v = hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
         }
-        dval[r] = g_v;
+        if (dval_bf) { const __bf16 b = (__bf16)g_v; dval_bf[r * 128] = __builtin_bit_cast(uint16_t, b); dbs[L.act] += g_v; }
+        else dval[r] = g_v;
         s[4] += (double)lossv;
+    }
+    if (dlogits_bf) {
+        for (int k = 0; k <= L.act; k++) {
+            const float t = wave_sum(dbs[k]);
+            if ((threadIdx.x & 63) == 0) sdb[threadIdx.x >> 6][k] = t;
+        }
     }
     for (int k = 0; k < 5; k++) {
         const double t = wave_sum_d_dpp(s[k]);
@@ -145,6 +165,8 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
     }
     __syncthreads();
     if (threadIdx.x < 5) loss_part[blockIdx.x * 8 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+    if (dlogits_bf && threadIdx.x <= L.act)
+        head_db_part[blockIdx.x * (L.act + 1) + threadIdx.x] = ((sdb[0][threadIdx.x] + sdb[1][threadIdx.x]) + sdb[2][threadIdx.x]) + sdb[3][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void loss_sums_kernel(const double* __restrict__ loss_part, int blocks, double* sums_out, float* grads_tail) {
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(256) void store_step_kernel(GenLayout L, int N, con
 // out[i] = sum over the S partial slabs in a fixed order: 64 elements per block, four lanes per element each adding a quarter of the slabs
 // (eight loads in flight at a time), then ((q0 + q1) + q2) + q3
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int64_t slab_stride, int S, int64_t n_w, const float* __restrict__ db_part,
-                                                       int db_chunks, int64_t n_b, float* __restrict__ gw, float* __restrict__ gb) {
+                                                       int db_chunks, int64_t db_stride, int64_t n_b, float* __restrict__ gw, float* __restrict__ gb) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + e;
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     if (i < n_w + n_b) {
         const bool w = i < n_w;
         const float* src = w ? slab + i : db_part + (i - n_w);
-        const int64_t stride = w ? slab_stride : n_b;
+        const int64_t stride = w ? slab_stride : db_stride;
         const int n = w ? S : db_chunks;
         const int per = (n + 3) / 4, k0 = q * per, k1 = k0 + per < n ? k0 + per : n;
         int k = k0;
@@ -321,8 +343,25 @@ inline unsigned grid_for(int64_t n, int per_block) { const int64_t g = (n + per_
 hipError_t gen_forward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, float* const* acts, float* scratch0,
                        float* scratch1, float* out, hipStream_t s) {
     const GenLayout& L = g.L;
-    const float* in = x;
     if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    if (g.bf16) {
+        // bf16 storage: the input is rounded once into g.xin_bf (or gen_gather left it there), every hidden layer writes bf16
+        if (x) { const hipError_t ce = launch_to_bf16_pad(x, rows, L.obs, g.xin_bf, g.ld_in0, s); if (ce != hipSuccess) return ce; }
+        const uint16_t* in = g.xin_bf;
+        int64_t ldi = g.ld_in0;
+        for (int l = 0; l < L.n_layers; l++) {
+            const int K = L.in_dim[l], N = L.out_dim[net][l];
+            const bool last = l == L.n_layers - 1;
+            uint16_t* hb = acts ? g.acts_bf[net][l] : g.tmp_bf[l & 1];
+            const hipError_t e = launch_matmul_bf16(false, false, rows, N, K, in, ldi, g.wplanes + g.wp_off[net][l], g.wp_kpad[l], last ? (void*)out : (void*)hb,
+                                                    last ? N : g.ld_h, !last, last ? PPO_MM_EPI_BIAS : PPO_MM_EPI_BIAS_TANH, params + L.b_off[net][l], 0, 1, 0,
+                                                    nullptr, 0, s);
+            if (e != hipSuccess) return e;
+            in = hb; ldi = g.ld_h;
+        }
+        return hipGetLastError();
+    }
+    const float* in = x;
     for (int l = 0; l < L.n_layers; l++) {
         const int K = L.in_dim[l], N = L.out_dim[net][l];
         const bool last = l == L.n_layers - 1;
@@ -351,7 +390,7 @@ hipError_t gen_heads(const GenLayout& L, int dist_kind, const float* logits, con
 hipError_t gen_gather(const GenLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs, const float* adv,
                       const float* ret, const float* values, const int32_t* idx, int64_t M, GenericCtx& g, hipStream_t s) {
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, L, obs, actions, masks, logprobs, adv, ret, values, idx, M, g.xin,
-                       g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2], g.row_f[3]);
+                       g.bf16 ? g.xin_bf : nullptr, g.ld_in0, g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2], g.row_f[3]);
     return hipGetLastError();
 }
 
@@ -379,10 +418,12 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
     const dim3 grid(GEN_LOSS_BLOCKS), block(256);
     if (hp.dist_kind == PPO_DIST_MASKED)
         hipLaunchKernelGGL(loss_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2],
-                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part);
+                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part, g.bf16 ? g.dout_bf[1] : nullptr,
+                           g.bf16 ? g.dout_bf[0] : nullptr, g.head_db_part);
     else
         hipLaunchKernelGGL(loss_kernel<PPO_DIST_CATEGORICAL>, grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, nullptr, g.row_f[0], g.row_f[1], g.row_f[2],
-                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part);
+                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part, g.bf16 ? g.dout_bf[1] : nullptr,
+                           g.bf16 ? g.dout_bf[0] : nullptr, g.head_db_part);
     return hipGetLastError();
 }
 
@@ -392,26 +433,67 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
                         hipStream_t s) {
     const GenLayout& L = g.L;
-    const float* d = dout;
     if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
-    for (int l = L.n_layers - 1; l >= 0; l--) {
-        const int K = L.in_dim[l], N = L.out_dim[net][l];
-        const float* in = l == 0 ? x : g.acts[net][l - 1];
-        // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single product would have N K / tile
-        // workgroups walking all rows, so the rows are cut into ranges -- every range its own partial slab, enough of them for two workgroups
-        // per CU, each a multiple of 64 rows -- and the slabs are added in a fixed order.
-        const int64_t n_w = (int64_t)N * K;
+    // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single product would have N K / tile
+    // workgroups walking all rows, so the rows are cut into ranges -- every range its own partial slab, enough of them for two workgroups
+    // per CU, each a multiple of 64 rows -- and the slabs are added in a fixed order.
+    auto ranges = [&](int N, int K) {
         const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 127) / 128);
         int64_t want = (512 + tiles - 1) / tiles;
         if (want > GEN_SPLIT_MFMA) want = GEN_SPLIT_MFMA;
         const int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;
-        const int S = (int)((rows + range - 1) / range);
+        return (int)((rows + range - 1) / range);
+    };
+    if (g.bf16) {
+        // bf16 storage: x, dout are not used -- the layer inputs are g.xin_bf / g.acts_bf[net], the head gradient g.dout_bf[net] (written by the
+        // loss kernel together with the head's bias-gradient block sums); the bias gradient of every other layer is summed, in f32, where its
+        // d(pre-activation) is produced (the tanh' epilogue of the layer above), per 128-row tile
+        const uint16_t* d = g.dout_bf[net];
+        int64_t ldd = 128;
+        if (rows % 64) {   // the contraction over rows runs in pairs of 32-row chunks: rows past the minibatch must contribute zeros
+            const int64_t tail = 64 - rows % 64;
+            for (int i = 0; i < 2; i++) {
+                if (hipMemsetAsync(g.dz_bf[i] + rows * g.ld_h, 0, (size_t)tail * g.ld_h * 2, s) != hipSuccess) return hipErrorUnknown;
+                if (hipMemsetAsync(g.dout_bf[i] + rows * 128, 0, (size_t)tail * 128 * 2, s) != hipSuccess) return hipErrorUnknown;
+            }
+        }
+        for (int l = L.n_layers - 1; l >= 0; l--) {
+            const int K = L.in_dim[l], N = L.out_dim[net][l];
+            const bool head = l == L.n_layers - 1;
+            const uint16_t* in = l == 0 ? g.xin_bf : g.acts_bf[net][l - 1];
+            const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
+            const int64_t n_w = (int64_t)N * K;
+            const int S = ranges(N, K);
+            hipError_t e = launch_matmul_bf16(true, true, N, K, rows, d, ldd, in, ldi, g.wslab, K, false, PPO_MM_EPI_NONE, nullptr, 0, S, g.wslab_stride, nullptr, 0, s);
+            if (e != hipSuccess) return e;
+            const float* dbp = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part;
+            const int dbc = head ? GEN_LOSS_BLOCKS : (int)((rows + 127) / 128);
+            const int64_t dbs = head ? L.act + 1 : g.ld_h;
+            hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, dbp, dbc, dbs, (int64_t)N,
+                               grads + L.w_off[net][l], grads + L.b_off[net][l]);
+            if (l > 0) {
+                uint16_t* nd = g.dz_bf[l & 1];
+                // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2), stored bf16; its column sums per 128-row tile -> cs_part
+                e = launch_matmul_bf16(false, true, rows, K, N, d, ldd, g.wplanes + g.wp_off[net][l], g.wp_kpad[l], nd, g.ld_h, true, PPO_MM_EPI_DTANH,
+                                       g.acts_bf[net][l - 1], g.ld_h, 1, 0, g.cs_part, g.ld_h, s);
+                if (e != hipSuccess) return e;
+                d = nd; ldd = g.ld_h;
+            }
+        }
+        return hipGetLastError();
+    }
+    const float* d = dout;
+    for (int l = L.n_layers - 1; l >= 0; l--) {
+        const int K = L.in_dim[l], N = L.out_dim[net][l];
+        const float* in = l == 0 ? x : g.acts[net][l - 1];
+        const int64_t n_w = (int64_t)N * K;
+        const int S = ranges(N, K);
         {   // ... and db beside it: the workgroups of the first column of tiles also sum their d tile over the rows (db_part[z][N])
             const hipError_t e = launch_matmul(true, true, N, K, rows, d, N, in, K, g.wslab, K, PPO_MM_EPI_NONE, nullptr, 0, g.gemm_prec, S, g.wslab_stride,
                                                g.db_part, N, nullptr, 0, 0, s);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, S, (int64_t)N,
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, g.db_part, S, (int64_t)N, (int64_t)N,
                            grads + L.w_off[net][l], grads + L.b_off[net][l]);
         if (l > 0) {
             float* nd = g.dz[(l & 1)];
