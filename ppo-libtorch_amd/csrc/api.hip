@@ -485,6 +485,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
                     off += 3ll * g.wp_npad[net][l] * g.wp_kpad[l];
                 }
             CK(dalloc(c, &g.wplanes, (size_t)off + 128 * 256));   // + slack for the staging's prefetch past the last chunk
+            if (cfg->compute_dtype == PPO_DTYPE_BF16) CK(dalloc(c, &g.wfrags, (size_t)off + 128 * 256));
             g.planes_dirty = true;
         }
         CK(dalloc(c, &g.act64, N * GL.n_heads));
@@ -703,6 +704,10 @@ extern "C" ppo_status ppo_params_init_orthogonal(ppo_ctx* c, int64_t seed) {
 // ---- generic networks (generic.hpp): critic / actor over n rows, chunked to the workspace size ----
 static ppo_status gen_values(ppo_ctx* c, const float* obs, int64_t n, float* value) {
     GenericCtx& g = *c->gen;
+    if (gen_fused_ok(g) && n <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small batch: the whole critic in one launch
+        HIPCHK(c, gen_fused_forward(g, B_<float>(c, PPO_BUF_PARAMS), 0, obs, nullptr, 0, n, false, value, c->stream));
+        return PPO_OK;
+    }
     for (int64_t off = 0; off < n; off += g.rows_max) {
         const int64_t rows = std::min<int64_t>(g.rows_max, n - off);
         HIPCHK(c, gen_forward(g, B_<float>(c, PPO_BUF_PARAMS), 0, obs + off * g.L.obs, rows, nullptr, g.dz[0], g.dz[1], value + off, c->stream));
@@ -714,7 +719,8 @@ static ppo_status gen_policy(ppo_ctx* c, const float* obs, const uint8_t* mask, 
     GenericCtx& g = *c->gen;
     for (int64_t off = 0; off < n; off += g.rows_max) {
         const int64_t rows = std::min<int64_t>(g.rows_max, n - off);
-        HIPCHK(c, gen_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, rows, nullptr, g.dz[0], g.dz[1], g.logits, c->stream));
+        if (gen_fused_ok(g) && rows <= GEN_FUSED_MAX_ROWS) HIPCHK(c, gen_fused_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, nullptr, 0, rows, false, g.logits, c->stream));
+        else HIPCHK(c, gen_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, rows, nullptr, g.dz[0], g.dz[1], g.logits, c->stream));
         HIPCHK(c, gen_heads(g.L, c->cfg.dist_kind, g.logits, mask ? mask + off * g.L.act : nullptr, forced ? forced + off * g.L.n_heads : nullptr, rows,
                             c->cfg.seed, c->cfg.env_offset + off, step_index, action ? action + off * g.L.n_heads : nullptr,
                             logprob ? logprob + off : nullptr, entropy ? entropy + off : nullptr, c->stream));
@@ -987,8 +993,13 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         ProfScope ps(c, PROF_FWD_BWD);
         HIPCHK(c, gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
                              B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), idx, M, g, c->stream));
-        HIPCHK(c, gen_forward(g, params, 1, g.xin, M, g.acts[1], nullptr, nullptr, g.logits, c->stream));
-        HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, c->stream));
+        if (gen_fused_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small minibatch: each net's forward pass is one launch that also leaves its hidden activations
+            HIPCHK(c, gen_fused_forward(g, params, 1, nullptr, g.xin_bf, g.ld_in0, M, true, g.logits, c->stream));
+            HIPCHK(c, gen_fused_forward(g, params, 0, nullptr, g.xin_bf, g.ld_in0, M, true, g.val, c->stream));
+        } else {
+            HIPCHK(c, gen_forward(g, params, 1, g.xin, M, g.acts[1], nullptr, nullptr, g.logits, c->stream));
+            HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, c->stream));
+        }
         HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
         HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream));
         HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, c->stream));
@@ -1008,7 +1019,18 @@ static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced) {
     float* params = B_<float>(c, PPO_BUF_PARAMS);
     float* next_obs = B_<float>(c, PPO_BUF_NEXT_OBS);
     const uint8_t* mask = c->cfg.dist_kind == PPO_DIST_MASKED ? c->cur_mask : nullptr;
-    {
+    if (gen_fused_ok(g)) {
+        // bf16 storage: the T steps { observation, actor, heads, stores, env transition } in ONE launch, then the critic over all stored observations
+        ProfScope ps(c, PROF_ROLLOUT);
+        HIPCHK(c, gen_fused_rollout(g, params, c->cfg.dist_kind, N, c->T, c->cfg.max_episode_steps, c->cfg.seed, c->cfg.env_offset, c->rollout_steps,
+                                    B_<int32_t>(c, PPO_BUF_EP_LEN), B_<float>(c, PPO_BUF_EP_REW), B_<float>(c, PPO_BUF_OBS), B_<uint8_t>(c, PPO_BUF_MASKS),
+                                    B_<int32_t>(c, PPO_BUF_ACTIONS), B_<float>(c, PPO_BUF_LOGPROBS), B_<float>(c, PPO_BUF_REWARDS), B_<float>(c, PPO_BUF_DONES),
+                                    B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), next_obs, B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->cur_mask, forced,
+                                    c->stream));
+        ppo_status s = gen_values(c, B_<float>(c, PPO_BUF_OBS), (int64_t)c->T * N, B_<float>(c, PPO_BUF_VALUES));
+        if (s == PPO_OK) s = gen_values(c, next_obs, N, B_<float>(c, PPO_BUF_NEXT_VALUE));
+        if (s != PPO_OK) return s;
+    } else {
         ProfScope ps(c, PROF_ROLLOUT);
         for (int t = 0; t < c->T; t++) {
             const size_t tn = (size_t)t * N;

@@ -55,6 +55,7 @@ struct GenericCtx {
     // weights of every layer pre-split into bf16 planes [t][n_pad][k_pad] (n_pad, k_pad: multiples of 128, zero padded) for the B operand of
     // the forward and d(input) products; rewritten (one launch) when the parameters have changed since the last use
     uint16_t* wplanes = nullptr;
+    uint16_t* wfrags = nullptr;    // bf16 storage: the same values in MFMA-fragment order (kernels_gemm.hip: weight_planes_kernel), same offsets
     int64_t wp_off[2][GEN_MAX_LAYERS] = {};
     int wp_npad[2][GEN_MAX_LAYERS] = {}, wp_kpad[GEN_MAX_LAYERS] = {};
     mutable bool planes_dirty = true;
@@ -105,6 +106,20 @@ hipError_t launch_matmul_bf16(bool trans_a, bool trans_b, int64_t M, int64_t N, 
                               void* c, int64_t ldc, bool c_bf16, int epilogue, const void* aux, int64_t ld_aux, int splits, int64_t c_zstride,
                               float* colsum, int64_t colsum_stride, hipStream_t s);
 hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s);
+
+// kernels_generic_fused.hip: bf16-storage networks whose layer inputs fit LDS -- a net's whole forward pass, or the whole T-step rollout of
+// the synthetic env, in one launch
+// One workgroup of the batch kernel streams ALL of a net's weights from L2 for its 64 rows: right for a step's or a small minibatch's rows (one
+// launch, no HBM traffic between layers), wrong for 65 536 (measured at configs[4]: 142 us per net against 112 for the five tiled products, whose
+// weight tiles are shared by 128 rows and whose activations stream from HBM at its rate)
+constexpr int64_t GEN_FUSED_MAX_ROWS = 8192;
+bool gen_fused_ok(const GenericCtx& g);
+hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
+                             float* out, hipStream_t s);
+hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,
+                             int64_t step_base, int32_t* ep_len, float* ep_rew, float* obs, uint8_t* masks, int32_t* actions, float* logprobs, float* rewards,
+                             float* dones, int32_t* fin_len, float* fin_rew, float* next_obs, int32_t* next_done, uint8_t* cur_mask, const int64_t* forced,
+                             hipStream_t s);
 
 // kernels_generic.hip
 struct ppo_ctx;

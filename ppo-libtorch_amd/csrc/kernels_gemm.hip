@@ -613,8 +613,12 @@ hipError_t launch_prec(const GemmArgs& g, bool ta, bool tb, int splits, hipStrea
 // round-to-nearest term), zeros in the padding.
 struct PlaneJob { int64_t src_off, dst_off, first; int N, K, n_pad, k_pad; };
 struct PlaneJobs { PlaneJob j[2 * GEN_MAX_LAYERS]; int n; int64_t total; };
+// frags (T = 1, may be null): a second copy of the same bf16 values in MFMA-fragment order for the fused forward kernels
+// (kernels_generic_fused.hip): [column block of 32 rows n][k step of 16][lane][8], lane (n % 32, kg) holding k = 16 ks + 8 kg .. + 7 of row n --
+// a wave's B-fragment load is then 1 KiB of consecutive bytes instead of 64 pieces of 32 different rows.
 template <int T>
-__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ params, uint16_t* __restrict__ planes, const PlaneJobs jobs) {
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ params, uint16_t* __restrict__ planes, uint16_t* __restrict__ frags,
+                                                            const PlaneJobs jobs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= jobs.total) return;
     int q = 0;
@@ -632,7 +636,12 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
         const float r2 = r1 - u2f(u1 & 0xffff0000u);
         d[0] = (uint16_t)(u0 >> 16); d[pe] = (uint16_t)(u1 >> 16); d[2 * pe] = (uint16_t)(f2u(r2) >> 16);
     } else {
-        d[0] = (uint16_t)(pack_rne(x, 0.0f) & 0xffffu);
+        const uint16_t b = (uint16_t)(pack_rne(x, 0.0f) & 0xffffu);
+        d[0] = b;
+        if (frags) {
+            const int64_t ksteps = J.k_pad / 16;
+            frags[J.dst_off + (((int64_t)(n >> 5) * ksteps + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)] = b;
+        }
     }
 }
 
@@ -727,7 +736,7 @@ hipError_t gen_weight_planes(const GenericCtx& g, const float* params, hipStream
         }
     jobs.total = first;
     const dim3 grid((unsigned)((first + 255) / 256)), block(256);
-    if (g.gemm_prec == PPO_MM_BF16) hipLaunchKernelGGL(weight_planes_kernel<1>, grid, block, 0, s, params, g.wplanes, jobs);
-    else hipLaunchKernelGGL(weight_planes_kernel<3>, grid, block, 0, s, params, g.wplanes, jobs);
+    if (g.gemm_prec == PPO_MM_BF16) hipLaunchKernelGGL(weight_planes_kernel<1>, grid, block, 0, s, params, g.wplanes, g.wfrags, jobs);
+    else hipLaunchKernelGGL(weight_planes_kernel<3>, grid, block, 0, s, params, g.wplanes, (uint16_t*)nullptr, jobs);
     return hipGetLastError();
 }

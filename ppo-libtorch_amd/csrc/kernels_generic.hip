@@ -439,6 +439,8 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
     // per CU, each a multiple of 64 rows -- and the slabs are added in a fixed order.
     auto ranges = [&](int N, int K) {
         const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 127) / 128);
+        // (256 workgroups for the bf16 product -- one eight-wave workgroup per CU -- halve the slabs the slab sum reads but measured slower overall:
+        // 31.5 against 22.6 us per product, 8.6 against 10.0 us per slab sum)
         int64_t want = (512 + tiles - 1) / tiles;
         if (want > GEN_SPLIT_MFMA) want = GEN_SPLIT_MFMA;
         const int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;

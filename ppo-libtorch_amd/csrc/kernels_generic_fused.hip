@@ -1,0 +1,379 @@
+// ppo-libtorch_amd/csrc/kernels_generic_fused.hip -- the whole forward pass of a bf16-storage network (generic.hpp; BASELINE configs[4]: obs 376,
+// 4 x 256, heads [3,3,3,2]) in ONE launch: a workgroup carries a tile of rows through every Linear + tanh layer of one net
+// (Agent.cpp:25-59 generalised) with the activations never leaving LDS.
+//
+//   rows x K tile of the layer input in LDS as bf16 (A operand, 16-byte fragment reads) ; the layer's weights come straight from L2 as B
+//   fragments, out of a copy kept in fragment order (a wave's load for one k step is 1 KiB of consecutive bytes; read row-major, the same
+//   load touched 32 different memory lines and the kernel was bound by L1 line lookups: 53 us per rollout step) -- all of a column
+//   block's loads are issued before its first MFMA ; eight waves, wave w owns output columns 32 (w + 8 j) ; v_mfma_f32_32x32x16_bf16, f32
+//   accumulation ; epilogue bias + tanh -> bf16 -> the OTHER LDS tile, which is the next layer's A operand.  One barrier per layer, no
+//   HBM traffic between layers, no per-layer launch.
+//
+// Two kernels on that core:
+//   generic_rollout_kernel   the T-step rollout of PPO_MultiDiscrete::train() (PPO_MultiDiscrete.cpp:547-575) for the synthetic env: per step
+//                            { observation (counter-based env) -> actor -> per-head (masked) categorical, sample, log-prob -> stores -> env
+//                            transition }, 32 envs per workgroup, the step loop INSIDE the kernel (envs never interact in a rollout).  Replaces
+//                            128 x { 5 layer products, heads, stores, 2 env kernels } = 1150 launches by one.
+//   generic_forward_kernel   a net over a batch of rows (critic over the rollout's T N + N observations; both nets of a minibatch step, which
+//                            also keep every hidden activation in HBM for the backward pass), 64 rows per workgroup.
+// Arithmetic = launch_matmul_bf16's (operands bf16 round-to-nearest-even, f32 accumulation, bias and tanh in f32); the order of the k sum
+// differs from the tiled kernel's only in chunking.
+#include "generic.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FU_WAVES = 8, FU_THREADS = 64 * FU_WAVES;
+constexpr int FU_KSTEPS = 24;   // k steps (of 16) whose B fragments are in flight at once: 96 registers
+
+__device__ __forceinline__ uint32_t fu_f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float fu_u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint16_t fu_bf16(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
+__device__ __forceinline__ uint32_t fu_pack(float x0, float x1) { const bf16x2 v = { (__bf16)x0, (__bf16)x1 }; return __builtin_bit_cast(uint32_t, v); }
+
+struct FusedNet {
+    GenLayout L;
+    int net;
+    const float* params;            // f32 master parameters (biases are read from here)
+    const uint16_t* wfrags;         // bf16 weights of every layer in MFMA-fragment order (gen_weight_planes: [column block][k step][lane][8])
+    int64_t wp_off[GEN_MAX_LAYERS]; // of THIS net
+    int wp_kpad[GEN_MAX_LAYERS];
+    int ldA;                        // LDS row pitch (bf16 elements): max(pad16(obs), pad32(hidden)) + 8
+};
+
+// Runs every layer of the net on the FM x 32 rows whose layer-0 input sits in tile0 ([rows][ldA] bf16, zero beyond obs up to a multiple of
+// 16).  Hidden activations alternate between tile1 and tile0; the head's f32 outputs land in s_out [rows][32] (columns beyond the head's width
+// are zero).  keep[l] != nullptr: hidden layer l's activation tile is also stored to keep[l] + row0 * ld_keep (rows < n_rows only).
+// Ends with a barrier: s_out and the last tile are visible to every thread.
+// The B fragments of a column block: ksteps x 16 bytes per lane, all in flight together.  A layer has at most FU_KSTEPS k steps per pass.
+struct BFrags { u32x4 q[FU_KSTEPS]; };
+__device__ __forceinline__ void load_bfrags(BFrags& b, const FusedNet& f, int l, int cb, int k0, int lane) {
+    const int ksteps = (f.L.in_dim[l] + 15) / 16;
+    const uint16_t* wblk = f.wfrags + f.wp_off[l] + ((int64_t)cb * (f.wp_kpad[l] / 16) * 64 + lane) * 8;   // a k step's fragments: 64 lanes x 16 consecutive bytes
+#pragma unroll
+    for (int j = 0; j < FU_KSTEPS; j++)   // unconditional loads (a k step past the end re-reads step 0 and is not used)
+        b.q[j] = *reinterpret_cast<const u32x4*>(wblk + (int64_t)(k0 + j < ksteps ? k0 + j : 0) * 512);
+}
+
+template <int FM>
+__device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0, uint16_t* tile1, float* s_out, uint16_t* const* keep, int64_t ld_keep, int64_t row0,
+                                             int n_rows, BFrags& pre) {
+    // `pre` holds, on entry, the fragments of (layer 0, column block = wave, k steps 0 ..) -- requested by the caller, e.g. while the input tile
+    // was still being written -- and on exit those of layer 0 again (for the next call): a layer's first fragments are always requested
+    // before the epilogue and the barrier of the layer above, so their trip to L2 is never waited for with nothing else to do.
+    const GenLayout& L = f.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kg = lane >> 5;
+    uint16_t* src = tile0;
+    uint16_t* dst = tile1;
+    for (int l = 0; l < L.n_layers; l++) {
+        const int K = L.in_dim[l], N = L.out_dim[f.net][l];
+        const bool last = l == L.n_layers - 1;
+        const int ksteps = (K + 15) / 16;
+        const int nblk = (N + 31) / 32;
+        const float* bias = f.params + L.b_off[f.net][l];
+        const int ln = last ? 0 : l + 1;   // the layer whose first fragments are requested during this one
+        for (int cb = wave; cb < nblk || cb == wave; cb += FU_WAVES) {   // every wave passes once (it may own no column block): it still prefetches
+            const bool own = cb < nblk;
+            f32x16 acc[FM];
+#pragma unroll
+            for (int i = 0; i < FM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+            for (int k0 = 0; k0 < ksteps; k0 += FU_KSTEPS) {
+                if (own && (cb != wave || k0 != 0)) load_bfrags(pre, f, l, cb, k0, lane);
+                if (own) {
+#pragma unroll
+                    for (int j = 0; j < FU_KSTEPS; j++) {
+                        if (k0 + j < ksteps) {
+#pragma unroll
+                            for (int i = 0; i < FM; i++) {
+                                const u32x4 a = *reinterpret_cast<const u32x4*>(src + (32 * i + li) * f.ldA + 16 * (k0 + j) + 8 * kg);
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pre.q[j]), acc[i], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            if (cb + FU_WAVES >= nblk) load_bfrags(pre, f, ln, wave, 0, lane);   // the wave's last pass of this layer: next layer's first fragments
+            if (own) {
+                // epilogue: lane's column n = 32 cb + li, register r <-> row (r & 3) + 8 (r >> 2) + 4 kg of block i
+                const int n = 32 * cb + li;
+                const float b = n < N ? bias[n] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < FM; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        const float v = acc[i][r] + b;
+                        if (last) s_out[row * 32 + (n & 31)] = n < N ? v : 0.0f;   // heads are at most 32 logits wide (PPO_MAX_ACT): one column block
+                        else dst[row * f.ldA + n] = fu_bf16(n < N ? tanh_mufu(v) : 0.0f);
+                    }
+            }
+        }
+        __syncthreads();
+        if (!last && keep && keep[l]) {   // the activation tile leaves for the backward pass in 16-byte row pieces
+            const int p8 = (N + 7) / 8;
+            for (int e = tid; e < 32 * FM * p8; e += FU_THREADS) {
+                const int row = e / p8, c8 = e % p8;
+                if (row < n_rows) *reinterpret_cast<u32x4*>(keep[l] + (row0 + row) * ld_keep + 8 * c8) = *reinterpret_cast<const u32x4*>(dst + row * f.ldA + 8 * c8);
+            }
+        }
+        uint16_t* t = src; src = dst; dst = t;
+    }
+}
+
+// observation j .. j + 3 of (env, step): four values from one Philox word each (kernels_generic.hip: syn_obs, bit for bit)
+__device__ __forceinline__ float4 syn_obs4(int64_t seed, int64_t env, int64_t step, int j4) {
+    const uint4 w = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)env, (uint32_t)step, (uint32_t)j4, 0x10u);
+    auto one = [](uint32_t x) {
+        const int sum = (int)(x & 255u) + (int)((x >> 8) & 255u) + (int)((x >> 16) & 255u) + (int)(x >> 24);
+        return (float)(sum - 510) * 0.0067658990621566772f;
+    };
+    return make_float4(one(w.x), one(w.y), one(w.z), one(w.w));
+}
+
+struct FusedRolloutArgs {
+    FusedNet f;
+    int dist_kind;
+    int N, T, max_episode_steps;
+    int64_t seed, env_offset, step_base;
+    int32_t* ep_len; float* ep_rew;
+    float* obs; uint8_t* masks; int32_t* actions; float* logprobs; float* rewards; float* dones;
+    int32_t* fin_len; float* fin_rew;
+    float* next_obs; int32_t* next_done; uint8_t* cur_mask;
+    const int64_t* forced;          // [T, N, H] or null
+};
+
+template <int DIST>
+__global__ __launch_bounds__(FU_THREADS, 1) void generic_rollout_kernel(const FusedRolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t fu_lds[];
+    const GenLayout& L = a.f.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint16_t* tile0 = fu_lds;
+    uint16_t* tile1 = fu_lds + 32 * a.f.ldA;
+    float* s_out = reinterpret_cast<float*>(fu_lds + 2 * 32 * a.f.ldA);      // [32][32]
+    uint8_t* s_mask = reinterpret_cast<uint8_t*>(s_out + 32 * 32);          // [2][32][PPO_MAX_ACT]: this step's and the next step's masks
+    const int e0 = blockIdx.x * 32;
+    const int O = L.obs, A = L.act, H = L.n_heads;
+    const int o4 = (O + 3) / 4, opad = (O + 15) / 16 * 16;
+    BFrags pre;
+    load_bfrags(pre, a.f, 0, wave, 0, lane);   // layer 0's first weight fragments travel while the first observation is formed
+    // per-env state lives in the registers of lanes 0..31 of wave 0 for the whole rollout
+    const bool env_lane = tid < 32 && e0 + tid < a.N;
+    const int64_t env_g = a.env_offset + e0 + tid;
+    int len = 0, prev_done = 0;
+    float rew = 0.0f;
+    if (env_lane) { len = a.ep_len[e0 + tid]; rew = a.ep_rew[e0 + tid]; prev_done = a.next_done[e0 + tid]; }
+
+    // Observation (and mask) of global step `step` for the workgroup's envs, formed by threads [t0, t0 + nt): f32 to obs_dst [N, O], bf16 to
+    // tile0 (the actor's layer-0 input), the mask to s_mask[slot] and mask_dst [N, A].  The synthetic env is memoryless (kernels_generic.hip),
+    // so step t + 1's observation does not wait for step t's action: waves 1..7 form it while wave 0 samples and steps the envs.
+    auto observe = [&](int64_t step, float* obs_dst, uint8_t* mask_dst, int slot, int t0, int nt) {
+        const int me = tid - t0;
+        if (me < 0 || me >= nt) return;
+        for (int e = me; e < 32 * o4; e += nt) {
+            const int env = e / o4, j4 = e % o4;
+            const float4 v = syn_obs4(a.seed, a.env_offset + e0 + env, step, j4);
+            const bool ok = e0 + env < a.N;
+            uint16_t* trow = tile0 + env * a.f.ldA + 4 * j4;
+            float* grow = obs_dst + (size_t)(e0 + env) * O + 4 * j4;
+            if (4 * j4 + 3 < O) {
+                *reinterpret_cast<uint2*>(trow) = make_uint2(fu_pack(v.x, v.y), fu_pack(v.z, v.w));
+                if (ok) {
+                    if ((O & 3) == 0) *reinterpret_cast<float4*>(grow) = v;
+                    else { grow[0] = v.x; grow[1] = v.y; grow[2] = v.z; grow[3] = v.w; }
+                }
+            } else {
+                const float vv[4] = { v.x, v.y, v.z, v.w };
+                for (int q = 0; q < 4; q++) if (4 * j4 + q < O) { trow[q] = fu_bf16(vv[q]); if (ok) grow[q] = vv[q]; }
+            }
+        }
+        for (int e = me; e < 32 * (opad - O); e += nt) tile0[(e / (opad - O)) * a.f.ldA + O + e % (opad - O)] = 0;   // zero k padding
+        if (me < 32) {
+            uint8_t* mrow = s_mask + (slot * 32 + me) * PPO_MAX_ACT;
+            uint32_t bits = 0xffffffffu;
+            if (DIST == PPO_DIST_MASKED)
+                bits = philox4x32_10((uint32_t)a.seed, (uint32_t)((uint64_t)a.seed >> 32), (uint32_t)(a.env_offset + e0 + me), (uint32_t)step, 0u, 0x12u).x;
+            int off = 0;
+            for (int h = 0; h < H; h++) {
+                bool any = false;
+                for (int k = 0; k < L.head_dims[h]; k++) { const bool v = (bits >> (off + k)) & 1u; any |= v; mrow[off + k] = v ? 1 : 0; }
+                if (!any) mrow[off] = 1;
+                off += L.head_dims[h];
+            }
+            if (e0 + me < a.N && mask_dst) for (int k = 0; k < A; k++) mask_dst[(size_t)(e0 + me) * A + k] = mrow[k];
+        }
+    };
+
+    observe(a.step_base, a.obs, a.masks, 0, 0, FU_THREADS);   // m_obs[0] = next_obs, m_action_masks[0] = next_mask (:553-555)
+    __syncthreads();
+    for (int t = 0; t < a.T; t++) {
+        const int64_t step = a.step_base + t;
+        const size_t tn = (size_t)t * a.N;
+        fused_layers<1>(a.f, tile0, tile1, s_out, nullptr, 0, 0, 32, pre);   // ends with a barrier: logits in s_out, tile0 free again
+        if (wave != 0) {
+            const bool more = t + 1 < a.T;   // the observation the agent sees next: row t + 1 of the buffers, or NEXT_OBS / the current mask after the last step
+            observe(step + 1, more ? a.obs + (tn + a.N) * O : a.next_obs, more ? (a.masks ? a.masks + (tn + a.N) * A : nullptr) : a.cur_mask, (t + 1) & 1, 64, FU_THREADS - 64);
+        } else if (env_lane) {
+            // per-head (masked) categorical on the row's logits, sample or forced action, summed log-prob (Agent.cpp:137-170; heads_kernel)
+            const uint8_t* mrow = s_mask + ((t & 1) * 32 + tid) * PPO_MAX_ACT;
+            float lp_sum = 0.0f;
+            int off = 0;
+            for (int h = 0; h < H; h++) {
+                const int Ah = L.head_dims[h];
+                float z[PPO_MAX_ACT], p[PPO_MAX_ACT];
+                for (int k = 0; k < Ah; k++) z[k] = s_out[tid * 32 + off + k];
+                categorical_head_fast<DIST>(z, p, DIST == PPO_DIST_MASKED ? mrow + off : nullptr, Ah);
+                int act;
+                if (a.forced) {
+                    act = (int)a.forced[(tn + e0 + tid) * H + h];
+                } else {
+                    const uint4 w = philox4x32_10((uint32_t)a.seed, (uint32_t)((uint64_t)a.seed >> 32), (uint32_t)env_g, (uint32_t)(step >> 2), (uint32_t)h, 0u);
+                    const uint32_t ws = (step & 3) == 0 ? w.x : ((step & 3) == 1 ? w.y : ((step & 3) == 2 ? w.z : w.w));
+                    act = sample_head(p, Ah, (float)(ws >> 8) * 0x1p-24f);
+                }
+                a.actions[(tn + e0 + tid) * H + h] = act;
+                float lp = 0.0f;
+                for (int k = 0; k < Ah; k++) if (k == act) lp = z[k];
+                lp_sum = h == 0 ? lp : lp_sum + lp;
+                off += Ah;
+            }
+            a.logprobs[tn + e0 + tid] = lp_sum;
+            a.dones[tn + e0 + tid] = (float)prev_done;                       // m_dones[step] = next_done (:554)
+            // env transition of this step (kernels_generic.hip: synthetic_transition_kernel, bit for bit)
+            const uint4 w = philox4x32_10((uint32_t)a.seed, (uint32_t)((uint64_t)a.seed >> 32), (uint32_t)env_g, (uint32_t)step, 0u, 0x11u);
+            const float r = (float)(w.x >> 8) * 0x1p-23f - 1.0f;
+            int term = (w.y >> 8) < 167772u ? 1 : 0;
+            len += 1;
+            rew += r;
+            if (len == a.max_episode_steps) term = 1;
+            int fl = 0;
+            float fr = 0.0f;
+            if (term) { fl = len; fr = rew; len = 0; rew = 0.0f; }
+            a.rewards[tn + e0 + tid] = r;
+            a.fin_len[tn + e0 + tid] = fl;
+            a.fin_rew[tn + e0 + tid] = fr;
+            prev_done = term;
+        }
+        __syncthreads();   // tile0 holds the next observation; s_out and the older mask slot are free
+    }
+    if (env_lane) { a.ep_len[e0 + tid] = len; a.ep_rew[e0 + tid] = rew; a.next_done[e0 + tid] = prev_done; }
+}
+
+struct FusedForwardArgs {
+    FusedNet f;
+    const float* x_f32;             // [rows][obs] f32 (rounded to bf16 on the way into LDS), or
+    const uint16_t* x_bf;           // [rows][ld_x] bf16, zero padded
+    int64_t ld_x, rows;
+    float* out;                     // [rows][out_dim(last)]
+    uint16_t* keep[GEN_MAX_LAYERS]; // hidden activations to keep (null: none), pitch ld_keep
+    int64_t ld_keep;
+};
+
+__global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t fu_lds[];
+    constexpr int FM = 2, RB = 32 * FM;
+    const GenLayout& L = a.f.L;
+    const int tid = threadIdx.x;
+    uint16_t* tile0 = fu_lds;
+    uint16_t* tile1 = fu_lds + RB * a.f.ldA;
+    float* s_out = reinterpret_cast<float*>(fu_lds + 2 * RB * a.f.ldA);      // [RB][32]
+    const int64_t row0 = (int64_t)blockIdx.x * RB;
+    const int n_rows = a.rows - row0 < RB ? (int)(a.rows - row0) : RB;
+    const int O = L.obs, opad = (O + 15) / 16 * 16;
+    BFrags pre;
+    load_bfrags(pre, a.f, 0, tid >> 6, 0, tid & 63);   // layer 0's first weight fragments travel while the input tile is loaded
+    if (a.x_bf) {
+        const int p8 = opad / 8;
+        for (int e = tid; e < RB * p8; e += FU_THREADS) {
+            const int row = e / p8, c8 = e % p8;
+            u32x4 v = { 0u, 0u, 0u, 0u };
+            if (row < n_rows) v = *reinterpret_cast<const u32x4*>(a.x_bf + (row0 + row) * a.ld_x + 8 * c8);
+            *reinterpret_cast<u32x4*>(tile0 + row * a.f.ldA + 8 * c8) = v;
+        }
+    } else {
+        const int p2 = opad / 2;
+        for (int e = tid; e < RB * p2; e += FU_THREADS) {
+            const int row = e / p2, k = 2 * (e % p2);
+            float x0 = 0.0f, x1 = 0.0f;
+            if (row < n_rows) {
+                if (k < O) x0 = a.x_f32[(row0 + row) * O + k];
+                if (k + 1 < O) x1 = a.x_f32[(row0 + row) * O + k + 1];
+            }
+            *reinterpret_cast<uint32_t*>(tile0 + row * a.f.ldA + k) = fu_pack(x0, x1);
+        }
+    }
+    __syncthreads();
+    fused_layers<FM>(a.f, tile0, tile1, s_out, a.keep, a.ld_keep, row0, n_rows, pre);
+    const int N = L.out_dim[a.f.net][L.n_layers - 1];
+    for (int e = tid; e < n_rows * N; e += FU_THREADS) a.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];
+}
+
+FusedNet make_fused_net(const GenericCtx& g, const float* params, int net) {
+    FusedNet f{};
+    f.L = g.L; f.net = net; f.params = params; f.wfrags = g.wfrags;
+    for (int l = 0; l < g.L.n_layers; l++) { f.wp_off[l] = g.wp_off[net][l]; f.wp_kpad[l] = g.wp_kpad[l]; }
+    const int a = (g.L.obs + 15) / 16 * 16, b = (g.L.hidden + 31) / 32 * 32;
+    f.ldA = (a > b ? a : b) + 8;
+    return f;
+}
+size_t fused_lds_bytes(const FusedNet& f, int rows) { return (size_t)2 * rows * f.ldA * 2 + (size_t)rows * 32 * 4 + 2 * 32 * PPO_MAX_ACT; }
+
+}  // namespace
+
+// The fused kernels need both LDS tiles of the widest layer input to fit (64 rows for the batch kernel) and a head of at most 32 logits.
+bool gen_fused_ok(const GenericCtx& g) {
+    if (!g.bf16 || g.L.act > 32) return false;
+    const FusedNet f = make_fused_net(g, nullptr, 0);
+    return fused_lds_bytes(f, 64) <= 150 * 1024;
+}
+
+hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
+                             float* out, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    FusedForwardArgs a{};
+    a.f = make_fused_net(g, params, net);
+    a.x_f32 = x_f32; a.x_bf = x_bf; a.ld_x = ld_x; a.rows = rows; a.out = out;
+    for (int l = 0; l < g.L.n_hidden; l++) a.keep[l] = keep ? g.acts_bf[net][l] : nullptr;
+    a.ld_keep = g.ld_h;
+    const size_t lds = fused_lds_bytes(a.f, 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(generic_forward_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(FU_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,
+                             int64_t step_base, int32_t* ep_len, float* ep_rew, float* obs, uint8_t* masks, int32_t* actions, float* logprobs, float* rewards,
+                             float* dones, int32_t* fin_len, float* fin_rew, float* next_obs, int32_t* next_done, uint8_t* cur_mask, const int64_t* forced,
+                             hipStream_t s) {
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    FusedRolloutArgs a{};
+    a.f = make_fused_net(g, params, 1);
+    a.dist_kind = dist_kind; a.N = N; a.T = T; a.max_episode_steps = max_episode_steps;
+    a.seed = seed; a.env_offset = env_offset; a.step_base = step_base;
+    a.ep_len = ep_len; a.ep_rew = ep_rew; a.obs = obs; a.masks = masks; a.actions = actions; a.logprobs = logprobs; a.rewards = rewards; a.dones = dones;
+    a.fin_len = fin_len; a.fin_rew = fin_rew; a.next_obs = next_obs; a.next_done = next_done; a.cur_mask = cur_mask; a.forced = forced;
+    const size_t lds = fused_lds_bytes(a.f, 32);
+    const dim3 grid((unsigned)((N + 31) / 32)), block(FU_THREADS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_rollout_kernel<PPO_DIST_MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_rollout_kernel<PPO_DIST_CATEGORICAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (dist_kind == PPO_DIST_MASKED) hipLaunchKernelGGL(generic_rollout_kernel<PPO_DIST_MASKED>, grid, block, lds, s, a);
+    else hipLaunchKernelGGL(generic_rollout_kernel<PPO_DIST_CATEGORICAL>, grid, block, lds, s, a);
+    return hipGetLastError();
+}

@@ -286,6 +286,34 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return ax < 0.12f ? small : bigs;
 }
 
+// categorical_head on the hardware exp2 / log2 / rcp units (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ULP each; log-probs within ~3e-7 of the
+// library version): for kernels where one wave evaluates the heads on a step's critical path.
+template <int DIST>
+__device__ __forceinline__ float categorical_head_fast(float* z, float* p, const uint8_t* mask, int A) {
+    float mx = -INFINITY;
+    for (int a = 0; a < A; a++) {
+        if (DIST == PPO_DIST_MASKED && mask && !mask[a]) z[a] = -1e8f;
+        mx = z[a] > mx ? z[a] : mx;
+    }
+    float se = 0.0f;
+    for (int a = 0; a < A; a++) { p[a] = fast_exp(z[a] - mx); se += p[a]; }
+    const float lse = fast_log(se) + mx;
+    const float rse = __builtin_amdgcn_rcpf(se);
+    float ent = 0.0f;
+    for (int a = 0; a < A; a++) {
+        z[a] = z[a] - lse;
+        p[a] = p[a] * rse;
+        if (DIST == PPO_DIST_CATEGORICAL) {
+            const float l = z[a] > 1.17549435e-38f ? z[a] : 1.17549435e-38f;
+            ent += l * p[a];
+        } else {
+            const float plp = z[a] * p[a];
+            ent += (mask == nullptr || mask[a]) ? plp : 0.0f;
+        }
+    }
+    return -ent;
+}
+
 // Wave-wide float sum, result in every lane, on the DPP cross-lane network (no LDS crossbar round trips, which cost ~100+
 // cycles each and are on the rollout's per-step dependency chain): butterfly inside each row of 16 lanes with
 // quad_perm / row_half_mirror / row_mirror, then the four row sums are read through scalar registers.  Fixed order.
