@@ -174,6 +174,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-selftest", action="store_true", help="N = 1 only: drive the multi-rank code path (RCCL all-reduces over a one-rank communicator, "
                     "three-kernel optimizer step) to see its per-step cost on one GPU; not a valid headline number")
+    ap.add_argument("--transport", choices=("auto", "exchange", "rccl"), default="auto", help="N > 1: the gradient all-reduce. exchange = one-shot direct "
+                    "exchange over HIP-IPC peer buffers (one kernel per rank and call); rccl = ncclAllReduce; auto = exchange, checked after the warm-up "
+                    "(no wait timed out, replicas bit-identical), RCCL if that check fails")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (exchange transport only)")
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel + GAE")
     args = ap.parse_args()
     W = WORKLOADS[args.workload]
@@ -199,16 +203,47 @@ def main():
     cfg = P.dist.shard_config(P.make_config, rank, world, N * world, env_kind=kind[0], dist_kind=kind[1], obs_size=obs,
                               head_dims=heads, hidden=W["hidden"], n_hidden=W["n_hidden"], num_steps=T, num_minibatches=4, update_epochs=10,
                               max_episode_steps=W["max_steps"], seed=2, total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98,
-                              gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True, device=local_rank,
+                              gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True,
+                              device=0 if args.same_device else local_rank,
                               compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32)
-    ctx = P.Context(cfg)
-    if args.comm_selftest and world == 1:
-        os.environ["PPO_COMM_SELFTEST"] = "1"
-        ctx.comm_init(P.comm_unique_id(), 0, 1)
-        del os.environ["PPO_COMM_SELFTEST"]
-    P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id)
-    ctx.init_orthogonal(2)   # same seed on every rank: replicated weights
-    ctx.env_reset()
+    def start(transport):
+        c = P.Context(cfg)
+        if args.comm_selftest and world == 1:
+            os.environ["PPO_COMM_SELFTEST"] = "1"
+            c.comm_init(P.comm_unique_id(), 0, 1)
+            del os.environ["PPO_COMM_SELFTEST"]
+        P.dist.bootstrap_comm(c, dist, rank, world, P.comm_unique_id, transport=transport)
+        c.init_orthogonal(2)   # same seed on every rank: replicated weights
+        c.env_reset()
+        for _ in range(args.warmup):
+            c.train_iteration()
+        c.sync()
+        return c
+
+    transport = "rccl" if args.transport == "rccl" else "exchange"
+    if world == 1:
+        transport = "none"
+    try:
+        ctx = start(transport)
+        ok = True
+        if transport == "exchange":
+            # the exchange has never run on this node before this job: after the warm-up no bounded wait may have run out and the replicas must
+            # hold bit-identical parameters (every rank adds the shards in rank order)
+            import hashlib
+            digest = hashlib.sha256(ctx.get_params().tobytes()).digest()
+            ok = ctx.comm_exchange_timeouts() == 0 and len(set(P.dist.gather_bytes(dist, digest))) == 1
+    except Exception as ex:   # e.g. IPC handles cannot be opened on this node
+        if transport != "exchange" or args.transport != "auto":
+            raise
+        sys.stderr.write("rank %d: exchange transport failed (%r)\n" % (rank, ex))
+        ctx, ok = None, False
+    if transport == "exchange" and not P.dist.all_ranks_agree(dist, ok):
+        if args.transport != "auto":
+            sys.exit("exchange transport failed its post-warm-up check")
+        if ctx is not None:
+            ctx.close()
+        transport = "rccl"
+        ctx = start(transport)
 
     def barrier():
         ctx.sync()
@@ -216,8 +251,6 @@ def main():
             dist.barrier()
         ctx.sync()
 
-    for _ in range(args.warmup):
-        ctx.train_iteration()
     ctx.profile_enable(args.profile)
     barrier()
     t0 = time.perf_counter()
@@ -301,7 +334,7 @@ def main():
             "data": "synthetic (counter-based env, random-init 4x256 actor/critic)" if generic else "synthetic (fixed-seed %s, random-init 2x64 actor/critic)" % ("CartPole-v1" if args.workload == "cartpole" else "MountainCar"),
             "config": {"workload": (W["label"] % (N, T)) + " (BASELINE.json configs[%d]%s)" % (W["cfg1"] if world == 1 else W["cfg8"], ", one GPU's share" if generic and world == 1 else ""),
                        "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
-                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 gradient all-reduce per optimizer step)" % world + (" [comm self-test]" if args.comm_selftest else "")},
+                       "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 gradient all-reduce per optimizer step%s)" % (world, {"exchange": ": one-shot direct exchange over IPC peer buffers", "rccl": ": RCCL", "none": ""}[transport]) + (" [comm self-test]" if args.comm_selftest else "") + (" [all ranks on ONE device: rehearsal]" if args.same_device and world > 1 else "")},
             "roofline": roof,
             "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_bytes / (gae_ms * 1e-3) / 1e9 if gae_ms else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gae_ms else None,

@@ -537,6 +537,53 @@ int benchReference(int64_t numEnvs, int64_t numSteps, int64_t updates) {
     return 0;
 }
 
+// Host-side fixtures: what the reference PRINTS and PARSES, for crafted inputs that
+// ppo-libtorch_amd/host/tests/host_facade_test.cpp feeds to the facade's own printPPOResults / PPOUtils.
+//   console_table.txt     the SB3-style table of PPO_Discrete::printPPOResults (PPO_Discrete.cpp:700-774) for four calls made in this order in ONE
+//                         process (stream manipulators persist between calls, as they do in train()): first update with episode statistics,
+//                         a later update with them, a later update without, a first update without
+//   host_utils.txt        PPOUtils::getLoadFromSteps / isNumber / getVectorMean (Utils.cpp:5-60) on a list of inputs
+void goldHost(const std::string& outDir) {
+    RunCfg c;   // 8 envs x 32 steps: m_batch_size = 256, update_epochs = 10, clip_coef = 0.2
+    enterScratchWithConfig(c, "hostgold");
+    PPO_Discrete algo;
+    static_cast<torch::optim::AdamWOptions&>(algo.m_optimizer->param_groups()[0].options()).lr(0.00075);
+    algo.m_clipfracs = { 0.125f, 0.0625f, 0.25f };
+    torch::Tensor kl = torch::tensor(0.00123456789f), ent = torch::tensor(-1.17549435e-38f), ev = torch::tensor(0.1762397289f);
+    torch::Tensor loss = torch::tensor(24.916658401f), pg = torch::tensor(-0.007237161f), vl = torch::tensor(27.17522430f);
+    std::stringstream ss;
+    std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
+    algo.m_episode_stats = std::make_unique<CircularBuffer>(100);
+    algo.m_episode_stats->add(21.0f, 22); algo.m_episode_stats->add(13.0f, 14); algo.m_episode_stats->add(-1.0f, 1); algo.m_episode_stats->add(499.0f, 500);
+    algo.printPPOResults(1, 256, std::chrono::milliseconds(123), std::chrono::milliseconds(4567), kl, ent, ev, loss, pg, vl);
+    algo.printPPOResults(2, 512, std::chrono::milliseconds(97), std::chrono::milliseconds(12345), kl, ent, ev, loss, pg, vl);
+    algo.m_episode_stats = std::make_unique<CircularBuffer>(100);
+    algo.printPPOResults(3, 768, std::chrono::milliseconds(97), std::chrono::milliseconds(23456), kl, ent, ev, loss, pg, vl);
+    algo.printPPOResults(1, 256, std::chrono::milliseconds(123), std::chrono::milliseconds(999), kl, ent, ev, loss, pg, vl);
+    std::cout.rdbuf(old);
+    { std::ofstream f(outDir + "/console_table.txt", std::ios::binary); f << ss.str(); }
+    std::ofstream u(outDir + "/host_utils.txt", std::ios::binary);
+    const char* names[] = { "./ModelCheckpoints/PPO_Agent_99840_steps.pt", "PPO_Agent_0_steps.pt", "./OptimizerCheckpoints/PPO_Optimizer_123456789_steps.pt",
+                            "PPO_Agent_steps.pt", "PPO_Agent_12ab_steps.pt", "/a/b/PPO_Agent_77", "./Models/PPO_Agent_5000000_steps.pt" };
+    for (const char* n : names) {
+        const std::string head = std::string(n).find("Optimizer") != std::string::npos ? "PPO_Optimizer_" : "PPO_Agent_";
+        const std::string r = PPOUtils::getLoadFromSteps(n, head);
+        u << "steps|" << n << "|" << head << "|" << r << "|" << (PPOUtils::isNumber(r) ? 1 : 0) << "\n";
+    }
+    const char* nums[] = { "123", "", "12a", "007", " 1", "-5" };
+    for (const char* n : nums) u << "isnum|" << n << "|" << (PPOUtils::isNumber(n) ? 1 : 0) << "\n";
+    char buf[64];
+    std::vector<std::vector<float>> vecs = { { 0.125f, 0.0625f, 0.25f }, { 1.0f }, { 0.1f, 0.2f, 0.3f, 0.4f } };
+    for (const auto& v : vecs) {
+        const float m = PPOUtils::getVectorMean(v);
+        uint32_t bits; std::memcpy(&bits, &m, 4);
+        std::snprintf(buf, sizeof buf, "%08x", bits);
+        u << "mean|";
+        for (size_t i = 0; i < v.size(); i++) { uint32_t b; std::memcpy(&b, &v[i], 4); char t[16]; std::snprintf(t, sizeof t, "%08x", b); u << (i ? "," : "") << t; }
+        u << "|" << buf << "\n";
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -575,8 +622,15 @@ int main(int argc, char** argv) {
             }
             return 0;
         }
+        if (mode == "hostgold" && argc > 2) {
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            goldHost(out);
+            return 0;
+        }
         if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));
-        std::cerr << "usage: ref_harness golden <outdir> | bench <num_envs> <num_steps> <updates>\n";
+        std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | bench <num_envs> <num_steps> <updates>\n";
         return 2;
     } catch (const std::exception& ex) {
         std::cerr << "[ref_harness] error: " << ex.what() << std::endl;

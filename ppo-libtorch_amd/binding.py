@@ -20,6 +20,7 @@ DIST_CATEGORICAL, DIST_MASKED = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
 ABI_VERSION = 2
 COMM_ID_BYTES = 128
+COMM_HANDLE_BYTES = 64
 
 BUF = dict(OBS=0, ACTIONS=1, LOGPROBS=2, REWARDS=3, DONES=4, VALUES=5, MASKS=6, ADVANTAGES=7, RETURNS=8, NEXT_OBS=9,
            NEXT_DONE=10, NEXT_VALUE=11, PARAMS=12, GRADS=13, EXP_AVG=14, EXP_AVG_SQ=15, ENV_STATE=16, EP_LEN=17, EP_REW=18,
@@ -40,7 +41,7 @@ ABI_SYMBOLS = [
     "ppo_rollout", "ppo_calc_advantage", "ppo_gae", "ppo_nstep_returns", "ppo_generate_permutations",
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",
     "ppo_read_stats", "ppo_set_learning_rate", "ppo_profile_enable", "ppo_profile_read", "ppo_comm_unique_id", "ppo_comm_init",
-    "ppo_comm_init_local",
+    "ppo_comm_init_local", "ppo_comm_exchange_handle", "ppo_comm_init_exchange", "ppo_comm_exchange_timeouts",
 ]
 
 
@@ -354,6 +355,31 @@ def _comm_init_local(self, group_id, rank, nranks):
 
 
 Context.comm_init_local = _comm_init_local
+
+
+def _comm_exchange_handle(self):
+    """IPC handle of this context's exchange buffer (one-shot direct exchange; ppo_hip.h)."""
+    buf = (C.c_char * COMM_HANDLE_BYTES)()
+    _check(lib().ppo_comm_exchange_handle(self.h, buf), self.h)
+    return bytes(buf)
+
+
+def _comm_init_exchange(self, handles, rank, nranks):
+    blob = b"".join(handles)
+    assert len(blob) == nranks * COMM_HANDLE_BYTES
+    buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+    _check(lib().ppo_comm_init_exchange(self.h, buf, C.c_int32(rank), C.c_int32(nranks)), self.h)
+
+
+def _comm_exchange_timeouts(self):
+    n = C.c_int32()
+    _check(lib().ppo_comm_exchange_timeouts(self.h, C.byref(n)), self.h)
+    return n.value
+
+
+Context.comm_exchange_handle = _comm_exchange_handle
+Context.comm_init_exchange = _comm_init_exchange
+Context.comm_exchange_timeouts = _comm_exchange_timeouts
 
 
 def comm_unique_id():

@@ -61,14 +61,37 @@ static bool load(std::string& err) {
 // ---------------------------------------------------------------------------------------------------------
 struct LocalGroup {
     int n = 0;
+    int device = -1;              // every member lives on this device (ppo_comm_init_local rejects others)
     std::mutex mu;
     std::condition_variable cv;
     int arrived = 0, joined = 0;
     uint64_t generation = 0;
+    bool failed = false;          // a member's launch failed inside the rendezvous: every waiter returns PPO_ERR_COMM instead of hanging
     void* bufs[8] = {};
     hipEvent_t ready[8] = {};
     hipEvent_t done[2] = { nullptr, nullptr };
+    ~LocalGroup() { for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); }
 };
+// ---------------------------------------------------------------------------------------------------------
+// One-shot direct exchange: the all-reduce of a latency-bound payload (36.6 KB of gradient per optimizer step) WITHOUT a
+// ring.  Every rank owns a small exchange buffer in fine-grained device memory -- two slots of payload + a flag each -- that its peers
+// map through HIP IPC handles (one process per GPU; over xGMI each peer is one point-to-point hop).  An all-reduce is ONE kernel per rank:
+// publish the own payload and flag, then for every rank in rank order wait for its flag and add its payload -- a fixed order, so every rank
+// forms bit-identical sums -- straight out of the peer's memory.  Two slots suffice: a rank overwrites slot s two calls later, and it cannot
+// get there before every peer has finished reading the call in between (whose sum it needed to proceed).
+// RCCL stays available (ppo_comm_init); this path is chosen by ppo_comm_init_exchange.
+// ---------------------------------------------------------------------------------------------------------
+struct ExchangeComm {
+    void* own = nullptr;              // [2][slot_bytes] payload slots, then [2] uint64 flags (fine-grained device memory of this rank)
+    size_t slot_bytes = 0;
+    void* peer[8] = {};               // mapped exchange buffers of every rank (peer[rank] == own)
+    bool opened[8] = {};
+    uint64_t seq = 0;                 // calls so far (same on every rank)
+    int32_t* timeout_flag = nullptr;  // device: set by a kernel whose bounded wait for a peer ran out
+};
+struct XchgPtrs { void* p[8]; };
+hipError_t launch_exchange_allreduce(void* buf, size_t count, bool f64, const XchgPtrs& peers, int rank, int n, size_t slot_bytes, uint64_t seq,
+                                     int32_t* timeout_flag, hipStream_t s);
 static std::map<int64_t, std::shared_ptr<LocalGroup>> g_local_groups;
 static std::mutex g_local_groups_mu;
 struct PtrPack { void* p[8]; };
@@ -87,6 +110,7 @@ struct ppo_ctx {
     rccl::Comm comm = nullptr;
     std::shared_ptr<LocalGroup> lgroup;   // in-process communicator (exclusive with comm)
     hipEvent_t lg_ready = nullptr;
+    std::unique_ptr<ExchangeComm> xchg;   // one-shot direct exchange over IPC peer buffers (exclusive with comm / lgroup)
 
     std::vector<void*> allocs;
     void* buf[PPO_BUF_COUNT_] = {};
@@ -170,6 +194,18 @@ struct ProfScope {
 };
 
 static thread_local std::string g_create_error;
+
+// Every entry point that allocates, creates events or launches does so on the CONTEXT's device and leaves the caller's current device as it
+// found it (a host that drives several contexts from one thread, or shares the thread with another HIP user such as PyTorch).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const ppo_ctx* c) {
+        if (!c) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->cfg.device) switched = hipSetDevice(c->cfg.device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
 static ppo_status fail(ppo_ctx* ctx, ppo_status code, const char* fmt, ...) {
     char buf[1024];
@@ -298,6 +334,10 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl::CommDestroy) rccl::CommDestroy(c->comm);
     if (c->lg_ready) (void)hipEventDestroy(c->lg_ready);
+    if (c->xchg) {
+        for (int r = 0; r < 8; r++) if (c->xchg->opened[r]) (void)hipIpcCloseMemHandle(c->xchg->peer[r]);
+        if (c->xchg->own) (void)hipFree(c->xchg->own);
+    }
     for (auto& sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->gen) { delete c->gen; c->gen = nullptr; }
@@ -346,6 +386,9 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     if (B / cfg->num_minibatches < 1) return fail(nullptr, PPO_ERR_INVALID, "minibatch_size = batch/num_minibatches is 0");
     if (B >= (1ll << 31)) return fail(nullptr, PPO_ERR_UNSUPPORTED, "batch of %lld rows exceeds int32 indexing", (long long)B);
 
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore_device{ caller_device };
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail(nullptr, PPO_ERR_HIP, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
     ppo_ctx* c = new ppo_ctx();
@@ -511,6 +554,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
 
 extern "C" ppo_status ppo_sync(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PPO_OK;
 }
@@ -529,18 +573,21 @@ extern "C" ppo_status ppo_buffer(ppo_ctx* c, int32_t which, void** dev_ptr, size
 }
 extern "C" ppo_status ppo_device_alloc(ppo_ctx* c, size_t bytes, void** dev_ptr) {
     NEED(c, c && dev_ptr, "null argument");
+    DeviceGuard dev_guard(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipMalloc(dev_ptr, std::max<size_t>(bytes, 16)));
     return PPO_OK;
 }
 extern "C" ppo_status ppo_device_free(ppo_ctx* c, void* dev_ptr) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(dev_ptr));
     return PPO_OK;
 }
 extern "C" ppo_status ppo_memcpy_h2d(ppo_ctx* c, void* dst_dev, const void* src_h, size_t bytes) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     HIPCHK(c, hipMemcpyAsync(dst_dev, src_h, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->gen) c->gen->planes_dirty = true;   // the copy may have landed in the parameters: re-split the weights before their next use
@@ -548,6 +595,7 @@ extern "C" ppo_status ppo_memcpy_h2d(ppo_ctx* c, void* dst_dev, const void* src_
 }
 extern "C" ppo_status ppo_memcpy_d2h(ppo_ctx* c, void* dst_h, const void* src_dev, size_t bytes) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     HIPCHK(c, hipMemcpyAsync(dst_h, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PPO_OK;
@@ -682,6 +730,7 @@ static void orthogonal_fill(float* W, int rows, int cols, double gain, int64_t s
 
 extern "C" ppo_status ppo_params_init_orthogonal(ppo_ctx* c, int64_t seed) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     std::vector<float> p((size_t)c->L.P, 0.0f);
     if (c->gen) {   // Agent.cpp:25-59 generalised: sqrt(2) on hidden layers, 1.0 on the value head, 0.01 on the policy head
         const GenLayout& GL = c->gen->L;
@@ -730,6 +779,7 @@ static ppo_status gen_policy(ppo_ctx* c, const float* obs, const uint8_t* mask, 
 
 extern "C" ppo_status ppo_get_value(ppo_ctx* c, const float* obs, int64_t n, float* value) {
     NEED(c, c && obs && value, "null argument");
+    DeviceGuard dev_guard(c);
     if (c->gen) return gen_values(c, obs, n, value);
     HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, obs, nullptr, nullptr, n, c->cfg.seed, c->cfg.env_offset, 0,
                                 nullptr, nullptr, nullptr, value, true, c->stream));
@@ -739,6 +789,7 @@ extern "C" ppo_status ppo_get_value(ppo_ctx* c, const float* obs, int64_t n, flo
 extern "C" ppo_status ppo_policy_act(ppo_ctx* c, const float* obs, const uint8_t* mask, const int64_t* forced_action, int64_t n,
                                      int64_t step_index, int64_t* action, float* logprob, float* entropy, float* value) {
     NEED(c, c && obs, "null argument");
+    DeviceGuard dev_guard(c);
     NEED(c, forced_action || action, "sampling needs an action output");
     if (c->gen) {
         ppo_status s = gen_policy(c, obs, mask, forced_action, n, step_index, action, logprob, entropy);
@@ -773,6 +824,7 @@ extern "C" ppo_status ppo_env_transition(int32_t env_kind, const float* state_in
 
 extern "C" ppo_status ppo_env_reset(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     if (c->gen) {   // synthetic env: memoryless, the observation of global step `rollout_steps` (0 after creation)
         HIPCHK(c, hipMemsetAsync(c->buf[PPO_BUF_EP_LEN], 0, (size_t)c->N * sizeof(int32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->buf[PPO_BUF_EP_REW], 0, (size_t)c->N * sizeof(float), c->stream));
@@ -789,6 +841,7 @@ extern "C" ppo_status ppo_env_reset(ppo_ctx* c) {
 
 extern "C" ppo_status ppo_env_step(ppo_ctx* c, const int64_t* action, float* obs, float* reward, int32_t* done) {
     NEED(c, c && action && obs && reward && done, "null argument");
+    DeviceGuard dev_guard(c);
     if (c->gen) {   // synthetic env: one step at the context's global step counter (the action does not influence it)
         HIPCHK(c, gen_synthetic_step(c->gen->L, c->N, c->cfg.seed, c->cfg.env_offset, c->rollout_steps, c->cfg.max_episode_steps,
                                      B_<int32_t>(c, PPO_BUF_EP_LEN), B_<float>(c, PPO_BUF_EP_REW), obs, c->cur_mask, reward, done, nullptr, nullptr, c->stream));
@@ -803,6 +856,7 @@ extern "C" ppo_status ppo_env_step(ppo_ctx* c, const int64_t* action, float* obs
 
 extern "C" ppo_status ppo_env_set_state_h(ppo_ctx* c, const float* state_h, const int32_t* ep_len_h, const float* ep_rew_h, const int32_t* reset_count_h) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     if (state_h) {
         ppo_status s = ppo_memcpy_h2d(c, c->scratch_obs, state_h, (size_t)c->N * c->O * sizeof(float));
         if (s != PPO_OK) return s;
@@ -819,6 +873,7 @@ extern "C" ppo_status ppo_env_set_state_h(ppo_ctx* c, const float* state_h, cons
 
 extern "C" ppo_status ppo_env_get_state_h(ppo_ctx* c, float* state_h, int32_t* ep_len_h, float* ep_rew_h, int32_t* reset_count_h) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     ppo_status s = PPO_OK;
     if (state_h) {
         HIPCHK(c, launch_aos_to_soa(c->scratch_obs, B_<float>(c, PPO_BUF_ENV_STATE), c->N, c->O, false, c->stream));
@@ -843,6 +898,7 @@ static ppo_status consume_finished_episodes(ppo_ctx* c) {
 
 extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     ppo_status s = consume_finished_episodes(c);
     if (s != PPO_OK) return s;
     if (c->gen) return gen_rollout(c, forced_actions);
@@ -921,6 +977,7 @@ static ppo_status run_scan(ppo_ctx* c) {
 
 extern "C" ppo_status ppo_calc_advantage(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     // bootstrap value if not done: next_value = Critic(next_obs) (PPO_Discrete.cpp:280)
     const ppo_status s = ppo_get_value(c, B_<float>(c, PPO_BUF_NEXT_OBS), c->N, B_<float>(c, PPO_BUF_NEXT_VALUE));
     if (s != PPO_OK) return s;
@@ -932,6 +989,7 @@ extern "C" ppo_status ppo_calc_advantage(ppo_ctx* c) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" ppo_status ppo_generate_permutations(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     HIPCHK(c, launch_permutations(B_<int32_t>(c, PPO_BUF_PERM), c->B, c->cfg.update_epochs, c->cfg.seed, c->updates, c->rank, c->stream));
     return PPO_OK;
 }
@@ -950,28 +1008,47 @@ static AdamCoef adam_coef(double lr, int64_t t) {
 
 static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
     if (c->world <= 1 && !c->force_collectives) return PPO_OK;
+    if (c->xchg) {
+        ExchangeComm& x = *c->xchg;
+        const size_t bytes = count * (f64 ? 8 : 4);
+        NEED(c, bytes <= x.slot_bytes, "all-reduce payload exceeds the exchange slot");
+        XchgPtrs pp{};
+        for (int r = 0; r < c->world; r++) pp.p[r] = x.peer[r];
+        x.seq += 1;
+        HIPCHK(c, launch_exchange_allreduce(buf, count, f64, pp, c->rank, c->world, x.slot_bytes, x.seq, x.timeout_flag, c->stream));
+        return PPO_OK;
+    }
     if (c->lgroup) {
         LocalGroup* g = c->lgroup.get();
         HIPCHK(c, hipEventRecord(c->lg_ready, c->stream));
         uint64_t my_gen;
+        hipError_t he = hipSuccess;
+        bool failed = false;
         {
             std::unique_lock<std::mutex> lk(g->mu);
+            if (g->failed) return fail(c, PPO_ERR_COMM, "in-process group has failed");
             g->bufs[c->rank] = buf;
             g->ready[c->rank] = c->lg_ready;
             my_gen = g->generation;
             if (++g->arrived == g->n) {
-                for (int r = 0; r < g->n; r++) HIPCHK(c, hipStreamWaitEvent(c->stream, g->ready[r], 0));
+                // last arriver: one kernel on its stream reads every rank's buffer.  Whatever happens here, the generation advances and everybody is
+                // woken: a failure is reported to all members instead of leaving them in cv.wait
+                for (int r = 0; r < g->n && he == hipSuccess; r++) he = hipStreamWaitEvent(c->stream, g->ready[r], 0);
                 PtrPack pk{};
                 for (int r = 0; r < g->n; r++) pk.p[r] = g->bufs[r];
-                HIPCHK(c, launch_local_allreduce(pk, g->n, count, f64, c->stream));
-                HIPCHK(c, hipEventRecord(g->done[my_gen & 1], c->stream));
+                if (he == hipSuccess) he = launch_local_allreduce(pk, g->n, count, f64, c->stream);
+                if (he == hipSuccess) he = hipEventRecord(g->done[my_gen & 1], c->stream);
+                if (he != hipSuccess) g->failed = true;
                 g->arrived = 0;
                 g->generation++;
                 g->cv.notify_all();
             } else {
                 g->cv.wait(lk, [&] { return g->generation != my_gen; });
             }
+            failed = g->failed;
         }
+        if (he != hipSuccess) return fail(c, PPO_ERR_HIP, "in-process all-reduce failed: %s", hipGetErrorString(he));
+        if (failed) return fail(c, PPO_ERR_COMM, "in-process all-reduce failed on another member of the group");
         HIPCHK(c, hipStreamWaitEvent(c->stream, g->done[my_gen & 1], 0));
         return PPO_OK;
     }
@@ -1120,6 +1197,7 @@ static hipError_t clip_adamw_any(ppo_ctx* c, int slot, double global_M, int worl
 
 extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* idx, int64_t M) {
     NEED(c, c && idx, "null argument");
+    DeviceGuard dev_guard(c);
     NEED(c, M >= 1 && M <= c->B, "minibatch size out of range");
     const int slot = c->steps_per_update;  // scratch slot
     {   // stand-alone call: the caller may have rewritten any rollout buffer since the last pack
@@ -1141,6 +1219,7 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
 
 extern "C" ppo_status ppo_allreduce_grads(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     if (c->world <= 1 && !c->force_collectives) return PPO_OK;
     // the slab reduction already left float copies of the loss sums behind the gradient: one collective carries both
     return allreduce_sum(c, c->buf[PPO_BUF_GRADS], (size_t)c->L.P + 8, false);
@@ -1163,6 +1242,7 @@ static ppo_status optimizer_step_slot(ppo_ctx* c, int slot, double global_M, boo
 
 extern "C" ppo_status ppo_optimizer_step(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     // stand-alone use: the slot's pinned coefficient must not be rewritten while a previous copy is in flight
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return optimizer_step_slot(c, c->steps_per_update, c->last_global_M, false);
@@ -1177,6 +1257,7 @@ extern "C" ppo_status ppo_set_learning_rate(ppo_ctx* c, double lr) {
 // All epochs x minibatches of one update, PPO_Discrete.cpp:567-644, then explained variance (:647-648).
 extern "C" ppo_status ppo_update(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     const int E = c->cfg.update_epochs, nmb = c->n_mb;
     ppo_status s = PPO_OK;
     const int32_t* perm = B_<int32_t>(c, PPO_BUF_PERM);
@@ -1239,6 +1320,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
 // One iteration of PPO_Discrete::train()'s loop (:511-659) without printing / checkpointing.
 extern "C" ppo_status ppo_train_iteration(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     if (c->cfg.anneal_lr && c->num_updates_total > 0) {
         // frac = 1.0 - (update - 1.0) / num_updates; lr_now = frac * m_learning_rate  (:515-517), update is 1-based
         const double frac = 1.0 - ((double)(c->updates + 1) - 1.0) / (double)c->num_updates_total;
@@ -1254,6 +1336,7 @@ extern "C" ppo_status ppo_train_iteration(ppo_ctx* c) {
 
 extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
     NEED(c, c && out, "null argument");
+    DeviceGuard dev_guard(c);
     std::memset(out, 0, sizeof *out);
     ppo_status s = consume_finished_episodes(c);
     if (s != PPO_OK) return s;
@@ -1299,6 +1382,7 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     // on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fwd/bwd; one launch in 8) and the GAE scan,
     //     3 = in-kernel phase stamps of the dominant kernel (diagnostic variant: read its SHARES, never its run time)
     c->profiling = (on == 0 || on == 3) ? 0u : (on == 2 ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE)) : 0xffffffffu);
@@ -1318,6 +1402,7 @@ extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
 
 extern "C" ppo_status ppo_profile_read(ppo_ctx* c, ppo_profile* out) {
     NEED(c, c && out, "null argument");
+    DeviceGuard dev_guard(c);
     std::memset(out, 0, sizeof *out);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int64_t* cnt[PROF_KINDS_] = { &out->fwd_bwd_launches, &out->gae_launches, &out->rollout_launches, &out->optimizer_launches, &out->reduce_launches };
@@ -1355,6 +1440,7 @@ extern "C" ppo_status ppo_comm_unique_id(void* id_out_h) {
 
 extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, int32_t nranks) {
     NEED(c, c && id_h, "null argument");
+    DeviceGuard dev_guard(c);
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
     NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
     // PPO_COMM_SELFTEST=1: a ONE-rank communicator is really created and every collective of the multi-rank path is really issued
@@ -1379,6 +1465,7 @@ extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, 
 // Joins the in-process group `group_id` as rank `rank` of `nranks` (all members live in this process, one host thread each).
 extern "C" ppo_status ppo_comm_init_local(ppo_ctx* c, int64_t group_id, int32_t rank, int32_t nranks) {
     NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
     NEED(c, nranks >= 1 && nranks <= 8 && rank >= 0 && rank < nranks, "bad rank / nranks (in-process groups hold at most 8 contexts)");
     NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
     NEED(c, c->comm == nullptr && !c->lgroup, "context already has a communicator");
@@ -1390,6 +1477,8 @@ extern "C" ppo_status ppo_comm_init_local(ppo_ctx* c, int64_t group_id, int32_t 
         if (it == g_local_groups.end()) {
             g = std::make_shared<LocalGroup>();
             g->n = nranks;
+            g->device = c->cfg.device;
+            HIPCHK(c, hipSetDevice(c->cfg.device));   // the group's events belong to its device
             HIPCHK(c, hipEventCreateWithFlags(&g->done[0], hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&g->done[1], hipEventDisableTiming));
             g_local_groups[group_id] = g;
@@ -1397,11 +1486,78 @@ extern "C" ppo_status ppo_comm_init_local(ppo_ctx* c, int64_t group_id, int32_t 
             g = it->second;
         }
         NEED(c, g->n == nranks, "group was created with a different size");
+        // one kernel on one device reads every member's buffer and the members wait on shared events: all of that is per device.  Several GPUs
+        // are driven by one process per GPU (ppo_comm_init / ppo_comm_init_exchange)
+        NEED(c, g->device == c->cfg.device, "in-process groups hold contexts of ONE device; use one process per GPU for several");
         if (++g->joined == g->n) g_local_groups.erase(group_id);  // complete: the id may be reused by a later group
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->lg_ready, hipEventDisableTiming));
     c->lgroup = g;
     c->world = nranks;
     c->rank = rank;
+    return PPO_OK;
+}
+
+// ---- one-shot direct exchange (see ExchangeComm) ----
+// Step 1 (every rank): allocate the exchange buffer and export its IPC handle.  payload capacity: the larger of the gradient (+ 8 loss sums) and the
+// advantage sums of one update.
+extern "C" ppo_status ppo_comm_exchange_handle(ppo_ctx* c, void* handle_out_h) {
+    NEED(c, c && handle_out_h, "null argument");
+    DeviceGuard dev_guard(c);
+    NEED(c, c->comm == nullptr && !c->lgroup, "context already has a communicator");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!c->xchg) {
+        std::unique_ptr<ExchangeComm> x(new ExchangeComm());
+        const size_t grad = ((size_t)c->L.P + 8) * sizeof(float), adv = (size_t)2 * c->steps_per_update * PPO_ADV_PARTS * sizeof(double);
+        x->slot_bytes = (std::max(grad, adv) + 255) / 256 * 256;
+        const size_t total = 2 * x->slot_bytes + 256;
+        // fine-grained device memory: stores of a running kernel become visible to peers' running kernels (coarse-grained memory is only
+        // coherent at kernel boundaries); plain hipMalloc as a fallback on a single device
+        hipError_t e = hipExtMallocWithFlags(&x->own, total, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); HIPCHK(c, hipMalloc(&x->own, total)); }
+        HIPCHK(c, hipMemset(x->own, 0, total));
+        HIPCHK(c, dalloc(c, &x->timeout_flag, 1));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->xchg = std::move(x);
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) <= PPO_COMM_HANDLE_BYTES, "IPC handle size");
+    hipIpcMemHandle_t h;
+    HIPCHK(c, hipIpcGetMemHandle(&h, c->xchg->own));
+    std::memset(handle_out_h, 0, PPO_COMM_HANDLE_BYTES);
+    std::memcpy(handle_out_h, &h, sizeof h);
+    return PPO_OK;
+}
+
+// Step 2 (every rank, after all handles have been gathered, e.g. over torch.distributed): map the peers' buffers and switch the context's
+// all-reduces to the exchange.  handles_h: nranks x PPO_COMM_HANDLE_BYTES in rank order.
+extern "C" ppo_status ppo_comm_init_exchange(ppo_ctx* c, const void* handles_h, int32_t rank, int32_t nranks) {
+    NEED(c, c && handles_h, "null argument");
+    DeviceGuard dev_guard(c);
+    NEED(c, nranks >= 1 && nranks <= 8 && rank >= 0 && rank < nranks, "bad rank / nranks (the direct exchange serves the 8 GPUs of one node)");
+    NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
+    NEED(c, c->xchg && c->xchg->own, "call ppo_comm_exchange_handle first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ExchangeComm& x = *c->xchg;
+    for (int r = 0; r < nranks; r++) {
+        if (r == rank) { x.peer[r] = x.own; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const char*>(handles_h) + (size_t)r * PPO_COMM_HANDLE_BYTES, sizeof h);
+        HIPCHK(c, hipIpcOpenMemHandle(&x.peer[r], h, hipIpcMemLazyEnablePeerAccess));
+        x.opened[r] = true;
+    }
+    c->world = nranks;
+    c->rank = rank;
+    c->force_collectives = nranks == 1;   // a one-rank exchange still runs the multi-rank code path (self-test)
+    return PPO_OK;
+}
+
+// 0: no all-reduce kernel of this context has given up waiting for a peer; otherwise the number of such events (a peer died or never joined)
+extern "C" ppo_status ppo_comm_exchange_timeouts(ppo_ctx* c, int32_t* count_out) {
+    NEED(c, c && count_out, "null argument");
+    DeviceGuard dev_guard(c);
+    *count_out = 0;
+    if (!c->xchg) return PPO_OK;
+    HIPCHK(c, hipMemcpyAsync(count_out, c->xchg->timeout_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PPO_OK;
 }

@@ -818,6 +818,61 @@ __global__ void local_allreduce_kernel(PtrPack8 pk, int n, size_t count) {
     for (int r = 0; r < n; r++) static_cast<Tp*>(pk.p[r])[i] = acc;
 }
 
+// One-shot direct exchange all-reduce (api.hip: ExchangeComm).  Exchange buffer of a rank: [2 slots][slot_bytes] payload, then two 8-byte
+// flags, then two 4-byte arrival counters.  Call number `seq` (1-based, the same on every rank) uses slot seq & 1.
+//   publish:  every thread copies its elements of buf into the own slot with system-scope stores, followed by a system-scope release; the
+//             workgroup that arrives last on the slot's counter stamps the slot's flag with seq
+//   gather:   for r = 0 .. n - 1 in order: rank r's flag must have reached seq (all of r's payload is published) -- thread 0 polls it with
+//             system-scope loads, at most ~2 s -- then every thread adds r's elements (system-scope loads: never from a stale cache line)
+//   result:   buf = the sum, formed in the same order on every rank.
+// A timeout leaves the sum incomplete and counts itself in timeout_flag: the kernel always ends.
+struct XchgPtrs8 { void* p[8]; };
+template <class Tp>
+__global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict__ buf, size_t count, XchgPtrs8 peers, int rank, int n, size_t slot_bytes,
+                                                                 unsigned long long seq, int32_t* timeout_flag) {
+    __shared__ int s_ok;
+    const int slot = (int)(seq & 1ull);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    char* base = static_cast<char*>(peers.p[rank]);
+    Tp* own = reinterpret_cast<Tp*>(base + slot * slot_bytes);
+    unsigned long long* own_flag = reinterpret_cast<unsigned long long*>(base + 2 * slot_bytes) + slot;
+    unsigned int* own_count = reinterpret_cast<unsigned int*>(base + 2 * slot_bytes + 16) + slot;
+    const Tp mine = i < count ? buf[i] : Tp(0);
+    if (i < count) __hip_atomic_store(&own[i], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the payload is visible to the peers before the flag moves
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int arrived = __hip_atomic_fetch_add(own_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(own_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(own_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const unsigned long long want = seq;
+    Tp acc = Tp(0);
+    for (int r = 0; r < n; r++) {
+        if (r == rank) { acc += mine; continue; }
+        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(peers.p[r]) + 2 * slot_bytes) + slot;
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+            for (;;) {
+                if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) { ok = 1; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // ~2 s
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        const int ok = s_ok;
+        __syncthreads();
+        if (!ok) { if (threadIdx.x == 0) atomicAdd(timeout_flag, 1); continue; }
+        const Tp* src = reinterpret_cast<const Tp*>(static_cast<const char*>(peers.p[r]) + slot * slot_bytes);
+        if (i < count) acc += __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (i < count) buf[i] = acc;
+}
+
 // K11 partial sums: per block {sum y, sum y^2, sum d, sum d^2} with y = returns, d = returns - values (float subtraction).
 __global__ __launch_bounds__(256) void explained_variance_kernel(const float* __restrict__ returns, const float* __restrict__ values,
                                                                   int64_t B, double* out) {
@@ -934,5 +989,16 @@ hipError_t launch_local_allreduce(const PtrPack& pk, int n, size_t count, bool f
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);
     if (f64) hipLaunchKernelGGL(local_allreduce_kernel<double>, grid, block, 0, s, q, n, count);
     else hipLaunchKernelGGL(local_allreduce_kernel<float>, grid, block, 0, s, q, n, count);
+    return hipGetLastError();
+}
+
+struct XchgPtrs { void* p[8]; };
+hipError_t launch_exchange_allreduce(void* buf, size_t count, bool f64, const XchgPtrs& peers, int rank, int n, size_t slot_bytes, uint64_t seq,
+                                     int32_t* timeout_flag, hipStream_t s) {
+    XchgPtrs8 q;
+    for (int i = 0; i < 8; i++) q.p[i] = peers.p[i];
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (f64) hipLaunchKernelGGL(exchange_allreduce_kernel<double>, grid, block, 0, s, static_cast<double*>(buf), count, q, rank, n, slot_bytes, (unsigned long long)seq, timeout_flag);
+    else hipLaunchKernelGGL(exchange_allreduce_kernel<float>, grid, block, 0, s, static_cast<float*>(buf), count, q, rank, n, slot_bytes, (unsigned long long)seq, timeout_flag);
     return hipGetLastError();
 }

@@ -60,12 +60,36 @@ def broadcast_bytes(dist, payload, src=0):
     return box[0]
 
 
-def bootstrap_comm(ctx, dist, rank, world, make_unique_id):
-    """Creates the RCCL communicator of `ctx`: rank 0 makes the id, everybody receives it, everybody joins."""
+def gather_bytes(dist, payload):
+    """Every rank's bytes object, in rank order, on every rank."""
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, payload)
+    return out
+
+
+def bootstrap_comm(ctx, dist, rank, world, make_unique_id, transport="rccl"):
+    """Gives `ctx` its communicator.
+    transport "rccl":     rank 0 makes the RCCL unique id, everybody receives it, everybody joins (ncclCommInitRank).
+    transport "exchange": the one-shot direct exchange (ppo_hip.h): every rank exports the IPC handle of its exchange buffer, the handles are
+                          gathered in rank order, every rank maps its peers' buffers.  No RCCL at all."""
     if world == 1:
         return
+    if transport == "exchange":
+        handles = gather_bytes(dist, ctx.comm_exchange_handle())
+        ctx.comm_init_exchange(handles, rank, world)
+        return
+    if transport != "rccl":
+        raise ValueError("transport must be 'rccl' or 'exchange'")
     ident = broadcast_bytes(dist, make_unique_id() if rank == 0 else None, src=0)
     ctx.comm_init(ident, rank, world)
+
+
+def all_ranks_agree(dist, ok):
+    """True iff `ok` is true on every rank."""
+    import torch
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
 
 
 def max_over_ranks(dist, value):

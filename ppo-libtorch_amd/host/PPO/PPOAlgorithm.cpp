@@ -104,7 +104,11 @@ Tensor PPOAlgorithm::bufferView(int which, std::vector<int64_t> shape, DType dt)
 
 void PPOAlgorithm::construct() {
     m_threadPool = std::make_shared<ThreadPool>(static_cast<int64_t>(std::thread::hardware_concurrency()));
-    if (!m_use_cuda) throw std::runtime_error("use_cuda = false: this build has no CPU path (the hot path runs on the MI355X only)");
+    if (!m_use_cuda) {
+        // The reference honours use_cuda = false by running on the CPU (PPO_Discrete.cpp:65), and its shipped CartPoleRecommendedSettings.toml
+        // sets it.  This build has no CPU path: the same configuration trains, on the GPU, and says so.
+        std::cout << "Warning: use_cuda = false requested, but this build has no CPU path; training on the gfx950 (HIP) device." << std::endl;
+    }
     m_device = std::make_shared<ppo::Device>(0);
     std::cout << "Using gfx950 (HIP) device " << m_device->ordinal() << std::endl;
     std::cout << "m_obs_size: " << m_obs_size << std::endl;
@@ -251,18 +255,51 @@ void PPOAlgorithm::saveCheckpoint(const std::string& agentFile, const std::strin
     int64_t step = 0;
     ppo::check(ppo_params_get_h(m_ctx, p.data(), P), m_ctx, "params");
     ppo::check(ppo_optimizer_get_h(m_ctx, m.data(), v.data(), P, &step), m_ctx, "optimizer");
-    std::ofstream fa(agentFile, std::ios::binary), fo(optimizerFile, std::ios::binary);
-    fa.write("PPOHIP01", 8); fa.write(reinterpret_cast<const char*>(&P), 8); fa.write(reinterpret_cast<const char*>(p.data()), P * 4);
-    fo.write("PPOHIP01", 8); fo.write(reinterpret_cast<const char*>(&P), 8); fo.write(reinterpret_cast<const char*>(&step), 8);
-    fo.write(reinterpret_cast<const char*>(m.data()), P * 4); fo.write(reinterpret_cast<const char*>(v.data()), P * 4);
+    // written under a temporary name and renamed once complete and flushed: a full disk never leaves a truncated file where the newest-file
+    // rule of loadPolicyFromCheckpoint would pick it up
+    const std::string ta = agentFile + ".tmp", to = optimizerFile + ".tmp";
+    {
+        std::ofstream fa(ta, std::ios::binary), fo(to, std::ios::binary);
+        fa.write("PPOHIP01", 8); fa.write(reinterpret_cast<const char*>(&P), 8); fa.write(reinterpret_cast<const char*>(p.data()), P * 4);
+        fo.write("PPOHIP01", 8); fo.write(reinterpret_cast<const char*>(&P), 8); fo.write(reinterpret_cast<const char*>(&step), 8);
+        fo.write(reinterpret_cast<const char*>(m.data()), P * 4); fo.write(reinterpret_cast<const char*>(v.data()), P * 4);
+        fa.flush(); fo.flush();
+        if (!fa.good() || !fo.good()) {
+            fa.close(); fo.close();
+            std::error_code ec;
+            fs::remove(ta, ec); fs::remove(to, ec);
+            throw std::runtime_error("could not write checkpoint " + agentFile + " / " + optimizerFile);
+        }
+    }
+    fs::rename(ta, agentFile);
+    fs::rename(to, optimizerFile);
 }
 
 static std::string newestFile(const fs::path& dir) {
     std::string best;
     fs::file_time_type when{};
-    for (const auto& e : fs::directory_iterator(dir))
+    for (const auto& e : fs::directory_iterator(dir)) {
+        if (e.path().extension() == ".tmp") continue;   // an interrupted save
         if (best.empty() || fs::last_write_time(e) > when) { best = e.path().string(); when = fs::last_write_time(e); }
+    }
     return best;
+}
+// true: the file is one of ours and holds n floats after its header.  A LibTorch zip/pickle checkpoint written by the reference itself (same
+// directory, same name scheme) or any other file is reported and skipped -- the agent then starts fresh, as when no checkpoint exists.
+static bool readHeader(std::ifstream& f, const std::string& name, int64_t P, bool optimizer, int64_t* step) {
+    char magic[8] = {};
+    int64_t n = 0;
+    f.read(magic, 8); f.read(reinterpret_cast<char*>(&n), 8);
+    if (optimizer && f) f.read(reinterpret_cast<char*>(step), 8);
+    if (!f || std::string(magic, 8) != "PPOHIP01") {
+        std::cout << "Checkpoint " << name << " is not in this build's format (a LibTorch .pt written by the reference is not supported); ignoring it." << std::endl;
+        return false;
+    }
+    if (n != P) {
+        std::cout << "Checkpoint " << name << " holds " << n << " parameters, this agent has " << P << "; ignoring it." << std::endl;
+        return false;
+    }
+    return true;
 }
 
 void PPOAlgorithm::loadPolicyFromCheckpoint() {
@@ -272,22 +309,24 @@ void PPOAlgorithm::loadPolicyFromCheckpoint() {
         return;
     }
     const int64_t P = ppo_param_count(m_ctx);
-    char magic[8];
-    int64_t n = 0;
     const std::string a = newestFile(modelDir);
     if (a.empty()) {
         std::cout << "No previous model checkpoint found at " << modelDir << ", initializing new agent!" << std::endl;
     } else {
         std::cout << "Loading model " << a << "..." << std::endl;
-        const std::string steps = PPOUtils::getLoadFromSteps(a, "PPO_Agent_");
-        m_global_step = PPOUtils::isNumber(steps) ? static_cast<uint64_t>(std::stoll(steps)) : 0;   // :809-811
-        std::cout << "Continuing training from step " << m_global_step << std::endl;
         std::ifstream f(a, std::ios::binary);
         std::vector<float> p(static_cast<size_t>(P));
-        f.read(magic, 8); f.read(reinterpret_cast<char*>(&n), 8);
-        if (!f || std::string(magic, 8) != "PPOHIP01" || n != P) throw std::runtime_error("checkpoint " + a + " does not match this agent");
-        f.read(reinterpret_cast<char*>(p.data()), P * 4);
-        ppo::check(ppo_params_set_h(m_ctx, p.data(), P), m_ctx, "load params");
+        if (readHeader(f, a, P, false, nullptr)) {
+            f.read(reinterpret_cast<char*>(p.data()), P * 4);
+            if (!f) {
+                std::cout << "Checkpoint " << a << " is truncated; ignoring it." << std::endl;
+            } else {
+                const std::string steps = PPOUtils::getLoadFromSteps(a, "PPO_Agent_");
+                m_global_step = PPOUtils::isNumber(steps) ? static_cast<uint64_t>(std::stoll(steps)) : 0;   // :809-811
+                std::cout << "Continuing training from step " << m_global_step << std::endl;
+                ppo::check(ppo_params_set_h(m_ctx, p.data(), P), m_ctx, "load params");
+            }
+        }
     }
     const std::string o = newestFile(optimDir);
     if (o.empty()) {
@@ -297,10 +336,11 @@ void PPOAlgorithm::loadPolicyFromCheckpoint() {
         std::ifstream f(o, std::ios::binary);
         std::vector<float> m(static_cast<size_t>(P)), v(static_cast<size_t>(P));
         int64_t step = 0;
-        f.read(magic, 8); f.read(reinterpret_cast<char*>(&n), 8); f.read(reinterpret_cast<char*>(&step), 8);
-        if (!f || std::string(magic, 8) != "PPOHIP01" || n != P) throw std::runtime_error("checkpoint " + o + " does not match this optimizer");
-        f.read(reinterpret_cast<char*>(m.data()), P * 4); f.read(reinterpret_cast<char*>(v.data()), P * 4);
-        ppo::check(ppo_optimizer_set_h(m_ctx, m.data(), v.data(), P, step), m_ctx, "load optimizer");
+        if (readHeader(f, o, P, true, &step)) {
+            f.read(reinterpret_cast<char*>(m.data()), P * 4); f.read(reinterpret_cast<char*>(v.data()), P * 4);
+            if (!f) std::cout << "Checkpoint " << o << " is truncated; ignoring it." << std::endl;
+            else ppo::check(ppo_optimizer_set_h(m_ctx, m.data(), v.data(), P, step), m_ctx, "load optimizer");
+        }
     }
 }
 

@@ -1,9 +1,12 @@
 // Exercises the C++ classes with the reference's names on a real GPU (run by tests/test_host_facade.py, -m gpu).
 // Prints "HOST_FACADE_OK" when every check holds.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <sstream>
 
 #include "../PPO/PPO_Discrete.h"
 #include "../PPO/PPO_MultiDiscrete.h"
@@ -15,8 +18,23 @@
 
 static void writeConfig(const char* body) { std::ofstream("PPOConfig.toml") << body; }
 
-int main() {
+// Splits a fixture line "a|b|c" at the bars.
+static std::vector<std::string> bars(const std::string& line) {
+    std::vector<std::string> out;
+    size_t at = 0;
+    for (;;) {
+        const size_t n = line.find('|', at);
+        out.push_back(line.substr(at, n == std::string::npos ? n : n - at));
+        if (n == std::string::npos) break;
+        at = n + 1;
+    }
+    return out;
+}
+
+// argv[1]: tests/golden (the fixtures oracle/ref_harness wrote from the reference itself)
+int main(int argc, char** argv) {
     namespace fs = std::filesystem;
+    const std::string golden = argc > 1 ? fs::absolute(argv[1]).string() : "";
     const fs::path scratch = fs::temp_directory_path() / "ppo_host_facade_test";
     fs::remove_all(scratch);
     fs::create_directories(scratch);
@@ -103,6 +121,95 @@ int main() {
         REQUIRE(a.entropy.cpu<float>()[0] > 1.0f);   // ~ln 3: true entropy on the masked path
         md.train();
         REQUIRE(md.m_global_step == 8192);
+    }
+    // ---- ThreadPool (Utils/ThreadPool.cpp:19-139): every queued job runs once, waitForJobsToFinish returns only when the queue is empty and no
+    //      job is running, the pool can be restarted, an exception inside a job is swallowed (:43-49) and does not kill its worker
+    {
+        ThreadPool pool(4);
+        pool.start();
+        std::atomic<int> ran{ 0 };
+        for (int round = 0; round < 3; round++) {
+            for (int i = 0; i < 500; i++) pool.queueJob([&ran, i] { if (i == 250) throw std::runtime_error("job failure"); ran.fetch_add(1); });
+            pool.waitForJobsToFinish();
+            REQUIRE(ran.load() == 499 * (round + 1) && !pool.busy());
+        }
+        pool.stop();
+        pool.start();
+        pool.queueJob([&ran] { ran.fetch_add(1); });
+        pool.waitForJobsToFinish();
+        REQUIRE(ran.load() == 3 * 499 + 1);
+        pool.stop();
+    }
+    // ---- use_cuda = false (the reference's shipped CartPoleRecommendedSettings.toml): a warning, not an exception; a checkpoint directory whose
+    //      newest file is not ours (e.g. a LibTorch .pt written by the reference): reported and ignored, the agent starts fresh
+    fs::remove_all("./ModelCheckpoints"); fs::remove_all("./OptimizerCheckpoints"); fs::remove_all("./Models");
+    fs::create_directories("./ModelCheckpoints"); fs::create_directories("./OptimizerCheckpoints");
+    std::ofstream("./ModelCheckpoints/PPO_Agent_4242_steps.pt") << "PK\x03\x04 not our format";
+    std::ofstream("./OptimizerCheckpoints/PPO_Optimizer_4242_steps.pt") << "PK\x03\x04 not our format";
+    writeConfig("[environment]\nobs_size = 4\naction_size = 2\n[general]\nseed = 2\ntotal_timesteps = 2560\nuse_cuda = false\n"
+                "[ppo]\nnum_envs = 8\nnum_steps = 32\nupdate_epochs = 10\n");
+    {
+        std::stringstream captured;
+        std::streambuf* old = std::cout.rdbuf(captured.rdbuf());
+        PPO_Discrete algo;
+        std::cout.rdbuf(old);
+        REQUIRE(captured.str().find("use_cuda = false requested") != std::string::npos);
+        REQUIRE(captured.str().find("is not in this build's format") != std::string::npos);
+        REQUIRE(algo.m_global_step == 0 && algo.m_batch_size == 256);
+        // ---- the console table (PPO_Discrete.cpp:700-774) against the reference's own printout of the same four calls (tests/golden/console_table.txt,
+        //      written by oracle/ref_harness hostgold): byte for byte, manipulator state carried from call to call as in train()
+        if (!golden.empty()) {
+            std::ifstream gf(golden + "/console_table.txt", std::ios::binary);
+            REQUIRE(gf.good());
+            std::stringstream want; want << gf.rdbuf();
+            REQUIRE(ppo_set_learning_rate(algo.m_ctx, (double)0.00075f) == PPO_OK);
+            algo.m_clipfracs = { 0.125f, 0.0625f, 0.25f };
+            auto scalar = [&](float v) { return ppo::Tensor::from_host<float>(dev, { v }, { 1 }); };
+            ppo::Tensor kl = scalar(0.00123456789f), ent = scalar(-1.17549435e-38f), ev = scalar(0.1762397289f), loss = scalar(24.916658401f),
+                        pg = scalar(-0.007237161f), vl = scalar(27.17522430f);
+            std::stringstream got;
+            old = std::cout.rdbuf(got.rdbuf());
+            algo.m_episode_stats = std::make_unique<CircularBuffer>(100);
+            algo.m_episode_stats->add(21.0f, 22); algo.m_episode_stats->add(13.0f, 14); algo.m_episode_stats->add(-1.0f, 1); algo.m_episode_stats->add(499.0f, 500);
+            algo.printPPOResults(1, 256, std::chrono::milliseconds(123), std::chrono::milliseconds(4567), kl, ent, ev, loss, pg, vl);
+            algo.printPPOResults(2, 512, std::chrono::milliseconds(97), std::chrono::milliseconds(12345), kl, ent, ev, loss, pg, vl);
+            algo.m_episode_stats = std::make_unique<CircularBuffer>(100);
+            algo.printPPOResults(3, 768, std::chrono::milliseconds(97), std::chrono::milliseconds(23456), kl, ent, ev, loss, pg, vl);
+            algo.printPPOResults(1, 256, std::chrono::milliseconds(123), std::chrono::milliseconds(999), kl, ent, ev, loss, pg, vl);
+            std::cout.rdbuf(old);
+            if (got.str() != want.str()) {
+                std::fprintf(stderr, "console table differs from the reference's:\n--- got\n%s\n--- want\n%s\n", got.str().c_str(), want.str().c_str());
+                return 1;
+            }
+        }
+    }
+    // ---- PPOUtils (Utils.cpp:5-60) on the reference's own answers (tests/golden/host_utils.txt)
+    if (!golden.empty()) {
+        std::ifstream uf(golden + "/host_utils.txt");
+        REQUIRE(uf.good());
+        std::string line;
+        int checked = 0;
+        while (std::getline(uf, line)) {
+            const std::vector<std::string> f = bars(line);
+            if (f[0] == "steps") {
+                REQUIRE(f.size() == 5);
+                const std::string r = PPOUtils::getLoadFromSteps(f[1], f[2]);
+                REQUIRE(r == f[3] && PPOUtils::isNumber(r) == (f[4] == "1"));
+            } else if (f[0] == "isnum") {
+                REQUIRE(f.size() == 3 && PPOUtils::isNumber(f[1]) == (f[2] == "1"));
+            } else if (f[0] == "mean") {
+                REQUIRE(f.size() == 3);
+                std::vector<float> v;
+                std::stringstream ss(f[1]);
+                std::string tok;
+                while (std::getline(ss, tok, ',')) { const uint32_t b = (uint32_t)std::stoul(tok, nullptr, 16); float x; std::memcpy(&x, &b, 4); v.push_back(x); }
+                const float m = PPOUtils::getVectorMean(v);
+                uint32_t mb; std::memcpy(&mb, &m, 4);
+                REQUIRE(mb == (uint32_t)std::stoul(f[2], nullptr, 16));
+            }
+            checked++;
+        }
+        REQUIRE(checked >= 16);
     }
     std::printf("HOST_FACADE_OK\n");
     return 0;

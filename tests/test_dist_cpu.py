@@ -57,6 +57,10 @@ def _worker(rank, world, port, out_dir):
     ident = P.dist.broadcast_bytes(dist, bytes(range(128)) if rank == 0 else None)
     assert ident == bytes(range(128))
     assert P.dist.max_over_ranks(dist, 1.0 + rank) == float(world)
+    # plumbing of the one-shot exchange's bootstrap: every rank's handle, in rank order, everywhere; and the post-warm-up agreement check
+    handles = P.dist.gather_bytes(dist, bytes([rank]) * 64)
+    assert handles == [bytes([r]) * 64 for r in range(world)]
+    assert P.dist.all_ranks_agree(dist, True) and not P.dist.all_ranks_agree(dist, rank != world - 1)
 
     g = O.read_pgld(os.path.join(G, "discrete_t128_n64_seed1.pgld"))
     T, N, U = 128, 64, "u1/"
@@ -96,10 +100,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process_step(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_step_equals_single_process_step(tmp_path, world):
+    """2 ranks, and the 8 of BASELINE configs[2] / configs[4] (64 envs -> 8 per rank): the sum over shards of the 1 / M_global-scaled shard
+    gradients, formed with the GLOBAL advantage statistics, is the single-process gradient of the concatenated minibatch."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     import oracle as O
     g = O.read_pgld(os.path.join(G, "discrete_t128_n64_seed1.pgld"))
     T, N, U = 128, 64, "u1/"

