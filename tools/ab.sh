@@ -13,7 +13,7 @@ for i in $(seq 1 $R); do
         python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile 1 2>/dev/null | tail -n 1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-44s' % '$src', round(d['value']/1e6,2), 'M env-steps/s', round(d['ms_per_step'],3), 'ms', round(1e3*d['roofline']['avg_launch_ms'],2), 'us/update launch', round(1e3*d['phase_ms_per_step']['rollout'],1), 'us rollout+values', round(25*d['phase_ms_per_step']['clip_adamw']+25*d['phase_ms_per_step']['grad_reduce'],2), 'us/optimizer step')"
+print('%-44s' % '$src', round(d['value']/1e6,2), 'M env-steps/s', round(d['ms_per_step'],3), 'ms', round(1e3*d['roofline']['avg_launch_ms'],2), 'us/update launch', round(1e3*d['phase_ms_per_step']['rollout'],1), 'us rollout+values', round(25*((d['phase_ms_per_step']['clip_adamw'] or 0)+(d['phase_ms_per_step']['grad_reduce'] or 0)),2), 'us/optimizer step')"
     done
 done
 cp /tmp/libppo_hip_orig.so ppo-libtorch_amd/libppo_hip.so
