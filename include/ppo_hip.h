@@ -238,7 +238,8 @@ PPO_API ppo_status ppo_generate_permutations(ppo_ctx* ctx);
 /* One minibatch, forward + losses + backward (:576-638) on batch rows idx i32 [M] (device).  Leaves the UNCLIPPED
  * gradient of the global-minibatch loss in GRADS (local contribution when sharded) and the loss scalars in the stats. */
 PPO_API ppo_status ppo_minibatch_forward_backward(ppo_ctx* ctx, const int32_t* idx, int64_t M);
-/* New in the build (no reference counterpart): sum GRADS over ranks with one RCCL all-reduce. No-op unsharded. */
+/* New in the build (no reference counterpart): sum GRADS over ranks with one all-reduce on the context's transport
+ * (direct exchange, RCCL or in-process group). No-op unsharded. */
 PPO_API ppo_status ppo_allreduce_grads(ppo_ctx* ctx);
 /* clip_grad_norm_ (:640; LibTorch clip_grad.h:22-85) + AdamW::step (:641; eps 1e-5f, betas .9/.999, weight_decay 1e-2,
  * :76-78) as one fused launch. */
@@ -247,7 +248,11 @@ PPO_API ppo_status ppo_optimizer_step(ppo_ctx* ctx);
 PPO_API ppo_status ppo_update(ppo_ctx* ctx);
 /* One iteration of the training loop (:511-659 minus printing/checkpoints): LR anneal, rollout, advantages, update. */
 PPO_API ppo_status ppo_train_iteration(ppo_ctx* ctx);
-/* Synchronises and returns the scalars of the last update (printPPOResults' inputs, :700-774). */
+/* Synchronises and returns the scalars of the last update (printPPOResults' inputs, :700-774).
+ * Sharded runs (n_ranks > 1): the loss scalars (pg / value / entropy loss, approx-KL, clipfrac, grad norm) ride the gradient
+ * all-reduce and are GLOBAL, identical on every rank; the episode statistics (ep_rew_mean, ep_len_mean, ep_count), the
+ * explained variance and global_step describe THIS rank's env shard only -- a caller that prints one table for the job
+ * averages them over ranks itself (bench.py reports the per-rank values of rank 0). */
 PPO_API ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
 /* LR anneal (:514-518) is applied by ppo_train_iteration; direct control for tests. */
 PPO_API ppo_status ppo_set_learning_rate(ppo_ctx* ctx, double lr);

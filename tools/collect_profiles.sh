@@ -26,5 +26,25 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
     echo "pmc pass $i done"
 done
 python3 $ROOT/tools/pmc_summary.py "$ROOT/profiles/${TAG}_pmc_per_dispatch.json" "$OUT"/pmc* > "$OUT/pmc_summary.txt"
+
+# the GAE scan by itself: kernel-only durations at 4096 / 8192 / 32768 envs (same trace holds the three sizes), and the floor probe -- a stream
+# kernel and the scan's own strip decomposition without the chain -- under the same tracer
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/gae_trace" -o run -- python3 $ROOT/tools/gae_sweep.py 4096 8192 32768 > "$OUT/gae_sweep.jsonl" 2> "$OUT/gae_trace.log"
+cp "$(find "$OUT/gae_trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_gae_kernel_stats.csv"
+grep '^{' "$OUT/gae_sweep.jsonl" > "$ROOT/profiles/${TAG}_gae_sweep.jsonl" || true
+if [ -x $ROOT/tools/probes/gae_floor ]; then
+    $ROOT/tools/probes/gae_floor 4096 8192 32768 > "$ROOT/profiles/${TAG}_gae_floor.jsonl"
+    rocprofv3 --kernel-trace --stats -f csv -d "$OUT/floor_trace" -o run -- $ROOT/tools/probes/gae_floor 4096 > "$OUT/floor_trace.log" 2>&1
+    cp "$(find "$OUT/floor_trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_gae_floor_kernel_stats.csv"
+fi
+# FETCH_SIZE calibration on the build's two read patterns (tools/pmc_summary.py)
+if [ -x $ROOT/tools/probes/fetch_calib ]; then
+    rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/calib" -o run -- $ROOT/tools/probes/fetch_calib > "$OUT/calib.log" 2>&1
+    python3 $ROOT/tools/pmc_summary.py "$ROOT/profiles/${TAG}_fetch_calib.json" "$OUT/calib" > "$OUT/calib_summary.txt"
+fi
+# one GPU's share of BASELINE configs[4] in bf16: kernel durations
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/c4_trace" -o run -- python3 $ROOT/tools/config4_bench.py > "$OUT/c4_bench.json" 2> "$OUT/c4_trace.log"
+cp "$(find "$OUT/c4_trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_config4_kernel_stats.csv"
+tail -n 1 "$OUT/c4_bench.json" > "$ROOT/profiles/${TAG}_config4_bench.json"
 cp "$ROOT"/profiles/${TAG}_* "$OUT/"
 echo done
