@@ -42,31 +42,42 @@ constexpr int MF_WAVES = 8, MF_THREADS = 64 * MF_WAVES;
 constexpr float TANH_C = 2.885390081777927f;        // 2 log2(e)
 constexpr float TANH_C_INV = 0.34657359027997264f;  // ln(2) / 2
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
-// (x0, x1) -> three dwords of packed bf16 pairs (low half = x0's term), exact: x = t1 + t2 + t3 when the exponent does not underflow
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    const uint32_t u0 = f2u(x0), u1 = f2u(x1);
-    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = x0 - u2f(u0 & 0xffff0000u), r1 = x1 - u2f(u1 & 0xffff0000u);
-    const uint32_t v0 = f2u(r0), v1 = f2u(r1);
-    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float q0 = r0 - u2f(v0 & 0xffff0000u), q1 = r1 - u2f(v1 & 0xffff0000u);
-    p3 = __builtin_amdgcn_perm(f2u(q1), f2u(q0), 0x07060302u);
+// two floats -> one dword of fp16 (low half = x0), round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pk_f16(float x0, float x1) {
+    uint32_t p;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(x0), "v"(x1));
+    return p;
 }
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 acc) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+// x - (float)half(p): the residual of a rounding to fp16 is a float, so this fused multiply-add with an fp16 source is exact
+__device__ __forceinline__ float resid_lo(uint32_t p, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
 }
-// the six products of one (A chunk, B chunk) pair, small terms first
-__device__ __forceinline__ f32x16 mfma_x3(const u32x4 a1, const u32x4 a2, const u32x4 a3, const u32x4 b1, const u32x4 b2, const u32x4 b3, f32x16 acc) {
-    acc = mfma_bf16(a3, b1, acc);
-    acc = mfma_bf16(a1, b3, acc);
-    acc = mfma_bf16(a2, b2, acc);
-    acc = mfma_bf16(a2, b1, acc);
-    acc = mfma_bf16(a1, b2, acc);
-    acc = mfma_bf16(a1, b1, acc);
+__device__ __forceinline__ float resid_hi(uint32_t p, float x) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
+    return r;
+}
+// (x0, x1) -> two dwords of packed fp16 pairs (low half = x0's term): x = t1 + t2 + d, |d| <= max(2^-24 |x|, 2^-25) for |x| < 65520
+// (four instructions per pair: the conversion packs, the residual reads its half of the pair directly)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& p1, uint32_t& p2) {
+    p1 = pk_f16(x0, x1);
+    p2 = pk_f16(resid_lo(p1, x0), resid_hi(p1, x1));
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+// the three products of one (A chunk, B chunk) pair, small terms first
+__device__ __forceinline__ f32x16 mfma_x2(const u32x4 a1, const u32x4 a2, const u32x4 b1, const u32x4 b2, f32x16 acc) {
+    acc = mfma_f16(a2, b1, acc);
+    acc = mfma_f16(a1, b2, acc);
+    acc = mfma_f16(a1, b1, acc);
     return acc;
 }
 // ds_read_b64_tr_b16: per group of 16 lanes a 4-row x 16-column block of 16-bit elements is read and delivered column-major: lane
@@ -98,15 +109,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 struct MfSmem {
     int w2, w1, b1, b2, w3, b3, wave0, wave_stride, s_reg, s_x, s_do, total;  // offsets in floats
 };
-// private region of a wave: one fp32 [sample][unit] image (h2, h1, dz1 in turn) or the three bf16 term images of dz2
-constexpr int MF_REGION = (3 * MT * NS / 2) > (MT * LS) ? (3 * MT * NS / 2) : (MT * LS);
+// private region of a wave: one fp32 [sample][unit] image (h2, h1, dz1 in turn) or the two fp16 term images of dz2
+constexpr int MF_REGION = (2 * MT * NS / 2) > (MT * LS) ? (2 * MT * NS / 2) : (MT * LS);
 __host__ __device__ inline MfSmem mf_smem(int obs, int aout) {
     MfSmem m;
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
     // ONE image per term of c W2, natural [n][k] order: the forward product reads rows (two 8-byte pieces per fragment), the backward
     // product reads the same bytes column-wise with the transposing LDS read ds_read_b64_tr_b16
-    m.w2 = take(3 * 64 * NS / 2);
+    m.w2 = take(2 * 64 * NS / 2);
     m.w1 = take(64 * obs);
     m.b1 = take(64);
     m.b2 = take(64);
@@ -136,11 +147,23 @@ __device__ __forceinline__ float tanh_scaled(float cz) {
     const float e = __builtin_amdgcn_exp2f(cz);
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// acc + lo(p) + hi(p) for a packed bf16 pair (v_dot2c_f32_bf16 against (1, 1))
+// acc + lo(p) + hi(p) for a packed fp16 pair (v_dot2c_f32_f16 against (1, 1))
 __device__ __forceinline__ float add_pair(uint32_t p, float acc) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), __builtin_bit_cast(bf16x2, 0x3f803f80u), acc, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, p), __builtin_bit_cast(f16x2, 0x3c003c00u), acc, false);
 }
+
+// largest of the lanes' non-negative floats (compared as integers: NaN patterns rank above infinity and win), on the DPP network
+#define MF_DPP_MAXU(v, CTRL) max((v), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (CTRL), 0xf, 0xf, false))
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v) {
+    v = MF_DPP_MAXU(v, 0xB1);    // quad_perm:[1,0,3,2]
+    v = MF_DPP_MAXU(v, 0x4E);    // quad_perm:[2,3,0,1]
+    v = MF_DPP_MAXU(v, 0x141);   // row_half_mirror
+    v = MF_DPP_MAXU(v, 0x140);   // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+__device__ __forceinline__ float pow2i(int e) { return u2f((uint32_t)(127 + e) << 23); }   // 2^e, -126 <= e <= 127
 
 // In-kernel phase stamps (diagnostic variant only, STAMP = true): cycles per phase of wave 0 of workgroup 0 of each net,
 // summed over its tiles, written to a debug buffer no other code reads.
@@ -182,7 +205,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     float* sB3 = smem + m.b3;
     float* wbase = smem + m.wave0 + wave * m.wave_stride;
     float* img = wbase + m.s_reg;
-    uint16_t* zimg = reinterpret_cast<uint16_t*>(img);   // the same bytes as three bf16 term images [term][sample][NS]
+    uint16_t* zimg = reinterpret_cast<uint16_t*>(img);   // the same bytes as two fp16 term images [term][sample][NS]
     float* sX = wbase + m.s_x;
     float* sDo = wbase + m.s_do;
     const float* __restrict__ P = a.params;
@@ -207,19 +230,17 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
     for (int i = 0; i < NS_; i++) wv[i] = P[se[i] < 0 ? 0 : se[i]];
     {
-        // 4096 weights, 8 per thread: each is scaled, cut into its three bf16 terms once per launch and stored at its natural [n][k] place
+        // 4096 weights, 8 per thread: each is scaled, cut into its two fp16 terms once per launch and stored at its natural [n][k] place
         uint16_t* wn = reinterpret_cast<uint16_t*>(smem + m.w2);
 #pragma unroll
         for (int i = 0; i < NW2; i++) {
             const int e = tid + i * MF_THREADS;
             const int n = e >> 6, k = e & 63;
             const float w = wv[i] * TANH_C;
-            const uint32_t u0 = f2u(w);
-            const float r1 = w - u2f(u0 & 0xffff0000u);
-            const uint32_t u1 = f2u(r1);
-            const float r2 = r1 - u2f(u1 & 0xffff0000u);
+            uint32_t p1, p2;
+            split2(w, 0.0f, p1, p2);
             const int pn = n * NS + k;
-            wn[pn] = (uint16_t)(u0 >> 16); wn[64 * NS + pn] = (uint16_t)(u1 >> 16); wn[2 * 64 * NS + pn] = (uint16_t)(f2u(r2) >> 16);
+            wn[pn] = (uint16_t)p1; wn[64 * NS + pn] = (uint16_t)p2;
         }
     }
 #pragma unroll
@@ -262,6 +283,19 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     }
     const float inv_std = uniform_f(1.0f / (std_f + 1e-8f));
     __syncthreads();
+    // Range of the fp16 terms of dz2 (gradients are ~1 / M): dz2 is formed already multiplied by 2^S, S a wave-uniform integer kept
+    // such that the tile's largest possible |dz2| 2^S -- (sum_a |dOut[a]|) max|W3|, since |1 - h^2| <= 1 -- stays below 2^14.  S only
+    // ever moves down, and when it does the gradient accumulators that carry the factor (dW2, db2, dW1, db1) move with it; the
+    // factor leaves in the epilogue.  Powers of two: every step is exact.
+    float w3max;
+    {
+        uint32_t mb = 0u;
+#pragma unroll
+        for (int k = 0; k < AMAX; k++) if (k < AOUT) mb = max(mb, f2u(fabsf(sW3[k * 64 + lane])));
+        w3max = u2f(wave_max_u(mb));
+    }
+    int S_w = 100;
+    float scaleS = pow2i(S_w);
     constexpr int L1S = (OBS + 1) / 2;   // K = OBS of layer 1 is contracted in ceil(OBS / 2) fp32 MFMA steps
 
     MF_STAMP(0);   // prologue: weights -> LDS
@@ -338,10 +372,10 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         // ---------------- layer 2 forward (MFMA): c z2^T[n][s] = c b2[n] + sum_k c W2[n][k] h1[s][k] ----------------
         float h2[32];
         {
-            // B operand = h1 itself (D layout): chunk c of the contraction is registers 8c .. 8c+7, cut into bf16 terms in place
-            uint32_t hp[3][16];
+            // B operand = h1 itself (D layout): chunk c of the contraction is registers 8c .. 8c+7, cut into fp16 terms in place
+            uint32_t hp[2][16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) split3(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j], hp[2][j]);
+            for (int j = 0; j < 16; j++) split2(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j]);
             // g = 4 t + c: row n = s + 32 t, contraction chunk c.  Fragment element e <-> k = 16 c + 8 (e >> 2) + 4 hi + (e & 3), the
             // unit register 8 c + e of a D-layout vector holds: two 8-byte pieces of the natural row
             auto afrag = [&](int g, int term) -> u32x4 {
@@ -351,7 +385,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                 return r;
             };
             f32x16 acc;
-            u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1), an3 = afrag(0, 2);
+            u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1);
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 const int t = g >> 2, c = g & 3;
@@ -362,13 +396,12 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                         acc[4 * qq] = b.x; acc[4 * qq + 1] = b.y; acc[4 * qq + 2] = b.z; acc[4 * qq + 3] = b.w;
                     }
                 }
-                const u32x4 a1 = an1, a2 = an2, a3 = an3;
-                if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); an3 = afrag(g + 1, 2); }
+                const u32x4 a1 = an1, a2 = an2;
+                if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); }
                 MF_PIN();
                 const u32x4 b1 = { hp[0][4 * c], hp[0][4 * c + 1], hp[0][4 * c + 2], hp[0][4 * c + 3] };
                 const u32x4 b2 = { hp[1][4 * c], hp[1][4 * c + 1], hp[1][4 * c + 2], hp[1][4 * c + 3] };
-                const u32x4 b3 = { hp[2][4 * c], hp[2][4 * c + 1], hp[2][4 * c + 2], hp[2][4 * c + 3] };
-                acc = mfma_x3(a1, a2, a3, b1, b2, b3, acc);
+                acc = mfma_x2(a1, a2, b1, b2, acc);
                 if (c == 3) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_scaled(acc[r]);
@@ -506,6 +539,31 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             }
         }
 
+        {
+            float dsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < AMAX; k++) if (k < AOUT) dsum += fabsf(dOut[k]);
+            const float tmax = u2f(wave_max_u(f2u(dsum))) * w3max;
+            const int e = (int)((f2u(tmax) >> 23) & 0xffu) - 127;     // floor(log2(tmax)) (128: inf / NaN, -127: zero / denormal)
+            if (e + S_w > 13) {
+                int S_new = 11 - e;
+                S_new = S_new < -100 ? -100 : S_new;
+                int d = S_new - S_w;
+                d = d < -126 ? -126 : d;
+                const float f = pow2i(d);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) gW2[i][j][r] *= f;
+#pragma unroll
+                for (int o = 0; o < OBS; o++) gW1[o] *= f;
+                gb1 *= f; gb2[0] *= f; gb2[1] *= f;
+                S_w = S_new;
+                scaleS = pow2i(S_w);
+            }
+        }
         MF_STAMP(4);   // head + loss
         // ---------------- h2 -> image; dOut -> [a][s]; then dW3[a][u = lane], db3 ----------------
         store_dlayout(img, h2, s, hi);
@@ -537,30 +595,31 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 
         MF_STAMP(5);   // h2 image + dW3
         // ---------------- dz2 = (sum_a dOut[a] W3[a][u]) (1 - h2^2), D layout ----------------
-        float dz2[32];
+        float dz2[32];   // carries the factor 2^S from here on, and so do dh1, dz1 and the accumulators they feed
 #pragma unroll
         for (int e = 0; e < 32; e++) dz2[e] = 0.0f;
 #pragma unroll
         for (int k = 0; k < AMAX; k++) {
             if (k < AOUT) {
+                const float dS = dOut[k] * scaleS;
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
                     const float4 w = ld4(&sW3[k * 64 + 8 * (g & 3) + 4 * hi + 32 * (g >> 2)]);
-                    dz2[4 * g] = __builtin_fmaf(dOut[k], w.x, dz2[4 * g]); dz2[4 * g + 1] = __builtin_fmaf(dOut[k], w.y, dz2[4 * g + 1]);
-                    dz2[4 * g + 2] = __builtin_fmaf(dOut[k], w.z, dz2[4 * g + 2]); dz2[4 * g + 3] = __builtin_fmaf(dOut[k], w.w, dz2[4 * g + 3]);
+                    dz2[4 * g] = __builtin_fmaf(dS, w.x, dz2[4 * g]); dz2[4 * g + 1] = __builtin_fmaf(dS, w.y, dz2[4 * g + 1]);
+                    dz2[4 * g + 2] = __builtin_fmaf(dS, w.z, dz2[4 * g + 2]); dz2[4 * g + 3] = __builtin_fmaf(dS, w.w, dz2[4 * g + 3]);
                 }
             }
         }
 #pragma unroll
         for (int e = 0; e < 32; e++) dz2[e] = dz2[e] * (1.0f - h2[e] * h2[e]);
-        // B operand of d(hidden 1): dz2 in place (D layout), cut into its bf16 terms -- the ONLY split of dz2: the same terms, written to
-        // the wave's region as three [sample][unit] bf16 images and read back transposed, are the A operand of dW2
-        uint32_t zp[3][16];
+        // B operand of d(hidden 1): dz2 in place (D layout), cut into its fp16 terms -- the ONLY split of dz2: the same terms, written to
+        // the wave's region as two [sample][unit] fp16 images and read back transposed, are the A operand of dW2
+        uint32_t zp[2][16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) split3(dz2[2 * j], dz2[2 * j + 1], zp[0][j], zp[1][j], zp[2][j]);
+        for (int j = 0; j < 16; j++) split2(dz2[2 * j], dz2[2 * j + 1], zp[0][j], zp[1][j]);
         wave_lds_fence();  // dW3 reads of the image are done
 #pragma unroll
-        for (int term = 0; term < 3; term++)
+        for (int term = 0; term < 2; term++)
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -571,13 +630,13 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         // Transposing read: the 16-lane group (lane >> 4) reads a 4-sample x 16-unit block; lane 4q + p supplies the address of sample row q,
         // units 4p .. 4p+3, and receives unit (lane & 15) of the four samples.
         const int tq = (lane & 15) >> 2, tp = lane & 3, tb = (lane >> 4) & 1;
-        u32x4 A[2][2][3];   // [chunk][tn][term]
+        u32x4 A[2][2][2];   // [chunk][tn][term]
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int tn = 0; tn < 2; tn++)
 #pragma unroll
-                for (int term = 0; term < 3; term++) {
+                for (int term = 0; term < 2; term++) {
                     const uint16_t* q = zimg + term * MT * NS + (16 * c + 8 * hi + tq) * NS + 32 * tn + 16 * tb + 4 * tp;
                     const uint2 lo2 = lds_read_tr16(q), hi2 = lds_read_tr16(q + 4 * NS);
                     const u32x4 r = { lo2.x, lo2.y, hi2.x, hi2.y };
@@ -588,7 +647,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         for (int tn = 0; tn < 2; tn++) {
             float cacc = 0.0f;
 #pragma unroll
-            for (int term = 2; term >= 0; term--)   // small terms first
+            for (int term = 1; term >= 0; term--)   // small terms first
 #pragma unroll
                 for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -602,7 +661,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         // ---------------- dW2[n][k] += sum_s dz2[s][n] h1[s][k]: two chunks of 16 samples, 24 MFMAs each ----------------
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            u32x4 B[2][3];
+            u32x4 B[2][2];
 #pragma unroll
             for (int tk = 0; tk < 2; tk++) {
                 float hb[8];
@@ -610,16 +669,16 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                 for (int e = 0; e < 8; e++) hb[e] = img[(16 * c + 8 * hi + e) * LS + s + 32 * tk];   // h1[sample][k = s + 32 tk]
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    uint32_t p1, p2, p3;
-                    split3(hb[2 * j], hb[2 * j + 1], p1, p2, p3);
-                    B[tk][0][j] = p1; B[tk][1][j] = p2; B[tk][2][j] = p3;
+                    uint32_t p1, p2;
+                    split2(hb[2 * j], hb[2 * j + 1], p1, p2);
+                    B[tk][0][j] = p1; B[tk][1][j] = p2;
                 }
             }
 #pragma unroll
             for (int tn = 0; tn < 2; tn++)
 #pragma unroll
                 for (int tk = 0; tk < 2; tk++)
-                    gW2[tn][tk] = mfma_x3(A[c][tn][0], A[c][tn][1], A[c][tn][2], B[tk][0], B[tk][1], B[tk][2], gW2[tn][tk]);
+                    gW2[tn][tk] = mfma_x2(A[c][tn][0], A[c][tn][1], B[tk][0], B[tk][1], gW2[tn][tk]);
         }
         MF_STAMP(7);   // dW2 MFMA
         // ---------------- c dh1^T[k][s] = sum_n c W2[n][k] dz2[s][n], c dz1 = c dh1 (1 - h1^2) ----------------
@@ -634,7 +693,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                 return r;
             };
             f32x16 acc;
-            u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1), an3 = afrag(0, 2);
+            u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1);
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 const int t = g >> 2, c = g & 3;
@@ -642,13 +701,12 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
                 }
-                const u32x4 a1 = an1, a2 = an2, a3 = an3;
-                if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); an3 = afrag(g + 1, 2); }
+                const u32x4 a1 = an1, a2 = an2;
+                if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); }
                 MF_PIN();
                 const u32x4 b1 = { zp[0][4 * c], zp[0][4 * c + 1], zp[0][4 * c + 2], zp[0][4 * c + 3] };
                 const u32x4 b2 = { zp[1][4 * c], zp[1][4 * c + 1], zp[1][4 * c + 2], zp[1][4 * c + 3] };
-                const u32x4 b3 = { zp[2][4 * c], zp[2][4 * c + 1], zp[2][4 * c + 2], zp[2][4 * c + 3] };
-                acc = mfma_x3(a1, a2, a3, b1, b2, b3, acc);
+                acc = mfma_x2(a1, a2, b1, b2, acc);
                 if (c == 3) {   // h1 comes back from its [sample][unit] image (still intact: dW2 only read it)
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
@@ -712,6 +770,19 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     // the two sample halves of the db2 partials meet; the layer-1 gradients lose the factor c they inherited from the scaled W2
 #pragma unroll
     for (int tn = 0; tn < 2; tn++) gb2[tn] += __shfl_xor(gb2[tn], 32, 64);
+    {   // the factor 2^S of the fp16 range leaves dW2, db2, dW1, db1 (exact)
+        const float invS = pow2i(-S_w);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) gW2[i][j][r] *= invS;
+        gb2[0] *= invS; gb2[1] *= invS;
+        gb1 *= invS;
+#pragma unroll
+        for (int o = 0; o < OBS; o++) gW1[o] *= invS;
+    }
     gb1 *= TANH_C_INV;
 #pragma unroll
     for (int o = 0; o < OBS; o++) gW1[o] *= TANH_C_INV;
@@ -811,7 +882,7 @@ template <int OBS>
 __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __restrict__ P, NetLayout L, const float* __restrict__ obs0, int64_t n0,
                                                              float* __restrict__ out0, const float* __restrict__ obs1, int64_t n1,
                                                              float* __restrict__ out1) {
-    __shared__ __attribute__((aligned(16))) uint16_t sW2p[3 * 64 * WS];
+    __shared__ __attribute__((aligned(16))) uint16_t sW2p[2 * 64 * WS];
     __shared__ __attribute__((aligned(16))) float sB1[64], sB2[64], sW3[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, hi = lane >> 5;
@@ -824,12 +895,10 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
             const int e = tid + i * 256;
             const int n = e >> 6, k = e & 63;
             const float w = wv[i] * TANH_C;   // tanh_scaled: c is folded into W1, b1, W2, b2
-            const uint32_t u0 = f2u(w);
-            const float r1 = w - u2f(u0 & 0xffff0000u);
-            const uint32_t u1 = f2u(r1);
-            const float r2 = r1 - u2f(u1 & 0xffff0000u);
+            uint32_t p1, p2;
+            split2(w, 0.0f, p1, p2);
             const int pf = n * WS + slot_of_unit(k);
-            sW2p[pf] = (uint16_t)(u0 >> 16); sW2p[64 * WS + pf] = (uint16_t)(u1 >> 16); sW2p[2 * 64 * WS + pf] = (uint16_t)(f2u(r2) >> 16);
+            sW2p[pf] = (uint16_t)p1; sW2p[64 * WS + pf] = (uint16_t)p2;
         }
     }
     if (tid < 64) { sB1[tid] = P[L.b1[0] + tid] * TANH_C; sB2[tid] = P[L.b2[0] + tid] * TANH_C; sW3[tid] = P[L.w3[0] + tid]; }
@@ -889,15 +958,15 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_scaled(acc[r]);
         }
-        uint32_t hp[3][16];
+        uint32_t hp[2][16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) split3(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j], hp[2][j]);
+        for (int j = 0; j < 16; j++) split2(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j]);
         auto aptr = [&](int g, int term) {
             return reinterpret_cast<const u32x4*>(sW2p + term * 64 * WS + (s + 32 * (g >> 2)) * WS + (g & 3) * 16 + hi * 8);
         };
         float part = 0.0f;
         f32x16 acc;
-        u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1), an3 = *aptr(0, 2);
+        u32x4 an1 = *aptr(0, 0), an2 = *aptr(0, 1);
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const int t = g >> 2, c = g & 3;
@@ -908,13 +977,12 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
                     acc[4 * qq] = b.x; acc[4 * qq + 1] = b.y; acc[4 * qq + 2] = b.z; acc[4 * qq + 3] = b.w;
                 }
             }
-            const u32x4 a1 = an1, a2 = an2, a3 = an3;
-            if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); an3 = *aptr(g + 1, 2); }
+            const u32x4 a1 = an1, a2 = an2;
+            if (g + 1 < 8) { an1 = *aptr(g + 1, 0); an2 = *aptr(g + 1, 1); }
             MF_PIN();
             const u32x4 b1 = { hp[0][4 * c], hp[0][4 * c + 1], hp[0][4 * c + 2], hp[0][4 * c + 3] };
             const u32x4 b2 = { hp[1][4 * c], hp[1][4 * c + 1], hp[1][4 * c + 2], hp[1][4 * c + 3] };
-            const u32x4 b3v = { hp[2][4 * c], hp[2][4 * c + 1], hp[2][4 * c + 2], hp[2][4 * c + 3] };
-            acc = mfma_x3(a1, a2, a3, b1, b2, b3v, acc);
+            acc = mfma_x2(a1, a2, b1, b2, acc);
             if (c == 3) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {   // units 8q + 4hi + 32t .. +3 are registers 4q .. 4q+3
