@@ -2,7 +2,7 @@
 //
 // Same contract as fwd_bwd_kernel in kernels_update.hip (reference PPO_Discrete.cpp:576-638), different machine mapping:
 // the three 64x64 contractions per sample and net -- layer-2 forward, d(hidden 1), and the weight gradient dW2 -- run on the
-// matrix cores as bf16 MFMAs over exact three-term splits of the fp32 operands (see "arithmetic" below).  Matrix cores are used
+// matrix cores as f16 MFMAs over two-term fp16 splits of the fp32 operands (see "arithmetic" below).  Matrix cores are used
 // only here because only here is the minibatch (131 072 rows at BASELINE configs[1]) a real contraction.  values_mfma_kernel at
 // the end of the file is the forward half of the same mapping for the batched critic evaluation of the rollout.
 //
@@ -14,16 +14,28 @@
 // order as long as A and B agree, a D-layout vector is directly the B operand of the next product when the weight operand is
 // fetched in that same order: forward and d(hidden) need NO data movement.
 // Only the products that contract over SAMPLES (dW2, dW3, dW1, bias gradients) need lane = unit: the tile goes through a
-// private LDS region of the wave -- h2, h1 and dz1 as 32 x 68-float images, dz2 as the three bf16 TERM images its d(hidden)
+// private LDS region of the wave -- h2, h1 and dz1 as 32 x 68-float images, dz2 as the two fp16 TERM images its d(hidden)
 // product has already formed (read back transposed by ds_read_b64_tr_b16: no second split of dz2).
 // Weight-gradient accumulators (64 registers for dW2) live in registers across all tiles of the wave; the waves of a
 // workgroup are then added in a fixed order through LDS and leave as ONE partial slab (deterministic, no float atomics).
 //
-// Arithmetic: every fp32 operand is cut (by truncation, exactly: x = t1 + t2 + t3, 8 mantissa bits each) into three bf16 terms and
-// every fp32 product a.b is issued as the six bf16 products a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 on v_mfma_f32_32x32x16_bf16 with
-// fp32 accumulation; the three dropped products are <= 3 x 2^-24 |a||b|, i.e. the result carries fp32 accuracy (no range loss: bf16
-// has the fp32 exponent).  The exact-fp32 instruction v_mfma_f32_32x32x2_f32 runs at the vector rate and excludes every other vector
-// instruction of its SIMD while it executes (tools/probes/mfma_coexec.hip); it is used only for layer 1 (K = obs_size <= 4).
+// Arithmetic: every fp32 operand x is carried as TWO fp16 terms, t1 = rn16(x), t2 = rn16(x - t1) (round to nearest even; x - t1 is
+// exact: one v_fma_mix_f32 with t1 read straight out of its packed pair), and every fp32 product a.b is issued as the three f16
+// products a1b1 + a1b2 + a2b1 on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  |x - t1 - t2| <= 2^-24 |x| and the dropped a2b2 is
+// <= 2^-24 |a||b| (|t2| <= 2^-12 |x|), so a product is off by <= 3 x 2^-24 |a||b|: fp32's own rounding.  fp16 has 5 exponent bits
+// where fp32 has 8; the range is handled per operand:
+//   * h1 (|h| <= 1) and c W2 are used as they are: below 2^-2 the second term runs into fp16's denormals and the representation error
+//     becomes absolute, <= 2^-25 -- a quarter of the rounding step of an fp32 number near 1, and h, W enter sums of O(1) terms.
+//     |c W2| must stay below 65504 (|W2| < 22 700); beyond that the conversion yields inf and the update fails loudly (NaN).
+//   * dz2 (~1 / minibatch size, times anything the advantages and returns carry) is formed already multiplied by 2^S, S a wave-uniform
+//     integer chosen from the tile's own data so that no |dz2| 2^S can pass 2^14 (see the tile loop); everything downstream of dz2
+//     carries the factor and the gradient accumulators lose it, exactly, in the epilogue.  Elements down to 2^-15 of the tile's bound
+//     keep the full 24 bits, smaller ones an absolute error of 2^-39 of it.
+// Per 32-sample tile and net: 72 f16 MFMAs (24 per contraction) + 4 fp32 ones for layer 1, and 4 vector instructions per pair of
+// values for a split (two conversions that also pack, two residuals).  Round 1-2's bf16 form of the same idea (three truncated bf16
+// terms, six products, 5.5 vector instructions per value) measured 52.7 us per launch against this form's 44.0, A/B in one call.
+// The exact-fp32 instruction v_mfma_f32_32x32x2_f32 runs at the vector rate and excludes every other vector instruction of its SIMD
+// while it executes (tools/probes/mfma_coexec.hip); it is used only for layer 1 (K = obs_size <= 4).
 //
 // tanh(z) = 1 - 2 / (1 + 2^(c z)), c = 2 log2(e).  c is folded into the LDS copies of W1, b1, W2, b2, so a pre-activation leaves the
 // matrix cores already scaled and tanh is four instructions (v_exp, v_add, v_rcp, v_fma).  The backward product through the scaled W2
@@ -36,8 +48,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MT = 32;              // samples per wave tile
 constexpr int LS = 68;              // padded row stride (floats) of an fp32 [sample][unit] image
-constexpr int NS = 68;              // bf16 per row of a term image (136 B: 32 rows x 8 B land on 64 distinct banks)
-constexpr int WS = 72;              // bf16 per padded row of values_mfma_kernel's weight operand (144 B: 16 rows x 16 B land on 16 distinct bank groups)
+constexpr int NS = 68;              // fp16 per row of a term image (136 B: 32 rows x 8 B land on 64 distinct banks)
+constexpr int WS = 72;              // fp16 per padded row of values_mfma_kernel's weight operand (144 B: 16 rows x 16 B land on 16 distinct bank groups)
 constexpr int MF_WAVES = 8, MF_THREADS = 64 * MF_WAVES;
 constexpr float TANH_C = 2.885390081777927f;        // 2 log2(e)
 constexpr float TANH_C_INV = 0.34657359027997264f;  // ln(2) / 2
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------
 // Critic over rows [0, n0) of obs0 and [0, n1) of obs1 on the matrix cores (m_values[step] = Critic(obs[step]),
 // PPO_Discrete.cpp:534-536, and the bootstrap value, :280): the forward half of mf_body<0> -- one wave per 32-row tile, layer 1 as
-// fp32 MFMA, layer 2 as three-term bf16 products, head as a 32-term dot product per half-lane.  Rows are contiguous, so the
+// fp32 MFMA, layer 2 as two-term fp16 products, head as a 32-term dot product per half-lane.  Rows are contiguous, so the
 // "gather" is one coalesced 16-byte load per row.
 // ---------------------------------------------------------------------------------------------------------
 template <int OBS>
@@ -1000,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
 
 }  // namespace
 
-// One 8-wave workgroup per CU (its split weight images and the eight wave regions need ~140 KB of LDS), half of them per net.
+// One 8-wave workgroup per CU (256 vector registers per wave: two waves per SIMD is all a CU holds; LDS ~95 KB), half of them per net.
 void update_blocks_mfma(int M, int n_blocks[2]) {
     const int total = 256;                                       // resident workgroups of the chip
     const int tiles = (M + MT - 1) / MT;
