@@ -32,6 +32,7 @@ python3 $ROOT/tools/pmc_summary.py "$ROOT/profiles/${TAG}_pmc_per_dispatch.json"
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/gae_trace" -o run -- python3 $ROOT/tools/gae_sweep.py 4096 8192 32768 > "$OUT/gae_sweep.jsonl" 2> "$OUT/gae_trace.log"
 cp "$(find "$OUT/gae_trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_gae_kernel_stats.csv"
 grep '^{' "$OUT/gae_sweep.jsonl" > "$ROOT/profiles/${TAG}_gae_sweep.jsonl" || true
+python3 $ROOT/tools/gae_by_size.py "$(find "$OUT/gae_trace" -name '*kernel_trace.csv' | head -n 1)" "$ROOT/profiles/${TAG}_gae_by_size.json" > "$OUT/gae_by_size.txt"
 if [ -x $ROOT/tools/probes/gae_floor ]; then
     $ROOT/tools/probes/gae_floor 4096 8192 32768 > "$ROOT/profiles/${TAG}_gae_floor.jsonl"
     rocprofv3 --kernel-trace --stats -f csv -d "$OUT/floor_trace" -o run -- $ROOT/tools/probes/gae_floor 4096 > "$OUT/floor_trace.log" 2>&1
