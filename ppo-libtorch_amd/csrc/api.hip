@@ -523,7 +523,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             for (int net = 0; net < 2; net++)
                 for (int l = 0; l < GL.n_layers; l++) {
                     g.wp_npad[net][l] = (GL.out_dim[net][l] + 127) / 128 * 128;
-                    g.wp_kpad[l] = (GL.in_dim[l] + 127) / 128 * 128;
+                    g.wp_kpad[l] = (GL.in_dim[l] + 127) / 128 * 128;   // the tiled kernel's chunking; the fused kernels walk it in passes of 8 k steps
                     g.wp_off[net][l] = off;
                     off += 3ll * g.wp_npad[net][l] * g.wp_kpad[l];
                 }
@@ -753,7 +753,7 @@ extern "C" ppo_status ppo_params_init_orthogonal(ppo_ctx* c, int64_t seed) {
 // ---- generic networks (generic.hpp): critic / actor over n rows, chunked to the workspace size ----
 static ppo_status gen_values(ppo_ctx* c, const float* obs, int64_t n, float* value) {
     GenericCtx& g = *c->gen;
-    if (gen_fused_ok(g) && n <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small batch: the whole critic in one launch
+    if (gen_fused_forward_ok(g) && n <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small batch: the whole critic in one launch
         HIPCHK(c, gen_fused_forward(g, B_<float>(c, PPO_BUF_PARAMS), 0, obs, nullptr, 0, n, false, value, c->stream));
         return PPO_OK;
     }
@@ -768,7 +768,7 @@ static ppo_status gen_policy(ppo_ctx* c, const float* obs, const uint8_t* mask, 
     GenericCtx& g = *c->gen;
     for (int64_t off = 0; off < n; off += g.rows_max) {
         const int64_t rows = std::min<int64_t>(g.rows_max, n - off);
-        if (gen_fused_ok(g) && rows <= GEN_FUSED_MAX_ROWS) HIPCHK(c, gen_fused_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, nullptr, 0, rows, false, g.logits, c->stream));
+        if (gen_fused_forward_ok(g) && rows <= GEN_FUSED_MAX_ROWS) HIPCHK(c, gen_fused_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, nullptr, 0, rows, false, g.logits, c->stream));
         else HIPCHK(c, gen_forward(g, B_<float>(c, PPO_BUF_PARAMS), 1, obs + off * g.L.obs, rows, nullptr, g.dz[0], g.dz[1], g.logits, c->stream));
         HIPCHK(c, gen_heads(g.L, c->cfg.dist_kind, g.logits, mask ? mask + off * g.L.act : nullptr, forced ? forced + off * g.L.n_heads : nullptr, rows,
                             c->cfg.seed, c->cfg.env_offset + off, step_index, action ? action + off * g.L.n_heads : nullptr,
@@ -1070,7 +1070,7 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         ProfScope ps(c, PROF_FWD_BWD);
         HIPCHK(c, gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
                              B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), idx, M, g, c->stream));
-        if (gen_fused_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small minibatch: each net's forward pass is one launch that also leaves its hidden activations
+        if (gen_fused_forward_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small minibatch: each net's forward pass is one launch that also leaves its hidden activations
             HIPCHK(c, gen_fused_forward(g, params, 1, nullptr, g.xin_bf, g.ld_in0, M, true, g.logits, c->stream));
             HIPCHK(c, gen_fused_forward(g, params, 0, nullptr, g.xin_bf, g.ld_in0, M, true, g.val, c->stream));
         } else {

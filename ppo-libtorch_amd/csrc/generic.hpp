@@ -109,11 +109,14 @@ hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* d
 
 // kernels_generic_fused.hip: bf16-storage networks whose layer inputs fit LDS -- a net's whole forward pass, or the whole T-step rollout of
 // the synthetic env, in one launch
-// One workgroup of the batch kernel streams ALL of a net's weights from L2 for its 64 rows: right for a step's or a small minibatch's rows (one
-// launch, no HBM traffic between layers), wrong for 65 536 (measured at configs[4]: 142 us per net against 112 for the five tiled products, whose
-// weight tiles are shared by 128 rows and whose activations stream from HBM at its rate)
-constexpr int64_t GEN_FUSED_MAX_ROWS = 8192;
+// One workgroup of the batch kernel streams ALL of a net's weights from L2 for each of its 64-row tiles.  In its first form (one tile per
+// workgroup, input staged by a scalar loop, lane = output column) it lost to the five tiled products at 65 536 rows (142 us per net against
+// 112); persistent, with the next tile's input prefetched into registers, the product transposed so that the epilogue stores 8-byte row
+// pieces, and a layer's weight fragments requested across the epilogue of the layer above, it wins there too (configs[4] minibatch step
+// 0.871 -> 0.822 ms, A/B in one call), so there is no row limit any more.
+constexpr int64_t GEN_FUSED_MAX_ROWS = 1 << 20;
 bool gen_fused_ok(const GenericCtx& g);
+bool gen_fused_forward_ok(const GenericCtx& g);
 hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
                              float* out, hipStream_t s);
 hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,

@@ -6,8 +6,10 @@
 //   fragments, out of a copy kept in fragment order (a wave's load for one k step is 1 KiB of consecutive bytes; read row-major, the same
 //   load touched 32 different memory lines and the kernel was bound by L1 line lookups: 53 us per rollout step) -- all of a column
 //   block's loads are issued before its first MFMA ; eight waves, wave w owns output columns 32 (w + 8 j) ; v_mfma_f32_32x32x16_bf16, f32
-//   accumulation ; epilogue bias + tanh -> bf16 -> the OTHER LDS tile, which is the next layer's A operand.  One barrier per layer, no
-//   HBM traffic between layers, no per-layer launch.
+//   accumulation.  The product is issued TRANSPOSED (weights as the A operand, rows as the B operand): the result then has lane = row
+//   and registers = 4-groups of consecutive output units, so the epilogue (bias + tanh -> bf16) leaves as 8-byte stores into the OTHER LDS
+//   tile, which is the next layer's operand (lane = column cost sixteen 2-byte stores per block and ~25 vector instructions per element of
+//   address arithmetic: 42 vector instructions per MFMA, measured).  One barrier per layer, no HBM traffic between layers, no per-layer launch.
 //
 // Two kernels on that core:
 //   generic_rollout_kernel   the T-step rollout of PPO_MultiDiscrete::train() (PPO_MultiDiscrete.cpp:547-575) for the synthetic env: per step
@@ -28,13 +30,19 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FU_WAVES = 8, FU_THREADS = 64 * FU_WAVES;
-constexpr int FU_KSTEPS = 24;   // k steps (of 16) whose B fragments are in flight at once: 96 registers
+constexpr int FU_KSTEPS = 16;   // k steps (of 16) whose weight fragments are in flight at once: 64 registers (a 256-wide layer in one pass)
 
 __device__ __forceinline__ uint32_t fu_f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float fu_u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 __device__ __forceinline__ uint16_t fu_bf16(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
 __device__ __forceinline__ uint32_t fu_pack(float x0, float x1) { const bf16x2 v = { (__bf16)x0, (__bf16)x1 }; return __builtin_bit_cast(uint32_t, v); }
 
+#ifdef FU_DBG_STAMPS
+// diagnostic build only: cycle stamps of wave 0 of one workgroup (tools/fused_fwd_probe.py); `dbg` is a local of the enclosing function
+#define FU_STAMP(i) do { if (dbg && threadIdx.x == 0) { dbg[i] = (unsigned int)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define FU_STAMP(i) do { } while (0)
+#endif
 struct FusedNet {
     GenLayout L;
     int net;
@@ -42,26 +50,33 @@ struct FusedNet {
     const uint16_t* wfrags;         // bf16 weights of every layer in MFMA-fragment order (gen_weight_planes: [column block][k step][lane][8])
     int64_t wp_off[GEN_MAX_LAYERS]; // of THIS net
     int wp_kpad[GEN_MAX_LAYERS];
-    int ldA;                        // LDS row pitch (bf16 elements): max(pad16(obs), pad32(hidden)) + 8
+    int ldA;                        // LDS row pitch (bf16 elements): the widest padded contraction length (a multiple of 256) + 8
 };
 
 // Runs every layer of the net on the FM x 32 rows whose layer-0 input sits in tile0 ([rows][ldA] bf16, zero beyond obs up to a multiple of
 // 16).  Hidden activations alternate between tile1 and tile0; the head's f32 outputs land in s_out [rows][32] (columns beyond the head's width
 // are zero).  keep[l] != nullptr: hidden layer l's activation tile is also stored to keep[l] + row0 * ld_keep (rows < n_rows only).
 // Ends with a barrier: s_out and the last tile are visible to every thread.
-// The B fragments of a column block: ksteps x 16 bytes per lane, all in flight together.  A layer has at most FU_KSTEPS k steps per pass.
+// The weight fragments of a column block: 16 bytes per lane and k step.  A layer's first FU_KSTEPS k steps travel while the layer above is
+// still in its epilogue (`pre`); what a wider layer has beyond them comes in passes of FU_KTAIL steps into the registers of the first
+// FU_KTAIL steps, as soon as those have been multiplied (no second register set: the kernels sit at the 256-register line).
+constexpr int FU_KTAIL = 8;
 struct BFrags { u32x4 q[FU_KSTEPS]; };
 __device__ __forceinline__ void load_bfrags(BFrags& b, const FusedNet& f, int l, int cb, int k0, int lane) {
-    const int ksteps = (f.L.in_dim[l] + 15) / 16;
     const uint16_t* wblk = f.wfrags + f.wp_off[l] + ((int64_t)cb * (f.wp_kpad[l] / 16) * 64 + lane) * 8;   // a k step's fragments: 64 lanes x 16 consecutive bytes
 #pragma unroll
-    for (int j = 0; j < FU_KSTEPS; j++)   // unconditional loads (a k step past the end re-reads step 0 and is not used)
-        b.q[j] = *reinterpret_cast<const u32x4*>(wblk + (int64_t)(k0 + j < ksteps ? k0 + j : 0) * 512);
+    for (int j = 0; j < FU_KSTEPS; j++)   // a layer narrower than FU_KSTEPS k steps reads on into the next column block: in bounds, not used
+        b.q[j] = *reinterpret_cast<const u32x4*>(wblk + (int64_t)(k0 + j) * 512);
+}
+__device__ __forceinline__ void load_btail(BFrags& b, const FusedNet& f, int l, int cb, int k0, int lane) {
+    const uint16_t* wblk = f.wfrags + f.wp_off[l] + ((int64_t)cb * (f.wp_kpad[l] / 16) * 64 + lane) * 8;
+#pragma unroll
+    for (int j = 0; j < FU_KTAIL; j++) b.q[j] = *reinterpret_cast<const u32x4*>(wblk + (int64_t)(k0 + j) * 512);
 }
 
 template <int FM>
 __device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0, uint16_t* tile1, float* s_out, uint16_t* const* keep, int64_t ld_keep, int64_t row0,
-                                             int n_rows, BFrags& pre) {
+                                             int n_rows, BFrags& pre, unsigned int* dbg = nullptr) {
     // `pre` holds, on entry, the fragments of (layer 0, column block = wave, k steps 0 ..) -- requested by the caller, e.g. while the input tile
     // was still being written -- and on exit those of layer 0 again (for the next call): a layer's first fragments are always requested
     // before the epilogue and the barrier of the layer above, so their trip to L2 is never waited for with nothing else to do.
@@ -73,7 +88,7 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0,
     for (int l = 0; l < L.n_layers; l++) {
         const int K = L.in_dim[l], N = L.out_dim[f.net][l];
         const bool last = l == L.n_layers - 1;
-        const int ksteps = (K + 15) / 16;
+        const int ksteps = f.wp_kpad[l] / 16;   // a multiple of 8; the weights of k >= K are zero, the tile's columns there finite
         const int nblk = (N + 31) / 32;
         const float* bias = f.params + L.b_off[f.net][l];
         const int ln = last ? 0 : l + 1;   // the layer whose first fragments are requested during this one
@@ -84,38 +99,92 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0,
             for (int i = 0; i < FM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
-            for (int k0 = 0; k0 < ksteps; k0 += FU_KSTEPS) {
-                if (own && (cb != wave || k0 != 0)) load_bfrags(pre, f, l, cb, k0, lane);
-                if (own) {
+            // bias of the lane's 16 output units (4 groups of 4 consecutive ones): requested before the products, used after them
+            float bv[16];
+            {
+                const bool vec = (N & 3) == 0;
 #pragma unroll
-                    for (int j = 0; j < FU_KSTEPS; j++) {
-                        if (k0 + j < ksteps) {
+                for (int q = 0; q < 4; q++) {
+                    const int n = 32 * cb + 8 * q + 4 * kg;
+                    if (vec) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias + (own && n < N ? n : 0));
+                        bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
+                    } else {
 #pragma unroll
-                            for (int i = 0; i < FM; i++) {
-                                const u32x4 a = *reinterpret_cast<const u32x4*>(src + (32 * i + li) * f.ldA + 16 * (k0 + j) + 8 * kg);
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pre.q[j]), acc[i], 0, 0, 0);
-                            }
+                        for (int e = 0; e < 4; e++) bv[4 * q + e] = bias[own && n + e < N ? n + e : 0];
+                    }
+                }
+            }
+            if (own) {
+                if (cb != wave) load_bfrags(pre, f, l, cb, 0, lane);   // a second column block of this wave (layers wider than 256): not prefetched
+                // the rows' fragments come from LDS four k steps at a time, all requested before the first product of the batch (read one by
+                // one in front of its MFMA, each product waits out an LDS round trip)
+                const uint16_t* xr[FM];
+#pragma unroll
+                for (int i = 0; i < FM; i++) xr[i] = src + (32 * i + li) * f.ldA + 8 * kg;
+                auto batch = [&](int kx, int jq) {   // k steps kx .. kx + 3 of the tile against fragments q[jq .. jq + 3]
+                    u32x4 x[FM][4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int i = 0; i < FM; i++) x[i][j] = *reinterpret_cast<const u32x4*>(xr[i] + 16 * (kx + j));
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int i = 0; i < FM; i++)   // D[n][row]: weights are the A operand, the rows the B operand
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pre.q[jq + j]), __builtin_bit_cast(bf16x8, x[i][j]), acc[i], 0, 0, 0);
+                };
+                FU_STAMP(32 + 4 * l);
+                batch(0, 0); batch(4, 4);
+                if (ksteps > FU_KSTEPS) load_btail(pre, f, l, cb, FU_KSTEPS, lane);   // ksteps is a multiple of 8
+                if (ksteps > FU_KTAIL) { batch(8, 8); batch(12, 12); }
+                for (int k0 = FU_KSTEPS; k0 < ksteps; k0 += FU_KTAIL) {
+                    batch(k0, 0); batch(k0 + 4, 4);
+                    if (k0 + FU_KTAIL < ksteps) load_btail(pre, f, l, cb, k0 + FU_KTAIL, lane);
+                }
+            }
+            FU_STAMP(33 + 4 * l);
+            // the wave's last pass of this layer: the next layer's first fragments are requested now -- by a wave with an epilogue to do in four
+            // pieces spread over it (sixteen loads in a row from all eight waves fill the CU's load queue: ~1 200 cycles of issue stall each)
+            const bool pf_next = cb + FU_WAVES >= nblk;
+            const uint16_t* nblkp = f.wfrags + f.wp_off[ln] + ((int64_t)wave * (f.wp_kpad[ln] / 16) * 64 + lane) * 8;
+            auto next_piece = [&](int pc) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) pre.q[4 * pc + j] = *reinterpret_cast<const u32x4*>(nblkp + (int64_t)(4 * pc + j) * 512);
+            };
+            if (pf_next && !own) { next_piece(0); next_piece(1); next_piece(2); next_piece(3); }
+            FU_STAMP(34 + 4 * l);   // the wave's last pass of this layer: next layer's first fragments
+            if (own) {
+                // epilogue: lane's row = 32 i + li, register r <-> unit 32 cb + (r & 3) + 8 (r >> 2) + 4 kg
+                const bool full = !last && (N & 31) == 0;   // every unit of the block exists: no guards (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < FM; i++) {
+                    const int row = 32 * i + li;
+                    uint16_t* drow = dst + row * f.ldA + 32 * cb + 4 * kg;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (pf_next && ((FM == 1) || (q & 1))) next_piece(FM == 1 ? q : 2 * i + (q >> 1));
+                        const int n = 32 * cb + 8 * q + 4 * kg;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = acc[i][4 * q + e] + bv[4 * q + e];
+                        if (full) {
+                            *reinterpret_cast<uint2*>(drow + 8 * q) = make_uint2(fu_pack(tanh_mufu(v[0]), tanh_mufu(v[1])), fu_pack(tanh_mufu(v[2]), tanh_mufu(v[3])));
+                        } else if (last) {   // heads are at most 32 logits wide (PPO_MAX_ACT): one column block
+                            *reinterpret_cast<float4*>(s_out + row * 32 + 8 * q + 4 * kg) =
+                                make_float4(n < N ? v[0] : 0.0f, n + 1 < N ? v[1] : 0.0f, n + 2 < N ? v[2] : 0.0f, n + 3 < N ? v[3] : 0.0f);
+                        } else {
+                            *reinterpret_cast<uint2*>(drow + 8 * q) =
+                                make_uint2(fu_pack(n < N ? tanh_mufu(v[0]) : 0.0f, n + 1 < N ? tanh_mufu(v[1]) : 0.0f),
+                                           fu_pack(n + 2 < N ? tanh_mufu(v[2]) : 0.0f, n + 3 < N ? tanh_mufu(v[3]) : 0.0f));
                         }
                     }
                 }
             }
-            if (cb + FU_WAVES >= nblk) load_bfrags(pre, f, ln, wave, 0, lane);   // the wave's last pass of this layer: next layer's first fragments
-            if (own) {
-                // epilogue: lane's column n = 32 cb + li, register r <-> row (r & 3) + 8 (r >> 2) + 4 kg of block i
-                const int n = 32 * cb + li;
-                const float b = n < N ? bias[n] : 0.0f;
-#pragma unroll
-                for (int i = 0; i < FM; i++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        const float v = acc[i][r] + b;
-                        if (last) s_out[row * 32 + (n & 31)] = n < N ? v : 0.0f;   // heads are at most 32 logits wide (PPO_MAX_ACT): one column block
-                        else dst[row * f.ldA + n] = fu_bf16(n < N ? tanh_mufu(v) : 0.0f);
-                    }
-            }
         }
+        FU_STAMP(8 + 2 * l);
         __syncthreads();
+        FU_STAMP(9 + 2 * l);
         if (!last && keep && keep[l]) {   // the activation tile leaves for the backward pass in 16-byte row pieces
             const int p8 = (N + 7) / 8;
             for (int e = tid; e < 32 * FM * p8; e += FU_THREADS) {
@@ -193,7 +262,10 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_rollout_kernel(const Fu
                 for (int q = 0; q < 4; q++) if (4 * j4 + q < O) { trow[q] = fu_bf16(vv[q]); if (ok) grow[q] = vv[q]; }
             }
         }
-        for (int e = me; e < 32 * (opad - O); e += nt) tile0[(e / (opad - O)) * a.f.ldA + O + e % (opad - O)] = 0;   // zero k padding
+        {   // zero the k padding and whatever a hidden layer's output left behind the observation (see generic_forward_kernel)
+            const int hpad = (L.hidden + 31) / 32 * 32, zhi = opad > hpad ? opad : hpad;
+            for (int e = me; e < 32 * (zhi - O); e += nt) tile0[(e / (zhi - O)) * a.f.ldA + O + e % (zhi - O)] = 0;
+        }
         if (me < 32) {
             uint8_t* mrow = s_mask + (slot * 32 + me) * PPO_MAX_ACT;
             uint32_t bits = 0xffffffffu;
@@ -210,6 +282,8 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_rollout_kernel(const Fu
         }
     };
 
+    for (int e = tid; e < 2 * 32 * a.f.ldA / 8; e += FU_THREADS) { const u32x4 z = { 0u, 0u, 0u, 0u }; reinterpret_cast<u32x4*>(fu_lds)[e] = z; }   // finite everywhere
+    __syncthreads();
     observe(a.step_base, a.obs, a.masks, 0, 0, FU_THREADS);   // m_obs[0] = next_obs, m_action_masks[0] = next_mask (:553-555)
     __syncthreads();
     for (int t = 0; t < a.T; t++) {
@@ -275,7 +349,16 @@ struct FusedForwardArgs {
     int64_t ld_keep;
 };
 
+// Persistent: one workgroup per CU walks the 64-row tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The NEXT tile's input travels from
+// HBM into registers (16-byte pieces, all requested together) while the current tile goes through its layers, so the only memory round
+// trip a workgroup ever waits for is its first.  (Staged by a plain loop -- two 4-byte loads, convert, store, per iteration -- the input
+// cost a tile 24 dependent round trips: 196 us for the critic over 65 536 rows, half of all wave cycles parked at s_waitcnt.)
+// 16-byte input pieces per thread and tile (eight threads per row): bf16 rows of up to 384 elements, f32 rows of up to 384
+template <bool BF> constexpr int fu_np() { return BF ? 6 : 12; }
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <bool BF>
 __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardArgs a) {
+    constexpr int FU_NP = fu_np<BF>();
     extern __shared__ __attribute__((aligned(16))) uint16_t fu_lds[];
     constexpr int FM = 2, RB = 32 * FM;
     const GenLayout& L = a.f.L;
@@ -283,43 +366,76 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
     uint16_t* tile0 = fu_lds;
     uint16_t* tile1 = fu_lds + RB * a.f.ldA;
     float* s_out = reinterpret_cast<float*>(fu_lds + 2 * RB * a.f.ldA);      // [RB][32]
-    const int64_t row0 = (int64_t)blockIdx.x * RB;
-    const int n_rows = a.rows - row0 < RB ? (int)(a.rows - row0) : RB;
     const int O = L.obs, opad = (O + 15) / 16 * 16;
+    const int64_t n_tiles = (a.rows + RB - 1) / RB;
     BFrags pre;
     load_bfrags(pre, a.f, 0, tid >> 6, 0, tid & 63);   // layer 0's first weight fragments travel while the input tile is loaded
-    if (a.x_bf) {
-        const int p8 = opad / 8;
-        for (int e = tid; e < RB * p8; e += FU_THREADS) {
-            const int row = e / p8, c8 = e % p8;
-            u32x4 v = { 0u, 0u, 0u, 0u };
-            if (row < n_rows) v = *reinterpret_cast<const u32x4*>(a.x_bf + (row0 + row) * a.ld_x + 8 * c8);
-            *reinterpret_cast<u32x4*>(tile0 + row * a.f.ldA + 8 * c8) = v;
+    // eight threads per row: thread (row = tid >> 3, sub = tid & 7) owns the row's 16-byte pieces sub, sub + 8, ... (8 bf16 or 4 floats each)
+    constexpr bool bf = BF;
+    const int ppr = bf ? opad / 8 : (O + 3) / 4;   // pieces per row (f32: O is a multiple of 4, host-checked)
+    const int prow = tid >> 3, sub = tid & 7;
+    u32x4 pf[FU_NP];
+    auto fetch = [&](int64_t tile) {   // unconditional loads: a piece that does not exist re-reads the operand's first bytes and is zeroed at use
+        const int64_t row = tile * RB + prow;
+        const bool rok = tile < n_tiles && row < a.rows;
+#pragma unroll
+        for (int p = 0; p < FU_NP; p++) {
+            const int piece = sub + 8 * p;
+            const bool ok = rok && piece < ppr;
+            if (bf) pf[p] = *reinterpret_cast<const u32x4*>(a.x_bf + (ok ? row * a.ld_x + 8 * piece : 0));
+            else pf[p] = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4a4*>(a.x_f32 + (ok ? row * O + 4 * piece : 0)));
         }
-    } else {
-        const int p2 = opad / 2;
-        for (int e = tid; e < RB * p2; e += FU_THREADS) {
-            const int row = e / p2, k = 2 * (e % p2);
-            float x0 = 0.0f, x1 = 0.0f;
-            if (row < n_rows) {
-                if (k < O) x0 = a.x_f32[(row0 + row) * O + k];
-                if (k + 1 < O) x1 = a.x_f32[(row0 + row) * O + k + 1];
-            }
-            *reinterpret_cast<uint32_t*>(tile0 + row * a.f.ldA + k) = fu_pack(x0, x1);
+    };
+    auto stage = [&](int64_t tile) {
+        const bool rok = tile * RB + prow < a.rows;
+#pragma unroll
+        for (int p = 0; p < FU_NP; p++) {
+            const int piece = sub + 8 * p;
+            if (piece >= ppr) continue;
+            u32x4 v = pf[p];
+            if (!rok) { v[0] = 0u; v[1] = 0u; v[2] = 0u; v[3] = 0u; }
+            if (bf) *reinterpret_cast<u32x4*>(tile0 + prow * a.f.ldA + 8 * piece) = v;
+            else *reinterpret_cast<uint2*>(tile0 + prow * a.f.ldA + 4 * piece) =
+                     make_uint2(fu_pack(fu_u2f(v[0]), fu_u2f(v[1])), fu_pack(fu_u2f(v[2]), fu_u2f(v[3])));
         }
-    }
+        // columns behind the input that a hidden layer's output (written to this tile two layers ago) may have left non-zero: layer 0 reads them
+        // against zero weights, which is only safe while they are finite -- clear them rather than argue
+        const int zlo = bf ? opad : O, hpad = (L.hidden + 31) / 32 * 32, zhi = opad > hpad ? opad : hpad;
+        for (int e = tid; e < RB * (zhi - zlo); e += FU_THREADS) tile0[(e / (zhi - zlo)) * a.f.ldA + zlo + e % (zhi - zlo)] = 0;
+    };
+    int64_t tile = blockIdx.x;
+    fetch(tile);
+    // both tiles start as zeros: columns no layer ever writes are read against zero weights and must hold finite numbers
+    for (int e = tid; e < 2 * RB * a.f.ldA / 8; e += FU_THREADS) { const u32x4 z = { 0u, 0u, 0u, 0u }; reinterpret_cast<u32x4*>(fu_lds)[e] = z; }
     __syncthreads();
-    fused_layers<FM>(a.f, tile0, tile1, s_out, a.keep, a.ld_keep, row0, n_rows, pre);
     const int N = L.out_dim[a.f.net][L.n_layers - 1];
-    for (int e = tid; e < n_rows * N; e += FU_THREADS) a.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t row0 = tile * RB;
+        const int n_rows = a.rows - row0 < RB ? (int)(a.rows - row0) : RB;
+        unsigned int* dbg = nullptr;
+#ifdef FU_DBG_STAMPS
+        if (blockIdx.x == 0 && tile == gridDim.x) dbg = reinterpret_cast<unsigned int*>(a.out + a.rows);   // the probe allocates 64 spare outputs
+#endif
+        FU_STAMP(0);
+        stage(tile);                  // tile0 is free: the previous tile's last layer ended with a barrier
+        FU_STAMP(1);
+        fetch(tile + gridDim.x);
+        FU_STAMP(2);
+        __syncthreads();
+        FU_STAMP(3);
+        fused_layers<FM>(a.f, tile0, tile1, s_out, a.keep, a.ld_keep, row0, n_rows, pre, dbg);
+        for (int e = tid; e < n_rows * N; e += FU_THREADS) a.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];
+        FU_STAMP(30);
+    }
 }
 
 FusedNet make_fused_net(const GenericCtx& g, const float* params, int net) {
     FusedNet f{};
     f.L = g.L; f.net = net; f.params = params; f.wfrags = g.wfrags;
     for (int l = 0; l < g.L.n_layers; l++) { f.wp_off[l] = g.wp_off[net][l]; f.wp_kpad[l] = g.wp_kpad[l]; }
-    const int a = (g.L.obs + 15) / 16 * 16, b = (g.L.hidden + 31) / 32 * 32;
-    f.ldA = (a > b ? a : b) + 8;
+    int kmax = 0;   // every layer reads its padded contraction length out of the tile
+    for (int l = 0; l < g.L.n_layers; l++) kmax = g.wp_kpad[l] > kmax ? g.wp_kpad[l] : kmax;
+    f.ldA = kmax + 8;
     return f;
 }
 size_t fused_lds_bytes(const FusedNet& f, int rows) { return (size_t)2 * rows * f.ldA * 2 + (size_t)rows * 32 * 4 + 2 * 32 * PPO_MAX_ACT; }
@@ -331,6 +447,13 @@ bool gen_fused_ok(const GenericCtx& g) {
     if (!g.bf16 || g.L.act > 32) return false;
     const FusedNet f = make_fused_net(g, nullptr, 0);
     return fused_lds_bytes(f, 64) <= 150 * 1024;
+}
+
+// generic_forward_kernel stages its input as 16-byte pieces held in registers: f32 observations need obs % 4 == 0, and a row at most 96 pieces
+bool gen_fused_forward_ok(const GenericCtx& g) {
+    if (!gen_fused_ok(g)) return false;
+    const int O = g.L.obs, opad = (O + 15) / 16 * 16;
+    return (O & 3) == 0 && O / 4 <= 8 * fu_np<false>() && opad / 8 <= 8 * fu_np<true>();
 }
 
 hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
@@ -345,11 +468,15 @@ hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, 
     const size_t lds = fused_lds_bytes(a.f, 64);
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(generic_forward_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(FU_THREADS), lds, s, a);
+    const int64_t n_tiles = (rows + 63) / 64;
+    const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
+    if (x_bf) hipLaunchKernelGGL(generic_forward_kernel<true>, grid, dim3(FU_THREADS), lds, s, a);
+    else hipLaunchKernelGGL(generic_forward_kernel<false>, grid, dim3(FU_THREADS), lds, s, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B of several builds on one GPU's share of configs[4] inside ONE gpurun call:  tools/c4_ab.sh ROUNDS lib_A.so lib_B.so ...
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+R=$1; shift
+cp ppo-libtorch_amd/libppo_hip.so /tmp/libppo_hip_orig.so
+for i in $(seq 1 $R); do
+    for src in "$@"; do
+        cp "$src" ppo-libtorch_amd/libppo_hip.so
+        python3 tools/config4_bench.py 2>/dev/null | tail -n 1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('%-36s' % '$src', round(d['env_steps_per_s']/1e6,3), 'M env-steps/s', round(d['minibatch_step_ms'],4), 'ms/step', round(d['rollout_ms'],3), 'ms rollout', round(d['optimizer_ms'],4), 'ms opt')"
+        python3 tools/fused_fwd_probe.py 2>/dev/null | tail -n 1
+    done
+done
+cp /tmp/libppo_hip_orig.so ppo-libtorch_amd/libppo_hip.so
