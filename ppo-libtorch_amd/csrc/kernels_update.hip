@@ -850,6 +850,9 @@ __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict_
     }
     const unsigned long long want = seq;
     Tp acc = Tp(0);
+    // a communicator on which a wait has ever run out is dead: later calls (and the later peers of this call) do not wait again, so a
+    // transport that does not work on a node costs its first call ~2 s, not 2 s per peer and call; the caller reads the count and falls back
+    bool dead = __hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (int r = 0; r < n; r++) {
         if (r == rank) { acc += mine; continue; }
         const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(peers.p[r]) + 2 * slot_bytes) + slot;
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict_
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
             for (;;) {
                 if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) { ok = 1; break; }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // ~2 s
+                if (dead || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // ~2 s
                 __builtin_amdgcn_s_sleep(8);
             }
             s_ok = ok;
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict_
         __syncthreads();
         const int ok = s_ok;
         __syncthreads();
-        if (!ok) { if (threadIdx.x == 0) atomicAdd(timeout_flag, 1); continue; }
+        if (!ok) { dead = true; if (threadIdx.x == 0) atomicAdd(timeout_flag, 1); continue; }
         const Tp* src = reinterpret_cast<const Tp*>(static_cast<const char*>(peers.p[r]) + slot * slot_bytes);
         if (i < count) acc += __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -96,3 +96,53 @@ def test_exchange_ranks_equal_single_context(tmp_path, world):
     # two full iterations with different minibatch partitions: the trajectories agree in distribution, not element-wise -- bound the distance loosely
     assert np.isfinite(params[0].view(np.float32)).all()
     assert np.abs(params[0].view(np.float32) - pw).max() < 0.05
+
+
+DEAD_WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from __graft_entry__ import load_package
+P = load_package()
+dist, rank, world = P.dist.init_process_group("gloo")
+cfg = P.dist.shard_config(P.make_config, rank, world, 64, num_steps=32, num_minibatches=2, update_epochs=2, seed=5, total_timesteps=4 * 64 * 32)
+ctx = P.Context(cfg)
+P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id, transport="exchange")
+if rank == 0:   # rank 1 never takes part: rank 0's first call waits out its ~2 s, every later call returns at once, and the count says so
+    times = []
+    for rep in range(3):
+        ctx.write("GRADS", np.ones(ctx.P, np.float32))
+        t0 = time.perf_counter()
+        P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
+        ctx.sync()
+        times.append(time.perf_counter() - t0)
+    json.dump(dict(times=times, timeouts=ctx.comm_exchange_timeouts()), open(os.path.join({out!r}, "dead.json"), "w"))
+dist.barrier()
+ctx.close()
+"""
+
+
+def test_exchange_gives_up_once_when_a_peer_never_arrives(tmp_path):
+    """A peer that never calls: the bounded wait ends the first kernel after ~2 s and marks the communicator dead; the calls after it do not
+    wait again (bench.py --transport auto reads the count after its warm-up and falls back to RCCL)."""
+    port = _free_port()
+    script = tmp_path / "dead.py"
+    script.write_text(DEAD_WORKER.format(root=ROOT, out=str(tmp_path)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("worker timed out")
+        outs.append(o.decode())
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = json.load(open(tmp_path / "dead.json"))
+    assert res["timeouts"] > 0
+    assert 1.0 < res["times"][0] < 6.0, res
+    assert res["times"][1] < 0.5 and res["times"][2] < 0.5, res
