@@ -1292,8 +1292,23 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
             const int64_t start = (int64_t)mbi * c->MB;
             const int64_t M = std::min<int64_t>(c->MB, c->B - start);
             const bool fused = c->world == 1 && !c->force_collectives && !c->gen;
-            s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !fused);
+            // sharded on the direct-exchange transport: the same two launches, the exchange folded into the slab reduction
+            const bool fused_x = c->world > 1 && c->xchg && !c->force_collectives && !c->gen;
+            s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !(fused || fused_x));
             if (s != PPO_OK) return s;
+            if (fused_x) {
+                ExchangeComm& x = *c->xchg;
+                c->opt_step += 1;
+                x.seq += 1;
+                ProfScope ps(c, PROF_OPT);
+                HIPCHK(c, launch_reduce_exchange_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums,
+                                                            B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                                                            c->cfg.max_grad_norm, c->adam_coefs + k, (double)M * c->world, c->hp, c->step_stats + k,
+                                                            c->clipfrac_accum, c->fused_partial, x.peer, c->rank, c->world, x.slot_bytes, x.seq, x.timeout_flag,
+                                                            c->stream));
+                c->last_stat_slot = k;
+                continue;
+            }
             if (fused) {
                 // single rank: two launches (slab reduction + sums of squares, then norm + clip + AdamW) instead of three
                 c->opt_step += 1;

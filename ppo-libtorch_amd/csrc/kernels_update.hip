@@ -599,7 +599,47 @@ struct FusedOptArgs {
     float max_norm; const AdamCoef* coef; double global_M; LossParams hp;
     StepStats* stats_out; double* clipfrac_accum;
     double* partial;            // [reduce workgroups][12] sums of squares
+    // XCHG: the one-shot direct exchange of exchange_allreduce_kernel (below), folded into the reduction: a sharded step is then the same two
+    // launches as a single-rank one -- reduce + exchange + sums of squares, then norm + clip + AdamW
+    void* peers[8]; int rank, n_ranks; size_t slot_bytes; unsigned long long seq; int32_t* timeout_flag;
 };
+// Waits (bounded) for every peer's flag of call `seq`: lane r of the calling wave polls peer r, so the n - 1 remote reads are in flight
+// together and an all-reduce costs two trips over the links (flags, then payloads), not two per peer.  Returns the mask of peers whose payload
+// may be read; a wait that runs out is counted in timeout_flag and marks the communicator dead (later calls do not wait again).
+__device__ __forceinline__ unsigned xchg_wait_all(void* const* peers, int rank, int n, size_t slot_bytes, int slot, unsigned long long seq, int32_t* timeout_flag) {
+    const int lane = threadIdx.x & 63;
+    const bool dead = __hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    int ok = 1;
+    if (lane < n && lane != rank) {
+        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(peers[lane]) + 2 * slot_bytes) + slot;
+        ok = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        for (;;) {
+            if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= seq) { ok = 1; break; }
+            if (dead || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // ~2 s
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) atomicAdd(timeout_flag, 1);
+    }
+    const unsigned long long m = __ballot(ok != 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // every lane reads payloads after the polling lanes saw the flags
+    return (unsigned)(m & 0xffu) | ~0xffu;
+}
+// own payload published (system scope) -> count the workgroup in; the last one of the grid stamps the slot's flag with the call number
+__device__ __forceinline__ void xchg_publish_done(const FusedOptArgs& a, int slot) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if ((threadIdx.x & 63) == 0) {
+        char* base = static_cast<char*>(a.peers[a.rank]);
+        unsigned long long* own_flag = reinterpret_cast<unsigned long long*>(base + 2 * a.slot_bytes) + slot;
+        unsigned int* own_count = reinterpret_cast<unsigned int*>(base + 2 * a.slot_bytes + 16) + slot;
+        const unsigned int arrived = __hip_atomic_fetch_add(own_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(own_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(own_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+template <bool XCHG>
 __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a) {
     __shared__ double part[16][64];
     const NetLayout& L = a.L;
@@ -632,8 +672,28 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
 #pragma unroll
                 for (int i = 0; i < 16; i++) sacc += part[i][lane];
                 g = (float)sacc;
-                a.grads[p] = g;
             }
+            if constexpr (XCHG) {
+                // this rank's share goes to its exchange slot; the sum over ranks is then formed in rank order out of the peers' slots
+                const int slot = (int)(a.seq & 1ull);
+                float* own = reinterpret_cast<float*>(static_cast<char*>(a.peers[a.rank]) + slot * a.slot_bytes);
+                if (p < L.P) __hip_atomic_store(&own[p], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                xchg_publish_done(a, slot);
+                const unsigned okm = xchg_wait_all(a.peers, a.rank, a.n_ranks, a.slot_bytes, slot, a.seq, a.timeout_flag);
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {   // all peers' elements requested together ...
+                    v[r] = 0.0f;
+                    if (r < a.n_ranks && r != a.rank && ((okm >> r) & 1u) && p < L.P)
+                        v[r] = __hip_atomic_load(reinterpret_cast<const float*>(static_cast<const char*>(a.peers[r]) + slot * a.slot_bytes) + p, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                float acc = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 8; r++) if (r < a.n_ranks) acc += r == a.rank ? g : v[r];   // ... added in rank order: every rank forms the same sum
+                g = acc;
+            }
+            if (p < L.P) a.grads[p] = g;
             // sums of squares per tensor of this workgroup's 64 gradients (a workgroup touches at most a few tensors)
             int tl = 0;
             for (int t = 0; t < L.n_tensors; t++) if (p >= L.tensor_off[t]) tl = t;
@@ -660,9 +720,30 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
                 double sacc = 0.0;
                 for (int i = 0; i < 16; i++) sacc += part[0][i];
                 a.sums_out[kk] = sacc;
+                part[1][kk] = sacc;
             }
         }
         if (threadIdx.x >= 5 && threadIdx.x < 8) a.sums_out[threadIdx.x] = 0.0;
+        if constexpr (XCHG) {
+            // the loss sums ride the exchange as eight floats behind the gradient (what ppo_allreduce_grads carries on the unfused path)
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int slot = (int)(a.seq & 1ull);
+                float* own = reinterpret_cast<float*>(static_cast<char*>(a.peers[a.rank]) + slot * a.slot_bytes);
+                const float mine = threadIdx.x < 5 ? (float)part[1][threadIdx.x] : 0.0f;
+                if (threadIdx.x < 8) __hip_atomic_store(&own[L.P + threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                xchg_publish_done(a, slot);
+                const unsigned okm = xchg_wait_all(a.peers, a.rank, a.n_ranks, a.slot_bytes, slot, a.seq, a.timeout_flag);
+                float acc = 0.0f;
+                for (int r = 0; r < a.n_ranks; r++) {
+                    if (r == a.rank) { acc += mine; continue; }
+                    if (!((okm >> r) & 1u)) continue;
+                    const float* src = reinterpret_cast<const float*>(static_cast<const char*>(a.peers[r]) + slot * a.slot_bytes);
+                    if (threadIdx.x < 8) acc += __hip_atomic_load(&src[L.P + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (threadIdx.x < 8) a.sums_out[threadIdx.x] = (double)acc;
+            }
+        }
     }
 }
 
@@ -830,7 +911,6 @@ struct XchgPtrs8 { void* p[8]; };
 template <class Tp>
 __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict__ buf, size_t count, XchgPtrs8 peers, int rank, int n, size_t slot_bytes,
                                                                  unsigned long long seq, int32_t* timeout_flag) {
-    __shared__ int s_ok;
     const int slot = (int)(seq & 1ull);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     char* base = static_cast<char*>(peers.p[rank]);
@@ -848,31 +928,24 @@ __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict_
             __hip_atomic_store(own_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    const unsigned long long want = seq;
-    Tp acc = Tp(0);
-    // a communicator on which a wait has ever run out is dead: later calls (and the later peers of this call) do not wait again, so a
-    // transport that does not work on a node costs its first call ~2 s, not 2 s per peer and call; the caller reads the count and falls back
-    bool dead = __hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    for (int r = 0; r < n; r++) {
-        if (r == rank) { acc += mine; continue; }
-        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(peers.p[r]) + 2 * slot_bytes) + slot;
-        if (threadIdx.x == 0) {
-            int ok = 0;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-            for (;;) {
-                if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want) { ok = 1; break; }
-                if (dead || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // ~2 s
-                __builtin_amdgcn_s_sleep(8);
-            }
-            s_ok = ok;
-        }
-        __syncthreads();
-        const int ok = s_ok;
-        __syncthreads();
-        if (!ok) { dead = true; if (threadIdx.x == 0) atomicAdd(timeout_flag, 1); continue; }
-        const Tp* src = reinterpret_cast<const Tp*>(static_cast<const char*>(peers.p[r]) + slot * slot_bytes);
-        if (i < count) acc += __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wave 0 waits for all peers at once (lane r polls peer r); the other waves learn the outcome through LDS
+    __shared__ unsigned s_okm;
+    if (threadIdx.x < 64) {
+        const unsigned okm = xchg_wait_all(peers.p, rank, n, slot_bytes, slot, seq, timeout_flag);
+        if (threadIdx.x == 0) s_okm = okm;
     }
+    __syncthreads();
+    const unsigned okm = s_okm;
+    Tp v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {   // all peers' elements requested together ...
+        v[r] = Tp(0);
+        if (r < n && r != rank && ((okm >> r) & 1u) && i < count)
+            v[r] = __hip_atomic_load(reinterpret_cast<const Tp*>(static_cast<const char*>(peers.p[r]) + slot * slot_bytes) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    Tp acc = Tp(0);
+#pragma unroll
+    for (int r = 0; r < 8; r++) if (r < n) acc += r == rank ? mine : v[r];   // ... added in rank order
     if (i < count) buf[i] = acc;
 }
 
@@ -952,12 +1025,31 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
                                     double* partial, hipStream_t s) {
-    FusedOptArgs a;
+    FusedOptArgs a{};
     a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;
     a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M;
     a.p_src = params; a.m_src = exp_avg; a.v_src = exp_avg_sq;
     a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.partial = partial;
-    hipLaunchKernelGGL(reduce_grads_sumsq_kernel, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(reduce_grads_sumsq_kernel<false>, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+// The same two launches for a sharded context on the direct-exchange transport: the reduction also publishes this rank's gradient (and loss
+// sums) to its exchange slot and adds the peers' in rank order.  global_M = the GLOBAL minibatch size.
+hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
+                                             double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
+                                             double global_M, const LossParams& hp, StepStats* stats_out, double* clipfrac_accum, double* partial,
+                                             void* const* peers, int rank, int n_ranks, size_t slot_bytes, uint64_t seq, int32_t* timeout_flag,
+                                             hipStream_t s) {
+    if (n_ranks < 1 || n_ranks > 8 || (size_t)(L.P + 8) * sizeof(float) > slot_bytes) return hipErrorInvalidValue;
+    FusedOptArgs a{};
+    a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;
+    a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M;
+    a.p_src = params; a.m_src = exp_avg; a.v_src = exp_avg_sq;
+    a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.partial = partial;
+    for (int r = 0; r < 8; r++) a.peers[r] = r < n_ranks ? peers[r] : nullptr;
+    a.rank = rank; a.n_ranks = n_ranks; a.slot_bytes = slot_bytes; a.seq = seq; a.timeout_flag = timeout_flag;
+    hipLaunchKernelGGL(reduce_grads_sumsq_kernel<true>, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();
 }

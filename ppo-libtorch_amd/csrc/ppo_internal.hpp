@@ -533,6 +533,11 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
                                     double* partial, hipStream_t s);
+hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
+                                             double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
+                                             double global_M, const LossParams& hp, StepStats* stats_out, double* clipfrac_accum, double* partial,
+                                             void* const* peers, int rank, int n_ranks, size_t slot_bytes, uint64_t seq, int32_t* timeout_flag,
+                                             hipStream_t s);
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
 struct EpisodeRing {
     float rew[100];
