@@ -21,6 +21,9 @@
 // still in flight, so the memory side sees ~1.6x the algorithmic reads (PMC).  Fetching every row once and handing row t + 1 over through
 // LDS (one more barrier and LDS pass before the walk) was built and measured in round 2, A/B in one call: SLOWER at every size (4 096 envs
 // 5.6 against 4.9 us, 8 192: 6.9 against 6.3, 32 768: 21.2 against 18.7) -- the duplicate requests are cheaper than the extra phase.
+// Folding the update kernel's record pack (pack_records_kernel: it consumes exactly the advantages and returns the store phase holds) into
+// this kernel was also built and measured in round 2: ONE launch of 18.2 us (21.6 in its first form) against 5.1 + 10.5 us for the two --
+// the pack is a job for B = T N threads, and inside the scan it has N / 16 workgroups of four waves to run on.  Not shipped.
 #include <cstdlib>
 
 #include "ppo_internal.hpp"

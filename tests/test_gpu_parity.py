@@ -563,6 +563,36 @@ def test_fused_rollout_equals_stepwise_api(P, N):
     b.close()
 
 
+@pytest.mark.parametrize("kind", ["cartpole", "mountaincar", "nstep", "odd_envs"])
+def test_train_iteration_equals_rollout_scan_update(P, kind):
+    """ppo_train_iteration against its three parts called one after the other (rollout, calc_advantage, update): same seeds, same arithmetic --
+    advantages, returns and parameters bit-identical, explained variance and loss equal.  (The iteration skips the stand-alone scan's
+    critic call: the rollout's epilogue already left NEXT_VALUE.)"""
+    kw = dict(num_envs=64, num_steps=32, num_minibatches=2, update_epochs=2, seed=8, total_timesteps=64 * 32 * 4, anneal_lr=False)
+    if kind == "mountaincar":
+        kw.update(env_kind=P.ENV_MOUNTAINCAR, dist_kind=P.DIST_MASKED, obs_size=2, head_dims=(3,), max_episode_steps=200)
+    if kind == "nstep":
+        kw.update(use_gae=False)
+    if kind == "odd_envs":
+        kw.update(num_envs=20, total_timesteps=20 * 32 * 4)
+    a, b = P.Context(P.make_config(**kw)), P.Context(P.make_config(**kw))
+    for c in (a, b):
+        c.init_orthogonal(4)
+        c.env_reset()
+    for _ in range(2):
+        a.train_iteration()
+        b.rollout()
+        b.calc_advantage()
+        b.update()
+    for name in ("ADVANTAGES", "RETURNS", "VALUES", "LOGPROBS"):
+        assert np.array_equal(bits(a.read(name)), bits(b.read(name))), name
+    assert np.array_equal(bits(a.get_params()), bits(b.get_params()))
+    sa, sb = a.stats(), b.stats()
+    assert abs(sa["explained_variance"] - sb["explained_variance"]) <= 1e-9 * max(1.0, abs(sb["explained_variance"]))
+    assert sa["loss"] == sb["loss"]
+    a.close(); b.close()
+
+
 def test_training_learns_cartpole(P):
     """De-facto acceptance test of the reference (README.md:169-178): ep_len_mean climbs.  256 envs x 128 steps x 25 updates."""
     ctx = P.Context(P.make_config(num_envs=256, num_steps=128, num_minibatches=4, update_epochs=4, seed=2, total_timesteps=256 * 128 * 25,
