@@ -24,6 +24,8 @@
 // Folding the update kernel's record pack (pack_records_kernel: it consumes exactly the advantages and returns the store phase holds) into
 // this kernel was also built and measured in round 2: ONE launch of 18.2 us (21.6 in its first form) against 5.1 + 10.5 us for the two --
 // the pack is a job for B = T N threads, and inside the scan it has N / 16 workgroups of four waves to run on.  Not shipped.
+// Nor is a walk whose next 16 rows are pulled out of LDS (pinned by sched_barrier) before the current 16-step chain runs: 5.18 against 4.91 us
+// at 4 096 envs, 6.42 / 6.25, 19.06 / 18.6 -- the walk is bound by its 256 dependent mul / add per env, not by the LDS hand-overs.
 #include <cstdlib>
 
 #include "ppo_internal.hpp"
