@@ -58,7 +58,17 @@ __global__ __launch_bounds__(256) void gather_kernel(GenLayout L, const float* _
     if (r >= M) return;
     const int64_t src = idx[r];
     if (xin_bf) {   // bf16 storage: rounded to nearest even, the row's padding stays zero
-        for (int o = lane; o < L.obs; o += 64) { const __bf16 b = (__bf16)obs[src * L.obs + o]; xin_bf[r * ld_bf + o] = __builtin_bit_cast(uint16_t, b); }
+        if ((L.obs & 3) == 0) {   // 16-byte loads, 8-byte stores (a row of 376 floats: two passes of the wave instead of six)
+            typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+            for (int o = 4 * lane; o < L.obs; o += 256) {
+                const f32x4a4 v = *reinterpret_cast<const f32x4a4*>(obs + src * L.obs + o);
+                const bf16x2v lo = { (__bf16)v[0], (__bf16)v[1] }, hi = { (__bf16)v[2], (__bf16)v[3] };
+                *reinterpret_cast<uint2*>(xin_bf + r * ld_bf + o) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+            }
+        } else {
+            for (int o = lane; o < L.obs; o += 64) { const __bf16 b = (__bf16)obs[src * L.obs + o]; xin_bf[r * ld_bf + o] = __builtin_bit_cast(uint16_t, b); }
+        }
     } else {
         for (int o = lane; o < L.obs; o += 64) xin[r * L.obs + o] = obs[src * L.obs + o];
     }
@@ -93,7 +103,8 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
             const int A = L.head_dims[h];
             for (int k = 0; k < A; k++) z[off + k] = logits[r * L.act + off + k];
             const uint8_t* mrow = (DIST == PPO_DIST_MASKED && row_mask) ? row_mask + r * L.act + off : nullptr;
-            headH[h] = categorical_head<DIST>(z + off, p + off, mrow, A);
+            // bf16 storage: log-softmax on the hardware exp2 / log2 units (~1 ULP each; the logits themselves carry bf16 rounding)
+            headH[h] = dlogits_bf ? categorical_head_fast<DIST>(z + off, p + off, mrow, A) : categorical_head<DIST>(z + off, p + off, mrow, A);
             const int a = row_act[r * L.n_heads + h];
             float lp = 0.0f;
             for (int k = 0; k < A; k++) if (k == a) lp = z[off + k];
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
             off += A;
         }
         const float logratio = nlp - oldlp[r];
-        const float ratio = expf(logratio);
+        const float ratio = dlogits_bf ? fast_exp(logratio) : expf(logratio);
         float adv = advs[r];
         if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
         const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
         else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half/half
         const float g_nlp = invM * d_ratio * ratio;
         const float g_ent = -hp.ent_coef * invM;
+        uint16_t drow[PPO_MAX_ACT];   // bf16 storage: the row's head gradients, stored below as 16-byte pieces
         off = 0;
         for (int h = 0; h < L.n_heads; h++) {
             const int A = L.head_dims[h];
@@ -122,10 +134,23 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
                 float d = g_nlp * ((k == a ? 1.0f : 0.0f) - p[off + k]);
                 if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[off + k] * (z[off + k] + headH[h]));
                 d = ok ? d : 0.0f;
-                if (dlogits_bf) { const __bf16 b = (__bf16)d; dlogits_bf[r * 128 + off + k] = __builtin_bit_cast(uint16_t, b); dbs[off + k] += d; }
+                if (dlogits_bf) { const __bf16 b = (__bf16)d; drow[off + k] = __builtin_bit_cast(uint16_t, b); dbs[off + k] += d; }
                 else dlogits[r * L.act + off + k] = d;
             }
             off += A;
+        }
+        if (dlogits_bf) {
+#pragma unroll
+            for (int c8 = 0; c8 < PPO_MAX_ACT / 8; c8++) {
+                if (8 * c8 >= L.act) break;
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k0 = 8 * c8 + 2 * j;
+                    w[j] = (k0 < L.act ? (uint32_t)drow[k0] : 0u) | ((k0 + 1 < L.act ? (uint32_t)drow[k0 + 1] : 0u) << 16);
+                }
+                *reinterpret_cast<uint4*>(dlogits_bf + r * 128 + 8 * c8) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
         }
         s[0] += (double)(l1 > l2 ? l1 : l2);
         s[1] += (double)ent;
@@ -149,7 +174,11 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
             lossv = un;
             g_v = hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
         }
-        if (dval_bf) { const __bf16 b = (__bf16)g_v; dval_bf[r * 128] = __builtin_bit_cast(uint16_t, b); dbs[L.act] += g_v; }
+        if (dval_bf) {
+            const __bf16 b = (__bf16)g_v;
+            *reinterpret_cast<uint4*>(dval_bf + r * 128) = make_uint4((uint32_t)__builtin_bit_cast(uint16_t, b), 0u, 0u, 0u);
+            dbs[L.act] += g_v;
+        }
         else dval[r] = g_v;
         s[4] += (double)lossv;
     }
