@@ -511,8 +511,8 @@ struct UpdateArgs {
 };
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
-// matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}: fp32 carried as three bf16 terms, six
-// v_mfma_f32_32x32x16_bf16 products per fp32 product (fp32 accuracy).  Gathers from the packed records.
+// matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}: fp32 carried as two fp16 terms, three
+// v_mfma_f32_32x32x16_f16 products per fp32 product (fp32 accuracy).  Gathers from the packed records.
 void update_blocks_mfma(int M, int n_blocks[2]);
 hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
 hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
