@@ -82,7 +82,8 @@ struct LocalGroup {
 // RCCL stays available (ppo_comm_init); this path is chosen by ppo_comm_init_exchange.
 // ---------------------------------------------------------------------------------------------------------
 struct ExchangeComm {
-    void* own = nullptr;              // [2][slot_bytes] payload slots, then [2] uint64 flags (fine-grained device memory of this rank)
+    void* own = nullptr;              // [2 parities][8 source ranks][slot_bytes] payload slots the PEERS write into, then flags and counters
+                                      // (fine-grained device memory of this rank; layout: kernels_update.hip, xchg_slot)
     size_t slot_bytes = 0;
     void* peer[8] = {};               // mapped exchange buffers of every rank (peer[rank] == own)
     bool opened[8] = {};
@@ -1525,7 +1526,7 @@ extern "C" ppo_status ppo_comm_exchange_handle(ppo_ctx* c, void* handle_out_h) {
         std::unique_ptr<ExchangeComm> x(new ExchangeComm());
         const size_t grad = ((size_t)c->L.P + 8) * sizeof(float), adv = (size_t)2 * c->steps_per_update * PPO_ADV_PARTS * sizeof(double);
         x->slot_bytes = (std::max(grad, adv) + 255) / 256 * 256;
-        const size_t total = 2 * x->slot_bytes + 256;
+        const size_t total = 16 * x->slot_bytes + 256;   // [2 parities][8 source ranks] payload slots, 16 flags, 2 counters (kernels_update.hip: xchg_slot)
         // fine-grained device memory: stores of a running kernel become visible to peers' running kernels (coarse-grained memory is only
         // coherent at kernel boundaries); plain hipMalloc as a fallback on a single device
         hipError_t e = hipExtMallocWithFlags(&x->own, total, hipDeviceMallocFinegrained);

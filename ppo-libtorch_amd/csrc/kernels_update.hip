@@ -603,15 +603,44 @@ struct FusedOptArgs {
     // launches as a single-rank one -- reduce + exchange + sums of squares, then norm + clip + AdamW
     void* peers[8]; int rank, n_ranks; size_t slot_bytes; unsigned long long seq; int32_t* timeout_flag;
 };
-// Waits (bounded) for every peer's flag of call `seq`: lane r of the calling wave polls peer r, so the n - 1 remote reads are in flight
-// together and an all-reduce costs two trips over the links (flags, then payloads), not two per peer.  Returns the mask of peers whose payload
-// may be read; a wait that runs out is counted in timeout_flag and marks the communicator dead (later calls do not wait again).
-__device__ __forceinline__ unsigned xchg_wait_all(void* const* peers, int rank, int n, size_t slot_bytes, int slot, unsigned long long seq, int32_t* timeout_flag) {
+// ---- the exchange buffer of a rank (fine-grained device memory, mapped by every peer; ExchangeComm in api.hip) ----
+//   payload  [2 parities][8 source ranks][slot_bytes]     rank s WRITES its share of call k into slot [k & 1][s] of EVERY rank's buffer
+//   flags    u64 [2][8]                                    ... then stamps flag [k & 1][s] of every rank's buffer with k
+//   counters u32 [2]                                       arrivals of the owner's own workgroups (local)
+// A rank PUSHES: stores over the links are posted, and what it then waits for and reads is its OWN memory -- one one-way trip per
+// all-reduce, where pulling (poll the peer's flag, then read the peer's payload) paid two round trips and kept the links busy with polls.
+// Reuse: a rank writes call k + 2 into a peer's parity-k slot only after its call k + 1 completed, i.e. after every peer had published
+// k + 1 -- which a peer does in a kernel that follows, in stream order, the one in which it read call k.
+__device__ __forceinline__ char* xchg_slot(void* base, size_t slot_bytes, int parity, int src) { return static_cast<char*>(base) + ((size_t)parity * 8 + src) * slot_bytes; }
+__device__ __forceinline__ unsigned long long* xchg_flag(void* base, size_t slot_bytes, int parity, int src) {
+    return reinterpret_cast<unsigned long long*>(static_cast<char*>(base) + 16 * slot_bytes) + parity * 8 + src;
+}
+__device__ __forceinline__ unsigned int* xchg_count(void* base, size_t slot_bytes, int parity) {
+    return reinterpret_cast<unsigned int*>(static_cast<char*>(base) + 16 * slot_bytes + 128) + parity;
+}
+// The caller's stores into the peers' slots are done: make them visible system-wide, count this workgroup in (one lane), and let the last
+// workgroup of the grid stamp this rank's flag in every peer's buffer (lane p stamps peer p).  Called by one whole wave per workgroup.
+__device__ __forceinline__ void xchg_publish_done(void* const* peers, int rank, int n, size_t slot_bytes, int parity, unsigned long long seq) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    const int lane = threadIdx.x & 63;
+    int last = 0;
+    if (lane == 0) {
+        unsigned int* cnt = xchg_count(peers[rank], slot_bytes, parity);
+        const unsigned int arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) { __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last && lane < n && lane != rank) __hip_atomic_store(xchg_flag(peers[lane], slot_bytes, parity, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Waits (bounded) until every peer's share of call `seq` has landed in THIS rank's buffer: lane r of the calling wave polls local flag r.
+// Returns the mask of peers whose slot may be read; a wait that runs out is counted in timeout_flag and marks the communicator dead
+// (later calls do not wait again).
+__device__ __forceinline__ unsigned xchg_wait_all(void* own, int rank, int n, size_t slot_bytes, int parity, unsigned long long seq, int32_t* timeout_flag) {
     const int lane = threadIdx.x & 63;
     const bool dead = __hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     int ok = 1;
     if (lane < n && lane != rank) {
-        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(peers[lane]) + 2 * slot_bytes) + slot;
+        const unsigned long long* flag = xchg_flag(own, slot_bytes, parity, lane);
         ok = 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
         for (;;) {
@@ -622,22 +651,8 @@ __device__ __forceinline__ unsigned xchg_wait_all(void* const* peers, int rank, 
         if (!ok) atomicAdd(timeout_flag, 1);
     }
     const unsigned long long m = __ballot(ok != 0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // every lane reads payloads after the polling lanes saw the flags
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // every lane reads the slots after the polling lanes saw the flags
     return (unsigned)(m & 0xffu) | ~0xffu;
-}
-// own payload published (system scope) -> count the workgroup in; the last one of the grid stamps the slot's flag with the call number
-__device__ __forceinline__ void xchg_publish_done(const FusedOptArgs& a, int slot) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if ((threadIdx.x & 63) == 0) {
-        char* base = static_cast<char*>(a.peers[a.rank]);
-        unsigned long long* own_flag = reinterpret_cast<unsigned long long*>(base + 2 * a.slot_bytes) + slot;
-        unsigned int* own_count = reinterpret_cast<unsigned int*>(base + 2 * a.slot_bytes + 16) + slot;
-        const unsigned int arrived = __hip_atomic_fetch_add(own_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            __hip_atomic_store(own_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(own_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
 }
 template <bool XCHG>
 __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a) {
@@ -674,23 +689,24 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
                 g = (float)sacc;
             }
             if constexpr (XCHG) {
-                // this rank's share goes to its exchange slot; the sum over ranks is then formed in rank order out of the peers' slots
-                const int slot = (int)(a.seq & 1ull);
-                float* own = reinterpret_cast<float*>(static_cast<char*>(a.peers[a.rank]) + slot * a.slot_bytes);
-                if (p < L.P) __hip_atomic_store(&own[p], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                xchg_publish_done(a, slot);
-                const unsigned okm = xchg_wait_all(a.peers, a.rank, a.n_ranks, a.slot_bytes, slot, a.seq, a.timeout_flag);
+                // this rank's share goes into its slot of every peer's buffer; the sum over ranks is then formed in rank order out of the OWN buffer
+                const int parity = (int)(a.seq & 1ull);
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if (r < a.n_ranks && r != a.rank && p < L.P)
+                        __hip_atomic_store(reinterpret_cast<float*>(xchg_slot(a.peers[r], a.slot_bytes, parity, a.rank)) + p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                xchg_publish_done(a.peers, a.rank, a.n_ranks, a.slot_bytes, parity, a.seq);
+                const unsigned okm = xchg_wait_all(a.peers[a.rank], a.rank, a.n_ranks, a.slot_bytes, parity, a.seq, a.timeout_flag);
                 float v[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) {   // all peers' elements requested together ...
+                for (int r = 0; r < 8; r++) {
                     v[r] = 0.0f;
                     if (r < a.n_ranks && r != a.rank && ((okm >> r) & 1u) && p < L.P)
-                        v[r] = __hip_atomic_load(reinterpret_cast<const float*>(static_cast<const char*>(a.peers[r]) + slot * a.slot_bytes) + p, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM);
+                        v[r] = __hip_atomic_load(reinterpret_cast<const float*>(xchg_slot(a.peers[a.rank], a.slot_bytes, parity, r)) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 float acc = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 8; r++) if (r < a.n_ranks) acc += r == a.rank ? g : v[r];   // ... added in rank order: every rank forms the same sum
+                for (int r = 0; r < 8; r++) if (r < a.n_ranks) acc += r == a.rank ? g : v[r];   // rank order: every rank forms the same sum
                 g = acc;
             }
             if (p < L.P) a.grads[p] = g;
@@ -728,18 +744,21 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
             // the loss sums ride the exchange as eight floats behind the gradient (what ppo_allreduce_grads carries on the unfused path)
             __syncthreads();
             if (threadIdx.x < 64) {
-                const int slot = (int)(a.seq & 1ull);
-                float* own = reinterpret_cast<float*>(static_cast<char*>(a.peers[a.rank]) + slot * a.slot_bytes);
+                const int parity = (int)(a.seq & 1ull);
                 const float mine = threadIdx.x < 5 ? (float)part[1][threadIdx.x] : 0.0f;
-                if (threadIdx.x < 8) __hip_atomic_store(&own[L.P + threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                xchg_publish_done(a, slot);
-                const unsigned okm = xchg_wait_all(a.peers, a.rank, a.n_ranks, a.slot_bytes, slot, a.seq, a.timeout_flag);
+                for (int r = 0; r < a.n_ranks; r++)
+                    if (r != a.rank && threadIdx.x < 8)
+                        __hip_atomic_store(reinterpret_cast<float*>(xchg_slot(a.peers[r], a.slot_bytes, parity, a.rank)) + L.P + threadIdx.x, mine, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                xchg_publish_done(a.peers, a.rank, a.n_ranks, a.slot_bytes, parity, a.seq);
+                const unsigned okm = xchg_wait_all(a.peers[a.rank], a.rank, a.n_ranks, a.slot_bytes, parity, a.seq, a.timeout_flag);
                 float acc = 0.0f;
                 for (int r = 0; r < a.n_ranks; r++) {
                     if (r == a.rank) { acc += mine; continue; }
                     if (!((okm >> r) & 1u)) continue;
-                    const float* src = reinterpret_cast<const float*>(static_cast<const char*>(a.peers[r]) + slot * a.slot_bytes);
-                    if (threadIdx.x < 8) acc += __hip_atomic_load(&src[L.P + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (threadIdx.x < 8)
+                        acc += __hip_atomic_load(reinterpret_cast<const float*>(xchg_slot(a.peers[a.rank], a.slot_bytes, parity, r)) + L.P + threadIdx.x, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 if (threadIdx.x < 8) a.sums_out[threadIdx.x] = (double)acc;
             }
@@ -899,39 +918,31 @@ __global__ void local_allreduce_kernel(PtrPack8 pk, int n, size_t count) {
     for (int r = 0; r < n; r++) static_cast<Tp*>(pk.p[r])[i] = acc;
 }
 
-// One-shot direct exchange all-reduce (api.hip: ExchangeComm).  Exchange buffer of a rank: [2 slots][slot_bytes] payload, then two 8-byte
-// flags, then two 4-byte arrival counters.  Call number `seq` (1-based, the same on every rank) uses slot seq & 1.
-//   publish:  every thread copies its elements of buf into the own slot with system-scope stores, followed by a system-scope release; the
-//             workgroup that arrives last on the slot's counter stamps the slot's flag with seq
-//   gather:   for r = 0 .. n - 1 in order: rank r's flag must have reached seq (all of r's payload is published) -- thread 0 polls it with
-//             system-scope loads, at most ~2 s -- then every thread adds r's elements (system-scope loads: never from a stale cache line)
+// One-shot direct exchange all-reduce (api.hip: ExchangeComm; buffer layout and protocol above, at xchg_slot).  Call number `seq` (1-based, the
+// same on every rank) uses parity seq & 1.
+//   publish:  every thread stores its elements of buf into this rank's slot of EVERY peer's buffer (system scope), release; the workgroup that
+//             arrives last on the parity's counter stamps this rank's flag in every peer's buffer with seq
+//   gather:   wave 0 waits until every peer's flag in the OWN buffer has reached seq (lane r polls flag r, at most ~2 s), then every thread adds
+//             the peers' elements out of the own buffer in rank order
 //   result:   buf = the sum, formed in the same order on every rank.
 // A timeout leaves the sum incomplete and counts itself in timeout_flag: the kernel always ends.
 struct XchgPtrs8 { void* p[8]; };
 template <class Tp>
 __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict__ buf, size_t count, XchgPtrs8 peers, int rank, int n, size_t slot_bytes,
                                                                  unsigned long long seq, int32_t* timeout_flag) {
-    const int slot = (int)(seq & 1ull);
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    char* base = static_cast<char*>(peers.p[rank]);
-    Tp* own = reinterpret_cast<Tp*>(base + slot * slot_bytes);
-    unsigned long long* own_flag = reinterpret_cast<unsigned long long*>(base + 2 * slot_bytes) + slot;
-    unsigned int* own_count = reinterpret_cast<unsigned int*>(base + 2 * slot_bytes + 16) + slot;
-    const Tp mine = i < count ? buf[i] : Tp(0);
-    if (i < count) __hip_atomic_store(&own[i], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the payload is visible to the peers before the flag moves
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int arrived = __hip_atomic_fetch_add(own_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            __hip_atomic_store(own_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(own_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    // wave 0 waits for all peers at once (lane r polls peer r); the other waves learn the outcome through LDS
     __shared__ unsigned s_okm;
+    const int parity = (int)(seq & 1ull);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const Tp mine = i < count ? buf[i] : Tp(0);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if (r < n && r != rank && i < count)
+            __hip_atomic_store(reinterpret_cast<Tp*>(xchg_slot(peers.p[r], slot_bytes, parity, rank)) + i, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: this thread's stores have landed before the workgroup is counted in
+    __syncthreads();
     if (threadIdx.x < 64) {
-        const unsigned okm = xchg_wait_all(peers.p, rank, n, slot_bytes, slot, seq, timeout_flag);
+        xchg_publish_done(peers.p, rank, n, slot_bytes, parity, seq);
+        const unsigned okm = xchg_wait_all(peers.p[rank], rank, n, slot_bytes, parity, seq, timeout_flag);
         if (threadIdx.x == 0) s_okm = okm;
     }
     __syncthreads();
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict_
     for (int r = 0; r < 8; r++) {   // all peers' elements requested together ...
         v[r] = Tp(0);
         if (r < n && r != rank && ((okm >> r) & 1u) && i < count)
-            v[r] = __hip_atomic_load(reinterpret_cast<const Tp*>(static_cast<const char*>(peers.p[r]) + slot * slot_bytes) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            v[r] = __hip_atomic_load(reinterpret_cast<const Tp*>(xchg_slot(peers.p[rank], slot_bytes, parity, r)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     Tp acc = Tp(0);
 #pragma unroll
