@@ -284,11 +284,13 @@ PPO_API ppo_status ppo_comm_init_local(ppo_ctx* ctx, int64_t group_id, int32_t r
 /* One-shot direct exchange (no reference counterpart): the latency-bound all-reduce (36.6 KB of gradient per optimizer step) without a
  * ring.  One process per GPU, up to the 8 GPUs of a node.  Every rank exports a small exchange buffer (fine-grained device memory, HIP IPC),
  * the handles are gathered by the host (e.g. torch.distributed), every rank maps its peers'; an all-reduce is then ONE kernel per rank that
- * publishes its payload and adds every rank's, in rank order (bit-identical sums everywhere), straight out of the peers' memory over xGMI.
+ * pushes its payload into its slot of every peer's buffer over xGMI and adds every rank's, in rank order (bit-identical sums everywhere), out
+ * of its own buffer.  Inside ppo_update the exchange rides in the gradient reduction: a sharded optimizer step is two launches, as on one GPU.
  *   1. ppo_comm_exchange_handle(ctx, handle)          on every rank
  *   2. gather the nranks handles in rank order
  *   3. ppo_comm_init_exchange(ctx, handles, rank, n)  on every rank
- * A kernel waits for a peer's flag at most ~2 s, then gives up and counts a timeout (ppo_comm_exchange_timeouts): it never spins forever. */
+ * A kernel waits for a peer's share at most ~2 s, then gives up, counts a timeout (ppo_comm_exchange_timeouts) and marks the communicator
+ * dead (no later call waits again): it never spins forever. */
 #define PPO_COMM_HANDLE_BYTES 64
 PPO_API ppo_status ppo_comm_exchange_handle(ppo_ctx* ctx, void* handle_out_h /* PPO_COMM_HANDLE_BYTES */);
 PPO_API ppo_status ppo_comm_init_exchange(ppo_ctx* ctx, const void* handles_h /* nranks x PPO_COMM_HANDLE_BYTES */, int32_t rank, int32_t nranks);
