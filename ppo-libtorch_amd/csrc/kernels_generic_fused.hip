@@ -86,7 +86,7 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0,
     uint16_t* src = tile0;
     uint16_t* dst = tile1;
     for (int l = 0; l < L.n_layers; l++) {
-        const int K = L.in_dim[l], N = L.out_dim[f.net][l];
+        const int N = L.out_dim[f.net][l];
         const bool last = l == L.n_layers - 1;
         const int ksteps = f.wp_kpad[l] / 16;   // a multiple of 8; the weights of k >= K are zero, the tile's columns there finite
         const int nblk = (N + 31) / 32;
