@@ -584,6 +584,44 @@ void goldHost(const std::string& outDir) {
     }
 }
 
+// (8) What the reference's constructor prints (getArgs' "Using config file ..." lines, the fallback message, the checkpoint message) and the
+// hyper-parameters it ends up with, for a full PPOConfig.toml, a partial one and none at all (PPO_Discrete.cpp:10-105, 107-255).  The
+// fixture carries the TOML text itself, so the facade's test feeds its own constructor exactly the same file.
+void goldGetArgs(const std::string& outDir) {
+    const std::string full =
+        "[environment]\nobs_size = 4\naction_size = 2\nmax_episode_steps = 321\n\n"
+        "[general]\nseed = 7\ntotal_timesteps = 4096\nuse_cuda = false\ntorch_deterministic = true\ncheckpoint_updates = 9\n\n"
+        "[ppo]\nlearning_rate = 0.00075\nnum_envs = 4\nnum_steps = 16\nanneal_lr = true\nuse_gae = false\ngamma = 0.97\ngae_lambda = 0.9\n"
+        "num_minibatches = 2\nupdate_epochs = 3\nnorm_adv = false\nclip_coef = 0.15\nclip_vloss = false\nent_coef = 0.001\nvf_coef = 0.25\nmax_grad_norm = 1.5\n";
+    const std::string partial =
+        "# only some keys: everything else keeps the constructor's default\n[general]\nseed = 11\n\n[ppo]\nnum_envs = 2\nnum_steps = 8\nnum_minibatches = 4\ngamma = 0.5\nanneal_lr = true\n";
+    struct V { const char* name; const std::string* toml; };
+    const V variants[] = { { "full", &full }, { "partial", &partial }, { "none", nullptr } };
+    std::ofstream out(outDir + "/getargs.txt", std::ios::binary);
+    for (const V& v : variants) {
+        std::string dir = makeScratchDir(std::string("getargs_") + v.name);
+        if (chdir(dir.c_str()) != 0) throw std::runtime_error("chdir failed");
+        if (v.toml) { std::ofstream f("PPOConfig.toml", std::ios::binary); f << *v.toml; }
+        std::stringstream ss;
+        std::cout.copyfmt(std::ios(nullptr));   // the constructor is the first thing the reference's driver runs: pristine stream state
+        std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
+        std::unique_ptr<PPO_Discrete> algo;
+        try { algo = std::make_unique<PPO_Discrete>(); } catch (...) { std::cout.rdbuf(old); throw; }
+        std::cout.rdbuf(old);
+        out << "== variant " << v.name << "\n-- toml\n" << (v.toml ? *v.toml : std::string("(none)\n")) << "-- stdout\n" << ss.str() << "-- fields\n";
+        out << std::setprecision(9);
+        out << "m_obs_size=" << algo->m_obs_size << "\nm_action_size=" << algo->m_action_size << "\nm_max_episode_steps=" << algo->m_max_episode_steps
+            << "\nm_seed=" << algo->m_seed << "\nm_total_timesteps=" << algo->m_total_timesteps << "\nm_use_cuda=" << (algo->m_use_cuda ? 1 : 0)
+            << "\nm_torch_deterministic=" << (algo->m_torch_deterministic ? 1 : 0) << "\nm_checkpoint_updates=" << algo->m_checkpoint_updates
+            << "\nm_learning_rate=" << algo->m_learning_rate << "\nm_num_envs=" << algo->m_num_envs << "\nm_num_steps=" << algo->m_num_steps
+            << "\nm_anneal_lr=" << (algo->m_anneal_lr ? 1 : 0) << "\nm_use_gae=" << (algo->m_use_gae ? 1 : 0) << "\nm_gamma=" << algo->m_gamma
+            << "\nm_gae_lambda=" << algo->m_gae_lambda << "\nm_num_minibatches=" << algo->m_num_minibatches << "\nm_update_epochs=" << algo->m_update_epochs
+            << "\nm_norm_adv=" << (algo->m_norm_adv ? 1 : 0) << "\nm_clip_coef=" << algo->m_clip_coef << "\nm_clip_vloss=" << (algo->m_clip_vloss ? 1 : 0)
+            << "\nm_ent_coef=" << algo->m_ent_coef << "\nm_vf_coef=" << algo->m_vf_coef << "\nm_max_grad_norm=" << algo->m_max_grad_norm
+            << "\nm_batch_size=" << algo->m_batch_size << "\nm_minibatch_size=" << algo->m_minibatch_size << "\n";
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -627,6 +665,7 @@ int main(int argc, char** argv) {
             std::string out = argv[2];
             if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
             goldHost(out);
+            goldGetArgs(out);
             return 0;
         }
         if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));

@@ -54,7 +54,7 @@ PPOAlgorithm::~PPOAlgorithm() {
 void PPOAlgorithm::getArgs() {
     const std::string path = "./PPOConfig.toml";
     if (!ppo::FlatToml::exists(path)) {
-        std::cout << "Config file " << path << " not found, using default PPO hyperparameters" << std::endl;
+        std::cout << "Could not find " << path << " file." << "\nUsing default PPO hyperparameters" << std::endl;   // the reference's words (:112-113)
         return;
     }
     try {

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <iomanip>
 #include <sstream>
 
 #include "../PPO/PPO_Discrete.h"
@@ -210,6 +211,97 @@ int main(int argc, char** argv) {
             checked++;
         }
         REQUIRE(checked >= 16);
+    }
+    // ---- the constructor's console output and the hyper-parameters it ends up with (PPO_Discrete.cpp:10-105, getArgs :107-255) against the
+    //      reference's own, for a full PPOConfig.toml, a partial one and none (tests/golden/getargs.txt carries the TOML text, the reference's
+    //      stdout and its fields).  The device line is this build's own, and so is the use_cuda = false warning.
+    if (!golden.empty()) {
+        struct ArgsProbe : PPOAlgorithm {   // getArgs without the GPU half of the constructor (the defaults describe no runnable env: obs 2, 1 action)
+            ArgsProbe() : PPOAlgorithm(PPO_ENV_CARTPOLE, PPO_DIST_CATEGORICAL, 2, 500) { getArgs(); }
+        };
+        std::ifstream gf(golden + "/getargs.txt", std::ios::binary);
+        REQUIRE(gf.good());
+        std::string line, name, section, toml, out;
+        std::vector<std::pair<std::string, std::string>> fields;
+        int variants = 0;
+        auto is_device_line = [](const std::string& l) { return l.rfind("Using ", 0) == 0 && l.find(" device") != std::string::npos; };
+        auto check = [&]() -> int {
+            if (name.empty()) return 0;
+            const fs::path dir = scratch / ("getargs_" + name);
+            fs::create_directories(dir);
+            fs::current_path(dir);
+            if (toml != "(none)\n") std::ofstream("PPOConfig.toml", std::ios::binary) << toml;
+            std::vector<std::string> want_args, want_rest;   // the reference's lines before / after its device line
+            {
+                std::istringstream is(out);
+                std::string l; bool after = false;
+                while (std::getline(is, l)) { if (is_device_line(l)) { after = true; continue; } (after ? want_rest : want_args).push_back(l); }
+            }
+            std::stringstream ss;
+            std::cout.copyfmt(std::ios(nullptr));
+            std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
+            ArgsProbe probe;
+            std::cout.rdbuf(old);
+            std::vector<std::string> got;
+            { std::string l; while (std::getline(ss, l)) got.push_back(l); }
+            if (got != want_args) {
+                std::fprintf(stderr, "getArgs output differs for variant %s:\n", name.c_str());
+                for (auto& l : got) std::fprintf(stderr, "  got : %s\n", l.c_str());
+                for (auto& l : want_args) std::fprintf(stderr, "  want: %s\n", l.c_str());
+                return 1;
+            }
+            std::ostringstream fo;
+            fo << std::setprecision(9);
+            fo << "m_obs_size=" << probe.m_obs_size << "\nm_action_size=" << probe.m_action_size << "\nm_max_episode_steps=" << probe.m_max_episode_steps
+               << "\nm_seed=" << probe.m_seed << "\nm_total_timesteps=" << probe.m_total_timesteps << "\nm_use_cuda=" << (probe.m_use_cuda ? 1 : 0)
+               << "\nm_torch_deterministic=" << (probe.m_torch_deterministic ? 1 : 0) << "\nm_checkpoint_updates=" << probe.m_checkpoint_updates
+               << "\nm_learning_rate=" << probe.m_learning_rate << "\nm_num_envs=" << probe.m_num_envs << "\nm_num_steps=" << probe.m_num_steps
+               << "\nm_anneal_lr=" << (probe.m_anneal_lr ? 1 : 0) << "\nm_use_gae=" << (probe.m_use_gae ? 1 : 0) << "\nm_gamma=" << probe.m_gamma
+               << "\nm_gae_lambda=" << probe.m_gae_lambda << "\nm_num_minibatches=" << probe.m_num_minibatches << "\nm_update_epochs=" << probe.m_update_epochs
+               << "\nm_norm_adv=" << (probe.m_norm_adv ? 1 : 0) << "\nm_clip_coef=" << probe.m_clip_coef << "\nm_clip_vloss=" << (probe.m_clip_vloss ? 1 : 0)
+               << "\nm_ent_coef=" << probe.m_ent_coef << "\nm_vf_coef=" << probe.m_vf_coef << "\nm_max_grad_norm=" << probe.m_max_grad_norm
+               << "\nm_batch_size=" << probe.m_batch_size << "\nm_minibatch_size=" << probe.m_minibatch_size << "\n";
+            std::string want_fields;
+            for (auto& kv : fields) want_fields += kv.first + "=" + kv.second + "\n";
+            if (fo.str() != want_fields) { std::fprintf(stderr, "fields differ for variant %s:\n%s--- want\n%s", name.c_str(), fo.str().c_str(), want_fields.c_str()); return 1; }
+            if (name == "full") {   // a runnable configuration: the whole constructor, line by line
+                std::stringstream cs;
+                std::cout.copyfmt(std::ios(nullptr));
+                std::streambuf* o2 = std::cout.rdbuf(cs.rdbuf());
+                {
+                    PPO_Discrete whole;
+                }
+                std::cout.rdbuf(o2);
+                std::vector<std::string> g2, w2 = want_args;
+                w2.insert(w2.end(), want_rest.begin(), want_rest.end());
+                std::string l;
+                while (std::getline(cs, l)) {
+                    if (l.rfind("Warning: use_cuda", 0) == 0 || is_device_line(l)) continue;
+                    g2.push_back(l);
+                }
+                if (g2 != w2) {
+                    std::fprintf(stderr, "constructor output differs:\n");
+                    for (auto& x : g2) std::fprintf(stderr, "  got : %s\n", x.c_str());
+                    for (auto& x : w2) std::fprintf(stderr, "  want: %s\n", x.c_str());
+                    return 1;
+                }
+            }
+            variants++;
+            return 0;
+        };
+        while (std::getline(gf, line)) {
+            if (line.rfind("== variant ", 0) == 0) {
+                if (check()) return 1;
+                name = line.substr(11); section.clear(); toml.clear(); out.clear(); fields.clear();
+            } else if (line == "-- toml" || line == "-- stdout" || line == "-- fields") {
+                section = line.substr(3);
+            } else if (section == "toml") toml += line + "\n";
+            else if (section == "stdout") out += line + "\n";
+            else if (section == "fields") { const size_t eq = line.find('='); fields.emplace_back(line.substr(0, eq), line.substr(eq + 1)); }
+        }
+        if (check()) return 1;
+        REQUIRE(variants == 3);
+        fs::current_path(scratch);
     }
     std::printf("HOST_FACADE_OK\n");
     return 0;

@@ -2,7 +2,8 @@
 CategoricalMasked, ThreadPool, CircularBuffer, PPOUtils; ppo-libtorch_amd/host/) exercised on a real GPU through the C-ABI:
 environment duck type, distributions, agent, TOML keys, the reference's obs-size error text, a short train() run with
 checkpoints in the reference's directories / file names, resume by newest mtime, the MultiDiscrete (masked) variant, the ThreadPool,
-use_cuda = false, foreign checkpoint files, and -- against fixtures written by the compiled reference -- printPPOResults byte for byte and PPOUtils."""
+use_cuda = false, foreign checkpoint files, and -- against fixtures written by the compiled reference -- printPPOResults byte for byte, PPOUtils,
+and the constructor's console lines + resulting hyper-parameters for a full / partial / missing PPOConfig.toml."""
 import os
 import subprocess
 
