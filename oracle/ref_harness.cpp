@@ -595,8 +595,13 @@ void goldGetArgs(const std::string& outDir) {
         "num_minibatches = 2\nupdate_epochs = 3\nnorm_adv = false\nclip_coef = 0.15\nclip_vloss = false\nent_coef = 0.001\nvf_coef = 0.25\nmax_grad_norm = 1.5\n";
     const std::string partial =
         "# only some keys: everything else keeps the constructor's default\n[general]\nseed = 11\n\n[ppo]\nnum_envs = 2\nnum_steps = 8\nnum_minibatches = 4\ngamma = 0.5\nanneal_lr = true\n";
-    struct V { const char* name; const std::string* toml; };
-    const V variants[] = { { "full", &full }, { "partial", &partial }, { "none", nullptr } };
+    // PPO_MultiDiscrete reads two more keys, between action_size and max_episode_steps (PPO_MultiDiscrete.cpp:136-144); PPO_Discrete ignores them
+    const std::string multi =
+        "[environment]\nobs_size = 2\naction_size = 3\naction_high = 2.5\naction_low = -0.5\nmax_episode_steps = 150\n\n"
+        "[general]\nseed = 3\ntotal_timesteps = 2048\n\n[ppo]\nnum_envs = 4\nnum_steps = 16\nnum_minibatches = 2\nent_coef = 0.02\n";
+    struct V { const char* name; const std::string* toml; bool multi; };
+    const V variants[] = { { "full", &full, false }, { "partial", &partial, false }, { "none", nullptr, false }, { "multidiscrete", &multi, true },
+                           { "discrete_ignores_action_bounds", &multi, false } };
     std::ofstream out(outDir + "/getargs.txt", std::ios::binary);
     for (const V& v : variants) {
         std::string dir = makeScratchDir(std::string("getargs_") + v.name);
@@ -606,8 +611,23 @@ void goldGetArgs(const std::string& outDir) {
         std::cout.copyfmt(std::ios(nullptr));   // the constructor is the first thing the reference's driver runs: pristine stream state
         std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
         std::unique_ptr<PPO_Discrete> algo;
-        try { algo = std::make_unique<PPO_Discrete>(); } catch (...) { std::cout.rdbuf(old); throw; }
+        std::unique_ptr<PPO_MultiDiscrete> malgo;
+        try { if (v.multi) malgo = std::make_unique<PPO_MultiDiscrete>(); else algo = std::make_unique<PPO_Discrete>(); } catch (...) { std::cout.rdbuf(old); throw; }
         std::cout.rdbuf(old);
+        if (v.multi) {   // same field list, read off the other class
+            auto& a = *malgo;
+            out << "== variant " << v.name << "\n-- toml\n" << *v.toml << "-- stdout\n" << ss.str() << "-- fields\n" << std::setprecision(9);
+            out << "m_obs_size=" << a.m_obs_size << "\nm_action_size=" << a.m_action_size << "\nm_max_episode_steps=" << a.m_max_episode_steps
+                << "\nm_seed=" << a.m_seed << "\nm_total_timesteps=" << a.m_total_timesteps << "\nm_use_cuda=" << (a.m_use_cuda ? 1 : 0)
+                << "\nm_torch_deterministic=" << (a.m_torch_deterministic ? 1 : 0) << "\nm_checkpoint_updates=" << a.m_checkpoint_updates
+                << "\nm_learning_rate=" << a.m_learning_rate << "\nm_num_envs=" << a.m_num_envs << "\nm_num_steps=" << a.m_num_steps
+                << "\nm_anneal_lr=" << (a.m_anneal_lr ? 1 : 0) << "\nm_use_gae=" << (a.m_use_gae ? 1 : 0) << "\nm_gamma=" << a.m_gamma
+                << "\nm_gae_lambda=" << a.m_gae_lambda << "\nm_num_minibatches=" << a.m_num_minibatches << "\nm_update_epochs=" << a.m_update_epochs
+                << "\nm_norm_adv=" << (a.m_norm_adv ? 1 : 0) << "\nm_clip_coef=" << a.m_clip_coef << "\nm_clip_vloss=" << (a.m_clip_vloss ? 1 : 0)
+                << "\nm_ent_coef=" << a.m_ent_coef << "\nm_vf_coef=" << a.m_vf_coef << "\nm_max_grad_norm=" << a.m_max_grad_norm
+                << "\nm_batch_size=" << a.m_batch_size << "\nm_minibatch_size=" << a.m_minibatch_size << "\n";
+            continue;
+        }
         out << "== variant " << v.name << "\n-- toml\n" << (v.toml ? *v.toml : std::string("(none)\n")) << "-- stdout\n" << ss.str() << "-- fields\n";
         out << std::setprecision(9);
         out << "m_obs_size=" << algo->m_obs_size << "\nm_action_size=" << algo->m_action_size << "\nm_max_episode_steps=" << algo->m_max_episode_steps

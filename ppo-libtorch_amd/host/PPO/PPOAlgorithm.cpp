@@ -64,9 +64,11 @@ void PPOAlgorithm::getArgs() {
         auto B = [&](const char* sec, const char* key, bool& dst) { if (auto v = cfg.boolean(sec, key)) { dst = *v; std::cout << "Using config file " << key << " = " << (dst ? "true" : "false") << std::endl; } };
         I("environment", "obs_size", m_obs_size);
         I("environment", "action_size", m_action_size);
+        if (m_env_kind == PPO_ENV_MOUNTAINCAR) {   // PPO_MultiDiscrete only, between action_size and max_episode_steps (PPO_MultiDiscrete.cpp:136-144)
+            F("environment", "action_high", m_action_high);
+            F("environment", "action_low", m_action_low);
+        }
         I("environment", "max_episode_steps", m_max_episode_steps);
-        F("environment", "action_high", m_action_high);
-        F("environment", "action_low", m_action_low);
         I("general", "seed", m_seed);
         I("general", "total_timesteps", m_total_timesteps);
         B("general", "use_cuda", m_use_cuda);

@@ -217,7 +217,7 @@ int main(int argc, char** argv) {
     //      stdout and its fields).  The device line is this build's own, and so is the use_cuda = false warning.
     if (!golden.empty()) {
         struct ArgsProbe : PPOAlgorithm {   // getArgs without the GPU half of the constructor (the defaults describe no runnable env: obs 2, 1 action)
-            ArgsProbe() : PPOAlgorithm(PPO_ENV_CARTPOLE, PPO_DIST_CATEGORICAL, 2, 500) { getArgs(); }
+            explicit ArgsProbe(bool multi) : PPOAlgorithm(multi ? PPO_ENV_MOUNTAINCAR : PPO_ENV_CARTPOLE, multi ? PPO_DIST_MASKED : PPO_DIST_CATEGORICAL, 2, multi ? 200 : 500) { getArgs(); }
         };
         std::ifstream gf(golden + "/getargs.txt", std::ios::binary);
         REQUIRE(gf.good());
@@ -240,7 +240,7 @@ int main(int argc, char** argv) {
             std::stringstream ss;
             std::cout.copyfmt(std::ios(nullptr));
             std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
-            ArgsProbe probe;
+            ArgsProbe probe(name == "multidiscrete");   // PPO_MultiDiscrete reads action_high / action_low, PPO_Discrete does not
             std::cout.rdbuf(old);
             std::vector<std::string> got;
             { std::string l; while (std::getline(ss, l)) got.push_back(l); }
@@ -300,7 +300,7 @@ int main(int argc, char** argv) {
             else if (section == "fields") { const size_t eq = line.find('='); fields.emplace_back(line.substr(0, eq), line.substr(eq + 1)); }
         }
         if (check()) return 1;
-        REQUIRE(variants == 3);
+        REQUIRE(variants == 5);
         fs::current_path(scratch);
     }
     std::printf("HOST_FACADE_OK\n");
