@@ -642,6 +642,62 @@ void goldGetArgs(const std::string& outDir) {
     }
 }
 
+// (9) A short train() run of the reference with checkpoints, then a second instance resuming in the same directory (PPO_Discrete.cpp:485-690,
+// 782-835): every console line that is not part of the per-update table (the table carries wall-clock numbers), the files the run leaves
+// behind, and the step the second instance resumes from.
+static std::string nonTableLines(const std::string& all) {
+    std::istringstream is(all);
+    std::string l, out;
+    while (std::getline(is, l)) { if (l.empty() || l[0] == '|' || l[0] == '-') continue; out += l + "\n"; }
+    return out;
+}
+static std::string listFiles() {
+    std::vector<std::string> names;
+    for (const char* d : { "ModelCheckpoints", "OptimizerCheckpoints", "Models" })
+        if (std::filesystem::exists(d)) for (auto const& e : std::filesystem::directory_iterator(d)) names.push_back(std::string(d) + "/" + e.path().filename().string());
+    std::sort(names.begin(), names.end());
+    std::string out;
+    for (auto& n : names) out += n + "\n";
+    return out;
+}
+void goldTrainRun(const std::string& outDir) {
+    const std::string toml =
+        "[environment]\nobs_size = 4\naction_size = 2\nmax_episode_steps = 500\n\n"
+        "[general]\nseed = 5\ntotal_timesteps = 384\nuse_cuda = false\ntorch_deterministic = true\ncheckpoint_updates = 2\n\n"
+        "[ppo]\nlearning_rate = 0.001\nnum_envs = 8\nnum_steps = 16\nanneal_lr = true\nnum_minibatches = 2\nupdate_epochs = 2\n";
+    std::string dir = makeScratchDir("trainrun");
+    if (chdir(dir.c_str()) != 0) throw std::runtime_error("chdir failed");
+    { std::ofstream f("PPOConfig.toml", std::ios::binary); f << toml; }
+    std::ofstream out(outDir + "/train_run.txt", std::ios::binary);
+    out << "-- toml\n" << toml;
+    auto captured = [&](auto&& fn) {
+        std::stringstream ss;
+        std::cout.copyfmt(std::ios(nullptr));
+        std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
+        try { fn(); } catch (...) { std::cout.rdbuf(old); throw; }
+        std::cout.rdbuf(old);
+        return ss.str();
+    };
+    {
+        std::unique_ptr<PPO_Discrete> algo;
+        const std::string c1 = captured([&] { algo = std::make_unique<PPO_Discrete>(); });
+        const std::string t1 = captured([&] { algo->train(); });
+        out << "-- phase1 constructor\n" << nonTableLines(c1) << "-- phase1 train\n" << nonTableLines(t1) << "-- phase1 files\n" << listFiles();
+    }
+    {   // a second instance in the same directory: the reference's resume.  Built against libstdc++ it THROWS: loadPolicyFromCheckpoint compares
+        // every file's last_write_time with a default-constructed file_time_type (:801-806), and libstdc++'s file_clock epoch is the year 2174,
+        // so no file is ever "newer", the name stays empty and PPOUtils::getLoadFromSteps("") runs off the string.  (MSVC's epoch is 1601:
+        // there it resumes.)  Recorded as a fact about the reference on this platform; the facade's resume is tested on its own.
+        std::string what = "(no exception)";
+        std::string c2;
+        try {
+            std::unique_ptr<PPO_Discrete> algo;
+            c2 = captured([&] { algo = std::make_unique<PPO_Discrete>(); });
+        } catch (const std::exception& ex) { what = ex.what(); }
+        out << "-- phase2 constructor\n" << nonTableLines(c2) << "-- phase2 resume exception\n" << what << "\n";
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -686,6 +742,7 @@ int main(int argc, char** argv) {
             if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
             goldHost(out);
             goldGetArgs(out);
+            goldTrainRun(out);
             return 0;
         }
         if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));

@@ -1,6 +1,8 @@
 // Exercises the C++ classes with the reference's names on a real GPU (run by tests/test_host_facade.py, -m gpu).
 // Prints "HOST_FACADE_OK" when every check holds.
 #include <atomic>
+#include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -301,6 +303,52 @@ int main(int argc, char** argv) {
         }
         if (check()) return 1;
         REQUIRE(variants == 5);
+        fs::current_path(scratch);
+    }
+    // ---- a short train() run with checkpoints against the reference's own run of the same PPOConfig.toml (tests/golden/train_run.txt): every
+    //      console line outside the per-update table (the table carries wall-clock numbers) and the files left behind.  The thread-pool line
+    //      names the machine's core count and the device line is this build's own.
+    if (!golden.empty()) {
+        std::ifstream gf(golden + "/train_run.txt", std::ios::binary);
+        REQUIRE(gf.good());
+        std::map<std::string, std::string> sec;
+        std::string line, cur;
+        while (std::getline(gf, line)) { if (line.rfind("-- ", 0) == 0) { cur = line.substr(3); sec[cur]; } else sec[cur] += line + "\n"; }
+        REQUIRE(sec.count("toml") && sec.count("phase1 constructor") && sec.count("phase1 train") && sec.count("phase1 files"));
+        const fs::path dir = scratch / "train_run";
+        fs::create_directories(dir);
+        fs::current_path(dir);
+        std::ofstream("PPOConfig.toml", std::ios::binary) << sec["toml"];
+        auto filtered = [](const std::string& all) {
+            std::istringstream is(all);
+            std::string l, out;
+            while (std::getline(is, l)) {
+                if (l.empty() || l[0] == '|' || l[0] == '-') continue;
+                if (l.rfind("Warning: use_cuda", 0) == 0 || l.rfind("Created ", 0) == 0) continue;
+                if (l.rfind("Using ", 0) == 0 && l.find(" device") != std::string::npos) continue;
+                out += l + "\n";
+            }
+            return out;
+        };
+        std::stringstream c1, t1;
+        std::cout.copyfmt(std::ios(nullptr));
+        std::streambuf* old = std::cout.rdbuf(c1.rdbuf());
+        {
+            PPO_Discrete algo;
+            std::cout.rdbuf(t1.rdbuf());
+            algo.train();
+        }
+        std::cout.rdbuf(old);
+        const std::string gc = filtered(c1.str()), wc = filtered(sec["phase1 constructor"]), gt = filtered(t1.str()), wt = filtered(sec["phase1 train"]);
+        if (gc != wc) { std::fprintf(stderr, "constructor lines differ:\n%s--- want\n%s", gc.c_str(), wc.c_str()); return 1; }
+        if (gt != wt) { std::fprintf(stderr, "train() lines differ:\n%s--- want\n%s", gt.c_str(), wt.c_str()); return 1; }
+        std::vector<std::string> names;
+        for (const char* d : { "ModelCheckpoints", "OptimizerCheckpoints", "Models" })
+            if (fs::exists(d)) for (auto const& e : fs::directory_iterator(d)) names.push_back(std::string(d) + "/" + e.path().filename().string());
+        std::sort(names.begin(), names.end());
+        std::string listing;
+        for (auto& n : names) listing += n + "\n";
+        if (listing != sec["phase1 files"]) { std::fprintf(stderr, "files differ:\n%s--- want\n%s", listing.c_str(), sec["phase1 files"].c_str()); return 1; }
         fs::current_path(scratch);
     }
     std::printf("HOST_FACADE_OK\n");
