@@ -648,7 +648,15 @@ void goldGetArgs(const std::string& outDir) {
 static std::string nonTableLines(const std::string& all) {
     std::istringstream is(all);
     std::string l, out;
-    while (std::getline(is, l)) { if (l.empty() || l[0] == '|' || l[0] == '-') continue; out += l + "\n"; }
+    while (std::getline(is, l)) {
+        if (l.empty() || l[0] == '-') continue;
+        if (l[0] == '|') {   // table rows whose value does not depend on the wall clock or on the random stream
+            bool keep = false;
+            for (const char* k : { "iterations", "total_timesteps", "clip_range", "learning_rate", "n_updates" }) keep |= l.find(std::string("|    ") + k + " ") == 0;
+            if (!keep) continue;
+        }
+        out += l + "\n";
+    }
     return out;
 }
 static std::string listFiles() {

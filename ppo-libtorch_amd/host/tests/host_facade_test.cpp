@@ -323,7 +323,12 @@ int main(int argc, char** argv) {
             std::istringstream is(all);
             std::string l, out;
             while (std::getline(is, l)) {
-                if (l.empty() || l[0] == '|' || l[0] == '-') continue;
+                if (l.empty() || l[0] == '-') continue;
+                if (l[0] == '|') {   // table rows whose value does not depend on the wall clock or on the random stream
+                    bool keep = false;
+                    for (const char* k : { "iterations", "total_timesteps", "clip_range", "learning_rate", "n_updates" }) keep |= l.find(std::string("|    ") + k + " ") == 0;
+                    if (!keep) continue;
+                }
                 if (l.rfind("Warning: use_cuda", 0) == 0 || l.rfind("Created ", 0) == 0) continue;
                 if (l.rfind("Using ", 0) == 0 && l.find(" device") != std::string::npos) continue;
                 out += l + "\n";
