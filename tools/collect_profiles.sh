@@ -29,7 +29,7 @@ python3 $ROOT/tools/pmc_summary.py "$ROOT/profiles/${TAG}_pmc_per_dispatch.json"
 
 # the GAE scan by itself: kernel-only durations at 4096 / 8192 / 32768 envs (same trace holds the three sizes), and the floor probe -- a stream
 # kernel and the scan's own strip decomposition without the chain -- under the same tracer
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/gae_trace" -o run -- python3 $ROOT/tools/gae_sweep.py 4096 8192 32768 > "$OUT/gae_sweep.jsonl" 2> "$OUT/gae_trace.log"
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/gae_trace" -o run -- python3 $ROOT/tools/gae_sweep.py 4096 8192 32768 131072 1048576 > "$OUT/gae_sweep.jsonl" 2> "$OUT/gae_trace.log"
 cp "$(find "$OUT/gae_trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_gae_kernel_stats.csv"
 grep '^{' "$OUT/gae_sweep.jsonl" > "$ROOT/profiles/${TAG}_gae_sweep.jsonl" || true
 python3 $ROOT/tools/gae_by_size.py "$(find "$OUT/gae_trace" -name '*kernel_trace.csv' | head -n 1)" "$ROOT/profiles/${TAG}_gae_by_size.json" > "$OUT/gae_by_size.txt"

@@ -24,7 +24,7 @@ for N in sizes:
     rewards = np.where(rng.random((T, N), dtype=np.float32) < 0.05, -1.0, 1.0).astype(np.float32)
     values = rng.standard_normal((T, N), dtype=np.float32)
     dones = (rng.random((T, N), dtype=np.float32) < 0.05).astype(np.float32)
-    if N >= 262144:
+    if N > 32768:
         dones[64] = 1.0   # property check below
     nv = rng.standard_normal(N, dtype=np.float32)
     nd = (rng.random(N) < 0.05).astype(np.int32)
