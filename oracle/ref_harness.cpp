@@ -668,15 +668,12 @@ static std::string listFiles() {
     for (auto& n : names) out += n + "\n";
     return out;
 }
-void goldTrainRun(const std::string& outDir) {
-    const std::string toml =
-        "[environment]\nobs_size = 4\naction_size = 2\nmax_episode_steps = 500\n\n"
-        "[general]\nseed = 5\ntotal_timesteps = 384\nuse_cuda = false\ntorch_deterministic = true\ncheckpoint_updates = 2\n\n"
-        "[ppo]\nlearning_rate = 0.001\nnum_envs = 8\nnum_steps = 16\nanneal_lr = true\nnum_minibatches = 2\nupdate_epochs = 2\n";
+template <class Algo>
+void goldTrainRun(const std::string& outFile, const std::string& toml) {
     std::string dir = makeScratchDir("trainrun");
     if (chdir(dir.c_str()) != 0) throw std::runtime_error("chdir failed");
     { std::ofstream f("PPOConfig.toml", std::ios::binary); f << toml; }
-    std::ofstream out(outDir + "/train_run.txt", std::ios::binary);
+    std::ofstream out(outFile, std::ios::binary);
     out << "-- toml\n" << toml;
     auto captured = [&](auto&& fn) {
         std::stringstream ss;
@@ -687,8 +684,8 @@ void goldTrainRun(const std::string& outDir) {
         return ss.str();
     };
     {
-        std::unique_ptr<PPO_Discrete> algo;
-        const std::string c1 = captured([&] { algo = std::make_unique<PPO_Discrete>(); });
+        std::unique_ptr<Algo> algo;
+        const std::string c1 = captured([&] { algo = std::make_unique<Algo>(); });
         const std::string t1 = captured([&] { algo->train(); });
         out << "-- phase1 constructor\n" << nonTableLines(c1) << "-- phase1 train\n" << nonTableLines(t1) << "-- phase1 files\n" << listFiles();
     }
@@ -699,8 +696,8 @@ void goldTrainRun(const std::string& outDir) {
         std::string what = "(no exception)";
         std::string c2;
         try {
-            std::unique_ptr<PPO_Discrete> algo;
-            c2 = captured([&] { algo = std::make_unique<PPO_Discrete>(); });
+            std::unique_ptr<Algo> algo;
+            c2 = captured([&] { algo = std::make_unique<Algo>(); });
         } catch (const std::exception& ex) { what = ex.what(); }
         out << "-- phase2 constructor\n" << nonTableLines(c2) << "-- phase2 resume exception\n" << what << "\n";
     }
@@ -750,7 +747,14 @@ int main(int argc, char** argv) {
             if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
             goldHost(out);
             goldGetArgs(out);
-            goldTrainRun(out);
+            goldTrainRun<PPO_Discrete>(out + "/train_run.txt",
+                "[environment]\nobs_size = 4\naction_size = 2\nmax_episode_steps = 500\n\n"
+                "[general]\nseed = 5\ntotal_timesteps = 384\nuse_cuda = false\ntorch_deterministic = true\ncheckpoint_updates = 2\n\n"
+                "[ppo]\nlearning_rate = 0.001\nnum_envs = 8\nnum_steps = 16\nanneal_lr = true\nnum_minibatches = 2\nupdate_epochs = 2\n");
+            goldTrainRun<PPO_MultiDiscrete>(out + "/train_run_multidiscrete.txt",
+                "[environment]\nobs_size = 2\naction_size = 3\naction_high = 1.0\naction_low = -1.0\nmax_episode_steps = 50\n\n"
+                "[general]\nseed = 9\ntotal_timesteps = 256\ncheckpoint_updates = 1\n\n"
+                "[ppo]\nlearning_rate = 0.0005\nnum_envs = 4\nnum_steps = 32\nnum_minibatches = 4\nupdate_epochs = 1\nent_coef = 0.01\n");
             return 0;
         }
         if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));

@@ -308,14 +308,14 @@ int main(int argc, char** argv) {
     // ---- a short train() run with checkpoints against the reference's own run of the same PPOConfig.toml (tests/golden/train_run.txt): every
     //      console line outside the per-update table (the table carries wall-clock numbers) and the files left behind.  The thread-pool line
     //      names the machine's core count and the device line is this build's own.
-    if (!golden.empty()) {
-        std::ifstream gf(golden + "/train_run.txt", std::ios::binary);
+    for (int which = 0; which < 2 && !golden.empty(); which++) {   // PPO_Discrete on CartPole, PPO_MultiDiscrete on MountainCar
+        std::ifstream gf(golden + (which == 0 ? "/train_run.txt" : "/train_run_multidiscrete.txt"), std::ios::binary);
         REQUIRE(gf.good());
         std::map<std::string, std::string> sec;
         std::string line, cur;
         while (std::getline(gf, line)) { if (line.rfind("-- ", 0) == 0) { cur = line.substr(3); sec[cur]; } else sec[cur] += line + "\n"; }
         REQUIRE(sec.count("toml") && sec.count("phase1 constructor") && sec.count("phase1 train") && sec.count("phase1 files"));
-        const fs::path dir = scratch / "train_run";
+        const fs::path dir = scratch / (which == 0 ? "train_run" : "train_run_md");
         fs::create_directories(dir);
         fs::current_path(dir);
         std::ofstream("PPOConfig.toml", std::ios::binary) << sec["toml"];
@@ -338,8 +338,12 @@ int main(int argc, char** argv) {
         std::stringstream c1, t1;
         std::cout.copyfmt(std::ios(nullptr));
         std::streambuf* old = std::cout.rdbuf(c1.rdbuf());
-        {
+        if (which == 0) {
             PPO_Discrete algo;
+            std::cout.rdbuf(t1.rdbuf());
+            algo.train();
+        } else {
+            PPO_MultiDiscrete algo;
             std::cout.rdbuf(t1.rdbuf());
             algo.train();
         }
