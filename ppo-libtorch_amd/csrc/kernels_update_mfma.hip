@@ -59,6 +59,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+// (Inline asm: LLVM forms neither instruction from C for gfx950 -- x - (float)h becomes a conversion and a subtraction -- and its hazard
+// recognizer does not look into asm blocks; an MFMA that reads a register these instructions wrote in the slot right before it is handled by
+// the hardware: tools/probes/asm_mfma_hazard.hip, 0 differences against the same sequence padded with s_nop.)
 // two floats -> one dword of fp16 (low half = x0), round to nearest even (v_cvt_pk_f16_f32)
 __device__ __forceinline__ uint32_t pk_f16(float x0, float x1) {
     uint32_t p;
