@@ -593,6 +593,29 @@ def test_train_iteration_equals_rollout_scan_update(P, kind):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("kind", ["cartpole", "mountaincar"])
+def test_headline_size_runs_are_bit_reproducible(P, kind):
+    """BASELINE configs[1] / configs[3] sizes, twice from the same seed: every buffer and every parameter bit-identical after two iterations.
+    The 256-workgroup update kernel adds its waves and workgroups in a fixed order (no float atomics), the permutations and the sampling are
+    counter-based: nothing in the path depends on scheduling."""
+    kw = dict(num_envs=4096, num_steps=128, num_minibatches=4, update_epochs=10, seed=21, total_timesteps=4096 * 128 * 4)
+    if kind == "mountaincar":
+        kw.update(env_kind=P.ENV_MOUNTAINCAR, dist_kind=P.DIST_MASKED, obs_size=2, head_dims=(3,), max_episode_steps=200, num_envs=8192,
+                  total_timesteps=8192 * 128 * 4)
+    runs = []
+    for _ in range(2):
+        c = P.Context(P.make_config(**kw))
+        c.init_orthogonal(3)
+        c.env_reset()
+        for _ in range(2):
+            c.train_iteration()
+        runs.append((c.get_params(), c.read("ADVANTAGES"), c.read("LOGPROBS"), c.read("ACTIONS"), c.stats()))
+        c.close()
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(bits(a) if a.dtype == np.float32 else a, bits(b) if b.dtype == np.float32 else b)
+    assert runs[0][4]["loss"] == runs[1][4]["loss"] and runs[0][4]["explained_variance"] == runs[1][4]["explained_variance"]
+
+
 def test_training_learns_cartpole(P):
     """De-facto acceptance test of the reference (README.md:169-178): ep_len_mean climbs.  256 envs x 128 steps x 25 updates."""
     ctx = P.Context(P.make_config(num_envs=256, num_steps=128, num_minibatches=4, update_epochs=4, seed=2, total_timesteps=256 * 128 * 25,
