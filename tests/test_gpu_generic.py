@@ -182,6 +182,25 @@ def test_config4_per_gpu_size_runs(P, dtype):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_config4_runs_are_bit_reproducible(P, dtype):
+    """The same configs[4] share twice from the same seed: parameters, log-probs and actions bit-identical (weight-gradient slabs, bias column
+    sums and loss partials are all added in a fixed order; sampling is counter-based)."""
+    outs = []
+    for _ in range(2):
+        ctx = P.Context(P.make_config(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=376, head_dims=(3, 3, 3, 2), hidden=256, n_hidden=4,
+                                      num_envs=2048, num_steps=32, num_minibatches=4, update_epochs=2, max_episode_steps=200, seed=4,
+                                      total_timesteps=4 * 2048 * 32, ent_coef=0.01, compute_dtype=dtype))
+        ctx.init_orthogonal(2)
+        ctx.env_reset()
+        for _ in range(2):
+            ctx.train_iteration()
+        outs.append((ctx.get_params(), ctx.read("LOGPROBS"), ctx.read("ACTIONS"), ctx.stats()["loss"]))
+        ctx.close()
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    assert np.array_equal(bits(outs[0][1]), bits(outs[1][1])) and np.array_equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
+
+
 def test_generic_two_rank_shards_equal_single_context(P):
     """Data parallelism on the generic path: two shards (env_offset / global_num_envs) reproduce their columns of the single-context rollout
     -- env buffers and actions bit for bit, network outputs to float noise (the library GEMM picks its kernel, and with it the order of
