@@ -446,9 +446,13 @@ __global__ __launch_bounds__(UPD_THREADS, 2) void fwd_bwd_kernel(UpdateArgs a) {
 // grads[p] = sum_b slab[net(p)][b][p - net_off] in a fixed order (16 contiguous groups of slabs, each summed in order by one
 // wave with its loads in flight together, then the 16 partials added in order): bit-reproducible, no float atomics.
 // The last block adds the per-workgroup loss sums the same way.
-__global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb0, int nb1,
+// The slab reductions (this kernel and reduce_grads_sumsq_kernel, which must add in the same order: the fused and the step-by-step paths are
+// bit-identical) run RED_WAVES waves per workgroup, each adding 1 / RED_WAVES of the slabs with all its loads in flight (measured, A/B in one call, per optimizer
+// step by events: 16 waves 13.4 us, 8 waves 12.7, 4 waves 13.2 and erratic)
+constexpr int RED_WAVES = 8;
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_kernel(const float* __restrict__ slab, const double* __restrict__ stat_slab, int nb0, int nb1,
                                                             NetLayout L, float* __restrict__ grads, double* __restrict__ sums_out) {
-    __shared__ double part[16][64];
+    __shared__ double part[RED_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (blockIdx.x + 1 < gridDim.x) {
         const int p = blockIdx.x * 64 + lane;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
             const int net = p >= L.net_off[1] ? 1 : 0;
             const int nb = net ? nb1 : nb0;
             const float* col = slab + (size_t)(net ? nb0 : 0) * Pmax + (p - L.net_off[net]);
-            const int b0 = (nb * w) / 16, b1 = (nb * (w + 1)) / 16;
+            const int b0 = (nb * w) / RED_WAVES, b1 = (nb * (w + 1)) / RED_WAVES;
             int b = b0;
             for (; b + 8 <= b1; b += 8) {
                 float v[8];
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
         if (w == 0 && p < L.P) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) s += part[k][lane];
+            for (int k = 0; k < RED_WAVES; k++) s += part[k][lane];
             grads[p] = (float)s;
         }
     } else {
@@ -483,14 +487,14 @@ __global__ __launch_bounds__(1024) void reduce_grads_kernel(const float* __restr
             const int net = k < 4 ? 1 : 0, col = k < 4 ? k : 0;
             const int nb = net ? nb1 : nb0;
             double v = 0.0;
-            for (int b = threadIdx.x; b < nb; b += 1024) v += stat_slab[((size_t)(net ? nb0 : 0) + b) * 8 + col];
+            for (int b = threadIdx.x; b < nb; b += 64 * RED_WAVES) v += stat_slab[((size_t)(net ? nb0 : 0) + b) * 8 + col];
             v = wave_sum_d(v);
             __syncthreads();
             if (lane == 0) part[0][w] = v;
             __syncthreads();
             if (threadIdx.x == 0) {
                 double s = 0.0;
-                for (int i = 0; i < 16; i++) s += part[0][i];
+                for (int i = 0; i < RED_WAVES; i++) s += part[0][i];
                 sums_out[k] = s;
                 grads[L.P + k] = (float)s;   // float copies ride behind the gradient so ONE all-reduce carries both
             }
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(NORM_THREADS) void grad_norm_kernel(const float* __
 
 // K9 (clip coefficient) + K10 (AdamW), element-parallel.  GRADS is left holding the UNCLIPPED gradient (the reference scales
 // .grad in place, clip_grad.h:79-81, but nothing reads it before zero_grad); the clip coefficient is applied on the fly.
-constexpr int ADAM_THREADS = 256;
+constexpr int ADAM_THREADS = 256;   // four waves: opt_total_norm spreads the twelve tensors' partials over waves 0..3
 __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ exp_avg,
                                                                   float* __restrict__ exp_avg_sq, NetLayout L, float max_norm,
                                                                   const double* __restrict__ norm2, const AdamCoef* __restrict__ coef_p,
@@ -655,8 +659,8 @@ __device__ __forceinline__ unsigned xchg_wait_all(void* own, int rank, int n, si
     return (unsigned)(m & 0xffu) | ~0xffu;
 }
 template <bool XCHG>
-__global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a) {
-    __shared__ double part[16][64];
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_sumsq_kernel(FusedOptArgs a) {
+    __shared__ double part[RED_WAVES][64];
     const NetLayout& L = a.L;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (blockIdx.x + 1 < gridDim.x) {
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
             const int net = p >= L.net_off[1] ? 1 : 0;
             const int nb = net ? a.nb1 : a.nb0;
             const float* col = a.slab + (size_t)(net ? a.nb0 : 0) * Pmax + (p - L.net_off[net]);
-            const int b0 = (nb * w) / 16, b1 = (nb * (w + 1)) / 16;
+            const int b0 = (nb * w) / RED_WAVES, b1 = (nb * (w + 1)) / RED_WAVES;
             int b = b0;
             for (; b + 8 <= b1; b += 8) {
                 float v[8];
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
             if (p < L.P) {
                 double sacc = 0.0;
 #pragma unroll
-                for (int i = 0; i < 16; i++) sacc += part[i][lane];
+                for (int i = 0; i < RED_WAVES; i++) sacc += part[i][lane];
                 g = (float)sacc;
             }
             if constexpr (XCHG) {
@@ -727,14 +731,14 @@ __global__ __launch_bounds__(1024) void reduce_grads_sumsq_kernel(FusedOptArgs a
             const int net = kk < 4 ? 1 : 0, col = kk < 4 ? kk : 0;
             const int nb = net ? a.nb1 : a.nb0;
             double v = 0.0;
-            for (int b = threadIdx.x; b < nb; b += 1024) v += a.stat_slab[((size_t)(net ? a.nb0 : 0) + b) * 8 + col];
+            for (int b = threadIdx.x; b < nb; b += 64 * RED_WAVES) v += a.stat_slab[((size_t)(net ? a.nb0 : 0) + b) * 8 + col];
             v = wave_sum_d(v);
             __syncthreads();
             if (lane == 0) part[0][w] = v;
             __syncthreads();
             if (threadIdx.x == 0) {
                 double sacc = 0.0;
-                for (int i = 0; i < 16; i++) sacc += part[0][i];
+                for (int i = 0; i < RED_WAVES; i++) sacc += part[0][i];
                 a.sums_out[kk] = sacc;
                 part[1][kk] = sacc;
             }
@@ -1017,7 +1021,7 @@ hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s) {
 
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64 + 1), dim3(1024), 0, s, slab, stat_slab, n_blocks[0], n_blocks[1], L, grads, sums_out);
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3((L.P + 63) / 64 + 1), dim3(64 * RED_WAVES), 0, s, slab, stat_slab, n_blocks[0], n_blocks[1], L, grads, sums_out);
     return hipGetLastError();
 }
 
@@ -1041,7 +1045,7 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
     a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M;
     a.p_src = params; a.m_src = exp_avg; a.v_src = exp_avg_sq;
     a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.partial = partial;
-    hipLaunchKernelGGL(reduce_grads_sumsq_kernel<false>, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(reduce_grads_sumsq_kernel<false>, dim3(fused_opt_blocks(L)), dim3(64 * RED_WAVES), 0, s, a);
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();
 }
@@ -1060,7 +1064,7 @@ hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* st
     a.hp = hp; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.partial = partial;
     for (int r = 0; r < 8; r++) a.peers[r] = r < n_ranks ? peers[r] : nullptr;
     a.rank = rank; a.n_ranks = n_ranks; a.slot_bytes = slot_bytes; a.seq = seq; a.timeout_flag = timeout_flag;
-    hipLaunchKernelGGL(reduce_grads_sumsq_kernel<true>, dim3(fused_opt_blocks(L)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(reduce_grads_sumsq_kernel<true>, dim3(fused_opt_blocks(L)), dim3(64 * RED_WAVES), 0, s, a);
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();
 }
