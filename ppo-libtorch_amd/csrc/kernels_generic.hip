@@ -223,7 +223,12 @@ __global__ __launch_bounds__(256) void gen_norm_kernel(const float* __restrict__
     const int t0 = L.tensor_off[t], len = L.tensor_off[t + 1] - t0;
     const int a0 = t0 + (int)(((int64_t)len * part) / GEN_NORM_PARTS), a1 = t0 + (int)(((int64_t)len * (part + 1)) / GEN_NORM_PARTS);
     double acc = 0.0;
-    for (int p = a0 + threadIdx.x; p < a1; p += 256) acc += (double)grads[p] * (double)grads[p];
+    int p = a0 + threadIdx.x;
+    for (; p + 3 * 256 < a1; p += 4 * 256) {   // four loads in flight per thread (a slice of a 256 x 376 tensor is 24 elements per thread)
+        const float g0 = grads[p], g1 = grads[p + 256], g2 = grads[p + 512], g3 = grads[p + 768];
+        acc += (double)g0 * (double)g0; acc += (double)g1 * (double)g1; acc += (double)g2 * (double)g2; acc += (double)g3 * (double)g3;
+    }
+    for (; p < a1; p += 256) acc += (double)grads[p] * (double)grads[p];
     acc = wave_sum_d_dpp(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -233,14 +238,28 @@ __global__ __launch_bounds__(256) void gen_adamw_kernel(float* __restrict__ para
                                                         float* __restrict__ exp_avg_sq, GenLayout L, float max_norm, const double* __restrict__ norm2,
                                                         const AdamCoef* __restrict__ coef_p, const double* __restrict__ loss_sums, double global_M,
                                                         LossParams hp, int world, int do_step, StepStats* stats_out, double* clipfrac_accum) {
-    double tot = 0.0;
-    for (int t = 0; t < L.n_tensors; t++) {
+    // total norm: thread t adds tensor t's partial sums (all its loads in flight), thread 0 adds the tensors -- the same sums in the same order
+    // as one thread doing all of it (which every thread used to do: 320 dependent loads in front of the element-wise step)
+    __shared__ double s_n2[4 * GEN_MAX_LAYERS];
+    __shared__ float s_total;
+    if ((int)threadIdx.x < L.n_tensors) {
+        double part[GEN_NORM_PARTS];
+#pragma unroll
+        for (int k = 0; k < GEN_NORM_PARTS; k++) part[k] = norm2[threadIdx.x * GEN_NORM_PARTS + k];
         double n2 = 0.0;
-        for (int k = 0; k < GEN_NORM_PARTS; k++) n2 += norm2[t * GEN_NORM_PARTS + k];
+#pragma unroll
+        for (int k = 0; k < GEN_NORM_PARTS; k++) n2 += part[k];
         const float nrm = (float)sqrt(n2);
-        tot += (double)nrm * nrm;
+        s_n2[threadIdx.x] = (double)nrm * nrm;
     }
-    const float total = (float)sqrt(tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < L.n_tensors; t++) tot += s_n2[t];
+        s_total = (float)sqrt(tot);
+    }
+    __syncthreads();
+    const float total = s_total;
     float c = max_norm / (total + 1e-6f);
     if (c > 1.0f) c = 1.0f;
     const AdamCoef k = *coef_p;
