@@ -207,6 +207,13 @@ def main():
                               gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True,
                               device=0 if args.same_device else local_rank,
                               compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32)
+    def warm(c):
+        c.init_orthogonal(2)   # same seed on every rank: replicated weights
+        c.env_reset()
+        for _ in range(args.warmup):
+            c.train_iteration()
+        c.sync()
+
     def start(transport):
         c = P.Context(cfg)
         if args.comm_selftest and world == 1:
@@ -214,36 +221,57 @@ def main():
             c.comm_init(P.comm_unique_id(), 0, 1)
             del os.environ["PPO_COMM_SELFTEST"]
         P.dist.bootstrap_comm(c, dist, rank, world, P.comm_unique_id, transport=transport)
-        c.init_orthogonal(2)   # same seed on every rank: replicated weights
-        c.env_reset()
-        for _ in range(args.warmup):
-            c.train_iteration()
-        c.sync()
+        warm(c)
         return c
 
-    transport = "rccl" if args.transport == "rccl" else "exchange"
-    if world == 1:
-        transport = "none"
-    try:
-        ctx = start(transport)
-        ok = True
-        if transport == "exchange":
-            # the exchange has never run on this node before this job: after the warm-up no bounded wait may have run out and the replicas must
-            # hold bit-identical parameters (every rank adds the shards in rank order)
+    def start_exchange():
+        """The exchange has never run on this node before this job, so it is brought up in checked stages.  Every rank walks the SAME sequence of
+        host collectives whether or not its own stage failed (a rank that left the sequence early would leave the others in a mismatched
+        collective); None = some rank failed, nothing is left open."""
+        c, err, handle = None, None, None
+        try:
+            c = P.Context(cfg)
+            handle = c.comm_exchange_handle()
+        except Exception as ex:
+            err = ex
+        handles = P.dist.gather_bytes(dist, handle)
+        if err is None:
+            try:
+                if any(h is None for h in handles):
+                    raise RuntimeError("a peer could not export its exchange buffer")
+                c.comm_init_exchange(handles, rank, world)
+            except Exception as ex:   # e.g. IPC handles cannot be opened on this node
+                err = ex
+        if P.dist.all_ranks_agree(dist, err is None):
+            # after the warm-up no bounded wait may have run out and the replicas must hold bit-identical parameters (every rank adds the
+            # shards in rank order)
             import hashlib
-            digest = hashlib.sha256(ctx.get_params().tobytes()).digest()
-            ok = ctx.comm_exchange_timeouts() == 0 and len(set(P.dist.gather_bytes(dist, digest))) == 1
-    except Exception as ex:   # e.g. IPC handles cannot be opened on this node
-        if transport != "exchange" or args.transport != "auto":
-            raise
-        sys.stderr.write("rank %d: exchange transport failed (%r)\n" % (rank, ex))
-        ctx, ok = None, False
-    if transport == "exchange" and not P.dist.all_ranks_agree(dist, ok):
-        if args.transport != "auto":
-            sys.exit("exchange transport failed its post-warm-up check")
-        if ctx is not None:
-            ctx.close()
-        transport = "rccl"
+            digest = None
+            try:
+                warm(c)
+                if c.comm_exchange_timeouts() == 0:
+                    digest = hashlib.sha256(c.get_params().tobytes()).digest()
+            except Exception as ex:
+                err = ex
+            digests = P.dist.gather_bytes(dist, digest)
+            if digest is None or len(set(digests)) != 1:
+                err = err or RuntimeError("replicas differ or a wait ran out after the warm-up")
+            if P.dist.all_ranks_agree(dist, err is None):
+                return c
+        if err is not None:
+            sys.stderr.write("rank %d: exchange transport failed (%r)\n" % (rank, err))
+        if c is not None:
+            c.close()
+        return None
+
+    transport = "none" if world == 1 else ("rccl" if args.transport == "rccl" else "exchange")
+    if transport == "exchange":
+        ctx = start_exchange()
+        if ctx is None:
+            if args.transport != "auto":
+                sys.exit("exchange transport failed its start-up checks")
+            transport = "rccl"
+    if transport != "exchange":
         ctx = start(transport)
 
     def barrier():
