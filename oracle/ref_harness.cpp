@@ -22,6 +22,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <random>
 #include <sstream>
@@ -703,6 +704,67 @@ void goldTrainRun(const std::string& outFile, const std::string& toml) {
     }
 }
 
+// The checkpoint files themselves (PPO_Discrete.cpp:662-685, 779-788): a short train() run, then the two `.pt` archives it left under
+// ./Models/ are copied out as fixtures together with what they hold (parameters in Agent::parameters() order, AdamW step counts and
+// moments), so the host facade's reader of the reference's files can be checked value for value.
+template <class Algo>
+void goldCheckpointFiles(const std::string& outDir, const std::string& tag, const std::string& toml, int64_t total_timesteps) {
+    std::string dir = makeScratchDir("ptgold_" + tag);
+    if (chdir(dir.c_str()) != 0) throw std::runtime_error("chdir failed");
+    { std::ofstream f("PPOConfig.toml", std::ios::binary); f << toml; }
+    std::stringstream sink;
+    std::streambuf* old = std::cout.rdbuf(sink.rdbuf());
+    std::unique_ptr<Algo> algo;
+    try { algo = std::make_unique<Algo>(); algo->train(); } catch (...) { std::cout.rdbuf(old); throw; }
+    std::cout.rdbuf(old);
+    const std::string stem = "./Models/PPO_";
+    const std::string sfx = "_" + std::to_string(total_timesteps) + "_steps.pt";
+    std::filesystem::copy_file(stem + "Agent" + sfx, outDir + "/ref_" + tag + "_agent.pt", std::filesystem::copy_options::overwrite_existing);
+    std::filesystem::copy_file(stem + "Optimizer" + sfx, outDir + "/ref_" + tag + "_optimizer.pt", std::filesystem::copy_options::overwrite_existing);
+    GoldWriter g;
+    std::vector<torch::Tensor> params = algo->m_agent->parameters();
+    g.add("params", flatParams(params));
+    auto mv = flatAdamState(*algo->m_optimizer, params);
+    g.add("exp_avg", mv[0]);
+    g.add("exp_avg_sq", mv[1]);
+    std::vector<int64_t> steps, numels;
+    for (const auto& p : params) {
+        auto& st = static_cast<torch::optim::AdamWParamState&>(*algo->m_optimizer->state().at(p.unsafeGetTensorImpl()));
+        steps.push_back(st.step());
+        numels.push_back(p.numel());
+    }
+    g.addI64("steps", steps, { (int64_t)steps.size() });
+    g.addI64("numels", numels, { (int64_t)numels.size() });
+    g.addF64("lr", { static_cast<torch::optim::AdamWOptions&>(algo->m_optimizer->param_groups()[0].options()).lr() }, { 1 });
+    g.save(outDir + "/ref_" + tag + "_checkpoint_values.pgld");
+}
+
+// The reference's own load calls on given files: an Agent and an AdamW built as PPO_Discrete's constructor builds them (:72-78), then
+// torch::load(m_agent, file) (:812) and torch::load(*m_optimizer, file) (:834).  What they now hold is written out, so archives produced
+// by the host facade's writer can be shown to load into the reference value for value.  (loadPolicyFromCheckpoint itself cannot be
+// driven here: built against libstdc++ it throws before it reaches these calls, see goldTrainRun.)
+void loadCheckpointFiles(const std::string& agentFile, const std::string& optimizerFile, int64_t obs, int64_t act, const std::string& outFile) {
+    auto device = std::make_shared<torch::Device>(torch::kCPU);
+    auto agent = std::make_shared<Agent>(obs, act, device);
+    auto optimizer = std::make_shared<torch::optim::AdamW>(agent->parameters(), torch::optim::AdamWOptions(0.5).eps(1e-5f));
+    torch::load(agent, agentFile);
+    torch::load(*optimizer, optimizerFile);
+    GoldWriter g;
+    std::vector<torch::Tensor> params = agent->parameters();
+    g.add("params", flatParams(params));
+    auto mv = flatAdamState(*optimizer, params);
+    g.add("exp_avg", mv[0]);
+    g.add("exp_avg_sq", mv[1]);
+    std::vector<int64_t> steps;
+    for (const auto& p : params) steps.push_back(static_cast<torch::optim::AdamWParamState&>(*optimizer->state().at(p.unsafeGetTensorImpl())).step());
+    g.addI64("steps", steps, { (int64_t)steps.size() });
+    auto& opt = static_cast<torch::optim::AdamWOptions&>(optimizer->param_groups()[0].options());
+    g.addF64("lr", { opt.lr() }, { 1 });
+    g.addF64("eps", { opt.eps() }, { 1 });
+    g.addF64("weight_decay", { opt.weight_decay() }, { 1 });
+    g.save(outFile);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -757,8 +819,26 @@ int main(int argc, char** argv) {
                 "[ppo]\nlearning_rate = 0.0005\nnum_envs = 4\nnum_steps = 32\nnum_minibatches = 4\nupdate_epochs = 1\nent_coef = 0.01\n");
             return 0;
         }
+        if (mode == "ptgold" && argc > 2) {
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            goldCheckpointFiles<PPO_Discrete>(out, "discrete",
+                "[environment]\nobs_size = 4\naction_size = 2\nmax_episode_steps = 500\n\n"
+                "[general]\nseed = 5\ntotal_timesteps = 384\nuse_cuda = false\ntorch_deterministic = true\ncheckpoint_updates = 2\n\n"
+                "[ppo]\nlearning_rate = 0.001\nnum_envs = 8\nnum_steps = 16\nanneal_lr = true\nnum_minibatches = 2\nupdate_epochs = 2\n", 384);
+            goldCheckpointFiles<PPO_MultiDiscrete>(out, "multidiscrete",
+                "[environment]\nobs_size = 2\naction_size = 3\naction_high = 1.0\naction_low = -1.0\nmax_episode_steps = 50\n\n"
+                "[general]\nseed = 9\ntotal_timesteps = 256\ncheckpoint_updates = 1\n\n"
+                "[ppo]\nlearning_rate = 0.0005\nnum_envs = 4\nnum_steps = 32\nnum_minibatches = 4\nupdate_epochs = 1\nent_coef = 0.01\n", 256);
+            return 0;
+        }
+        if (mode == "ptload" && argc > 6) {
+            loadCheckpointFiles(argv[2], argv[3], std::atol(argv[4]), std::atol(argv[5]), argv[6]);
+            return 0;
+        }
         if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));
-        std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | bench <num_envs> <num_steps> <updates>\n";
+        std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | ptgold <outdir> | ptload <agent.pt> <optimizer.pt> <obs> <act> <out.pgld> | bench <num_envs> <num_steps> <updates>\n";
         return 2;
     } catch (const std::exception& ex) {
         std::cerr << "[ref_harness] error: " << ex.what() << std::endl;

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "../Config/Toml.h"
+#include "../Utils/TorchArchive.h"
 #include "PPO_Discrete.h"
 #include "PPO_MultiDiscrete.h"
 
@@ -249,29 +250,28 @@ void PPOAlgorithm::train() {
     m_threadPool->stop();
 }
 
-// Checkpoint files keep the reference's directories and names; the payload is the flat tensors in Agent::parameters() order
-// (LibTorch's zip/pickle container is not reproduced): "PPOHIP01", count, floats [, step, exp_avg, exp_avg_sq].
+// Checkpoint files keep the reference's directories, names AND container: LibTorch module archives (Utils/TorchArchive.h), so a run can
+// be resumed from files the reference wrote and the reference can load what this build writes.  The agent archive holds the twelve
+// tensors of Agent::parameters(), the optimizer archive AdamW's step / exp_avg / exp_avg_sq per parameter and the options it ran with.
 void PPOAlgorithm::saveCheckpoint(const std::string& agentFile, const std::string& optimizerFile) {
     const int64_t P = ppo_param_count(m_ctx);
     std::vector<float> p(static_cast<size_t>(P)), m(static_cast<size_t>(P)), v(static_cast<size_t>(P));
     int64_t step = 0;
     ppo::check(ppo_params_get_h(m_ctx, p.data(), P), m_ctx, "params");
     ppo::check(ppo_optimizer_get_h(m_ctx, m.data(), v.data(), P, &step), m_ctx, "optimizer");
+    ppo_stats st{};
+    ppo::check(ppo_read_stats(m_ctx, &st), m_ctx, "stats");
     // written under a temporary name and renamed once complete and flushed: a full disk never leaves a truncated file where the newest-file
-    // rule of loadPolicyFromCheckpoint would pick it up
+    // rule of loadPolicyFromCheckpoint would pick it up.  (The archive's internal directory is named after the final file, as LibTorch's is.)
     const std::string ta = agentFile + ".tmp", to = optimizerFile + ".tmp";
-    {
-        std::ofstream fa(ta, std::ios::binary), fo(to, std::ios::binary);
-        fa.write("PPOHIP01", 8); fa.write(reinterpret_cast<const char*>(&P), 8); fa.write(reinterpret_cast<const char*>(p.data()), P * 4);
-        fo.write("PPOHIP01", 8); fo.write(reinterpret_cast<const char*>(&P), 8); fo.write(reinterpret_cast<const char*>(&step), 8);
-        fo.write(reinterpret_cast<const char*>(m.data()), P * 4); fo.write(reinterpret_cast<const char*>(v.data()), P * 4);
-        fa.flush(); fo.flush();
-        if (!fa.good() || !fo.good()) {
-            fa.close(); fo.close();
-            std::error_code ec;
-            fs::remove(ta, ec); fs::remove(to, ec);
-            throw std::runtime_error("could not write checkpoint " + agentFile + " / " + optimizerFile);
-        }
+    try {
+        ppo::pt::writeAgent(ta, m_obs_size, 64, m_action_size, p, fs::path(agentFile).stem().string());
+        ppo::pt::writeOptimizer(to, m_obs_size, 64, m_action_size, m, v, step, st.learning_rate, static_cast<double>(1e-5f), 0.01,
+                                     fs::path(optimizerFile).stem().string());
+    } catch (const std::exception&) {
+        std::error_code ec;
+        fs::remove(ta, ec); fs::remove(to, ec);
+        throw std::runtime_error("could not write checkpoint " + agentFile + " / " + optimizerFile);
     }
     fs::rename(ta, agentFile);
     fs::rename(to, optimizerFile);
@@ -286,20 +286,22 @@ static std::string newestFile(const fs::path& dir) {
     }
     return best;
 }
-// true: the file is one of ours and holds n floats after its header.  A LibTorch zip/pickle checkpoint written by the reference itself (same
-// directory, same name scheme) or any other file is reported and skipped -- the agent then starts fresh, as when no checkpoint exists.
-static bool readHeader(std::ifstream& f, const std::string& name, int64_t P, bool optimizer, int64_t* step) {
-    char magic[8] = {};
-    int64_t n = 0;
-    f.read(magic, 8); f.read(reinterpret_cast<char*>(&n), 8);
-    if (optimizer && f) f.read(reinterpret_cast<char*>(step), 8);
-    if (!f || std::string(magic, 8) != "PPOHIP01") {
-        std::cout << "Checkpoint " << name << " is not in this build's format (a LibTorch .pt written by the reference is not supported); ignoring it." << std::endl;
+// The tensors of an archive, flattened in file order, if they are exactly this agent's twelve (shape by shape); otherwise the reason is
+// printed and the file ignored -- the agent then starts fresh, as when no checkpoint exists.
+static bool flattenFor(const std::vector<ppo::pt::NamedTensor>& tensors, const std::vector<std::vector<int64_t>>& shapes, const std::string& file,
+                       std::vector<float>& flat) {
+    if (tensors.size() != shapes.size()) {
+        std::cout << "Checkpoint " << file << " holds " << tensors.size() << " tensors, this agent has " << shapes.size() << "; ignoring it." << std::endl;
         return false;
     }
-    if (n != P) {
-        std::cout << "Checkpoint " << name << " holds " << n << " parameters, this agent has " << P << "; ignoring it." << std::endl;
-        return false;
+    flat.clear();
+    for (size_t i = 0; i < shapes.size(); i++) {
+        if (tensors[i].sizes != shapes[i]) {
+            std::cout << "Checkpoint " << file << ": tensor " << tensors[i].name << " does not have the shape of this agent's parameter " << i
+                      << " (obs_size / action_size differ?); ignoring it." << std::endl;
+            return false;
+        }
+        flat.insert(flat.end(), tensors[i].values.begin(), tensors[i].values.end());
     }
     return true;
 }
@@ -311,23 +313,22 @@ void PPOAlgorithm::loadPolicyFromCheckpoint() {
         return;
     }
     const int64_t P = ppo_param_count(m_ctx);
+    const auto shapes = ppo::pt::agentShapes(m_obs_size, 64, m_action_size);
     const std::string a = newestFile(modelDir);
     if (a.empty()) {
         std::cout << "No previous model checkpoint found at " << modelDir << ", initializing new agent!" << std::endl;
     } else {
         std::cout << "Loading model " << a << "..." << std::endl;
-        std::ifstream f(a, std::ios::binary);
-        std::vector<float> p(static_cast<size_t>(P));
-        if (readHeader(f, a, P, false, nullptr)) {
-            f.read(reinterpret_cast<char*>(p.data()), P * 4);
-            if (!f) {
-                std::cout << "Checkpoint " << a << " is truncated; ignoring it." << std::endl;
-            } else {
+        try {
+            std::vector<float> p;
+            if (flattenFor(ppo::pt::readAgent(a).tensors, shapes, a, p)) {
                 const std::string steps = PPOUtils::getLoadFromSteps(a, "PPO_Agent_");
                 m_global_step = PPOUtils::isNumber(steps) ? static_cast<uint64_t>(std::stoll(steps)) : 0;   // :809-811
                 std::cout << "Continuing training from step " << m_global_step << std::endl;
                 ppo::check(ppo_params_set_h(m_ctx, p.data(), P), m_ctx, "load params");
             }
+        } catch (const std::runtime_error& ex) {   // not an archive, truncated, damaged: say why and start fresh
+            std::cout << ex.what() << "; ignoring it." << std::endl;
         }
     }
     const std::string o = newestFile(optimDir);
@@ -335,13 +336,24 @@ void PPOAlgorithm::loadPolicyFromCheckpoint() {
         std::cout << "No previous optimizer checkpoint found at " << optimDir << ", initializing new optimizer!" << std::endl;
     } else {
         std::cout << "Loading optimizer " << o << "..." << std::endl;
-        std::ifstream f(o, std::ios::binary);
-        std::vector<float> m(static_cast<size_t>(P)), v(static_cast<size_t>(P));
-        int64_t step = 0;
-        if (readHeader(f, o, P, true, &step)) {
-            f.read(reinterpret_cast<char*>(m.data()), P * 4); f.read(reinterpret_cast<char*>(v.data()), P * 4);
-            if (!f) std::cout << "Checkpoint " << o << " is truncated; ignoring it." << std::endl;
-            else ppo::check(ppo_optimizer_set_h(m_ctx, m.data(), v.data(), P, step), m_ctx, "load optimizer");
+        try {
+            const ppo::pt::OptimizerFile f = ppo::pt::readOptimizer(o);
+            std::vector<float> m, v;
+            bool same_step = true;
+            for (int64_t s : f.step) same_step = same_step && s == f.step[0];
+            if (!same_step) {
+                std::cout << "Checkpoint " << o << ": the parameters are at different step counts; ignoring it." << std::endl;
+            } else if (flattenFor(f.exp_avg, shapes, o, m) && flattenFor(f.exp_avg_sq, shapes, o, v)) {
+                ppo::check(ppo_optimizer_set_h(m_ctx, m.data(), v.data(), P, f.step[0]), m_ctx, "load optimizer");
+                // torch::load(optimizer) also brings back the options the file was saved with (:834): the learning rate is taken over (train()
+                // overwrites it per update when anneal_lr is set, exactly as there); the other AdamW options are fixed in this build
+                ppo::check(ppo_set_learning_rate(m_ctx, f.lr), m_ctx, "lr");
+                if (f.beta1 != 0.9 || f.beta2 != 0.999 || f.eps != static_cast<double>(1e-5f) || f.weight_decay != 0.01 || f.amsgrad)
+                    std::cout << "Checkpoint " << o << " was saved with AdamW options other than the reference's (betas 0.9/0.999, eps 1e-5, weight_decay 0.01);"
+                              << " this build keeps the reference's." << std::endl;
+            }
+        } catch (const std::runtime_error& ex) {
+            std::cout << ex.what() << "; ignoring it." << std::endl;
         }
     }
 }

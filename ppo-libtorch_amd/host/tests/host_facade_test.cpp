@@ -13,6 +13,7 @@
 
 #include "../PPO/PPO_Discrete.h"
 #include "../PPO/PPO_MultiDiscrete.h"
+#include "../Utils/TorchArchive.h"
 
 #define REQUIRE(cond)                                                                 \
     do {                                                                              \
@@ -38,6 +39,7 @@ static std::vector<std::string> bars(const std::string& line) {
 int main(int argc, char** argv) {
     namespace fs = std::filesystem;
     const std::string golden = argc > 1 ? fs::absolute(argv[1]).string() : "";
+    const std::string keep = argc > 2 ? fs::absolute(argv[2]).string() : "";   // where the final checkpoint pair of the training run below is left for the caller
     const fs::path scratch = fs::temp_directory_path() / "ppo_host_facade_test";
     fs::remove_all(scratch);
     fs::create_directories(scratch);
@@ -107,10 +109,28 @@ int main(int argc, char** argv) {
         REQUIRE(fs::exists("./Models/PPO_Agent_32768_steps.pt") && fs::exists("./ModelCheckpoints/PPO_Agent_16384_steps.pt") &&
                 fs::exists("./OptimizerCheckpoints/PPO_Optimizer_32768_steps.pt"));
         REQUIRE(!algo.m_episode_stats->empty() && algo.m_episode_stats->avgLength() > 8.0);
+        if (!keep.empty()) {   // tests/test_host_facade.py hands these to the compiled reference's own torch::load calls
+            fs::create_directories(keep);
+            fs::copy_file("./Models/PPO_Agent_32768_steps.pt", keep + "/PPO_Agent_32768_steps.pt", fs::copy_options::overwrite_existing);
+            fs::copy_file("./Models/PPO_Optimizer_32768_steps.pt", keep + "/PPO_Optimizer_32768_steps.pt", fs::copy_options::overwrite_existing);
+        }
     }
     {
         PPO_Discrete resumed;   // picks up the newest checkpoint (mtime) and its step count from the file name
         REQUIRE(resumed.m_global_step == 32768);
+        // ... and holds what the files hold: parameters, AdamW moments, step count (8 updates x 4 epochs x 4 minibatches)
+        const ppo::pt::AgentFile fa = ppo::pt::readAgent("./ModelCheckpoints/PPO_Agent_32768_steps.pt");
+        const ppo::pt::OptimizerFile fo = ppo::pt::readOptimizer("./OptimizerCheckpoints/PPO_Optimizer_32768_steps.pt");
+        const int64_t P = ppo_param_count(resumed.m_ctx);
+        std::vector<float> p((size_t)P), m((size_t)P), v((size_t)P), want_p, want_m;
+        int64_t step = 0;
+        REQUIRE(ppo_params_get_h(resumed.m_ctx, p.data(), P) == PPO_OK && ppo_optimizer_get_h(resumed.m_ctx, m.data(), v.data(), P, &step) == PPO_OK);
+        for (const auto& t : fa.tensors) want_p.insert(want_p.end(), t.values.begin(), t.values.end());
+        for (const auto& t : fo.exp_avg) want_m.insert(want_m.end(), t.values.begin(), t.values.end());
+        REQUIRE(fa.tensors.size() == 12 && fa.tensors[0].name == "m_Critic.criticInputLayer.weight" && fa.tensors[11].name == "m_Actor.actorOutputLayer.bias");
+        REQUIRE(want_p.size() == (size_t)P && std::memcmp(want_p.data(), p.data(), (size_t)P * 4) == 0);
+        REQUIRE(want_m.size() == (size_t)P && std::memcmp(want_m.data(), m.data(), (size_t)P * 4) == 0);
+        REQUIRE(step == 8 * 4 * 4 && fo.step.size() == 12 && fo.step[0] == step && fo.eps == (double)1e-5f);
     }
     fs::remove_all("./ModelCheckpoints"); fs::remove_all("./OptimizerCheckpoints");
     writeConfig("[environment]\nobs_size = 2\naction_size = 3\nmax_episode_steps = 200\n[general]\nseed = 1\ntotal_timesteps = 8192\ncheckpoint_updates = 100\n"
@@ -144,11 +164,11 @@ int main(int argc, char** argv) {
         pool.stop();
     }
     // ---- use_cuda = false (the reference's shipped CartPoleRecommendedSettings.toml): a warning, not an exception; a checkpoint directory whose
-    //      newest file is not ours (e.g. a LibTorch .pt written by the reference): reported and ignored, the agent starts fresh
+    //      newest file is no readable archive (cut short; another program's): reported with the reason and ignored, the agent starts fresh
     fs::remove_all("./ModelCheckpoints"); fs::remove_all("./OptimizerCheckpoints"); fs::remove_all("./Models");
     fs::create_directories("./ModelCheckpoints"); fs::create_directories("./OptimizerCheckpoints");
-    std::ofstream("./ModelCheckpoints/PPO_Agent_4242_steps.pt") << "PK\x03\x04 not our format";
-    std::ofstream("./OptimizerCheckpoints/PPO_Optimizer_4242_steps.pt") << "PK\x03\x04 not our format";
+    std::ofstream("./ModelCheckpoints/PPO_Agent_4242_steps.pt") << "PK\x03\x04 the start of an archive and nothing else";
+    std::ofstream("./OptimizerCheckpoints/PPO_Optimizer_4242_steps.pt") << "PPOHIP01 some other program's file";
     writeConfig("[environment]\nobs_size = 4\naction_size = 2\n[general]\nseed = 2\ntotal_timesteps = 2560\nuse_cuda = false\n"
                 "[ppo]\nnum_envs = 8\nnum_steps = 32\nupdate_epochs = 10\n");
     {
@@ -157,7 +177,8 @@ int main(int argc, char** argv) {
         PPO_Discrete algo;
         std::cout.rdbuf(old);
         REQUIRE(captured.str().find("use_cuda = false requested") != std::string::npos);
-        REQUIRE(captured.str().find("is not in this build's format") != std::string::npos);
+        REQUIRE(captured.str().find("PPO_Agent_4242_steps.pt: has no ZIP end-of-central-directory record (truncated?); ignoring it.") != std::string::npos);
+        REQUIRE(captured.str().find("PPO_Optimizer_4242_steps.pt: has no ZIP end-of-central-directory record (truncated?); ignoring it.") != std::string::npos);
         REQUIRE(algo.m_global_step == 0 && algo.m_batch_size == 256);
         // ---- the console table (PPO_Discrete.cpp:700-774) against the reference's own printout of the same four calls (tests/golden/console_table.txt,
         //      written by oracle/ref_harness hostgold): byte for byte, manipulator state carried from call to call as in train()
@@ -358,6 +379,58 @@ int main(int argc, char** argv) {
         std::string listing;
         for (auto& n : names) listing += n + "\n";
         if (listing != sec["phase1 files"]) { std::fprintf(stderr, "files differ:\n%s--- want\n%s", listing.c_str(), sec["phase1 files"].c_str()); return 1; }
+        fs::current_path(scratch);
+    }
+    // ---- resume from files the REFERENCE wrote (tests/golden/ref_*_agent.pt / ref_*_optimizer.pt: what its train() left under ./Models/, copied
+    //      out by oracle/ref_harness ptgold): the constructor picks them up from the checkpoint directories, the context then holds exactly the
+    //      reference's parameters and AdamW state, and training goes on from the step count in the file name
+    for (int which = 0; which < 2 && !golden.empty(); which++) {
+        const std::string tag = which == 0 ? "discrete" : "multidiscrete";
+        const fs::path dir = scratch / ("resume_ref_" + tag);
+        fs::create_directories(dir / "ModelCheckpoints"); fs::create_directories(dir / "OptimizerCheckpoints");
+        fs::current_path(dir);
+        const int64_t steps_done = which == 0 ? 384 : 256;
+        fs::copy_file(golden + "/ref_" + tag + "_agent.pt", "ModelCheckpoints/PPO_Agent_" + std::to_string(steps_done) + "_steps.pt");
+        fs::copy_file(golden + "/ref_" + tag + "_optimizer.pt", "OptimizerCheckpoints/PPO_Optimizer_" + std::to_string(steps_done) + "_steps.pt");
+        std::ofstream("PPOConfig.toml", std::ios::binary)
+            << (which == 0 ? "[environment]\nobs_size = 4\naction_size = 2\nmax_episode_steps = 500\n[general]\nseed = 5\ntotal_timesteps = 640\ncheckpoint_updates = 100\n"
+                             "[ppo]\nlearning_rate = 0.001\nnum_envs = 8\nnum_steps = 16\nanneal_lr = false\nnum_minibatches = 2\nupdate_epochs = 2\n"
+                           : "[environment]\nobs_size = 2\naction_size = 3\naction_high = 1.0\naction_low = -1.0\nmax_episode_steps = 50\n[general]\nseed = 9\n"
+                             "total_timesteps = 512\ncheckpoint_updates = 100\n[ppo]\nlearning_rate = 0.0005\nnum_envs = 4\nnum_steps = 32\nnum_minibatches = 4\nupdate_epochs = 1\n");
+        const ppo::pt::AgentFile fa = ppo::pt::readAgent(golden + "/ref_" + tag + "_agent.pt");
+        const ppo::pt::OptimizerFile fo = ppo::pt::readOptimizer(golden + "/ref_" + tag + "_optimizer.pt");
+        std::vector<float> want_p, want_m, want_v;
+        for (const auto& t : fa.tensors) want_p.insert(want_p.end(), t.values.begin(), t.values.end());
+        for (const auto& t : fo.exp_avg) want_m.insert(want_m.end(), t.values.begin(), t.values.end());
+        for (const auto& t : fo.exp_avg_sq) want_v.insert(want_v.end(), t.values.begin(), t.values.end());
+        std::stringstream cap;
+        std::streambuf* old = std::cout.rdbuf(cap.rdbuf());
+        std::unique_ptr<PPOAlgorithm> algo;
+        if (which == 0) algo = std::make_unique<PPO_Discrete>(); else algo = std::make_unique<PPO_MultiDiscrete>();
+        std::cout.rdbuf(old);
+        REQUIRE(cap.str().find("Loading model ./ModelCheckpoints/PPO_Agent_" + std::to_string(steps_done) + "_steps.pt...") != std::string::npos);
+        REQUIRE(cap.str().find("Continuing training from step " + std::to_string(steps_done)) != std::string::npos);
+        REQUIRE(cap.str().find("ignoring it") == std::string::npos);
+        REQUIRE(algo->m_global_step == (uint64_t)steps_done);
+        const int64_t P = ppo_param_count(algo->m_ctx);
+        std::vector<float> p((size_t)P), m((size_t)P), v((size_t)P);
+        int64_t step = 0;
+        REQUIRE(ppo_params_get_h(algo->m_ctx, p.data(), P) == PPO_OK && ppo_optimizer_get_h(algo->m_ctx, m.data(), v.data(), P, &step) == PPO_OK);
+        REQUIRE(want_p.size() == (size_t)P && std::memcmp(want_p.data(), p.data(), (size_t)P * 4) == 0);
+        REQUIRE(std::memcmp(want_m.data(), m.data(), (size_t)P * 4) == 0 && std::memcmp(want_v.data(), v.data(), (size_t)P * 4) == 0);
+        REQUIRE(step == fo.step[0] && step > 0);
+        ppo_stats st{};
+        REQUIRE(ppo_read_stats(algo->m_ctx, &st) == PPO_OK && st.learning_rate == fo.lr);   // torch::load(optimizer) brings the saved rate back (:834)
+        old = std::cout.rdbuf(cap.rdbuf());
+        algo->train();   // the remaining (total_timesteps - steps_done) / batch_size updates (:496)
+        std::cout.rdbuf(old);
+        const int64_t batch = which == 0 ? 128 : 128, updates = ((which == 0 ? 640 : 512) - steps_done) / batch;
+        REQUIRE(algo->m_global_step == (uint64_t)(steps_done + updates * batch));
+        REQUIRE(ppo_optimizer_get_h(algo->m_ctx, m.data(), v.data(), P, &step) == PPO_OK && step == fo.step[0] + updates * (which == 0 ? 4 : 4));
+        REQUIRE(ppo_params_get_h(algo->m_ctx, p.data(), P) == PPO_OK);
+        bool finite = true, moved = false;
+        for (int64_t i = 0; i < P; i++) { finite = finite && std::isfinite(p[(size_t)i]); moved = moved || p[(size_t)i] != want_p[(size_t)i]; }
+        REQUIRE(finite && moved);
         fs::current_path(scratch);
     }
     std::printf("HOST_FACADE_OK\n");

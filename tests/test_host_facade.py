@@ -38,12 +38,30 @@ def test_host_sources_keep_the_reference_api_surface():
 
 
 @pytest.mark.gpu
-def test_host_facade_on_gpu():
+def test_host_facade_on_gpu(tmp_path):
     exe = os.path.join(HOST, "host_facade_test")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-j", "4", "-C", HOST])
     # the fixtures the compiled reference wrote (oracle/ref_harness hostgold): its console table for four crafted calls, its PPOUtils answers
-    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden"), str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "HOST_FACADE_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    # the checkpoint pair its train() run on the GPU left under ./Models/, through the compiled REFERENCE's own torch::load(m_agent, ...) /
+    # torch::load(*m_optimizer, ...) (oracle/ref_harness ptload): the reference ends up holding exactly the values this build saved
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    tool = os.path.join(HOST, "torch_archive_tool")
+    if os.path.exists(ref):
+        import sys
+        import numpy as np
+        sys.path.insert(0, ROOT)
+        import oracle as O
+        a, o = str(tmp_path / "PPO_Agent_32768_steps.pt"), str(tmp_path / "PPO_Optimizer_32768_steps.pt")
+        lr = subprocess.run([ref, "ptload", a, o, "4", "2", str(tmp_path / "loaded.pgld")], capture_output=True, text=True, timeout=120)
+        assert lr.returncode == 0, lr.stderr[-2000:]
+        got = O.read_pgld(str(tmp_path / "loaded.pgld"))
+        saved = np.array([int(w, 16) for line in subprocess.run([tool, "dump-agent", a], capture_output=True, text=True, check=True).stdout.splitlines()
+                          for w in line.split()[3:]], dtype=np.uint32)
+        assert saved.size == 9155 and np.array_equal(got["params"].view(np.uint32), saved)
+        assert list(got["steps"]) == [128] * 12 and got["eps"][0] == float(np.float32(1e-5))
+        assert np.isfinite(got["exp_avg"]).all() and (got["exp_avg_sq"] >= 0).all() and np.abs(got["exp_avg"]).max() > 0
     # the SB3-style table of the reference's printPPOResults
     assert "ep_len_mean" in r.stdout and "policy_gradient_loss" in r.stdout and "explained_variance" in r.stdout
