@@ -103,6 +103,9 @@ struct ppo_ctx {
     NetLayout L{};
     LossParams hp{};
     hipStream_t stream = nullptr;
+    // generic networks in bf16 storage: the critic's forward and backward passes of a minibatch step run on a second stream beside the actor's
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     int T = 0, N = 0, O = 0, H = 0, A = 0;
     int64_t B = 0, MB = 0;
@@ -345,6 +348,9 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->adam_coefs_h) (void)hipHostFree(c->adam_coefs_h);
     for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -492,10 +498,12 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
                 for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts_bf[net][l], RB * g.ld_h));
             for (int i = 0; i < 2; i++) {
                 CK(dalloc(c, &g.tmp_bf[i], RB * g.ld_h));
-                CK(dalloc(c, &g.dz_bf[i], RB * g.ld_h));
+                CK(dalloc(c, &g.dz_bf[0][i], RB * g.ld_h));
+                CK(dalloc(c, &g.dz_bf[1][i], RB * g.ld_h));
                 CK(dalloc(c, &g.dout_bf[i], RB * 128));
             }
-            CK(dalloc(c, &g.cs_part, (R / 128 + 1) * g.ld_h));
+            CK(dalloc(c, &g.cs_part[0], (R / 128 + 1) * g.ld_h));
+            CK(dalloc(c, &g.cs_part[1], (R / 128 + 1) * g.ld_h));
             CK(dalloc(c, &g.head_db_part, (size_t)GEN_LOSS_BLOCKS * (GL.act + 1)));
         } else {
             for (int net = 0; net < 2; net++)
@@ -517,6 +525,12 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             for (int l = 0; l < GL.n_layers; l++) mx = std::max<int64_t>(mx, (int64_t)std::max(GL.out_dim[0][l], GL.out_dim[1][l]) * (GL.in_dim[l] + 1));
             g.wslab_stride = (mx + 3) & ~3ll;
             CK(dalloc(c, &g.wslab, (size_t)(GEN_SPLIT_MFMA + 1) * g.wslab_stride));
+            if (g.bf16) {
+                CK(dalloc(c, &g.wslab1, (size_t)(GEN_SPLIT_MFMA + 1) * g.wslab_stride));
+                CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
             CK(dalloc(c, &g.db_part, (size_t)GEN_DB_CHUNKS * std::max(GL.hidden, GL.act)));
         }
         {   // bf16 planes of every layer's weights, padded to tile multiples (kernels_gemm.hip: PlaneStage)
@@ -1071,16 +1085,25 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         ProfScope ps(c, PROF_FWD_BWD);
         HIPCHK(c, gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
                              B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), idx, M, g, c->stream));
-        if (gen_fused_forward_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage, small minibatch: each net's forward pass is one launch that also leaves its hidden activations
+        const bool two = g.bf16 && c->stream2 != nullptr;   // the critic's passes on their own stream: a kernel of one net fills the CUs the other net's kernel is draining
+        auto fork = [&]() -> hipError_t { const hipError_t e = hipEventRecord(c->ev_fork, c->stream); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream2, c->ev_fork, 0); };
+        auto join = [&]() -> hipError_t { const hipError_t e = hipEventRecord(c->ev_join, c->stream2); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->ev_join, 0); };
+        hipStream_t s0 = two ? c->stream2 : c->stream;
+        if (two && g.planes_dirty) { HIPCHK(c, gen_weight_planes(g, params, c->stream)); g.planes_dirty = false; }   // shared by both nets: before the fork
+        if (two) HIPCHK(c, fork());
+        if (gen_fused_forward_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage: each net's forward pass is one launch that also leaves its hidden activations
             HIPCHK(c, gen_fused_forward(g, params, 1, nullptr, g.xin_bf, g.ld_in0, M, true, g.logits, c->stream));
-            HIPCHK(c, gen_fused_forward(g, params, 0, nullptr, g.xin_bf, g.ld_in0, M, true, g.val, c->stream));
+            HIPCHK(c, gen_fused_forward(g, params, 0, nullptr, g.xin_bf, g.ld_in0, M, true, g.val, s0));
         } else {
             HIPCHK(c, gen_forward(g, params, 1, g.xin, M, g.acts[1], nullptr, nullptr, g.logits, c->stream));
-            HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, c->stream));
+            HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, s0));
         }
+        if (two) HIPCHK(c, join());   // the loss reads the logits and the values
         HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
+        if (two) HIPCHK(c, fork());
         HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream));
-        HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, c->stream));
+        HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, s0));
+        if (two) HIPCHK(c, join());   // the flat gradient is complete
     }
     {
         ProfScope ps(c, PROF_REDUCE);

@@ -500,11 +500,12 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
         // d(pre-activation) is produced (the tanh' epilogue of the layer above), per 128-row tile
         const uint16_t* d = g.dout_bf[net];
         int64_t ldd = 128;
+        float* wslab = net == 1 ? g.wslab1 : g.wslab;   // every scratch buffer of this pass belongs to the net: the other net's pass may be running
         if (rows % 64) {   // the contraction over rows runs in pairs of 32-row chunks: rows past the minibatch must contribute zeros
             const int64_t tail = 64 - rows % 64;
             for (int i = 0; i < 2; i++) {
-                if (hipMemsetAsync(g.dz_bf[i] + rows * g.ld_h, 0, (size_t)tail * g.ld_h * 2, s) != hipSuccess) return hipErrorUnknown;
-                if (hipMemsetAsync(g.dout_bf[i] + rows * 128, 0, (size_t)tail * 128 * 2, s) != hipSuccess) return hipErrorUnknown;
+                if (hipMemsetAsync(g.dz_bf[net][i] + rows * g.ld_h, 0, (size_t)tail * g.ld_h * 2, s) != hipSuccess) return hipErrorUnknown;
+                if (i == net && hipMemsetAsync(g.dout_bf[i] + rows * 128, 0, (size_t)tail * 128 * 2, s) != hipSuccess) return hipErrorUnknown;
             }
         }
         for (int l = L.n_layers - 1; l >= 0; l--) {
@@ -514,18 +515,18 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
             const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
             const int64_t n_w = (int64_t)N * K;
             const int S = ranges(N, K);
-            hipError_t e = launch_matmul_bf16(true, true, N, K, rows, d, ldd, in, ldi, g.wslab, K, false, PPO_MM_EPI_NONE, nullptr, 0, S, g.wslab_stride, nullptr, 0, s);
+            hipError_t e = launch_matmul_bf16(true, true, N, K, rows, d, ldd, in, ldi, wslab, K, false, PPO_MM_EPI_NONE, nullptr, 0, S, g.wslab_stride, nullptr, 0, s);
             if (e != hipSuccess) return e;
-            const float* dbp = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part;
+            const float* dbp = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part[net];
             const int dbc = head ? GEN_LOSS_BLOCKS : (int)((rows + 127) / 128);
             const int64_t dbs = head ? L.act + 1 : g.ld_h;
-            hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, g.wslab, g.wslab_stride, S, n_w, dbp, dbc, dbs, (int64_t)N,
+            hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, wslab, g.wslab_stride, S, n_w, dbp, dbc, dbs, (int64_t)N,
                                grads + L.w_off[net][l], grads + L.b_off[net][l]);
             if (l > 0) {
-                uint16_t* nd = g.dz_bf[l & 1];
+                uint16_t* nd = g.dz_bf[net][l & 1];
                 // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2), stored bf16; its column sums per 128-row tile -> cs_part
                 e = launch_matmul_bf16(false, true, rows, K, N, d, ldd, g.wplanes + g.wp_off[net][l], g.wp_kpad[l], nd, g.ld_h, true, PPO_MM_EPI_DTANH,
-                                       g.acts_bf[net][l - 1], g.ld_h, 1, 0, g.cs_part, g.ld_h, s);
+                                       g.acts_bf[net][l - 1], g.ld_h, 1, 0, g.cs_part[net], g.ld_h, s);
                 if (e != hipSuccess) return e;
                 d = nd; ldd = g.ld_h;
             }
