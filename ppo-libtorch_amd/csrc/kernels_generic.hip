@@ -198,6 +198,157 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
         head_db_part[blockIdx.x * (L.act + 1) + threadIdx.x] = ((sdb[0][threadIdx.x] + sdb[1][threadIdx.x]) + sdb[2][threadIdx.x]) + sdb[3][threadIdx.x];
 }
 
+// The same loss for bf16 storage with every per-row array in REGISTERS: loss_kernel indexes z / p / dbs with run-time head offsets, which sends
+// them to scratch memory (416 B per thread; 41 us for 65 536 rows).  Here the loops over heads (NH) and logits (AM) have compile-time bounds and a
+// logit takes part in a head's pass when `off <= k < off + A` -- wave-uniform predicates.  Same operations in the same order per row as
+// categorical_head_fast + loss_kernel, so both give the same bits.
+template <int DIST, int NH, int AM>
+__global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams hp, const float* __restrict__ logits, const float* __restrict__ val,
+                                                       const int32_t* __restrict__ row_act, const uint8_t* __restrict__ row_mask,
+                                                       const float* __restrict__ oldlp, const float* __restrict__ advs, const float* __restrict__ rets,
+                                                       const float* __restrict__ oldv, int64_t M, float invM, const float* __restrict__ stat2,
+                                                       double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf, float* head_db_part) {
+    __shared__ double red[5][4];
+    __shared__ float sdb[4][AM + 1];
+    float dbs[AM + 1];
+#pragma unroll
+    for (int k = 0; k <= AM; k++) dbs[k] = 0.0f;
+    double s[5] = { 0, 0, 0, 0, 0 };
+    const float mean_f = stat2[0], inv_std = stat2[1];
+    const float clip = hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip;
+    const int act = L.act, n_heads = L.n_heads;
+    const bool masked = DIST == PPO_DIST_MASKED && row_mask != nullptr;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < M; r += (int64_t)gridDim.x * 256) {
+        float z[AM], p[AM];
+        bool ok[AM];
+#pragma unroll
+        for (int k = 0; k < AM; k++) {
+            z[k] = k < act ? logits[r * act + k] : 0.0f;
+            ok[k] = !masked || (k < act && row_mask[r * act + k] != 0);
+            if (masked && !ok[k]) z[k] = -1e8f;
+            p[k] = 0.0f;
+        }
+        float nlp = 0.0f, ent = 0.0f, headH[NH];
+        int off = 0;
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            headH[h] = 0.0f;
+            if (h < n_heads) {
+                const int A = L.head_dims[h];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < AM; k++) if (k >= off && k < off + A) mx = z[k] > mx ? z[k] : mx;
+                float se = 0.0f;
+#pragma unroll
+                for (int k = 0; k < AM; k++) if (k >= off && k < off + A) { p[k] = fast_exp(z[k] - mx); se += p[k]; }
+                const float lse = fast_log(se) + mx;
+                const float rse = __builtin_amdgcn_rcpf(se);
+                const int a = row_act[r * n_heads + h];
+                float e = 0.0f, lp = 0.0f;
+#pragma unroll
+                for (int k = 0; k < AM; k++) if (k >= off && k < off + A) {
+                    z[k] = z[k] - lse;
+                    p[k] = p[k] * rse;
+                    if (DIST == PPO_DIST_CATEGORICAL) {
+                        const float l = z[k] > 1.17549435e-38f ? z[k] : 1.17549435e-38f;
+                        e += l * p[k];
+                    } else {
+                        const float plp = z[k] * p[k];
+                        e += ok[k] ? plp : 0.0f;
+                    }
+                    if (k - off == a) lp = z[k];
+                }
+                headH[h] = -e;
+                if (h == 0) { nlp = lp; ent = headH[h]; } else { nlp += lp; ent += headH[h]; }
+                off += A;
+            }
+        }
+        const float logratio = nlp - oldlp[r];
+        const float ratio = fast_exp(logratio);
+        float adv = advs[r];
+        if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
+        const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
+        const float l1 = -adv * ratio, l2 = -adv * rc;
+        const bool inside = (ratio >= lo && ratio <= hi_c);
+        float d_ratio;
+        if (l1 > l2) d_ratio = -adv;
+        else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+        else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half/half
+        const float g_nlp = invM * d_ratio * ratio;
+        const float g_ent = -hp.ent_coef * invM;
+        uint32_t drow[AM];   // the row's head gradients as bf16 bit patterns (zero beyond the policy's width)
+#pragma unroll
+        for (int k = 0; k < AM; k++) drow[k] = 0u;
+        off = 0;
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            if (h < n_heads) {
+                const int A = L.head_dims[h];
+                const int a = row_act[r * n_heads + h];
+#pragma unroll
+                for (int k = 0; k < AM; k++) if (k >= off && k < off + A) {
+                    float d = g_nlp * ((k - off == a ? 1.0f : 0.0f) - p[k]);
+                    if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[k] * (z[k] + headH[h]));
+                    d = ok[k] ? d : 0.0f;
+                    const __bf16 b = (__bf16)d;
+                    drow[k] = (uint32_t)__builtin_bit_cast(uint16_t, b);
+                    dbs[k] += d;
+                }
+                off += A;
+            }
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < AM / 8; c8++) {
+            if (8 * c8 < act)
+                *reinterpret_cast<uint4*>(dlogits_bf + r * 128 + 8 * c8) = make_uint4(drow[8 * c8] | (drow[8 * c8 + 1] << 16), drow[8 * c8 + 2] | (drow[8 * c8 + 3] << 16),
+                                                                                     drow[8 * c8 + 4] | (drow[8 * c8 + 5] << 16), drow[8 * c8 + 6] | (drow[8 * c8 + 7] << 16));
+        }
+        s[0] += (double)(l1 > l2 ? l1 : l2);
+        s[1] += (double)ent;
+        s[2] += (double)((ratio - 1.0f) - logratio);
+        s[3] += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
+        // value loss (:603-625)
+        const float v = val[r], R = rets[r], vold = oldv[r];
+        const float un = (v - R) * (v - R);
+        float g_v, lossv;
+        if (hp.clip_vloss) {
+            const float dv = v - vold;
+            const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+            const float vc = vold + dvc;
+            const float cl = (vc - R) * (vc - R);
+            lossv = un > cl ? un : cl;
+            const bool vin = (dv >= -clip && dv <= clip);
+            const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+            const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);
+            g_v = hp.vf_coef * 0.5f * invM * d;
+        } else {
+            lossv = un;
+            g_v = hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+        }
+        const __bf16 bv = (__bf16)g_v;
+        *reinterpret_cast<uint4*>(dval_bf + r * 128) = make_uint4((uint32_t)__builtin_bit_cast(uint16_t, bv), 0u, 0u, 0u);
+        dbs[AM] += g_v;
+        s[4] += (double)lossv;
+    }
+#pragma unroll
+    for (int k = 0; k <= AM; k++) {
+        if (k < act || k == AM) {
+            const float t = wave_sum(dbs[k]);
+            if ((threadIdx.x & 63) == 0) sdb[threadIdx.x >> 6][k] = t;
+        }
+    }
+    for (int k = 0; k < 5; k++) {
+        const double t = wave_sum_d_dpp(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) loss_part[blockIdx.x * 8 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+    if ((int)threadIdx.x <= act) {   // head_db_part[block][0 .. act - 1] = d(logits) column sums, [act] = the d(value) sum
+        const int k = (int)threadIdx.x < act ? (int)threadIdx.x : AM;
+        head_db_part[blockIdx.x * (act + 1) + threadIdx.x] = ((sdb[0][k] + sdb[1][k]) + sdb[2][k]) + sdb[3][k];
+    }
+}
+
 __global__ __launch_bounds__(256) void loss_sums_kernel(const double* __restrict__ loss_part, int blocks, double* sums_out, float* grads_tail) {
     __shared__ double red[5][4];
     for (int k = 0; k < 5; k++) {
@@ -464,6 +615,17 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
                     const AdvStat* adv_stat, hipStream_t s) {
     hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(1), 0, s, adv_stat, global_M, (adv_stat && hp.norm_adv) ? 1 : 0, g.row_f[4]);
     const dim3 grid(GEN_LOSS_BLOCKS), block(256);
+    if (g.bf16) {   // bf16 storage: per-row arrays in registers, bounds 4 heads x 16 logits or the ABI's maximum
+        const uint8_t* mask = hp.dist_kind == PPO_DIST_MASKED ? g.row_mask : nullptr;
+#define GEN_LOSS_REG(DIST, NH, AM)                                                                                                                     \
+        hipLaunchKernelGGL((loss_reg_kernel<DIST, NH, AM>), grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, mask, g.row_f[0], g.row_f[1], g.row_f[2], \
+                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.loss_part, g.dout_bf[1], g.dout_bf[0], g.head_db_part)
+        const bool small = L.n_heads <= 4 && L.act <= 16;
+        if (hp.dist_kind == PPO_DIST_MASKED) { if (small) GEN_LOSS_REG(PPO_DIST_MASKED, 4, 16); else GEN_LOSS_REG(PPO_DIST_MASKED, PPO_MAX_HEADS, PPO_MAX_ACT); }
+        else { if (small) GEN_LOSS_REG(PPO_DIST_CATEGORICAL, 4, 16); else GEN_LOSS_REG(PPO_DIST_CATEGORICAL, PPO_MAX_HEADS, PPO_MAX_ACT); }
+#undef GEN_LOSS_REG
+        return hipGetLastError();
+    }
     if (hp.dist_kind == PPO_DIST_MASKED)
         hipLaunchKernelGGL(loss_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2],
                            g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part, g.bf16 ? g.dout_bf[1] : nullptr,

@@ -166,6 +166,12 @@ def test_bf16_ragged_shapes(P):
     _check_shape(P, obs_dim=20, hidden=48, n_hidden=2, heads=(2, 3), N=48, T=10, nmb=2, masked=True, seed=13, dtype=1)
 
 
+@pytest.mark.parametrize("masked", [True, False])
+def test_bf16_many_heads(P, masked):
+    """bf16 storage beyond four heads / sixteen logits: the loss kernel's second register layout (eight heads, 32 logits -- the ABI's maximum)."""
+    _check_shape(P, obs_dim=24, hidden=64, n_hidden=2, heads=(5, 3, 4, 2, 3, 3), N=64, T=12, nmb=2, masked=masked, seed=21, dtype=1)
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 def test_config4_per_gpu_size_runs(P, dtype):
     """configs[4] per-GPU share (16 384 envs / 8 GPUs = 2048 envs x 128 steps, 4 minibatches): two whole iterations, f32 and bf16."""
