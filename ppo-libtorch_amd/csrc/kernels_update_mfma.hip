@@ -930,31 +930,25 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
     __syncthreads();
     const int64_t n = n0 + n1;
     const int64_t n_tiles = (n + MT - 1) / MT;
-    // the observation row of a tile is requested one tile ahead (unconditional loads: a missing row reads row 0 and is zeroed at use)
+    // the observation row of a tile is requested one tile ahead (unconditional loads: a missing row reads row 0 and is zeroed at use).  A lane
+    // loads only what it feeds to layer 1 -- elements hi, 2 + hi, ... of its sample's row, the B operand of k step stp -- so nothing is selected
+    // per lane afterwards (a select between array elements by `hi` sends the array to scratch memory)
     auto load_x = [&](int64_t tl, float* xo) {
         const int64_t r = tl * MT + s;
         const bool ok = r < n;
         const float* src = !ok ? obs0 : (r < n0 ? obs0 + r * OBS : obs1 + (r - n0) * OBS);
-        if constexpr (OBS == 4) {
-            const float4 v = *reinterpret_cast<const float4*>(src);
-            xo[0] = v.x; xo[1] = v.y; xo[2] = v.z; xo[3] = v.w;
-        } else if constexpr (OBS == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(src);
-            xo[0] = v.x; xo[1] = v.y;
-        } else {
 #pragma unroll
-            for (int o = 0; o < OBS; o++) xo[o] = src[o];
-        }
+        for (int stp = 0; stp < L1S; stp++) xo[stp] = src[(2 * stp + 1 < OBS) ? 2 * stp + hi : 2 * stp];   // odd OBS: the last step's upper half is zeroed at use
     };
     const int64_t tile_step = (int64_t)gridDim.x * 4;
-    float x_n[OBS];
+    float x_n[L1S];
     load_x((int64_t)blockIdx.x * 4 + wave, x_n);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += tile_step) {
         const int64_t row = tile * MT + s;
         const bool valid = row < n;
-        float x[OBS];
+        float xb[L1S];
 #pragma unroll
-        for (int o = 0; o < OBS; o++) x[o] = valid ? x_n[o] : 0.0f;
+        for (int stp = 0; stp < L1S; stp++) xb[stp] = (valid && (2 * stp + 1 < OBS || hi == 0)) ? x_n[stp] : 0.0f;
         load_x(tile + tile_step, x_n);
         float h1[32];
 #pragma unroll
@@ -967,8 +961,7 @@ __global__ __launch_bounds__(256, 2) void values_mfma_kernel(const float* __rest
             }
 #pragma unroll
             for (int stp = 0; stp < L1S; stp++) {
-                const float xb = (2 * stp + 1 < OBS) ? (hi ? x[2 * stp + 1] : x[2 * stp]) : (hi ? 0.0f : x[2 * stp]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1op[t][stp], xb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1op[t][stp], xb[stp], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_scaled(acc[r]);
