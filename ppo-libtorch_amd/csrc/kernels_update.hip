@@ -931,17 +931,24 @@ __global__ void local_allreduce_kernel(PtrPack8 pk, int n, size_t count) {
 //   result:   buf = the sum, formed in the same order on every rank.
 // A timeout leaves the sum incomplete and counts itself in timeout_flag: the kernel always ends.
 struct XchgPtrs8 { void* p[8]; };
+// The grid is bounded (launch_exchange_allreduce: at most XCHG_MAX_BLOCKS workgroups, each walking the buffer in strides): every workgroup
+// waits for flags that a peer stamps only when ITS last workgroup has arrived, so all workgroups of a rank must be resident at once --
+// a grid sized by the element count (1 800 workgroups for configs[4]'s 460 k gradient floats) can exceed what the chip holds and then
+// waits for workgroups that cannot start.
+constexpr int XCHG_MAX_BLOCKS = 256;
 template <class Tp>
 __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict__ buf, size_t count, XchgPtrs8 peers, int rank, int n, size_t slot_bytes,
                                                                  unsigned long long seq, int32_t* timeout_flag) {
     __shared__ unsigned s_okm;
     const int parity = (int)(seq & 1ull);
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const Tp mine = i < count ? buf[i] : Tp(0);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const Tp mine = buf[i];
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-        if (r < n && r != rank && i < count)
-            __hip_atomic_store(reinterpret_cast<Tp*>(xchg_slot(peers.p[r], slot_bytes, parity, rank)) + i, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 0; r < 8; r++)
+            if (r < n && r != rank)
+                __hip_atomic_store(reinterpret_cast<Tp*>(xchg_slot(peers.p[r], slot_bytes, parity, rank)) + i, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: this thread's stores have landed before the workgroup is counted in
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -951,17 +958,20 @@ __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict_
     }
     __syncthreads();
     const unsigned okm = s_okm;
-    Tp v[8];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+        const Tp mine = buf[i];
+        Tp v[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {   // all peers' elements requested together ...
-        v[r] = Tp(0);
-        if (r < n && r != rank && ((okm >> r) & 1u) && i < count)
-            v[r] = __hip_atomic_load(reinterpret_cast<const Tp*>(xchg_slot(peers.p[rank], slot_bytes, parity, r)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 0; r < 8; r++) {   // all peers' elements requested together ...
+            v[r] = Tp(0);
+            if (r < n && r != rank && ((okm >> r) & 1u))
+                v[r] = __hip_atomic_load(reinterpret_cast<const Tp*>(xchg_slot(peers.p[rank], slot_bytes, parity, r)) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        Tp acc = Tp(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) if (r < n) acc += r == rank ? mine : v[r];   // ... added in rank order
+        buf[i] = acc;
     }
-    Tp acc = Tp(0);
-#pragma unroll
-    for (int r = 0; r < 8; r++) if (r < n) acc += r == rank ? mine : v[r];   // ... added in rank order
-    if (i < count) buf[i] = acc;
 }
 
 // K11 partial sums: per block {sum y, sum y^2, sum d, sum d^2} with y = returns, d = returns - values (float subtraction).
@@ -1107,7 +1117,8 @@ hipError_t launch_exchange_allreduce(void* buf, size_t count, bool f64, const Xc
                                      int32_t* timeout_flag, hipStream_t s) {
     XchgPtrs8 q;
     for (int i = 0; i < 8; i++) q.p[i] = peers.p[i];
-    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    const size_t blocks = (count + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 1 ? 1 : (blocks > (size_t)XCHG_MAX_BLOCKS ? (size_t)XCHG_MAX_BLOCKS : blocks))), block(256);
     if (f64) hipLaunchKernelGGL(exchange_allreduce_kernel<double>, grid, block, 0, s, static_cast<double*>(buf), count, q, rank, n, slot_bytes, (unsigned long long)seq, timeout_flag);
     else hipLaunchKernelGGL(exchange_allreduce_kernel<float>, grid, block, 0, s, static_cast<float*>(buf), count, q, rank, n, slot_bytes, (unsigned long long)seq, timeout_flag);
     return hipGetLastError();

@@ -146,3 +146,60 @@ def test_exchange_gives_up_once_when_a_peer_never_arrives(tmp_path):
     assert res["timeouts"] > 0
     assert 1.0 < res["times"][0] < 6.0, res
     assert res["times"][1] < 0.5 and res["times"][2] < 0.5, res
+
+
+GENERIC_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from __graft_entry__ import load_package
+P = load_package()
+dist, rank, world = P.dist.init_process_group("gloo")
+cfg = P.dist.shard_config(P.make_config, rank, world, 128, env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=64, head_dims=(3, 2), hidden=256,
+                          n_hidden=2, num_steps=16, num_minibatches=2, update_epochs=2, max_episode_steps=10, seed=7, total_timesteps=4 * 128 * 16,
+                          compute_dtype={dtype})
+ctx = P.Context(cfg)
+P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id, transport="exchange")
+# the transport on this network's gradient (~170 k floats: more 256-element blocks than the kernel's grid, so every workgroup strides)
+pattern = (np.arange(ctx.P) % 251).astype(np.float32)
+for rep in range(3):
+    ctx.write("GRADS", pattern * (rank + 1) * (rep + 1))
+    P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
+    assert np.array_equal(ctx.read("GRADS"), pattern * (rep + 1) * (world * (world + 1) // 2)), (rank, rep)
+ctx.init_orthogonal(3)
+ctx.env_reset()
+for _ in range(2):
+    ctx.train_iteration()
+st = ctx.stats()
+json.dump(dict(rank=rank, P=int(ctx.P), timeouts=ctx.comm_exchange_timeouts(), params=ctx.get_params().view(np.uint32).tolist(), loss=st["loss"]),
+          open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
+dist.barrier()
+ctx.close()
+"""
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_exchange_with_a_generic_network(tmp_path, dtype):
+    """The exchange under the generic path (any widths; f32 and bf16 storage, the latter with its two streams): a gradient far larger than the
+    reference's 9 155 floats, so the exchange kernel's bounded grid walks it in strides; two ranks end bit-identical with no wait run out."""
+    port = _free_port()
+    script = tmp_path / "generic.py"
+    script.write_text(GENERIC_WORKER.format(root=ROOT, out=str(tmp_path), dtype=dtype))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("worker timed out")
+        outs.append(o.decode())
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert res[0]["P"] > 256 * 256 and all(r["timeouts"] == 0 for r in res)
+    assert res[0]["params"] == res[1]["params"]
+    assert np.isfinite(np.array(res[0]["params"], np.uint32).view(np.float32)).all() and np.isfinite(res[0]["loss"])
