@@ -206,15 +206,26 @@ template <int DIST, int NH, int AM>
 __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams hp, const float* __restrict__ logits, const float* __restrict__ val,
                                                        const int32_t* __restrict__ row_act, const uint8_t* __restrict__ row_mask,
                                                        const float* __restrict__ oldlp, const float* __restrict__ advs, const float* __restrict__ rets,
-                                                       const float* __restrict__ oldv, int64_t M, float invM, const float* __restrict__ stat2,
-                                                       double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf, float* head_db_part) {
+                                                       const float* __restrict__ oldv, int64_t M, float invM, const AdvStat* __restrict__ adv_stat,
+                                                       double global_M, double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf, float* head_db_part) {
     __shared__ double red[5][4];
     __shared__ float sdb[4][AM + 1];
     float dbs[AM + 1];
 #pragma unroll
     for (int k = 0; k <= AM; k++) dbs[k] = 0.0f;
     double s[5] = { 0, 0, 0, 0, 0 };
-    const float mean_f = stat2[0], inv_std = stat2[1];
+    // mean and 1 / (Bessel std + 1e-8) of the minibatch's advantages from the PPO_ADV_PARTS partial sums (adv_finish_kernel's arithmetic, formed
+    // here by every thread from wave-uniform loads: one launch less per step); adv_stat == nullptr: no normalisation
+    float mean_f = 0.0f, std_f = 0.0f;
+    if (adv_stat) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += adv_stat[i].s1; t2 += adv_stat[i].s2; }
+        const double mean = t1 / global_M;
+        const double var = (t2 - t1 * mean) / (global_M - 1.0);
+        mean_f = (float)mean;
+        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+    }
+    const float inv_std = 1.0f / (std_f + 1e-8f);
     const float clip = hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip;
     const int act = L.act, n_heads = L.n_heads;
     const bool masked = DIST == PPO_DIST_MASKED && row_mask != nullptr;
@@ -613,19 +624,20 @@ __global__ void adv_finish_kernel(const AdvStat* adv_stat, double global_M, int 
 
 hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& g, int64_t M, double inv_global_M, double global_M,
                     const AdvStat* adv_stat, hipStream_t s) {
-    hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(1), 0, s, adv_stat, global_M, (adv_stat && hp.norm_adv) ? 1 : 0, g.row_f[4]);
     const dim3 grid(GEN_LOSS_BLOCKS), block(256);
     if (g.bf16) {   // bf16 storage: per-row arrays in registers, bounds 4 heads x 16 logits or the ABI's maximum
         const uint8_t* mask = hp.dist_kind == PPO_DIST_MASKED ? g.row_mask : nullptr;
 #define GEN_LOSS_REG(DIST, NH, AM)                                                                                                                     \
         hipLaunchKernelGGL((loss_reg_kernel<DIST, NH, AM>), grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, mask, g.row_f[0], g.row_f[1], g.row_f[2], \
-                           g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.loss_part, g.dout_bf[1], g.dout_bf[0], g.head_db_part)
+                           g.row_f[3], M, (float)inv_global_M, (adv_stat && hp.norm_adv) ? adv_stat : nullptr, global_M, g.loss_part, g.dout_bf[1], g.dout_bf[0], \
+                           g.head_db_part)
         const bool small = L.n_heads <= 4 && L.act <= 16;
         if (hp.dist_kind == PPO_DIST_MASKED) { if (small) GEN_LOSS_REG(PPO_DIST_MASKED, 4, 16); else GEN_LOSS_REG(PPO_DIST_MASKED, PPO_MAX_HEADS, PPO_MAX_ACT); }
         else { if (small) GEN_LOSS_REG(PPO_DIST_CATEGORICAL, 4, 16); else GEN_LOSS_REG(PPO_DIST_CATEGORICAL, PPO_MAX_HEADS, PPO_MAX_ACT); }
 #undef GEN_LOSS_REG
         return hipGetLastError();
     }
+    hipLaunchKernelGGL(adv_finish_kernel, dim3(1), dim3(1), 0, s, adv_stat, global_M, (adv_stat && hp.norm_adv) ? 1 : 0, g.row_f[4]);
     if (hp.dist_kind == PPO_DIST_MASKED)
         hipLaunchKernelGGL(loss_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, g.row_mask, g.row_f[0], g.row_f[1], g.row_f[2],
                            g.row_f[3], M, (float)inv_global_M, g.row_f[4], g.dlogits, g.dval, g.loss_part, g.bf16 ? g.dout_bf[1] : nullptr,
