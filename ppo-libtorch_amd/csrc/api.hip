@@ -105,7 +105,11 @@ struct ppo_ctx {
     hipStream_t stream = nullptr;
     // generic networks in bf16 storage: the critic's forward and backward passes of a minibatch step run on a second stream beside the actor's
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_gather = nullptr;
+    // ppo_update tells a minibatch step which rows the NEXT step will gather (nullptr: none): the step requests that gather on the second stream once its
+    // own backward passes are done, beside its reduction / optimizer tail; gen_pre_* = what has been gathered ahead
+    const int32_t* gen_next_idx = nullptr; int64_t gen_next_M = 0;
+    const int32_t* gen_pre_idx = nullptr; int64_t gen_pre_M = 0;
     std::string err;
     int T = 0, N = 0, O = 0, H = 0, A = 0;
     int64_t B = 0, MB = 0;
@@ -350,6 +354,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_gather) (void)hipEventDestroy(c->ev_gather);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -519,6 +524,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         CK(dalloc(c, &g.row_f[4], R + 2));
         CK(dalloc(c, &g.row_act, R * GL.n_heads));
         CK(dalloc(c, &g.row_mask, R * GL.act));
+
         CK(dalloc(c, &g.loss_part, (size_t)GEN_LOSS_BLOCKS * 8));
         {
             int64_t mx = 0;
@@ -530,6 +536,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
                 CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
                 CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
                 CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                CK(hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
             }
             CK(dalloc(c, &g.db_part, (size_t)GEN_DB_CHUNKS * std::max(GL.hidden, GL.act)));
         }
@@ -1083,9 +1090,14 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
     float* grads = B_<float>(c, PPO_BUF_GRADS);
     {
         ProfScope ps(c, PROF_FWD_BWD);
-        HIPCHK(c, gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
-                             B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), idx, M, g, c->stream));
         const bool two = g.bf16 && c->stream2 != nullptr;   // the critic's passes on their own stream: a kernel of one net fills the CUs the other net's kernel is draining
+        auto gather = [&](const int32_t* rows, int64_t n, hipStream_t st) {
+            return gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
+                              B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), rows, n, g, st);
+        };
+        if (two && c->gen_pre_idx == idx && c->gen_pre_M == M) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather, 0));   // gathered ahead by the step before
+        else HIPCHK(c, gather(idx, M, c->stream));
+        c->gen_pre_idx = nullptr;
         auto fork = [&]() -> hipError_t { const hipError_t e = hipEventRecord(c->ev_fork, c->stream); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream2, c->ev_fork, 0); };
         auto join = [&]() -> hipError_t { const hipError_t e = hipEventRecord(c->ev_join, c->stream2); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->ev_join, 0); };
         hipStream_t s0 = two ? c->stream2 : c->stream;
@@ -1104,6 +1116,17 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream));
         HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, s0));
         if (two) HIPCHK(c, join());   // the flat gradient is complete
+        if (two && c->gen_next_idx) {
+            // nothing reads this step's gathered rows any more: the next step's gather (42 us of HBM streaming) runs on the second stream beside the
+            // loss sums, the all-reduce, the norm, AdamW and the weight planes -- small kernels, one after the other, that leave the chip idle.
+            // (Requested at the START of the step instead, into a second set of buffers, it does not overlap at all: its 16 k small workgroups take
+            // every CU slot that frees up and the forward pass's one-per-CU workgroups start when it has drained -- measured, same time as no
+            // gather-ahead.)
+            HIPCHK(c, fork());
+            HIPCHK(c, gather(c->gen_next_idx, c->gen_next_M, c->stream2));
+            HIPCHK(c, hipEventRecord(c->ev_gather, c->stream2));
+            c->gen_pre_idx = c->gen_next_idx; c->gen_pre_M = c->gen_next_M;
+        }
     }
     {
         ProfScope ps(c, PROF_REDUCE);
@@ -1310,6 +1333,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         HIPCHK(c, hipEventRecord(c->coef_copied[half], c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->clipfrac_accum, 0, 2 * sizeof(double), c->stream));  // m_clipfracs reset, :564
+    c->gen_pre_idx = nullptr;   // nothing gathered ahead survives an update (an error return may have left a claim behind)
     int k = 0;
     for (int e = 0; e < E; e++) {
         for (int mbi = 0; mbi < nmb; mbi++, k++) {
@@ -1318,7 +1342,15 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
             const bool fused = c->world == 1 && !c->force_collectives && !c->gen;
             // sharded on the direct-exchange transport: the same two launches, the exchange folded into the slab reduction
             const bool fused_x = c->world > 1 && c->xchg && !c->force_collectives && !c->gen;
+            {   // the step after this one (next minibatch, or the first one of the next epoch), for the generic path's gather-ahead
+                const bool more = mbi + 1 < nmb || e + 1 < E;
+                const int e2 = mbi + 1 < nmb ? e : e + 1, m2 = mbi + 1 < nmb ? mbi + 1 : 0;
+                const int64_t start2 = (int64_t)m2 * c->MB;
+                c->gen_next_idx = more ? perm + (size_t)e2 * c->B + start2 : nullptr;
+                c->gen_next_M = more ? std::min<int64_t>(c->MB, c->B - start2) : 0;
+            }
             s = fwd_bwd(c, perm + (size_t)e * c->B + start, M, k, !(fused || fused_x));
+            c->gen_next_idx = nullptr;
             if (s != PPO_OK) return s;
             if (fused_x) {
                 ExchangeComm& x = *c->xchg;

@@ -9,7 +9,7 @@ for i in $(seq 1 $R); do
         python3 tools/config4_bench.py 2>/dev/null | tail -n 1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-36s' % '$src', round(d['env_steps_per_s']/1e6,3), 'M env-steps/s', round(d['minibatch_step_ms'],4), 'ms/step', round(d['rollout_ms'],3), 'ms rollout', round(d['optimizer_ms'],4), 'ms opt')"
+print('%-36s' % '$src', round(d['env_steps_per_s']/1e6,3), 'M env-steps/s', round(d['minibatch_step_ms'],4), 'ms/step', round(d.get('update_ms_per_step',0),4), 'ms all-in/step', round(d['rollout_ms'],3), 'ms rollout', round(d['optimizer_ms'],4), 'ms opt')"
         python3 tools/fused_fwd_probe.py 2>/dev/null | tail -n 1
     done
 done

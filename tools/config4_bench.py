@@ -27,6 +27,10 @@ flops = 3 * 2 * 2 * (376 * 256 + 3 * 256 * 256) * M + 3 * 2 * (256 * 1 + 256 * 1
 fb_ms = p["fwd_bwd_ms"] / max(p["fwd_bwd_launches"], 1)
 print(json.dumps({"dtype": os.environ.get("DTYPE", "bf16"), "workload": "configs[4] per GPU: synthetic env, obs 376, 4x256, heads [3,3,3,2], %d envs x %d steps" % (N, T),
                   "env_steps_per_s": K * N * T / dt, "ms_per_iteration": 1e3 * dt / K, "rollout_ms": p["rollout_ms"] / K,
+                  # minibatch_step_ms: HIP events around gather + forward + loss + backward of a step (with bf16 storage the next step's gather runs ahead,
+                  # beside the optimizer tail, so only an update's first gather is inside); update_ms_per_step: everything between the rollout and the
+                  # next one, per optimizer step -- (iteration - rollout) / 40 by the wall clock
                   "minibatch_step_ms": fb_ms, "minibatch_step_TFLOPs": flops / (fb_ms * 1e-3) / 1e12, "optimizer_ms": p["optimizer_ms"] / max(p["optimizer_launches"], 1),
+                  "update_ms_per_step": (1e3 * dt / K - p["rollout_ms"] / K) / 40,
                   "loss": st["loss"], "entropy": st["entropy_loss"]}))
 ctx.close()
