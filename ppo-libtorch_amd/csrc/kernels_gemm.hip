@@ -565,7 +565,8 @@ hipError_t launch_one(const GemmArgs& g, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(DB ? 2 : 1) * T * (tile_elems(BM, TA) + tile_elems(BN, TB)) * sizeof(uint16_t);
     auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, T, VEC, BP, DB, ABF, CBF>;
     if constexpr (DB) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static std::atomic<unsigned long long> lds_ok{0};
+        const hipError_t attr = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(kern), (int)lds);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, g);

@@ -466,12 +466,11 @@ hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, 
     for (int l = 0; l < g.L.n_hidden; l++) a.keep[l] = keep ? g.acts_bf[net][l] : nullptr;
     a.ld_keep = g.ld_h;
     const size_t lds = fused_lds_bytes(a.f, 64);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_forward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_forward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static std::atomic<unsigned long long> lds_ok[2] = {};
+    {
+        const hipError_t e = x_bf ? allow_dynamic_lds(lds_ok[0], reinterpret_cast<const void*>(&generic_forward_kernel<true>))
+                                  : allow_dynamic_lds(lds_ok[1], reinterpret_cast<const void*>(&generic_forward_kernel<false>));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int64_t n_tiles = (rows + 63) / 64;
     const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
@@ -493,12 +492,11 @@ hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_
     a.fin_len = fin_len; a.fin_rew = fin_rew; a.next_obs = next_obs; a.next_done = next_done; a.cur_mask = cur_mask; a.forced = forced;
     const size_t lds = fused_lds_bytes(a.f, 32);
     const dim3 grid((unsigned)((N + 31) / 32)), block(FU_THREADS);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_rollout_kernel<PPO_DIST_MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_rollout_kernel<PPO_DIST_CATEGORICAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static std::atomic<unsigned long long> lds_ok[2] = {};
+    {
+        const hipError_t e = dist_kind == PPO_DIST_MASKED ? allow_dynamic_lds(lds_ok[0], reinterpret_cast<const void*>(&generic_rollout_kernel<PPO_DIST_MASKED>))
+                                                          : allow_dynamic_lds(lds_ok[1], reinterpret_cast<const void*>(&generic_rollout_kernel<PPO_DIST_CATEGORICAL>));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     if (dist_kind == PPO_DIST_MASKED) hipLaunchKernelGGL(generic_rollout_kernel<PPO_DIST_MASKED>, grid, block, lds, s, a);
     else hipLaunchKernelGGL(generic_rollout_kernel<PPO_DIST_CATEGORICAL>, grid, block, lds, s, a);

@@ -1007,13 +1007,9 @@ hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.n_blocks[0], 2), block(UPD_THREADS);  // the VALU kernel uses equal shares
 #define PPO_LAUNCH_UPD(DIST, OBS)                                                                                     \
     do {                                                                                                              \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_kernel<DIST, OBS>),             \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
-            if (e != hipSuccess) return e;                                                                            \
-            attr_set = true;                                                                                          \
-        }                                                                                                             \
+        static std::atomic<unsigned long long> lds_ok{0};                                                             \
+        const hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(&fwd_bwd_kernel<DIST, OBS>));    \
+        if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL((fwd_bwd_kernel<DIST, OBS>), grid, block, shmem, s, a);                                    \
     } while (0)
     if (a.L.obs == 4) {

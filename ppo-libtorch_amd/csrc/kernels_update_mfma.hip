@@ -1032,16 +1032,10 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.n_blocks[0] + a.n_blocks[1])), block(MF_THREADS);
 #define PPO_LAUNCH_MF(DIST, OBS, AMAX, EXACT)                                                                          \
     do {                                                                                                               \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
-            if (e == hipSuccess)                                                                                       \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
-            if (e != hipSuccess) return e;                                                                             \
-            attr_set = true;                                                                                           \
-        }                                                                                                              \
+        static std::atomic<unsigned long long> lds_ok{0}, lds_ok_stamp{0};                                              \
+        hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>)); \
+        if (e == hipSuccess && a.stamps) e = allow_dynamic_lds(lds_ok_stamp, reinterpret_cast<const void*>(&fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>)); \
+        if (e != hipSuccess) return e;                                                                                 \
         if (a.stamps) hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, true>), grid, block, shmem, s, a); \
         else hipLaunchKernelGGL((fwd_bwd_mfma_kernel<DIST, OBS, AMAX, EXACT, false>), grid, block, shmem, s, a);       \
     } while (0)

@@ -15,6 +15,20 @@
 
 #define PPO_HIDDEN 64          // one hidden unit per lane of a 64-wide wavefront
 #define PPO_MAX_OBS 8
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) acts on the CURRENT device's copy of a kernel: a call site remembers, per device ordinal, that it
+// has been made (one bit each; `done` is the site's own static).  Thread-safe: the worst a race does is set the attribute twice.
+#include <atomic>
+inline hipError_t allow_dynamic_lds(std::atomic<unsigned long long>& done, const void* kernel, int bytes = 160 * 1024) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 #define PPO_MAX_ACT 32         // sum of head widths
 #define PPO_TILE 64            // samples per update tile
 #define PPO_LDS_STRIDE 68      // padded row stride (floats) of [unit][sample] LDS tiles: 16-B aligned, bank-spreading
