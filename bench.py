@@ -180,7 +180,8 @@ def main():
                     "exchange over HIP-IPC peer buffers (one kernel per rank and call); rccl = ncclAllReduce; auto = exchange, checked after the warm-up "
                     "(no wait timed out, replicas bit-identical), RCCL if that check fails")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (exchange transport only)")
-    ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel + GAE")
+    ap.add_argument("--profile", type=int, default=-1, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel (1 launch in 8) + GAE, "
+                    "4 the same with 1 launch in 41; default: 4 from 20 steps up (>= 20 samples), 2 below")
     args = ap.parse_args()
     W = WORKLOADS[args.workload]
 
@@ -281,6 +282,8 @@ def main():
             dist.barrier()
         ctx.sync()
 
+    if args.profile < 0:
+        args.profile = 4 if args.steps >= 20 else 2
     ctx.profile_enable(args.profile)
     barrier()
     t0 = time.perf_counter()
@@ -357,7 +360,7 @@ def main():
                                  "frac": f16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None},
                     "rocprof": rocprof_kernel_us("fwd_bwd_mfma_kernel") if args.workload == "cartpole" else None}
         roof.update({"flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
-                     "sampling": "HIP events on the context's stream around 1 launch in 8 (--profile 2), every launch with --profile 1"})
+                     "sampling": "HIP events on the context's stream around 1 launch in %s (--profile %d)" % ({1: "1", 2: "8", 4: "41"}.get(args.profile, "?"), args.profile)})
         phases = {"rollout": "rollout", "gae": "gae", "grad_reduce": "reduce", "clip_adamw": "optimizer"}
         out = {
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,

@@ -268,7 +268,9 @@ typedef struct ppo_profile {
 } ppo_profile;
 /* on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fused forward/backward; ONE launch in 8 is bracketed: an
  * event pair costs the stream ~3 us, 40 pairs per update were 8 % of the run) and the GAE scan,
- * 3 = in-kernel phase stamps of the dominant kernel (diagnostic kernel variant; read shares, not run time) */
+ * 3 = in-kernel phase stamps of the dominant kernel (diagnostic kernel variant; read shares, not run time),
+ * 4 = as 2 with ONE launch in 41 (about one per update, a different step each time): five pairs per 2.4 ms iteration still cost 1.7 % of it
+ *     (219.4 against 215.5 M env-steps/s), one costs 0.3 % */
 PPO_API ppo_status ppo_profile_enable(ppo_ctx* ctx, int32_t on);
 PPO_API ppo_status ppo_profile_read(ppo_ctx* ctx, ppo_profile* out);  /* synchronises; resets the accumulators */
 

@@ -1455,9 +1455,11 @@ extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
     NEED(c, c != nullptr, "null ctx");
     DeviceGuard dev_guard(c);
     // on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fwd/bwd; one launch in 8) and the GAE scan,
-    //     3 = in-kernel phase stamps of the dominant kernel (diagnostic variant: read its SHARES, never its run time)
-    c->profiling = (on == 0 || on == 3) ? 0u : (on == 2 ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE)) : 0xffffffffu);
-    c->prof_every = on == 2 ? 8 : 1;   // mode 2 samples the update kernel: 1 launch in 8 (5 of an update's 40), every GAE launch
+    //     3 = in-kernel phase stamps of the dominant kernel (diagnostic variant: read its SHARES, never its run time),
+    //     4 = as 2 with one launch in 41 (about one per update, a different step of the update every time)
+    const bool sampled = on == 2 || on == 4;
+    c->profiling = (on == 0 || on == 3) ? 0u : (sampled ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE)) : 0xffffffffu);
+    c->prof_every = on == 2 ? 8 : (on == 4 ? 41 : 1);   // modes 2 / 4 sample the update kernel (5 / ~1 of an update's 40 launches), every GAE launch
     c->prof_count = 0;
     c->stamping = on == 3;
     if (c->profiling) {   // events are created here, not inside the region being timed
