@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 
-python3 $ROOT/bench.py --steps 20 --warmup 3 --profile 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 $ROOT/bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -n 1 "$OUT/bench.json" > "$ROOT/profiles/${TAG}_bench.json"
 
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o run -- $BENCH > "$OUT/trace.log" 2>&1
