@@ -227,44 +227,8 @@ def main():
         return c
 
     def start_exchange():
-        """The exchange has never run on this node before this job, so it is brought up in checked stages.  Every rank walks the SAME sequence of
-        host collectives whether or not its own stage failed (a rank that left the sequence early would leave the others in a mismatched
-        collective); None = some rank failed, nothing is left open."""
-        c, err, handle = None, None, None
-        try:
-            c = P.Context(cfg)
-            handle = c.comm_exchange_handle()
-        except Exception as ex:
-            err = ex
-        handles = P.dist.gather_bytes(dist, handle)
-        if err is None:
-            try:
-                if any(h is None for h in handles):
-                    raise RuntimeError("a peer could not export its exchange buffer")
-                c.comm_init_exchange(handles, rank, world)
-            except Exception as ex:   # e.g. IPC handles cannot be opened on this node
-                err = ex
-        if P.dist.all_ranks_agree(dist, err is None):
-            # after the warm-up no bounded wait may have run out and the replicas must hold bit-identical parameters (every rank adds the
-            # shards in rank order)
-            import hashlib
-            digest = None
-            try:
-                warm(c)
-                if c.comm_exchange_timeouts() == 0:
-                    digest = hashlib.sha256(c.get_params().tobytes()).digest()
-            except Exception as ex:
-                err = ex
-            digests = P.dist.gather_bytes(dist, digest)
-            if digest is None or len(set(digests)) != 1:
-                err = err or RuntimeError("replicas differ or a wait ran out after the warm-up")
-            if P.dist.all_ranks_agree(dist, err is None):
-                return c
-        if err is not None:
-            sys.stderr.write("rank %d: exchange transport failed (%r)\n" % (rank, err))
-        if c is not None:
-            c.close()
-        return None
+        # brought up in checked stages (dist.start_exchange_checked): None = some rank failed a stage, nothing is left open
+        return P.dist.start_exchange_checked(lambda: P.Context(cfg), warm, dist, rank, world)
 
     transport = "none" if world == 1 else ("rccl" if args.transport == "rccl" else "exchange")
     if transport == "exchange":

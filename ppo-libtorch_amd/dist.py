@@ -97,3 +97,49 @@ def max_over_ranks(dist, value):
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def start_exchange_checked(make_ctx, warm, dist, rank, world, log=None):
+    """Brings a context up on the one-shot direct exchange in checked stages -- the exchange has never run on a node before the job that uses
+    it.  Every rank walks the SAME sequence of host collectives whether or not its own stage failed (a rank that left the sequence early
+    would leave the others in a mismatched collective):
+        1. create the context and export its exchange handle        -> all-gather of the handles (None from a rank that failed)
+        2. map the peers' buffers                                   -> agreement
+        3. `warm(ctx)` (initialise, reset, warm-up iterations)      -> all-gather of a digest of the parameters (None: failed or a wait ran out)
+        4. every digest present and equal (replicas bit-identical)  -> agreement
+    Returns the context, or None when any rank failed any stage (this rank's context is then closed)."""
+    import hashlib
+    import sys
+    log = log or sys.stderr.write
+    c, err, handle = None, None, None
+    try:
+        c = make_ctx()
+        handle = c.comm_exchange_handle()
+    except Exception as ex:
+        err = ex
+    handles = gather_bytes(dist, handle)
+    if err is None:
+        try:
+            if any(h is None for h in handles):
+                raise RuntimeError("a peer could not export its exchange buffer")
+            c.comm_init_exchange(handles, rank, world)
+        except Exception as ex:   # e.g. IPC handles cannot be opened on this node
+            err = ex
+    if all_ranks_agree(dist, err is None):
+        digest = None
+        try:
+            warm(c)
+            if c.comm_exchange_timeouts() == 0:
+                digest = hashlib.sha256(c.get_params().tobytes()).digest()
+        except Exception as ex:
+            err = ex
+        digests = gather_bytes(dist, digest)
+        if digest is None or len(set(digests)) != 1:
+            err = err or RuntimeError("replicas differ or a wait ran out after the warm-up")
+        if all_ranks_agree(dist, err is None):
+            return c
+    if err is not None:
+        log("rank %d: exchange transport failed (%r)\n" % (rank, err))
+    if c is not None:
+        c.close()
+    return None

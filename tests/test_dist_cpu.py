@@ -127,3 +127,75 @@ def test_sharded_step_equals_single_process_step(tmp_path, world):
         assert abs(total - float(dp["total"])) <= 1e-6 * max(1.0, total)
         params, m, v = O.adamw_step(params, clipped, m, v, 1e-3, step + 1)
         assert np.abs(params - dp["params"]).max() <= 1e-6
+
+
+class _FakeCtx:
+    """Stands where binding.Context stands in dist.start_exchange_checked: fails at the stage `fail_at` names (on the rank that gets one)."""
+    def __init__(self, rank, fail_at, log):
+        self.rank, self.fail_at, self.log, self.closed = rank, fail_at, log, False
+        if fail_at == "create":
+            raise RuntimeError("no device")
+
+    def comm_exchange_handle(self):
+        if self.fail_at == "handle":
+            raise RuntimeError("cannot export")
+        return b"handle-of-rank-%d" % self.rank
+
+    def comm_init_exchange(self, handles, rank, world):
+        assert handles == [b"handle-of-rank-%d" % r for r in range(world)]
+        if self.fail_at == "map":
+            raise RuntimeError("hipIpcOpenMemHandle: invalid argument")
+
+    def comm_exchange_timeouts(self):
+        return 3 if self.fail_at == "timeout" else 0
+
+    def get_params(self):
+        import numpy as np
+        return np.full(16, 1.0 + (self.rank if self.fail_at == "diverge" else 0), np.float32)
+
+    def close(self):
+        self.closed = True
+
+
+def _exchange_worker(rank, world, port, out_dir, scenario, bad_rank):
+    import json
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    P = load_package()
+    dist, rank, world = P.dist.init_process_group("gloo")
+    made, lines = [], []
+    fail_at = scenario if rank == bad_rank else None
+
+    def make():
+        c = _FakeCtx(rank, fail_at, lines)
+        made.append(c)
+        return c
+
+    def warm(c):
+        if c.fail_at == "warm":
+            raise RuntimeError("kernel fault")
+
+    got = P.dist.start_exchange_checked(make, warm, dist, rank, world, log=lines.append)
+    json.dump(dict(ok=got is not None, closed=[c.closed for c in made], lines=lines), open(os.path.join(out_dir, "x%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["fine", "create", "handle", "map", "warm", "timeout", "diverge"])
+def test_exchange_start_up_agrees_on_every_rank(tmp_path, scenario):
+    """bench.py --transport auto brings the direct exchange up in checked stages (dist.start_exchange_checked).  Whatever stage fails, and on
+    whichever single rank, every rank must come out with the same verdict -- through the same sequence of host collectives, so nobody hangs --
+    and a rank that gives up closes its context.  Fake contexts over gloo: the failures themselves cannot be provoked on a GPU box."""
+    import json
+    import torch.multiprocessing as mp
+    world, bad_rank = 2, 1
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path), scenario, bad_rank), nprocs=world, join=True)
+    res = [json.load(open(tmp_path / ("x%d.json" % r))) for r in range(world)]
+    want_ok = scenario == "fine"
+    assert [r["ok"] for r in res] == [want_ok] * world
+    for r, x in enumerate(res):
+        if want_ok:
+            assert x["closed"] == [False] and x["lines"] == []
+        else:
+            assert all(x["closed"])                                   # whatever was created has been closed
+            if r == bad_rank or scenario in ("timeout", "diverge"):
+                assert any("exchange transport failed" in line for line in x["lines"]), x
