@@ -210,8 +210,15 @@ def main():
                               device=0 if args.same_device else local_rank,
                               compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32)
     def warm(c):
-        c.init_orthogonal(2)   # same seed on every rank: replicated weights
-        c.env_reset()
+        try:
+            c.init_orthogonal(2)   # same seed on every rank: replicated weights
+            c.env_reset()
+            c.sync()
+        finally:
+            # every rank has its code object loaded and its envs reset before anyone starts the first iteration: a kernel of the direct exchange
+            # waits ~2 s for a peer's share, and a rank that is still loading must not use that up (reached by every rank: see the callers)
+            if dist is not None:
+                dist.barrier()
         for _ in range(args.warmup):
             c.train_iteration()
         c.sync()
