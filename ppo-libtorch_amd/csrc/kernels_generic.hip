@@ -657,13 +657,14 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
     const GenLayout& L = g.L;
     if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
     // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single product would have N K / tile
-    // workgroups walking all rows, so the rows are cut into ranges -- every range its own partial slab, enough of them for two workgroups
+    // workgroups walking all rows, so the rows are cut into ranges -- every range its own partial slab, enough of them for one or two workgroups
     // per CU, each a multiple of 64 rows -- and the slabs are added in a fixed order.
     auto ranges = [&](int N, int K) {
         const int64_t tiles = (int64_t)((N + 127) / 128) * ((K + 127) / 128);
-        // (256 workgroups for the bf16 product -- one eight-wave workgroup per CU -- halve the slabs the slab sum reads but measured slower overall:
-        // 31.5 against 22.6 us per product, 8.6 against 10.0 us per slab sum)
-        int64_t want = (512 + tiles - 1) / tiles;
+        // 256 workgroups -- one eight-wave workgroup per CU: alone on the chip that is slower than 512 (31.5 against 22.6 us per product, 8.6 against
+        // 10.0 us per slab sum), but the two nets' passes run side by side on two streams and there half the slab bytes win: 0.709 -> 0.705 ms per
+        // minibatch step (A/B in one call; 128 workgroups: 0.762)
+        int64_t want = ((g.bf16 ? 256 : 512) + tiles - 1) / tiles;   // f32 (one stream, two four-wave workgroups per CU): 512
         if (want > GEN_SPLIT_MFMA) want = GEN_SPLIT_MFMA;
         const int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;
         return (int)((rows + range - 1) / range);
