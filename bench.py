@@ -2,7 +2,13 @@
 """bench.py -- env-steps/sec (rollout + GAE + update) of the MI355X-native PPO hot path, BASELINE.json's metric.
 
   python bench.py --gpus N --steps K --warmup W [--workload cartpole|mountaincar|config4]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+  N > 1, either way:  * the plain command above: before anything touches HIP the process starts N FRESH rank processes
+                        (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>), relays rank 0's JSON
+                        line and exits with their return code;
+                      * python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... (RANK / WORLD_SIZE in the environment).
+  Gradient all-reduce of N > 1 (--transport): auto = RCCL (ncclAllReduce over xGMI, the transport BASELINE.json names); only when its bring-up fails,
+  the one-shot direct exchange, brought up in checked stages.  exchange / both = the direct exchange as an opt-in A/B (both: RCCL is `value`, the
+  exchange is reported beside it in `transport_ab`).  The transport that ran and why are top-level fields of the line.
 
 A "step" is one pass of the hot path over one batch: one iteration of PPO_Discrete::train()'s loop (reference
 PPO/PPO_Discrete.cpp:511-659) = rollout of num_steps x num_envs env-steps, GAE scan, update_epochs x num_minibatches optimizer
@@ -100,6 +106,17 @@ def committed_jsonl(suffix):
         return None
 
 
+def gae_floor_us():
+    """Committed floor probe (tools/probes/gae_floor: the scan's own strip decomposition with the chain replaced by nothing), back-to-back us at 4096 envs."""
+    d = committed_jsonl("_gae_floor.jsonl")
+    if not d:
+        return None
+    for row in d["rows"]:
+        if row.get("N") == 4096:
+            return {"empty_launch_us": row.get("empty_us"), "plain_stream_us": row.get("stream_us"), "chain_free_strip_us": row.get("column_us"), "source": d["source"]}
+    return None
+
+
 def run_reference(num_envs, num_steps, updates, timeout=900):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if not os.path.exists(ref):
@@ -121,7 +138,9 @@ def cpu_baseline(num_envs, num_steps, obs, act):
     if r:
         out = {"value": r["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(r["threads"]), "kind": "reference",
                "sample": "1 full update iteration (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch CPU, "
-                         "ThreadPool(hardware_concurrency), %d envs x %d steps (the headline workload has %d envs: bounded sample)" % (sample_envs, num_steps, num_envs)}
+                         "ThreadPool(hardware_concurrency), %d envs x %d steps (the headline workload has %d envs: bounded sample)" % (sample_envs, num_steps, num_envs),
+               "note": "%d-thread ThreadPool, oversubscribed (one job per env per step: the pool's queue lock dominates); %d-env sample of the %d-env workload; "
+                       "a reported baseline -- the GPU/CPU ratio says nothing about kernel quality" % (int(r["threads"]), sample_envs, num_envs)}
         # BASELINE.json configs[0]: the reference's own CPU-runnable case, 8 envs x 128 steps
         c1 = run_reference(8, 128, 20)
         if c1:
@@ -164,7 +183,7 @@ WORKLOADS = {
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: a timed region of ~0.5 s at the headline workload (200 x 2.5 ms) -- long enough for an outside observer's GPU-activity sampling to see it
@@ -176,22 +195,113 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm-selftest", action="store_true", help="N = 1 only: drive the multi-rank code path (RCCL all-reduces over a one-rank communicator, "
                     "three-kernel optimizer step) to see its per-step cost on one GPU; not a valid headline number")
-    ap.add_argument("--transport", choices=("auto", "exchange", "rccl"), default="auto", help="N > 1: the gradient all-reduce. exchange = one-shot direct "
-                    "exchange over HIP-IPC peer buffers (one kernel per rank and call); rccl = ncclAllReduce; auto = exchange, checked after the warm-up "
-                    "(no wait timed out, replicas bit-identical), RCCL if that check fails")
+    ap.add_argument("--transport", choices=("auto", "rccl", "exchange", "both"), default="auto", help="N > 1: the gradient all-reduce. rccl = ncclAllReduce over xGMI; "
+                    "exchange = one-shot direct exchange over HIP-IPC peer buffers (one kernel per rank and call), brought up in checked stages; auto = RCCL, the "
+                    "exchange only if RCCL cannot be brought up (with --same-device: the exchange, RCCL refuses two ranks on one device); both = RCCL timed as "
+                    "`value`, then the exchange timed beside it (`transport_ab`)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (exchange transport only)")
     ap.add_argument("--profile", type=int, default=-1, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel (1 launch in 8) + GAE, "
                     "4 the same with 1 launch in 41; default: 4 from 20 steps up (>= 20 samples), 2 below")
-    args = ap.parse_args()
+    ap.add_argument("--bringup-timeout", type=float, default=300.0, help="N > 1: seconds a rank may spend between start and the end of the warm-up before it gives up "
+                    "and exits non-zero (a hung communicator bring-up must not hang the job)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launcher: seconds the rank processes may run before their process group is killed")
+    ap.add_argument("--fallback-reason", default=None, help=argparse.SUPPRESS)   # set by the self-launcher on its one retry
+    ap.add_argument("--launch-worker", default=None, help=argparse.SUPPRESS)     # tests: the script the self-launcher starts instead of this file
+    args, unknown = ap.parse_known_args(argv)
+    if unknown and not args.launch_worker:   # a stand-in worker of the tests may take flags of its own
+        ap.error("unrecognized arguments: %s" % " ".join(unknown))
+    return args
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no torchrun environment: this process has not touched HIP and never will -- it starts N FRESH rank processes
+    through torch.distributed.run, relays their stderr as it comes and rank 0's JSON line at the end, and exits with their return code.  A failed
+    run with --transport auto is retried ONCE, in fresh processes again, on the other transport (never in place, never by re-executing a process
+    that has initialised the GPU)."""
+    import signal
+
+    def visible_gpus():
+        try:
+            import torch   # device_count() does not initialise HIP
+            return int(torch.cuda.device_count())
+        except Exception:
+            return -1
+    n_vis = visible_gpus()
+    if not args.same_device and 0 <= n_vis < args.gpus and not args.launch_worker:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible; on a one-GPU box rehearse with --same-device\n" % (args.gpus, n_vis))
+        return 2
+    worker = args.launch_worker or os.path.abspath(__file__)
+    passthrough = [a for a in argv]
+
+    def attempt(extra):
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the direct exchange both share device memory across processes
+        env.setdefault("OMP_NUM_THREADS", "1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), worker] + passthrough + extra
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=args.launch_timeout)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)   # exactly the process group started above
+            except ProcessLookupError:
+                pass
+            out, _ = proc.communicate()
+            rc = 124
+            sys.stderr.write("bench.py: rank processes killed after %.0f s (--launch-timeout)\n" % args.launch_timeout)
+        lines = [l for l in (out or "").splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
+        for l in (out or "").splitlines():
+            if l not in lines:
+                sys.stderr.write(l + "\n")   # anything a rank printed besides the line
+        return rc, (lines[-1] if lines else None)
+
+    rc, line = attempt([])
+    if (rc != 0 or line is None) and args.transport == "auto" and not args.same_device:
+        sys.stderr.write("bench.py: run on RCCL failed (rc %d); one retry in fresh processes on the direct exchange\n" % rc)
+        rc, line = attempt(["--transport", "exchange", "--fallback-reason", "the run with --transport auto (RCCL first) exited with rc %d" % rc])
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
     W = WORKLOADS[args.workload]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs one process per GPU: launch with `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before this process's first HIP call (ppo_hip.h, direct exchange; RCCL needs it too)
+
+    # N > 1: nothing between here and the end of the warm-up may hang the job -- a rank that is still bringing its communicator up after
+    # --bringup-timeout seconds exits non-zero (torch.distributed.run then ends the other ranks)
+    watchdog = None
+    if world > 1 and args.bringup_timeout > 0:
+        import threading
+
+        def give_up():
+            sys.stderr.write("bench.py rank %d: communicator bring-up / warm-up still running after %.0f s -- giving up\n" % (rank, args.bringup_timeout))
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(args.bringup_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     from __graft_entry__ import load_package
     P = load_package()
@@ -216,57 +326,124 @@ def main():
             c.sync()
         finally:
             # every rank has its code object loaded and its envs reset before anyone starts the first iteration: a kernel of the direct exchange
-            # waits ~2 s for a peer's share, and a rank that is still loading must not use that up (reached by every rank: see the callers)
+            # waits a bounded time for a peer's share, and a rank that is still loading must not use that up (reached by every rank: see the callers)
             if dist is not None:
                 dist.barrier()
         for _ in range(args.warmup):
             c.train_iteration()
         c.sync()
 
-    def start(transport):
-        c = P.Context(cfg)
-        if args.comm_selftest and world == 1:
-            os.environ["PPO_COMM_SELFTEST"] = "1"
-            c.comm_init(P.comm_unique_id(), 0, 1)
-            del os.environ["PPO_COMM_SELFTEST"]
-        P.dist.bootstrap_comm(c, dist, rank, world, P.comm_unique_id, transport=transport)
+    def start_rccl():
+        """RCCL bring-up in agreed stages (every rank walks the same host collectives whether or not its own stage failed).  None = some rank failed."""
+        c, err = None, None
+        try:
+            c = P.Context(cfg)
+            if args.comm_selftest and world == 1:
+                os.environ["PPO_COMM_SELFTEST"] = "1"
+                c.comm_init(P.comm_unique_id(), 0, 1)
+                del os.environ["PPO_COMM_SELFTEST"]
+        except Exception as ex:
+            err = ex
+        if world > 1:
+            ident = None
+            if rank == 0 and err is None:
+                try:
+                    ident = P.comm_unique_id()
+                except Exception as ex:
+                    err = ex
+            ident = P.dist.broadcast_bytes(dist, ident, src=0)
+            if err is None:
+                try:
+                    if ident is None:
+                        raise RuntimeError("rank 0 could not make an RCCL unique id")
+                    c.comm_init(ident, rank, world)
+                except Exception as ex:
+                    err = ex
+            if not P.dist.all_ranks_agree(dist, err is None):
+                if err is not None:
+                    sys.stderr.write("rank %d: RCCL bring-up failed (%r)\n" % (rank, err))
+                if c is not None:
+                    c.close()
+                return None, repr(err) if err is not None else "a peer failed RCCL bring-up"
+        elif err is not None:
+            raise err
         warm(c)
-        return c
+        return c, None
 
     def start_exchange():
         # brought up in checked stages (dist.start_exchange_checked): None = some rank failed a stage, nothing is left open
         return P.dist.start_exchange_checked(lambda: P.Context(cfg), warm, dist, rank, world)
 
-    transport = "none" if world == 1 else ("rccl" if args.transport == "rccl" else "exchange")
-    if transport == "exchange":
-        ctx = start_exchange()
-        if ctx is None:
-            if args.transport != "auto":
-                sys.exit("exchange transport failed its start-up checks")
-            transport = "rccl"
-    if transport != "exchange":
-        ctx = start(transport)
-
-    def barrier():
-        ctx.sync()
+    def timed(c):
+        """K steps bracketed by barrier + synchronize on both sides; max over ranks.  A direct-exchange wait that ran out makes ctx.sync() raise
+        (PPO_ERR_COMM) and the count is agreed over the ranks besides: a run whose replicas diverged prints no number."""
+        def barrier():
+            c.sync()
+            if dist is not None:
+                dist.barrier()
+            c.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            c.train_iteration()
+        barrier()
+        dt = time.perf_counter() - t0
         if dist is not None:
-            dist.barrier()
-        ctx.sync()
+            dt = P.dist.max_over_ranks(dist, dt)
+            if not P.dist.all_ranks_agree(dist, c.comm_exchange_timeouts() == 0):
+                sys.stderr.write("rank %d: a direct-exchange wait ran out inside the timed region: no number\n" % rank)
+                sys.stderr.flush()
+                os._exit(4)
+        return dt
+
+    requested = args.transport
+    fallback_reason = args.fallback_reason
+    if world == 1:
+        transport = "none"
+        ctx, _ = start_rccl()
+    else:
+        first = "exchange" if (requested == "exchange" or (requested == "auto" and args.same_device)) else "rccl"
+        if requested in ("rccl", "both") and args.same_device:
+            sys.exit("RCCL refuses two ranks on one device: --same-device rehearses the direct exchange only")
+        if requested == "auto" and args.same_device:
+            fallback_reason = fallback_reason or "--same-device: RCCL cannot place two ranks on one device"
+        ctx, transport = None, first
+        if first == "rccl":
+            ctx, why = start_rccl()
+            if ctx is None:
+                if requested != "auto":
+                    sys.exit("RCCL transport failed its bring-up: %s" % why)
+                fallback_reason = "RCCL bring-up failed: %s" % why
+                transport = "exchange"
+        if ctx is None:
+            ctx = start_exchange()
+            if ctx is None:
+                sys.exit("direct-exchange transport failed its start-up checks")
+    if watchdog is not None:
+        watchdog.cancel()
 
     if args.profile < 0:
         args.profile = 4 if args.steps >= 20 else 2
     ctx.profile_enable(args.profile)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.train_iteration()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(ctx)
     prof = ctx.profile_read()
     ctx.profile_enable(0)
-    if dist is not None:
-        dt = P.dist.max_over_ranks(dist, dt)
     st = ctx.stats()
+
+    # opt-in A/B: the same K steps on the one-shot direct exchange, in a second context, after the RCCL number is in hand
+    transport_ab = None
+    if world > 1 and requested == "both":
+        try:
+            cx = start_exchange()
+            if cx is None:
+                transport_ab = {"transport": "exchange", "failed": "start-up checks"}
+            else:
+                dtx = timed(cx)
+                transport_ab = {"transport": "exchange", "value": args.steps * (args.envs or W["envs"]) * args.num_steps * world / dtx, "unit": "env-steps/s",
+                                "ms_per_step": 1e3 * dtx / args.steps}
+                cx.close()
+        except Exception as ex:   # every rank takes the same branch: start_exchange_checked agrees on failures, timed() raises on all or none
+            transport_ab = {"transport": "exchange", "failed": repr(ex)}
 
     # GAE scan back to back, outside the timed region: on the context's own buffers (this workload's size) and on fresh buffers of the three
     # sizes the roofline is quoted at -- wall time of 200 launches / 200: no event pair (~3 us on a 5 us launch), no foreign kernel in front
@@ -318,17 +495,19 @@ def main():
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None, "traffic": None}
         else:
+            # what the matrix cores execute: per 32-sample tile and net 72 v_mfma_f32_32x32x16_f16 (three f16 products per fp32 product)
             f16_fl = 2 * ((M + 31) // 32) * 72 * (2 * 32 * 32 * 16)
             roof = {"kernel": "fwd_bwd_mfma_kernel (gather+forward+PPO loss+backward; fp32 carried as two fp16 terms, three f16 MFMA products per fp32 product)",
-                    "bound": "mfma",
-                    # algorithmic fp32 FLOP/s against the fp32 matrix peak (the arithmetic the path delivers); the fp16 decomposition executes
-                    # three half-precision products per fp32 product, so this ratio may pass 1 -- the instruction stream itself is in "executed"
-                    "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if fb_ms else None,
+                    # the roofline of the instruction stream the kernel issues: executed f16 MFMA FLOP/s against the dense f16 matrix peak.  It cannot
+                    # pass 1 and it shows the headroom; the kernel is held below it by the LDS pipe and the vector work around each MFMA (`limiter`).
+                    "bound": "mfma", "limiter": "lds+valu (LDS pipe ~55 % busy, ~18 vector instructions per MFMA: DESIGN.md section 4)",
+                    "achieved": f16_fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": f16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
+                    "executed_flops_per_launch": f16_fl,
+                    # the arithmetic the path DELIVERS (algorithmic fp32 FLOP of forward + backward of both nets), for comparison with an fp32 implementation:
+                    # 157.3 TFLOP/s is the peak of the fp32 matrix instruction, which this kernel does not issue -- a yardstick, not this kernel's roofline
+                    "achieved_fp32_equiv": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "fp32_mfma_peak": F32_PEAK_TFLOPS,
                     "traffic": (fb_tr or {}).get("bytes"), "traffic_detail": fb_tr,
-                    # what the matrix cores actually execute: per 32-sample tile and net 72 v_mfma_f32_32x32x16_f16
-                    "executed": {"unit": "TFLOP/s f16", "achieved": f16_fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS,
-                                 "frac": f16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None},
                     "rocprof": rocprof_kernel_us("fwd_bwd_mfma_kernel") if args.workload == "cartpole" else None}
         roof.update({"flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
                      "sampling": "HIP events on the context's stream around 1 launch in %s (--profile %d)" % ({1: "1", 2: "8", 4: "41"}.get(args.profile, "?"), args.profile)})
@@ -337,6 +516,9 @@ def main():
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if generic else "f32",
+            # the gradient all-reduce that ran (N > 1), what was asked for, and why they differ if they do
+            "transport": transport, "transport_requested": requested if world > 1 else None, "transport_fallback_reason": fallback_reason,
+            "comm_ranks": world, "transport_ab": transport_ab,
             "data": "synthetic (counter-based env, random-init 4x256 actor/critic)" if generic else "synthetic (fixed-seed %s, random-init 2x64 actor/critic)" % ("CartPole-v1" if args.workload == "cartpole" else "MountainCar"),
             "config": {"workload": (W["label"] % (N, T)) + " (BASELINE.json configs[%d]%s)" % (W["cfg1"] if world == 1 else W["cfg8"], ", one GPU's share" if generic and world == 1 else ""),
                        "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
@@ -354,6 +536,13 @@ def main():
                                               "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gae_ms else None,
                                               "timing": "HIP events around the launch inside the iteration (the event pair adds ~3 us to a ~5 us launch)"},
                              "back_to_back_sizes": gae_rows,
+                             # the 40 % bar of BASELINE.json, stated in one place: the smallest measured size that clears it, what the headline's
+                             # per-GPU size (configs[1] / [2]: 4096 envs) reaches, and the committed floor of a launch that moves the same bytes
+                             "bar": {"target_frac": 0.40,
+                                     "size_met_from_envs": next((r["envs"] for r in gae_rows if r["frac"] >= 0.40), None),
+                                     "frac_at_config1": next((r["frac"] for r in gae_rows if r["envs"] == 4096), None),
+                                     "budget_us_at_config1": (20 * 4096 * T + 8 * 4096) / (0.40 * HBM_PEAK_GBS * 1e9) * 1e6,
+                                     "floor_us": gae_floor_us()},
                              "rocprof": rocprof_kernel_us("gae_kernel<16") if args.workload == "cartpole" else None,
                              "floor_probe": committed_jsonl("_gae_floor.jsonl")},
             # HIP-event time per iteration of the phases that were bracketed (--profile 1 brackets all of them); null = not sampled in this run

@@ -28,7 +28,7 @@ extern "C" {
 
 #define PPO_MAX_HEADS 8
 #define PPO_API __attribute__((visibility("default")))
-#define PPO_ABI_VERSION 2
+#define PPO_ABI_VERSION 3
 
 typedef int32_t ppo_status;
 enum { PPO_OK = 0, PPO_ERR_INVALID = 1, PPO_ERR_HIP = 2, PPO_ERR_STATE = 3, PPO_ERR_COMM = 4, PPO_ERR_UNSUPPORTED = 5 };
@@ -249,10 +249,11 @@ PPO_API ppo_status ppo_update(ppo_ctx* ctx);
 /* One iteration of the training loop (:511-659 minus printing/checkpoints): LR anneal, rollout, advantages, update. */
 PPO_API ppo_status ppo_train_iteration(ppo_ctx* ctx);
 /* Synchronises and returns the scalars of the last update (printPPOResults' inputs, :700-774).
- * Sharded runs (n_ranks > 1): the loss scalars (pg / value / entropy loss, approx-KL, clipfrac, grad norm) ride the gradient
- * all-reduce and are GLOBAL, identical on every rank; the episode statistics (ep_rew_mean, ep_len_mean, ep_count), the
- * explained variance and global_step describe THIS rank's env shard only -- a caller that prints one table for the job
- * averages them over ranks itself (bench.py reports the per-rank values of rank 0). */
+ * Sharded runs (2..8 ranks): every number is the JOB's and identical on every rank, as the reference prints one table (:700-774).  The loss scalars
+ * (pg / value / entropy loss, approx-KL, clipfrac, grad norm) ride the gradient all-reduce; the explained-variance sums (:647-648) and every
+ * rank's ring of finished episodes, each episode tagged with its position in the reference's push order (step, then global env index; :474-480),
+ * ride the per-update all-reduce of the advantage sums, and the host rebuilds the job's CircularBuffer(100) from the union: ep_rew_mean /
+ * ep_len_mean / ep_count are what ONE context over all envs would report.  They describe the state at the last ppo_update. */
 PPO_API ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
 /* LR anneal (:514-518) is applied by ppo_train_iteration; direct control for tests. */
 PPO_API ppo_status ppo_set_learning_rate(ppo_ctx* ctx, double lr);
@@ -291,12 +292,17 @@ PPO_API ppo_status ppo_comm_init_local(ppo_ctx* ctx, int64_t group_id, int32_t r
  *   1. ppo_comm_exchange_handle(ctx, handle)          on every rank
  *   2. gather the nranks handles in rank order
  *   3. ppo_comm_init_exchange(ctx, handles, rank, n)  on every rank
- * A kernel waits for a peer's share at most ~2 s, then gives up, counts a timeout (ppo_comm_exchange_timeouts) and marks the communicator
- * dead (no later call waits again): it never spins forever. */
+ * A kernel never spins forever: it waits for a peer's share at most the wait limit (default 30 s, ppo_comm_set_wait_limit -- keep it above any
+ * host-side skew between ranks: a checkpoint write, a statistics read-back), then gives up with an incomplete sum, sets the timeout flag
+ * (ppo_comm_exchange_timeouts: zero / non-zero) and marks the communicator dead (no later call waits again).  The failure is REPORTED: the next
+ * ppo_sync, ppo_read_stats or ppo_profile_read of the context returns PPO_ERR_COMM (the replicas have diverged; the job must stop).
+ * HIP IPC between processes needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of every rank on hosts whose driver only supports dmabuf IPC
+ * (set before the process's first HIP call; ppo-libtorch_amd/dist.py does it at import). */
 #define PPO_COMM_HANDLE_BYTES 64
 PPO_API ppo_status ppo_comm_exchange_handle(ppo_ctx* ctx, void* handle_out_h /* PPO_COMM_HANDLE_BYTES */);
 PPO_API ppo_status ppo_comm_init_exchange(ppo_ctx* ctx, const void* handles_h /* nranks x PPO_COMM_HANDLE_BYTES */, int32_t rank, int32_t nranks);
-PPO_API ppo_status ppo_comm_exchange_timeouts(ppo_ctx* ctx, int32_t* count_out);
+PPO_API ppo_status ppo_comm_set_wait_limit(ppo_ctx* ctx, double seconds);
+PPO_API ppo_status ppo_comm_exchange_timeouts(ppo_ctx* ctx, int32_t* nonzero_out);
 
 #ifdef __cplusplus
 }

@@ -803,6 +803,23 @@ int main(int argc, char** argv) {
             }
             return 0;
         }
+        if (mode == "golden_shipped" && argc > 2) {
+            // round 3 (missing #3): the shapes the reference itself ships and BASELINE.json configs[0] names, as they are
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            {
+                RunCfg c;  // Environments/CartPoleRecommendedSettings.toml AS SHIPPED: action_size = 1 (always action 0), 8 envs x 32 steps, seed 2
+                c.action_size = 1; c.updates = 2;
+                goldTrainScenario<PPO_Discrete, false>(c, "shipped", out + "/discrete_shipped_toml_t32_n8_act1.pgld");
+            }
+            {
+                RunCfg c;  // BASELINE.json configs[0]: 8 parallel envs, 128 steps, the recommended settings with action_size = 2
+                c.num_steps = 128; c.updates = 2;
+                goldTrainScenario<PPO_Discrete, false>(c, "config0", out + "/discrete_config0_t128_n8_seed2.pgld");
+            }
+            return 0;
+        }
         if (mode == "hostgold" && argc > 2) {
             char buf[4096];
             std::string out = argv[2];

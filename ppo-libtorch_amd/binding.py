@@ -18,7 +18,7 @@ MM_EPI_NONE, MM_EPI_BIAS, MM_EPI_BIAS_TANH, MM_EPI_DTANH = 0, 1, 2, 3
 MM_F32X3, MM_BF16 = 0, 1
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 COMM_HANDLE_BYTES = 64
 
@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",
     "ppo_read_stats", "ppo_set_learning_rate", "ppo_profile_enable", "ppo_profile_read", "ppo_comm_unique_id", "ppo_comm_init",
     "ppo_comm_init_local", "ppo_comm_exchange_handle", "ppo_comm_init_exchange", "ppo_comm_exchange_timeouts",
+    "ppo_comm_set_wait_limit",
 ]
 
 
@@ -377,6 +378,12 @@ def _comm_exchange_timeouts(self):
     return n.value
 
 
+def _comm_set_wait_limit(self, seconds):
+    """How long a direct-exchange kernel waits for a peer before it gives up (default 30 s; ppo_hip.h)."""
+    _check(lib().ppo_comm_set_wait_limit(self.h, C.c_double(seconds)), self.h)
+
+
+Context.comm_set_wait_limit = _comm_set_wait_limit
 Context.comm_exchange_handle = _comm_exchange_handle
 Context.comm_init_exchange = _comm_init_exchange
 Context.comm_exchange_timeouts = _comm_exchange_timeouts

@@ -88,7 +88,9 @@ struct ExchangeComm {
     void* peer[8] = {};               // mapped exchange buffers of every rank (peer[rank] == own)
     bool opened[8] = {};
     uint64_t seq = 0;                 // calls so far (same on every rank)
-    int32_t* timeout_flag = nullptr;  // device: set by a kernel whose bounded wait for a peer ran out
+    int32_t* timeout_flag = nullptr;  // device int32[4]: [0] set by a kernel whose bounded wait for a peer ran out; [2..3] = the wait limit as a u64 in
+                                      // ticks of the 100 MHz counter (kernels_update.hip: xchg_wait_all)
+    double wait_seconds = 30.0;       // larger than any realistic host-side skew between ranks (checkpoint write, statistics read-back, code-object load)
 };
 struct XchgPtrs { void* p[8]; };
 hipError_t launch_exchange_allreduce(void* buf, size_t count, bool f64, const XchgPtrs& peers, int rank, int n, size_t slot_bytes, uint64_t seq,
@@ -130,7 +132,9 @@ struct ppo_ctx {
     float* slab = nullptr;
     double* stat_slab = nullptr;
     double* loss_sums = nullptr;
-    AdvStat* adv_stats = nullptr;       // [steps_per_update] + 1 scratch slot
+    AdvStat* adv_stats = nullptr;       // [steps_per_update] + 1 scratch slot; sits right BEHIND gstats so that one all-reduce per update carries both
+    double* gstats = nullptr;           // [PPO_GSTAT_DOUBLES] job-global statistics block of a sharded run (ppo_internal.hpp: PPO_GSTAT_*)
+    bool have_gstats = false;           // the block holds the all-reduced statistics of the last ppo_update
     AdamCoef* adam_coefs = nullptr;     // device [steps_per_update + 1]
     AdamCoef* adam_coefs_h = nullptr;   // pinned mirror, two halves used alternately
     hipEvent_t coef_copied[2] = { nullptr, nullptr };  // H2D copy of each half has completed
@@ -320,12 +324,24 @@ static ppo_status ensure_reset_table(ppo_ctx* c, int64_t need) {
     return PPO_OK;
 }
 
+// Direct exchange: a kernel whose bounded wait for a peer ran out has summed only the shares that arrived and marked the communicator dead.  The
+// stream is idle here (every caller has just synchronised it): turn the flag into an error instead of letting diverged replicas train on.
+static ppo_status comm_health(ppo_ctx* c) {
+    if (!c->xchg || !c->xchg->timeout_flag) return PPO_OK;
+    int32_t f = 0;
+    HIPCHK(c, hipMemcpy(&f, c->xchg->timeout_flag, sizeof f, hipMemcpyDeviceToHost));
+    if (f != 0)
+        return fail(c, PPO_ERR_COMM, "direct exchange: an all-reduce gave up waiting for a peer after %.1f s; its sums were incomplete, the replicas have "
+                                     "diverged and the communicator is dead (every later all-reduce returns at once)", c->xchg->wait_seconds);
+    return PPO_OK;
+}
+
 static ppo_status check_device_flag(ppo_ctx* c) {
     int32_t f = 0;
     HIPCHK(c, hipMemcpyAsync(&f, c->error_flag, sizeof f, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (f & 1) return fail(c, PPO_ERR_STATE, "CartPole reset-stream table exhausted (capacity %d resets per env)", c->reset_cap);
-    return PPO_OK;
+    return comm_health(c);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -467,7 +483,12 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));
     CK(dalloc(c, &c->stat_slab, (size_t)2 * c->max_blocks_per_net * 8));
     CK(dalloc(c, &c->loss_sums, 8));
-    CK(dalloc(c, &c->adv_stats, ((size_t)c->steps_per_update + 1) * PPO_ADV_PARTS));
+    {   // [gstats | adv_stats] contiguous: a sharded update sends both in ONE all-reduce
+        double* blk = nullptr;
+        CK(dalloc(c, &blk, (size_t)PPO_GSTAT_DOUBLES + ((size_t)c->steps_per_update + 1) * PPO_ADV_PARTS * (sizeof(AdvStat) / sizeof(double))));
+        c->gstats = blk;
+        c->adv_stats = reinterpret_cast<AdvStat*>(blk + PPO_GSTAT_DOUBLES);
+    }
     CK(dalloc(c, &c->adam_coefs, (size_t)c->steps_per_update + 1));
     CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), 2 * ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
     CK(hipEventCreateWithFlags(&c->coef_copied[0], hipEventDisableTiming));
@@ -578,7 +599,7 @@ extern "C" ppo_status ppo_sync(ppo_ctx* c) {
     NEED(c, c != nullptr, "null ctx");
     DeviceGuard dev_guard(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PPO_OK;
+    return comm_health(c);
 }
 extern "C" void* ppo_stream(ppo_ctx* c) { return c ? c->stream : nullptr; }
 extern "C" ppo_status ppo_get_config(const ppo_ctx* c, ppo_config* out) {
@@ -913,7 +934,9 @@ extern "C" ppo_status ppo_env_get_state_h(ppo_ctx* c, float* state_h, int32_t* e
 static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced);
 static ppo_status consume_finished_episodes(ppo_ctx* c) {
     if (!c->fin_pending) return PPO_OK;
-    HIPCHK(c, launch_episode_ring_update(B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), c->T, c->N, c->row_counts, c->group_bits, c->ring, c->stream));
+    // the rollout that left these episodes has already advanced rollout_steps by T
+    HIPCHK(c, launch_episode_ring_update(B_<int32_t>(c, PPO_BUF_FIN_LEN), B_<float>(c, PPO_BUF_FIN_REW), c->T, c->N, c->row_counts, c->group_bits, c->ring,
+                                         c->rollout_steps - c->T, c->cfg.global_num_envs, c->cfg.env_offset, c->stream));
     c->fin_pending = false;
     return PPO_OK;
 }
@@ -1308,19 +1331,37 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
     const int E = c->cfg.update_epochs, nmb = c->n_mb;
     ppo_status s = PPO_OK;
     const int32_t* perm = B_<int32_t>(c, PPO_BUF_PERM);
+    // returns, values and advantages are fixed for the whole update: the sample records and the explained-variance sums (:647-648) are formed first,
+    // so that a sharded run can send its statistics along with the advantage sums
+    s = pack_records(c);
+    if (s != PPO_OK) return s;
+    if (!c->use_mfma || c->gen)   // otherwise pack_records left the sums
+        HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
+    // sharded: this rank's slot of the job-global statistics block (explained-variance sums, its ring of finished episodes with their positions in
+    // the reference's push order) rides in front of the advantage sums -- one all-reduce per update, and ppo_read_stats is the same on every rank
+    const bool sharded = (c->world > 1 || c->force_collectives) && c->world <= 8;
+    if (sharded) {
+        s = consume_finished_episodes(c);
+        if (s != PPO_OK) return s;
+        HIPCHK(c, launch_gstats_pack(c->ev_sums, c->ring, c->rank, c->gstats, c->stream));
+    }
     if (c->cfg.norm_adv) {
         // the advantages and the permutations are fixed for the whole update: the permutations of all epochs and the statistics of ALL
         // minibatches in one launch (and, when sharded, one small all-reduce) instead of a reduction inside every optimizer step
         HIPCHK(c, launch_permutations_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), B_<int32_t>(c, PPO_BUF_PERM), c->B, E, c->MB, c->cfg.seed, c->updates,
                                                 c->rank, c->adv_stats, c->stream));
-        s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
+        if (sharded) s = allreduce_sum(c, c->gstats, (size_t)PPO_GSTAT_DOUBLES + (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
+        else s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
     } else {
         s = ppo_generate_permutations(c);
         if (s != PPO_OK) return s;
+        if (sharded) {
+            s = allreduce_sum(c, c->gstats, (size_t)PPO_GSTAT_DOUBLES, true);
+            if (s != PPO_OK) return s;
+        }
     }
-    s = pack_records(c);
-    if (s != PPO_OK) return s;
+    c->have_gstats = sharded;
     // AdamW scalars of every step of this update, one async copy.  The pinned mirror has two halves used alternately; a half is
     // rewritten only once its previous copy has completed (normally long ago: no stall, and no stream-wide synchronisation).
     {
@@ -1381,8 +1422,6 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
             if (s != PPO_OK) return s;
         }
     }
-    if (!c->use_mfma || c->gen)   // otherwise pack_records left the sums
-        HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
     c->have_ev = true;
     c->updates += 1;
     return PPO_OK;
@@ -1422,6 +1461,40 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
     double cf[2] = { 0, 0 };
     HIPCHK(c, hipMemcpy(cf, c->clipfrac_accum, sizeof cf, hipMemcpyDeviceToHost));
     out->clipfrac_mean = cf[1] > 0 ? cf[0] / cf[1] : 0.0;
+    if (c->have_gstats) {
+        // sharded: the all-reduced block of the last ppo_update holds every rank's explained-variance sums and ring -- the same bytes on every rank
+        std::vector<double> g(PPO_GSTAT_DOUBLES);
+        HIPCHK(c, hipMemcpy(g.data(), c->gstats, g.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double n = (double)c->B * c->world;
+        const double var_y = (g[1] - g[0] * g[0] / n) / (n - 1.0), var_d = (g[3] - g[2] * g[2] / n) / (n - 1.0);
+        out->explained_variance = (double)(1.0f - (float)var_d / (float)var_y);  // :647-648 over the job's whole batch
+        // the job's CircularBuffer(100): the newest 100 episodes of the union, in the reference's push order (step, then global env index)
+        struct Ep { double key, len, rew; };
+        std::vector<Ep> eps;
+        for (int r = 0; r < c->world; r++) {
+            const double* slot = g.data() + PPO_GSTAT_HEAD + (size_t)r * PPO_GSTAT_RANK;
+            const int size = (int)slot[1];
+            for (int i = 0; i < size && i < 100; i++) eps.push_back({ slot[4 + 3 * i], slot[4 + 3 * i + 1], slot[4 + 3 * i + 2] });
+        }
+        std::sort(eps.begin(), eps.end(), [](const Ep& a, const Ep& b) { return a.key < b.key; });
+        const size_t keep = std::min<size_t>(eps.size(), 100), first = eps.size() - keep;
+        if (keep > 0) {
+            // the reference sums the ring from slot 0 upwards (Utils.h:72-78); a float sum depends on that order, so the merged episodes are laid
+            // out as the single ring would hold them: episode number j of the job sits in slot j % 100
+            double total = 0;
+            for (int r = 0; r < c->world; r++) total += g[PPO_GSTAT_HEAD + (size_t)r * PPO_GSTAT_RANK];
+            std::vector<Ep> ring_order(keep);
+            for (size_t i = 0; i < keep; i++) {
+                const long long j = (long long)total - (long long)keep + (long long)i;   // 0-based episode number
+                ring_order[keep < 100 ? i : (size_t)(j % 100)] = eps[first + i];
+            }
+            double sl = 0, sr = 0;
+            for (size_t i = 0; i < keep; i++) { sl += ring_order[i].len; sr += ring_order[i].rew; }
+            out->ep_len_mean = sl / (double)keep;
+            out->ep_rew_mean = (double)(float)(sr / (double)keep);
+        }
+        out->ep_count = (int32_t)keep;
+    } else {
     if (c->have_ev) {
         static_assert(PPO_EV_BLOCKS * 4 * sizeof(double) <= 32768, "stack buffer");
         double ev[PPO_EV_BLOCKS * 4];
@@ -1441,6 +1514,7 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
         out->ep_rew_mean = (double)(float)(sr / ring.size); // avgReward returns float (Utils.h:72-74)
     }
     out->ep_count = ring.size;
+    }
     out->learning_rate = c->lr;
     out->global_step = c->global_step;
     out->optimizer_steps = c->opt_step;
@@ -1478,6 +1552,10 @@ extern "C" ppo_status ppo_profile_read(ppo_ctx* c, ppo_profile* out) {
     DeviceGuard dev_guard(c);
     std::memset(out, 0, sizeof *out);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        const ppo_status hs = comm_health(c);
+        if (hs != PPO_OK) return hs;
+    }
     int64_t* cnt[PROF_KINDS_] = { &out->fwd_bwd_launches, &out->gae_launches, &out->rollout_launches, &out->optimizer_launches, &out->reduce_launches };
     double* ms[PROF_KINDS_] = { &out->fwd_bwd_ms, &out->gae_ms, &out->rollout_ms, &out->optimizer_ms, &out->reduce_ms };
     for (auto& sp : c->spans) {
@@ -1589,7 +1667,9 @@ extern "C" ppo_status ppo_comm_exchange_handle(ppo_ctx* c, void* handle_out_h) {
         hipError_t e = hipExtMallocWithFlags(&x->own, total, hipDeviceMallocFinegrained);
         if (e != hipSuccess) { (void)hipGetLastError(); HIPCHK(c, hipMalloc(&x->own, total)); }
         HIPCHK(c, hipMemset(x->own, 0, total));
-        HIPCHK(c, dalloc(c, &x->timeout_flag, 1));
+        HIPCHK(c, dalloc(c, &x->timeout_flag, 4));
+        const unsigned long long ticks = (unsigned long long)(x->wait_seconds * 1e8);   // s_memrealtime: 100 MHz
+        HIPCHK(c, hipMemcpy(x->timeout_flag + 2, &ticks, sizeof ticks, hipMemcpyHostToDevice));
         HIPCHK(c, hipDeviceSynchronize());
         c->xchg = std::move(x);
     }
@@ -1624,7 +1704,22 @@ extern "C" ppo_status ppo_comm_init_exchange(ppo_ctx* c, const void* handles_h, 
     return PPO_OK;
 }
 
-// 0: no all-reduce kernel of this context has given up waiting for a peer; otherwise the number of such events (a peer died or never joined)
+// How long a kernel of the direct exchange waits for a peer's share before it gives up (default 30 s).  Call after ppo_comm_exchange_handle.
+extern "C" ppo_status ppo_comm_set_wait_limit(ppo_ctx* c, double seconds) {
+    NEED(c, c != nullptr, "null ctx");
+    DeviceGuard dev_guard(c);
+    NEED(c, c->xchg && c->xchg->timeout_flag, "call ppo_comm_exchange_handle first");
+    NEED(c, seconds >= 1e-3 && seconds <= 3600.0, "wait limit must lie in [1 ms, 1 h]");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->xchg->wait_seconds = seconds;
+    const unsigned long long ticks = (unsigned long long)(seconds * 1e8);
+    HIPCHK(c, hipMemcpy(c->xchg->timeout_flag + 2, &ticks, sizeof ticks, hipMemcpyHostToDevice));
+    return PPO_OK;
+}
+
+// 0: no all-reduce kernel of this context has given up waiting for a peer; non-zero: at least one has (a peer died or never joined) -- read it as
+// a boolean: every polling lane that gives up adds to it, and so does every later call on the dead communicator.  Never fails because of the
+// flag itself (ppo_sync / ppo_read_stats / ppo_profile_read do: PPO_ERR_COMM).
 extern "C" ppo_status ppo_comm_exchange_timeouts(ppo_ctx* c, int32_t* count_out) {
     NEED(c, c && count_out, "null argument");
     DeviceGuard dev_guard(c);

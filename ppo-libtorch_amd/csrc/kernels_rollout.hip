@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void episode_count_kernel(const int32_t* __res
 
 __global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restrict__ fin_len, const float* __restrict__ fin_rew, int T, int N,
                                                           const int32_t* __restrict__ row_counts, const uint64_t* __restrict__ group_bits,
-                                                          EpisodeRing* ring) {
+                                                          EpisodeRing* ring, int64_t step_base, int64_t global_num_envs, int64_t env_offset) {
     // Only the last 100 finished episodes of the rollout survive in the ring.  The window of rows that holds them is found from
     // the row counts (kept in LDS: the serial loops below must not pay a memory round trip per row); inside the window every
     // finished episode knows its rank j in (step, env) order from prefix popcounts, and exactly those with j >= W - 100 are
@@ -620,6 +620,7 @@ __global__ __launch_bounds__(64) void episode_push_kernel(const int32_t* __restr
                     const int slot = (head + j) % 100;
                     ring->len[slot] = fin_len[(size_t)t * N + n];
                     ring->rew[slot] = fin_rew[(size_t)t * N + n];
+                    ring->key[slot] = (step_base + t) * global_num_envs + env_offset + n;
                 }
                 j++;
             }
@@ -785,9 +786,9 @@ hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t*
 }
 
 hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, uint64_t* group_bits,
-                                      EpisodeRing* ring, hipStream_t s) {
+                                      EpisodeRing* ring, int64_t step_base, int64_t global_num_envs, int64_t env_offset, hipStream_t s) {
     hipLaunchKernelGGL(episode_count_kernel, dim3((unsigned)T), dim3(256), 0, s, fin_len, N, row_counts, group_bits);
-    hipLaunchKernelGGL(episode_push_kernel, dim3(1), dim3(64), 0, s, fin_len, fin_rew, T, N, row_counts, group_bits, ring);
+    hipLaunchKernelGGL(episode_push_kernel, dim3(1), dim3(64), 0, s, fin_len, fin_rew, T, N, row_counts, group_bits, ring, step_base, global_num_envs, env_offset);
     return hipGetLastError();
 }
 

@@ -637,11 +637,14 @@ __device__ __forceinline__ void xchg_publish_done(void* const* peers, int rank, 
     if (last && lane < n && lane != rank) __hip_atomic_store(xchg_flag(peers[lane], slot_bytes, parity, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Waits (bounded) until every peer's share of call `seq` has landed in THIS rank's buffer: lane r of the calling wave polls local flag r.
-// Returns the mask of peers whose slot may be read; a wait that runs out is counted in timeout_flag and marks the communicator dead
-// (later calls do not wait again).
+// Returns the mask of peers whose slot may be read; a wait that runs out sets timeout_flag[0] (zero / non-zero: every polling lane of every
+// workgroup that gives up adds to it) and marks the communicator dead: later calls do not wait again, and the host reports PPO_ERR_COMM from
+// its next synchronising call (api.hip: comm_health).  The limit, in ticks of the 100 MHz s_memrealtime counter, sits behind the flag as a
+// u64 at timeout_flag + 2 (ppo_comm_set_wait_limit; default 30 s -- larger than any host-side skew between ranks such as a checkpoint write).
 __device__ __forceinline__ unsigned xchg_wait_all(void* own, int rank, int n, size_t slot_bytes, int parity, unsigned long long seq, int32_t* timeout_flag) {
     const int lane = threadIdx.x & 63;
     const bool dead = __hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const unsigned long long limit = *reinterpret_cast<const unsigned long long*>(timeout_flag + 2);
     int ok = 1;
     if (lane < n && lane != rank) {
         const unsigned long long* flag = xchg_flag(own, slot_bytes, parity, lane);
@@ -649,7 +652,7 @@ __device__ __forceinline__ unsigned xchg_wait_all(void* own, int rank, int n, si
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
         for (;;) {
             if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= seq) { ok = 1; break; }
-            if (dead || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;   // ~2 s
+            if (dead || __builtin_amdgcn_s_memrealtime() - t0 > limit) break;
             __builtin_amdgcn_s_sleep(8);
         }
         if (!ok) atomicAdd(timeout_flag, 1);
@@ -926,10 +929,10 @@ __global__ void local_allreduce_kernel(PtrPack8 pk, int n, size_t count) {
 // same on every rank) uses parity seq & 1.
 //   publish:  every thread stores its elements of buf into this rank's slot of EVERY peer's buffer (system scope), release; the workgroup that
 //             arrives last on the parity's counter stamps this rank's flag in every peer's buffer with seq
-//   gather:   wave 0 waits until every peer's flag in the OWN buffer has reached seq (lane r polls flag r, at most ~2 s), then every thread adds
+//   gather:   wave 0 waits until every peer's flag in the OWN buffer has reached seq (lane r polls flag r, bounded: xchg_wait_all), then every thread adds
 //             the peers' elements out of the own buffer in rank order
 //   result:   buf = the sum, formed in the same order on every rank.
-// A timeout leaves the sum incomplete and counts itself in timeout_flag: the kernel always ends.
+// A timeout leaves the sum incomplete and sets timeout_flag: the kernel always ends, and the host turns the flag into PPO_ERR_COMM.
 struct XchgPtrs8 { void* p[8]; };
 // The grid is bounded (launch_exchange_allreduce: at most XCHG_MAX_BLOCKS workgroups, each walking the buffer in strides): every workgroup
 // waits for flags that a peer stamps only when ITS last workgroup has arrived, so all workgroups of a rank must be resident at once --
@@ -988,6 +991,34 @@ __global__ __launch_bounds__(256) void explained_variance_kernel(const float* __
     if ((threadIdx.x & 63) == 0) { red[w][0] = sy; red[w][1] = sy2; red[w][2] = sd; red[w][3] = sd2; }
     __syncthreads();
     if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// This rank's contribution to the job-global statistics block (ppo_internal.hpp: PPO_GSTAT_*).  One workgroup: zero the block, add the
+// PPO_EV_BLOCKS explained-variance rows in a fixed order (thread j: rows j and j + 256, then a fixed tree), copy the ring into the rank's slot.
+__global__ __launch_bounds__(256) void gstats_pack_kernel(const double* __restrict__ ev_sums, const EpisodeRing* __restrict__ ring, int rank, double* __restrict__ g) {
+    __shared__ double red[256][4];
+    static_assert(PPO_EV_BLOCKS == 512, "two explained-variance rows per thread");
+    const int j = threadIdx.x;
+    for (int i = j; i < PPO_GSTAT_DOUBLES; i += 256) g[i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[j][q] = ev_sums[j * 4 + q] + ev_sums[(j + 256) * 4 + q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (j < o) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[j][q] += red[j + o][q];
+        }
+        __syncthreads();
+    }
+    if (j < 4) g[j] = red[0][j];
+    double* slot = g + PPO_GSTAT_HEAD + (size_t)rank * PPO_GSTAT_RANK;
+    const int size = ring->size;
+    if (j == 0) { slot[0] = (double)ring->total; slot[1] = (double)size; }
+    if (j < size && j < 100) {
+        slot[4 + 3 * j + 0] = (double)ring->key[j];
+        slot[4 + 3 * j + 1] = (double)ring->len[j];
+        slot[4 + 3 * j + 2] = (double)ring->rew[j];
+    }
 }
 
 }  // namespace
@@ -1095,6 +1126,12 @@ hipError_t launch_permutations_adv_stats(const float* advantages, int32_t* perm,
 
 hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s) {
     hipLaunchKernelGGL(explained_variance_kernel, dim3(PPO_EV_BLOCKS), dim3(256), 0, s, returns, values, B, sums4);
+    return hipGetLastError();
+}
+
+hipError_t launch_gstats_pack(const double* ev_sums, const EpisodeRing* ring, int rank, double* gstats, hipStream_t s) {
+    if (rank < 0 || rank >= 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gstats_pack_kernel, dim3(1), dim3(256), 0, s, ev_sums, ring, rank, gstats);
     return hipGetLastError();
 }
 

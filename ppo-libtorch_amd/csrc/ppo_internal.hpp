@@ -81,6 +81,16 @@ struct LossParams {
 struct AdvStat { double s1, s2; };
 #define PPO_ADV_PARTS 32  // partial sums per minibatch (one workgroup each), added in order by the consumer (A/B on one box, tools/ab.sh: 32 parts 56.7 us per update launch and 161.7 M env-steps/s, 8 parts 57.9 us and 158.5 M)
 #define PPO_EV_BLOCKS 512 // partial rows of the explained-variance sums, added in order by the host
+// Job-global statistics block of a sharded run (doubles; summed over ranks by the per-update all-reduce, every rank writes only its own slot, so the
+// "sum" is a gather): the reference prints ONE table for the job (PPO_Discrete.cpp:474-480, 647-648, 700-774), so every rank must hold the same numbers.
+//   [0..3]   explained-variance sums {sum y, sum y^2, sum d, sum d^2} of this rank's shard (added over ranks = the global sums)
+//   [4..7]   reserved (zero)
+//   rank r:  [8 + r * PPO_GSTAT_RANK + 0] finished episodes so far, [.. + 1] entries in this rank's ring, [.. + 4 + 3 i + {0, 1, 2}] = {key, length, reward}
+//            of ring entry i; key = (absolute rollout step) * global_num_envs + global env index = the position of the episode in the reference's
+//            push order, so the host rebuilds the job's CircularBuffer(100) exactly: the newest 100 keys of the union.
+#define PPO_GSTAT_HEAD 8
+#define PPO_GSTAT_RANK (4 + 3 * 100)
+#define PPO_GSTAT_DOUBLES (PPO_GSTAT_HEAD + 8 * PPO_GSTAT_RANK)
 
 // Device-side record of one optimizer step's scalars (doubles so the host reads them as-is).
 struct StepStats {
@@ -558,9 +568,12 @@ struct EpisodeRing {
     int32_t len[100];
     int32_t size, head;
     int64_t total;
+    int64_t key[100];   // (absolute rollout step) * global_num_envs + global env index: the episode's position in the reference's push order
 };
 hipError_t launch_episode_ring_update(const int32_t* fin_len, const float* fin_rew, int T, int N, int32_t* row_counts, uint64_t* group_bits,
-                                      EpisodeRing* ring, hipStream_t s);
+                                      EpisodeRing* ring, int64_t step_base, int64_t global_num_envs, int64_t env_offset, hipStream_t s);
+// this rank's contribution to the job-global statistics block (PPO_GSTAT_*): zeroes the block, then writes the head and the rank's own slot
+hipError_t launch_gstats_pack(const double* ev_sums, const EpisodeRing* ring, int rank, double* gstats, hipStream_t s);
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s);
 hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s);

@@ -8,6 +8,11 @@ id, barriers and the max-over-ranks of the timing.
 """
 import os
 
+# HIP IPC between processes (RCCL's intra-node transport and the direct exchange's peer buffers) needs dmabuf IPC on hosts whose driver supports
+# nothing else; without it hipIpcGetMemHandle / ncclCommInitRank fail with "invalid argument".  It must be in the environment before the process's
+# first HIP call, which is why it is set where the multi-process path is imported, not where a communicator is made.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def shard_envs(global_num_envs, rank, world):
     """Contiguous equal shards.  Returns (num_envs, env_offset)."""
@@ -48,6 +53,8 @@ def init_process_group(backend="gloo"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: gloo must not depend on the host name resolving
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist, rank, world

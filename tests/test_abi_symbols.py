@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(P):
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
     assert [e for e in exported if e.startswith("ppo_")] == decl
     assert all(e.startswith("ppo_") or e.startswith("_") for e in exported)  # nothing else leaks from the C-ABI
-    assert lib.ppo_abi_version() == P.binding.ABI_VERSION == 2
+    assert lib.ppo_abi_version() == P.binding.ABI_VERSION == 3
 
 
 def test_struct_mirrors_match_header(P):

@@ -35,11 +35,14 @@ for rep in range(5):   # several calls: both slots, flags reused
     assert np.array_equal(got, pattern * (rep + 1) * (world * (world + 1) // 2)), (rank, rep)
 ctx.init_orthogonal(9)
 ctx.env_reset()
-for _ in range(2):
-    ctx.train_iteration()
+ctx.train_iteration()
+st1 = ctx.stats()     # after the FIRST iteration the job's rollout is, column for column, the single context's: its statistics must be too
+ctx.train_iteration()
 p = ctx.get_params()
 st = ctx.stats()
-out = dict(rank=rank, timeouts=ctx.comm_exchange_timeouts(), params=p.view(np.uint32).tolist(), loss=st["loss"], steps=st["optimizer_steps"])
+keys = ("ep_len_mean", "ep_rew_mean", "ep_count", "explained_variance", "global_step", "loss", "pg_loss", "v_loss")
+out = dict(rank=rank, timeouts=ctx.comm_exchange_timeouts(), params=p.view(np.uint32).tolist(), loss=st["loss"], steps=st["optimizer_steps"],
+           st1=dict((k, st1[k]) for k in keys), st2=dict((k, st[k]) for k in keys))
 json.dump(out, open(os.path.join({out!r}, "rank%d.json" % rank), "w"))
 dist.barrier()
 ctx.close()
@@ -89,10 +92,19 @@ def test_exchange_ranks_equal_single_context(tmp_path, world):
     whole = P.Context(P.make_config(num_envs=N, num_steps=T, num_minibatches=2, update_epochs=2, seed=5, total_timesteps=4 * N * T, anneal_lr=False))
     whole.init_orthogonal(9)
     whole.env_reset()
-    for _ in range(2):
-        whole.train_iteration()
+    whole.train_iteration()
+    w1 = whole.stats()
+    whole.train_iteration()
     pw = whole.get_params()
     whole.close()
+    # job-global statistics (ppo_hip.h, ppo_read_stats): identical on every rank after every update, and after the first iteration -- whose
+    # rollout is the single context's, column for column -- equal to what ONE context over all the envs reports (PPO_Discrete.cpp:474-480, 647-648)
+    for r in range(1, world):
+        assert res[r]["st1"] == res[0]["st1"] and res[r]["st2"] == res[0]["st2"], r
+    assert res[0]["st1"]["ep_count"] == w1["ep_count"] > 0
+    assert res[0]["st1"]["ep_len_mean"] == w1["ep_len_mean"] and res[0]["st1"]["ep_rew_mean"] == w1["ep_rew_mean"]
+    assert res[0]["st1"]["global_step"] == w1["global_step"] == N * T
+    assert abs(res[0]["st1"]["explained_variance"] - w1["explained_variance"]) <= 2e-6
     # two full iterations with different minibatch partitions: the trajectories agree in distribution, not element-wise -- bound the distance loosely
     assert np.isfinite(params[0].view(np.float32)).all()
     assert np.abs(params[0].view(np.float32) - pw).max() < 0.05
@@ -108,23 +120,34 @@ dist, rank, world = P.dist.init_process_group("gloo")
 cfg = P.dist.shard_config(P.make_config, rank, world, 64, num_steps=32, num_minibatches=2, update_epochs=2, seed=5, total_timesteps=4 * 64 * 32)
 ctx = P.Context(cfg)
 P.dist.bootstrap_comm(ctx, dist, rank, world, P.comm_unique_id, transport="exchange")
-if rank == 0:   # rank 1 never takes part: rank 0's first call waits out its ~2 s, every later call returns at once, and the count says so
-    times = []
+if rank == 0:   # rank 1 never takes part: rank 0's first call waits out its limit (set to 2 s here; default 30), every later call returns at once,
+    # and the failure is REPORTED: the synchronising call after it returns PPO_ERR_COMM
+    ctx.comm_set_wait_limit(2.0)
+    times, errors = [], []
     for rep in range(3):
         ctx.write("GRADS", np.ones(ctx.P, np.float32))
         t0 = time.perf_counter()
         P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
-        ctx.sync()
+        try:
+            ctx.sync()
+            errors.append("")
+        except P.binding.PPOError as ex:
+            errors.append(str(ex))
         times.append(time.perf_counter() - t0)
-    json.dump(dict(times=times, timeouts=ctx.comm_exchange_timeouts()), open(os.path.join({out!r}, "dead.json"), "w"))
+    try:
+        ctx.stats()
+        stats_error = ""
+    except P.binding.PPOError as ex:
+        stats_error = str(ex)
+    json.dump(dict(times=times, errors=errors, stats_error=stats_error, timeouts=ctx.comm_exchange_timeouts()), open(os.path.join({out!r}, "dead.json"), "w"))
 dist.barrier()
 ctx.close()
 """
 
 
 def test_exchange_gives_up_once_when_a_peer_never_arrives(tmp_path):
-    """A peer that never calls: the bounded wait ends the first kernel after ~2 s and marks the communicator dead; the calls after it do not
-    wait again (bench.py --transport auto reads the count after its warm-up and falls back to RCCL)."""
+    """A peer that never calls: the bounded wait ends the first kernel after its limit and marks the communicator dead; the calls after it do not
+    wait again, and ppo_sync / ppo_read_stats return PPO_ERR_COMM from then on -- a run whose replicas diverged cannot report a number."""
     port = _free_port()
     script = tmp_path / "dead.py"
     script.write_text(DEAD_WORKER.format(root=ROOT, out=str(tmp_path)))
@@ -143,7 +166,9 @@ def test_exchange_gives_up_once_when_a_peer_never_arrives(tmp_path):
         outs.append(o.decode())
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     res = json.load(open(tmp_path / "dead.json"))
-    assert res["timeouts"] > 0
+    assert res["timeouts"] != 0
+    assert all("gave up waiting for a peer" in e for e in res["errors"]), res
+    assert "gave up waiting for a peer" in res["stats_error"], res
     assert 1.0 < res["times"][0] < 6.0, res
     assert res["times"][1] < 0.5 and res["times"][2] < 0.5, res
 
@@ -203,3 +228,39 @@ def test_exchange_with_a_generic_network(tmp_path, dtype):
     assert res[0]["P"] > 256 * 256 and all(r["timeouts"] == 0 for r in res)
     assert res[0]["params"] == res[1]["params"]
     assert np.isfinite(np.array(res[0]["params"], np.uint32).view(np.float32)).all() and np.isfinite(res[0]["loss"])
+
+
+def test_plain_bench_command_rehearses_two_ranks_on_this_gpu():
+    """The driver's plain command, `python bench.py --gpus 2 ...`, with no torchrun environment: bench.py starts the two rank processes itself
+    (before anything touches HIP), they rendezvous, bring the transport up, run, and rank 0's ONE line comes back with the transport that ran.
+    On this one-GPU box the ranks share the device (--same-device), which only the direct exchange supports -- the line says so."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--steps", "2", "--warmup", "1", "--envs", "256"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["comm_ranks"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["transport"] == "exchange" and d["transport_requested"] == "auto" and "same-device" in d["transport_fallback_reason"]
+    assert d["config"]["global_batch"] == 2 * 256 * 128 and d["value"] > 0
+    assert "dp2" in d["config"]["parallelism"]
+
+
+def test_bench_single_gpu_line_carries_the_rebased_roofline():
+    """N = 1 through the same entry: roofline.frac is the executed f16 MFMA stream against the dense f16 peak (cannot pass 1), the fp32-equivalent
+    rate sits beside it, the GAE bar is one object, the transport fields are present and empty."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ro = d["roofline"]
+    assert ro["bound"] == "mfma" and ro["peak"] == 2500.0 and 0.05 < ro["frac"] < 1.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    assert ro["achieved_fp32_equiv"] > 50 and "limiter" in ro
+    bar = d["gae_roofline"]["bar"]
+    assert bar["target_frac"] == 0.40 and bar["frac_at_config1"] > 0.1 and bar["size_met_from_envs"] in (4096, 8192, 32768, None)
+    assert d["transport"] == "none" and d["comm_ranks"] == 1 and d["transport_ab"] is None

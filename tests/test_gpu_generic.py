@@ -29,7 +29,10 @@ def P():
 # tanh (hardware exp2 against tanhf), which now and then tips a value across a bf16 rounding boundary (one part in 256 of that activation).
 # Measured at configs[4]'s shape (tools/bf16_dev_report.py): log-prob 6e-4 max / 4e-6 mean, value 2e-3 max / 2e-5 mean, losses 2e-6, gradient 2e-4
 # of its largest element -- against 0.38 / 1e-2 / 1e-2 between the bf16 and the f32 arithmetic themselves.
-TOL = {0: dict(fwd=5e-6, agree=0.995, loss=1e-5, grad=1e-4, same=1e-6), 1: dict(fwd=4e-3, agree=0.98, loss=3e-5, grad=1e-3, same=1e-6)}
+# PARITY UNPINNED for every shape in this file: the reference hard-wires 2 x 64 networks (Agent.cpp:25-59), so nothing the reference holds can pin a
+# 4 x 256 network or bf16 arithmetic; the yardstick is the oracle's own generic / bf16 mode (ORC_DTYPE_BF16), whose f32 2 x 64 case IS pinned.
+# bf16 bars = ~3x the measured values above (log-prob 6e-4 -> 2e-3, value 2e-3 -> 4e-3 (2x), losses 2e-6 -> 6e-6, gradient 2e-4 -> 6e-4 of max).
+TOL = {0: dict(fwd=5e-6, fwd_v=5e-6, agree=0.995, loss=1e-5, grad=1e-4, same=1e-6), 1: dict(fwd=2e-3, fwd_v=4e-3, agree=0.98, loss=6e-6, grad=6e-4, same=1e-6)}
 
 
 def _check_shape(P, obs_dim, hidden, n_hidden, heads, N, T, nmb, masked, seed, max_steps=40, dtype=0):
@@ -84,8 +87,8 @@ def _check_shape(P, obs_dim, hidden, n_hidden, heads, N, T, nmb, masked, seed, m
     rows = np.random.default_rng(0).choice(T * N, min(T * N, 1024), replace=False)
     lp_o, en_o, v_o = O.evaluate(net, params, flat_obs[rows], flat_act[rows], flat_mask[rows] if masked else None)
     np.testing.assert_allclose(logp.reshape(-1)[rows], lp_o, rtol=0, atol=tol["fwd"])
-    np.testing.assert_allclose(values.reshape(-1)[rows], v_o, rtol=0, atol=tol["fwd"])
-    np.testing.assert_allclose(next_value[:64], O.get_value(net, params, next_obs[:64]), rtol=0, atol=tol["fwd"])
+    np.testing.assert_allclose(values.reshape(-1)[rows], v_o, rtol=0, atol=tol["fwd_v"])
+    np.testing.assert_allclose(next_value[:64], O.get_value(net, params, next_obs[:64]), rtol=0, atol=tol["fwd_v"])
     a_o, _, _, _ = O.act(net, params, obs[3], seed, 3, 0, masks[3] if masked else None)
     assert (a_o == actions[3]).mean() >= tol["agree"]
     # stand-alone entry points agree with the rollout's stores

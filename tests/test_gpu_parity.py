@@ -15,7 +15,9 @@ from __graft_entry__ import load_package
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DISCRETE = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1"]
+DISCRETE = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1",
+            # the shapes the reference ships and BASELINE.json configs[0] names, as they are (oracle/ref_harness.cpp: golden_shipped)
+            "discrete_shipped_toml_t32_n8_act1", "discrete_config0_t128_n8_seed2"]
 MASKED = ["multidiscrete_mountaincar_t32_n16"]
 
 
@@ -198,6 +200,65 @@ def test_fused_rollout_teacher_forced(P, name):
     ctx.close()
 
 
+def _masked_ctx_from_reference_state(P, g, meta):
+    """MountainCar::reset draws from std::random_device in the reference (MountainCar.cpp:79-88): unseedable, so the reference's own initial
+    observations are injected (ppo_env_set_state_h) -- from there on the env is deterministic given the actions."""
+    ctx = make_ctx(P, meta)
+    ctx.env_reset()
+    N = meta["N"]
+    ctx.env_set_state(state=g["init_obs"], ep_len=np.zeros(N, np.int32), ep_rew=np.zeros(N, np.float32))
+    return ctx
+
+
+@pytest.mark.parametrize("name", MASKED)
+def test_masked_step_envs_bit_exact(P, name):
+    """PPO_MultiDiscrete::stepEnvs (PPO_MultiDiscrete.cpp:434-504) with the reference's own sampled actions from the reference's initial state:
+    obs / reward / done bit for bit against the reference's rollout trace."""
+    g, meta = load(name)
+    ctx = _masked_ctx_from_reference_state(P, g, meta)
+    N, U = meta["N"], "u1/"
+    obs, done = g["init_obs"], np.zeros(N, np.int32)
+    for t in range(meta["T"]):
+        assert np.array_equal(bits(obs), bits(g[U + "obs"][t])), (name, t)
+        assert np.array_equal(done.astype(np.float32), g[U + "dones"][t])
+        # m_actions[step] = action broadcasts [N,1] into [N,action_size] (PPO_MultiDiscrete.cpp:93,562): column 0 is the action
+        obs, rew, done = ctx.env_step(g[U + "actions"][t][:, :1].astype(np.int64))
+        assert np.array_equal(rew, g[U + "rewards"][t])
+    assert np.array_equal(bits(obs), bits(g[U + "next_obs"])) and np.array_equal(done, g[U + "next_done"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", MASKED)
+def test_masked_fused_rollout_teacher_forced(P, name):
+    """The MultiDiscrete twin of the rollout (PPO_MultiDiscrete.cpp:547-571: getActionMask, getActionAndValueMasked, stores, stepEnvs) as ONE launch,
+    pinned to the reference's own trace: the reference's initial state and actions injected, OBS / REWARDS / DONES / MASKS / ACTIONS / NEXT_* bit for
+    bit, log-prob / value / entropy-free network outputs within fp32 noise (3e-6), then calcAdvantage bit-exact on the device's own values."""
+    g, meta = load(name)
+    ctx = _masked_ctx_from_reference_state(P, g, meta)
+    T, N, A, U = meta["T"], meta["N"], meta["act"], "u1/"
+    ctx.set_params(g[U + "params_before"])
+    ctx.rollout(g[U + "actions"][:, :, :1].astype(np.int64))
+    assert np.array_equal(bits(ctx.read("OBS", (T, N, meta["obs"]))), bits(g[U + "obs"]))
+    assert np.array_equal(ctx.read("REWARDS", (T, N)), g[U + "rewards"])
+    assert np.array_equal(ctx.read("DONES", (T, N)), g[U + "dones"])
+    assert np.array_equal(ctx.read("MASKS", (T, N, A)), g[U + "action_masks"].astype(np.uint8))
+    assert np.array_equal(ctx.read("ACTIONS", (T, N)), g[U + "actions"][:, :, 0].astype(np.int32))
+    assert np.array_equal(bits(ctx.read("NEXT_OBS", (N, meta["obs"]))), bits(g[U + "next_obs"]))
+    assert np.array_equal(ctx.read("NEXT_DONE"), g[U + "next_done"])
+    np.testing.assert_allclose(ctx.read("LOGPROBS", (T, N)), g[U + "logprobs"], rtol=0, atol=3e-6)  # tanh/exp/log ULPs
+    np.testing.assert_allclose(ctx.read("VALUES", (T, N)), g[U + "values"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(ctx.read("NEXT_VALUE"), g[U + "next_value"].ravel(), rtol=0, atol=3e-6)
+    adv, ret = ctx.calc_advantage()
+    o_adv, o_ret = O.gae(ctx.read("REWARDS", (T, N)), ctx.read("VALUES", (T, N)), ctx.read("DONES", (T, N)), ctx.read("NEXT_VALUE"),
+                         ctx.read("NEXT_DONE"), meta["gamma"], meta["lam"])
+    assert np.array_equal(bits(adv), bits(o_adv)) and np.array_equal(bits(ret), bits(o_ret))
+    np.testing.assert_allclose(adv, g[U + "gae_advantages"], rtol=0, atol=2e-4)
+    st = ctx.stats()
+    ref = g[U + "ep_stats"]
+    assert st["ep_count"] == int(ref[2])   # T = 32 < max_episode_steps = 200 and the goal is out of reach in 32 steps: no episode ends
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", DISCRETE + MASKED)
 def test_policy_forward_teacher_forced(P, name):
     g, meta = load(name)
@@ -284,7 +345,9 @@ def _load_batch(ctx, g, U, meta):
 @pytest.mark.parametrize("name", DISCRETE + MASKED)
 def test_minibatch_step_matches_reference(P, name):
     """One optimizer step (steps 1 and 2 of update 1) on the reference's batch with the reference's minibatch indices:
-    losses within 1e-5 (north_star), gradients within 1e-4 relative, AdamW moments and parameters within float noise."""
+    losses within 1e-5 (north_star), gradients within 5e-6 of the largest element (measured ~5e-7: 3 x the measured value would be 1.5e-6; 5e-6 is
+    the bar VERDICT round 2 set), AdamW moments within 1e-5 relative of the reference's (they are bit-exact GIVEN the reference's gradient --
+    test_adamw_bit_exact_given_reference_gradient; here they inherit the gradient's own 5e-7) and parameters within 1e-6."""
     g, meta = load(name)
     ctx = make_ctx(P, meta)
     U = "u1/"
@@ -304,13 +367,16 @@ def test_minibatch_step_matches_reference(P, name):
                        ("clipfrac", "clipfrac_last"), ("loss", "loss"), ("total_norm", "total_norm")):
             assert abs(st[key] - ref[n]) <= 1e-5 * max(1.0, abs(ref[n])), (name, k, n, st[key], ref[n])
         gref = g[K + "grads"]
-        assert np.abs(grads - gref).max() <= 1e-6 + 1e-4 * np.abs(gref).max(), (name, k)
+        gmax = np.abs(gref).max()
+        assert np.abs(grads - gref).max() <= 5e-6 * gmax, (name, k, np.abs(grads - gref).max() / gmax)
         ctx.optimizer_step()
         m, v, step = ctx.get_optimizer()
         assert step == k + 1
-        np.testing.assert_allclose(m, g[K + "exp_avg"], rtol=2e-4, atol=1e-9)
-        np.testing.assert_allclose(v, g[K + "exp_avg_sq"], rtol=4e-4, atol=1e-15)
-        np.testing.assert_allclose(ctx.get_params(), g[K + "params_after"], rtol=0, atol=2e-6)
+        # moments: absolute bars scaled by the largest element (an element near zero carries the ABSOLUTE error of the gradient's largest terms)
+        mref, vref = g[K + "exp_avg"], g[K + "exp_avg_sq"]
+        assert np.abs(m - mref).max() <= 5e-6 * np.abs(mref).max(), (name, k, np.abs(m - mref).max() / np.abs(mref).max())
+        assert np.abs(v - vref).max() <= 1e-5 * np.abs(vref).max(), (name, k, np.abs(v - vref).max() / np.abs(vref).max())
+        np.testing.assert_allclose(ctx.get_params(), g[K + "params_after"], rtol=0, atol=1e-6)
     ctx.close()
 
 
@@ -326,16 +392,14 @@ def test_adamw_bit_exact_given_reference_gradient(P, name):
     ctx.write("GRADS", g[K + "grads"])
     ctx.optimizer_step()
     m, v, step = ctx.get_optimizer()
-    # the clip coefficient comes from the device's own norm; equal to the reference's when the float norms agree
+    # the clip coefficient comes from the device's own total norm: the moments can only be bit-identical to the reference's when the two float
+    # norms are the SAME float.  That is asserted, not assumed -- there is no weaker branch to fall into.
     total_ref = np.float32(g[U + "step_scalars"][0, 6])
-    assert abs(ctx.stats()["total_norm"] - float(total_ref)) <= 2e-7 * float(total_ref) + 1e-12
-    if np.float32(ctx.stats()["total_norm"]) == total_ref:
-        assert np.array_equal(bits(m), bits(g[K + "exp_avg"]))
-        assert np.array_equal(bits(v), bits(g[K + "exp_avg_sq"]))
-        ulp = np.abs(bits(ctx.get_params()).astype(np.int64) - bits(g[K + "params_after"]).astype(np.int64))
-        assert ulp.max() <= 4 and (ulp != 0).mean() <= 2e-3
-    else:
-        np.testing.assert_allclose(m, g[K + "exp_avg"], rtol=1e-6)
+    assert np.float32(ctx.stats()["total_norm"]) == total_ref, (ctx.stats()["total_norm"], float(total_ref))
+    assert np.array_equal(bits(m), bits(g[K + "exp_avg"]))
+    assert np.array_equal(bits(v), bits(g[K + "exp_avg_sq"]))
+    ulp = np.abs(bits(ctx.get_params()).astype(np.int64) - bits(g[K + "params_after"]).astype(np.int64))
+    assert ulp.max() <= 4 and (ulp != 0).mean() <= 2e-3
     ctx.close()
 
 
@@ -760,26 +824,87 @@ def test_sharded_update_equals_single_context(P, world):
         assert np.array_equal(bits(out[0][k][2]), bits(out[1][k][2]))   # replicas stay bit-identical
 
 
-@pytest.mark.parametrize("epochs,nmb,iters,tol", [(1, 1, 1, 2e-6), (2, 4, 2, 1e-4)])
-def test_rccl_single_rank_selftest(P, monkeypatch, epochs, nmb, iters, tol):
+@pytest.mark.parametrize("world,N,T,max_steps", [(2, 128, 64, 40), (8, 128, 64, 40), (4, 16, 32, 25)])
+def test_sharded_job_statistics_equal_single_context(P, world, N, T, max_steps):
+    """ppo_read_stats of a sharded run is the JOB's table, identical on every rank (the reference prints one: PPO_Discrete.cpp:700-774).  Every
+    rank's ring of finished episodes, tagged with the episodes' positions in the reference's push order (step, then global env index; :474-480),
+    and its explained-variance sums (:647-648) ride the per-update all-reduce; the host rebuilds the job's CircularBuffer(100).  After the FIRST
+    iteration the job's rollout is, column for column, the single context's (same weights, global RNG streams), so the statistics must be the
+    single context's: episode means exactly (more than 100 finished episodes in the first two shapes, fewer in the third), explained variance to
+    float noise.  After the second iteration (permutations are per shard) they must still be the same on every rank."""
+    import threading
+    base = dict(num_steps=T, num_minibatches=2, update_epochs=1, seed=9, max_episode_steps=max_steps, total_timesteps=T * N * 4)
+    whole = P.Context(P.make_config(num_envs=N, **base))
+    whole.init_orthogonal(4)
+    params = whole.get_params()
+    whole.env_reset()
+    whole.train_iteration()
+    w1 = whole.stats()
+    whole.close()
+    keys = ("ep_len_mean", "ep_rew_mean", "ep_count", "explained_variance", "global_step", "loss", "approx_kl", "clipfrac_mean")
+    out, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            ctx = P.Context(P.dist.shard_config(P.make_config, rank, world, N, **base))
+            ctx.comm_init_local(4321 + world, rank, world)
+            ctx.set_params(params)
+            ctx.env_reset()
+            ctx.train_iteration()
+            s1 = ctx.stats()
+            ctx.train_iteration()
+            s2 = ctx.stats()
+            out[rank] = ({k: s1[k] for k in keys}, {k: s2[k] for k in keys})
+            ctx.close()
+        except Exception as ex:
+            errors.append(ex)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(o is not None for o in out)
+    for r in range(1, world):
+        assert out[r] == out[0], r
+    s1 = out[0][0]
+    assert s1["ep_count"] == w1["ep_count"] and (s1["ep_count"] == 100) == (N > 16)
+    assert s1["ep_len_mean"] == w1["ep_len_mean"] and s1["ep_rew_mean"] == w1["ep_rew_mean"]
+    assert s1["global_step"] == w1["global_step"] == N * T
+    assert abs(s1["explained_variance"] - w1["explained_variance"]) <= 2e-6
+
+
+def _rccl_selftest_ctx(P, monkeypatch, cfg, selftest):
+    ctx = P.Context(P.make_config(**cfg))
+    if selftest:
+        monkeypatch.setenv("PPO_COMM_SELFTEST", "1")
+        ctx.comm_init(P.comm_unique_id(), 0, 1)
+        monkeypatch.delenv("PPO_COMM_SELFTEST")
+    return ctx
+
+
+@pytest.mark.parametrize("epochs,nmb,iters", [(1, 1, 1), (2, 4, 2)])
+def test_rccl_single_rank_selftest(P, monkeypatch, epochs, nmb, iters):
     """The RCCL calls of the multi-rank path on ONE GPU: with PPO_COMM_SELFTEST=1 a one-rank communicator is really created
     (ncclGetUniqueId / ncclCommInitRank from the dlopen'ed librccl) and every collective of an update really goes through
-    ncclAllReduce (f32 gradient + loss-sum tail per optimizer step, f64 advantage sums per update), followed by the three-kernel
-    optimizer path the ranks of a multi-GPU job take.  Sums over one rank are the identity, so ONE optimizer step must reproduce the
-    plain single-context step to float noise (2e-6: the two optimizer paths add the squares of the gradient in different orders).
-    Over 16 steps the two trajectories drift apart like any two fp32 implementations (AdamW divides by sqrt(v)): bound 1e-4."""
+    ncclAllReduce (f32 gradient + loss-sum tail per optimizer step, f64 statistics block + advantage sums per update), followed by the
+    three-kernel optimizer path the ranks of a multi-GPU job take.  Sums over one rank are the identity, so the run must reproduce the
+    plain single-context run to float noise.  Both contexts are driven with the SAME forced actions (the env is deterministic given
+    them), so a sampled action cannot flip on a 1e-7 difference of a logit and the 16-step case stays a numerics check: parameters within
+    2e-5 (measured ~2e-6: the two optimizer paths add the squares of the gradient in different orders and AdamW divides by sqrt(v))."""
     cfg = dict(num_envs=256, num_steps=64, num_minibatches=nmb, update_epochs=epochs, seed=7, total_timesteps=256 * 64 * 4)
+    rng = np.random.default_rng(11)
+    forced = [rng.integers(0, 2, size=(64, 256, 1)).astype(np.int64) for _ in range(iters)]
 
     def run(selftest):
-        ctx = P.Context(P.make_config(**cfg))
-        if selftest:
-            monkeypatch.setenv("PPO_COMM_SELFTEST", "1")
-            ctx.comm_init(P.comm_unique_id(), 0, 1)
-            monkeypatch.delenv("PPO_COMM_SELFTEST")
+        ctx = _rccl_selftest_ctx(P, monkeypatch, cfg, selftest)
         ctx.init_orthogonal(7)
         ctx.env_reset()
-        for _ in range(iters):
-            ctx.train_iteration()
+        for k in range(iters):
+            ctx.rollout(forced[k])
+            ctx.calc_advantage()
+            ctx.update()
         out = (ctx.get_params(), ctx.stats())
         ctx.close()
         return out
@@ -788,9 +913,23 @@ def test_rccl_single_rank_selftest(P, monkeypatch, epochs, nmb, iters, tol):
     p1, s1 = run(True)
     assert np.all(np.isfinite(p1))
     assert s1["optimizer_steps"] == s0["optimizer_steps"] == iters * epochs * nmb
-    assert np.abs(p1 - p0).max() <= 10 * tol, np.abs(p1 - p0).max()
-    for key in ("pg_loss", "v_loss", "loss", "approx_kl", "total_norm"):
-        assert abs(s1[key] - s0[key]) <= tol * max(1.0, abs(s0[key])), (key, s1[key], s0[key])
+    assert np.abs(p1 - p0).max() <= 2e-5, np.abs(p1 - p0).max()
+    for key in ("pg_loss", "v_loss", "loss", "approx_kl", "total_norm", "explained_variance", "ep_len_mean", "ep_rew_mean"):
+        assert abs(s1[key] - s0[key]) <= 2e-5 * max(1.0, abs(s0[key])), (key, s1[key], s0[key])
+    assert s1["ep_count"] == s0["ep_count"]
+
+
+def test_rccl_single_rank_selftest_free_running(P, monkeypatch):
+    """The same path with its own sampled rollouts, two iterations: finiteness and bookkeeping only (sampled actions may flip on float noise)."""
+    cfg = dict(num_envs=256, num_steps=64, num_minibatches=4, update_epochs=2, seed=7, total_timesteps=256 * 64 * 4)
+    ctx = _rccl_selftest_ctx(P, monkeypatch, cfg, True)
+    ctx.init_orthogonal(7)
+    ctx.env_reset()
+    for _ in range(2):
+        ctx.train_iteration()
+    st = ctx.stats()
+    assert np.all(np.isfinite(ctx.get_params())) and np.isfinite(st["loss"]) and st["optimizer_steps"] == 16
+    ctx.close()
 
 
 def test_orthogonal_init_statistics(P):

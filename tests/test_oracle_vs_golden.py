@@ -14,7 +14,9 @@ import pytest
 import oracle as O
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DISCRETE = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1"]
+DISCRETE = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1",
+            # the shapes the reference ships and BASELINE.json configs[0] names, as they are (oracle/ref_harness.cpp: golden_shipped)
+            "discrete_shipped_toml_t32_n8_act1", "discrete_config0_t128_n8_seed2"]
 MASKED = ["multidiscrete_mountaincar_t32_n16"]
 
 
