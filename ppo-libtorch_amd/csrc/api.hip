@@ -1659,7 +1659,7 @@ extern "C" ppo_status ppo_comm_exchange_handle(ppo_ctx* c, void* handle_out_h) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (!c->xchg) {
         std::unique_ptr<ExchangeComm> x(new ExchangeComm());
-        const size_t grad = ((size_t)c->L.P + 8) * sizeof(float), adv = (size_t)2 * c->steps_per_update * PPO_ADV_PARTS * sizeof(double);
+        const size_t grad = ((size_t)c->L.P + 8) * sizeof(float), adv = ((size_t)PPO_GSTAT_DOUBLES + (size_t)2 * c->steps_per_update * PPO_ADV_PARTS) * sizeof(double);   // [statistics block | advantage sums]
         x->slot_bytes = (std::max(grad, adv) + 255) / 256 * 256;
         const size_t total = 16 * x->slot_bytes + 256;   // [2 parities][8 source ranks] payload slots, 16 flags, 2 counters (kernels_update.hip: xchg_slot)
         // fine-grained device memory: stores of a running kernel become visible to peers' running kernels (coarse-grained memory is only
