@@ -16,11 +16,16 @@
 //   (iv) all threads then stream A_t and R_t = A_t + v_t to HBM with coalesced 16-byte stores.
 // A done flag cuts the chain (c_t = 0 => A_t = delta_t exactly): that is the "segmented" part; it needs no special
 // handling in the serial walk and costs nothing.
-// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done).  v_{t+1} and
-// dones_{t+1} are requested a second time by the thread that forms delta_t while a neighbour's request for the same row (as its v_t) is
-// still in flight, so the memory side sees ~1.6x the algorithmic reads (PMC).  Fetching every row once and handing row t + 1 over through
-// LDS (one more barrier and LDS pass before the walk) was built and measured in round 2, A/B in one call: SLOWER at every size (4 096 envs
-// 5.6 against 4.9 us, 8 192: 6.9 against 6.3, 32 768: 21.2 against 18.7) -- the duplicate requests are cheaper than the extra phase.
+// Algorithmic HBM traffic: 12 B read + 8 B written per (t, n) element, + 8 B per env (next_value, next_done).
+// Round 2's kernel moved 2.0x the algorithmic READS past the L2 (PMC: 12.7 MB against 6.3 MB at 4 096 envs).  The larger half of that was NOT the
+// second request for v_{t+1}: a 16-column strip reads 64-byte row pieces, half of a 128-byte memory line, and its neighbour strip, which owns the
+// other half, was the NEXT workgroup -- on the next XCD, behind another L2 -- so every line was fetched twice from the memory side.  Workgroups are
+// now mapped to strips so that the two halves of a line are read on the same XCD (strip_of_block below).
+// v_{t+1} is still requested by the thread that forms delta_t although a neighbouring lane requests the same row as its v_t: that request is
+// served by L1 / L2.  Three ways of avoiding it were built and measured, each A/B in one call (in-trace us at 4 096 / 8 192 / 32 768 envs;
+// shipped: 5.0 / 6.25 / 18.55): handing row t + 1 over between lanes with ds_bpermute (memory-side reads 1.00x of algorithmic: profiles/
+// r03_v1_gae_traffic.json) 5.3 / 7.1 / 19.1; a thread owning 2 or 4 CONSECUTIVE rows of a float4 column and fetching v of rows r .. r + ITERS
+// once 5.05 / 6.8 / 19.0; round 2's hand-over through LDS behind one more barrier 5.6 / 6.9 / 21.2.  The duplicate request is the cheapest.
 // Folding the update kernel's record pack (pack_records_kernel: it consumes exactly the advantages and returns the store phase holds) into
 // this kernel was also built and measured in round 2: ONE launch of 18.2 us (21.6 in its first form) against 5.1 + 10.5 us for the two --
 // the pack is a job for B = T N threads, and inside the scan it has N / 16 workgroups of four waves to run on.  Not shipped.
@@ -36,6 +41,16 @@ constexpr int GAE_TC = 128;       // time steps per LDS tile
 constexpr int GAE_THREADS = 256;
 constexpr int GAE_WALK = 16;      // rows the serial walk pulls into registers at a time
 
+// Workgroup -> strip.  Workgroups are dealt to the 8 XCDs round-robin by index (each XCD has its own L2).  A strip narrower than a 128-byte
+// memory line (16 columns = 64 bytes per row) shares every line with its neighbour strip: pair the two on ONE XCD -- workgroup b runs on
+// XCD b % 8 as its (b / 8)-th workgroup; consecutive workgroups of an XCD take the two halves of a pair.  Needs the grid to be a multiple of 16.
+template <int EPB>
+__device__ __forceinline__ int strip_of_block(int b, int grid) {
+    if (EPB * 4 >= 128 || (grid & 15) != 0) return b;
+    const int xcd = b & 7, k = b >> 3;
+    return (((k >> 1) << 3) + xcd) * 2 + (k & 1);
+}
+
 // MODE 0: GAE.  MODE 1: n-step returns (PPO_Discrete.cpp:309-329: ret_t = r_t + (gamma*nnt_t)*ret_{t+1}; adv = ret - v).
 template <int EPB, int MODE, bool VEC>
 __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
@@ -47,7 +62,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float sC[GAE_TC * EPB];
     __shared__ __attribute__((aligned(16))) float sV[GAE_TC * EPB];
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * EPB;
+    const int n0 = strip_of_block<EPB>((int)blockIdx.x, (int)gridDim.x) * EPB;
     const float gl = gamma * gae_lambda;  // the C++ float product of PPO_Discrete.cpp:301
 
     float carry = 0.0f;                                   // A_{t+1} (MODE 0) / ret_{t+1} (MODE 1) entering the tile
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
                     rw[i] = *reinterpret_cast<const float4*>(rewards + g);
                     vv[i] = *reinterpret_cast<const float4*>(values + g);
                     if (t + 1 < T) {
-                        nvv[i] = *reinterpret_cast<const float4*>(values + g + N);
+                        nvv[i] = *reinterpret_cast<const float4*>(values + g + N);   // served by L1 / L2: a neighbouring lane requests the same row as its v_t
                         dd[i] = *reinterpret_cast<const float4*>(dones + g + N);
                     } else {
                         nvv[i] = *reinterpret_cast<const float4*>(next_value + n0 + c);
