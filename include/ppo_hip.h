@@ -255,6 +255,13 @@ PPO_API ppo_status ppo_train_iteration(ppo_ctx* ctx);
  * ride the per-update all-reduce of the advantage sums, and the host rebuilds the job's CircularBuffer(100) from the union: ep_rew_mean /
  * ep_len_mean / ep_count are what ONE context over all envs would report.  They describe the state at the last ppo_update. */
 PPO_API ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
+/* The same read in two steps, for a host that prints a table per update (printPPOResults, :700-774) and must not drain the GPU to do it:
+ * ppo_stats_snapshot enqueues, behind the work enqueued so far, asynchronous copies of everything the statistics are made of into one pinned block
+ * and notes the host-side training state; ppo_stats_snapshot_read waits for that snapshot only -- iterations enqueued after it keep running -- and
+ * decodes it.  ppo_read_stats = snapshot + read + ppo_sync.  At most two snapshots may be pending (a host that runs one iteration ahead takes the
+ * next one before it reads the previous one); they are read oldest first. */
+PPO_API ppo_status ppo_stats_snapshot(ppo_ctx* ctx);
+PPO_API ppo_status ppo_stats_snapshot_read(ppo_ctx* ctx, ppo_stats* out);
 /* LR anneal (:514-518) is applied by ppo_train_iteration; direct control for tests. */
 PPO_API ppo_status ppo_set_learning_rate(ppo_ctx* ctx, double lr);
 

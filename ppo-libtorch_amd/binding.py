@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",
     "ppo_read_stats", "ppo_set_learning_rate", "ppo_profile_enable", "ppo_profile_read", "ppo_comm_unique_id", "ppo_comm_init",
     "ppo_comm_init_local", "ppo_comm_exchange_handle", "ppo_comm_init_exchange", "ppo_comm_exchange_timeouts",
-    "ppo_comm_set_wait_limit",
+    "ppo_comm_set_wait_limit", "ppo_stats_snapshot", "ppo_stats_snapshot_read",
 ]
 
 
@@ -335,6 +335,15 @@ class Context:
     def stats(self):
         s = Stats()
         _check(lib().ppo_read_stats(self.h, C.byref(s)), self.h)
+        return s.as_dict()
+
+    def stats_snapshot(self):
+        """Enqueue a statistics snapshot behind the work enqueued so far (ppo_hip.h); read it later with stats_snapshot_read()."""
+        _check(lib().ppo_stats_snapshot(self.h), self.h)
+
+    def stats_snapshot_read(self):
+        s = Stats()
+        _check(lib().ppo_stats_snapshot_read(self.h, C.byref(s)), self.h)
         return s.as_dict()
 
     def profile_enable(self, on=1):

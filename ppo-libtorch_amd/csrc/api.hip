@@ -100,6 +100,21 @@ static std::mutex g_local_groups_mu;
 struct PtrPack { void* p[8]; };
 hipError_t launch_local_allreduce(const PtrPack& pk, int n, size_t count, bool f64, hipStream_t s);
 
+// pinned host block a statistics snapshot lands in (device pieces first, then the host-side training state at snapshot time)
+struct StatsSnap {
+    StepStats st;
+    double cf[2];
+    double ev[PPO_EV_BLOCKS * 4];
+    EpisodeRing ring;
+    double gstats[PPO_GSTAT_DOUBLES];
+    int32_t error_flag, xchg_flag;
+    // host side
+    bool have_step, have_ev, have_gstats;
+    int world;
+    int64_t B, global_step, opt_step, updates;
+    double lr;
+};
+
 struct ppo_ctx {
     ppo_config cfg{};
     NetLayout L{};
@@ -173,6 +188,12 @@ struct ppo_ctx {
     bool have_ev = false;
     int last_stat_slot = -1;
     double last_global_M = 1.0;
+
+    // statistics snapshot (ppo_stats_snapshot / ppo_stats_snapshot_read): everything ppo_read_stats decodes, copied asynchronously into ONE pinned block
+    // behind the work enqueued so far; the reader waits for the snapshot's event only, so a host may enqueue the next iteration before it reads
+    struct StatsSnap* snap = nullptr;   // [2]: a host that runs one iteration ahead takes snapshot k + 1 before it reads snapshot k
+    hipEvent_t snap_ev[2] = { nullptr, nullptr };
+    int snap_oldest = 0, snap_count = 0; // FIFO of pending snapshots
 
     // profiling: (start, stop) event pairs per instrumented launch
     uint32_t profiling = 0;         // bit k set: time launches of kind k
@@ -336,14 +357,6 @@ static ppo_status comm_health(ppo_ctx* c) {
     return PPO_OK;
 }
 
-static ppo_status check_device_flag(ppo_ctx* c) {
-    int32_t f = 0;
-    HIPCHK(c, hipMemcpyAsync(&f, c->error_flag, sizeof f, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (f & 1) return fail(c, PPO_ERR_STATE, "CartPole reset-stream table exhausted (capacity %d resets per env)", c->reset_cap);
-    return comm_health(c);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // lifecycle
 // ---------------------------------------------------------------------------------------------------------
@@ -367,6 +380,8 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (c->gen) { delete c->gen; c->gen = nullptr; }
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->adam_coefs_h) (void)hipHostFree(c->adam_coefs_h);
+    if (c->snap) (void)hipHostFree(c->snap);
+    for (hipEvent_t e : c->snap_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -491,6 +506,9 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     }
     CK(dalloc(c, &c->adam_coefs, (size_t)c->steps_per_update + 1));
     CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), 2 * ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&c->snap), 2 * sizeof(StatsSnap)));
+    CK(hipEventCreateWithFlags(&c->snap_ev[0], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->snap_ev[1], hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->coef_copied[0], hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->coef_copied[1], hipEventDisableTiming));
     CK(dalloc(c, &c->step_stats, (size_t)c->steps_per_update + 1));
@@ -1444,45 +1462,80 @@ extern "C" ppo_status ppo_train_iteration(ppo_ctx* c) {
     return ppo_update(c);
 }
 
-extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
-    NEED(c, c && out, "null argument");
+// Statistics are read in two steps so that reading them does not have to drain the stream:
+//   ppo_stats_snapshot       enqueues, behind everything enqueued so far, asynchronous copies of every device piece the statistics are made of into
+//                            ONE pinned host block, records an event, and notes the host-side training state (learning rate, step counters);
+//   ppo_stats_snapshot_read  waits for THAT event (not for the stream) and decodes the block.
+// A host that prints a table per update (the facade's train()) takes the snapshot right behind ppo_update, enqueues the next iteration, and only then
+// reads: the GPU works through iteration k + 1 while the host formats iteration k.  ppo_read_stats = snapshot + read.
+extern "C" ppo_status ppo_stats_snapshot(ppo_ctx* c) {
+    NEED(c, c != nullptr, "null ctx");
     DeviceGuard dev_guard(c);
-    std::memset(out, 0, sizeof *out);
     ppo_status s = consume_finished_episodes(c);
     if (s != PPO_OK) return s;
-    s = check_device_flag(c);  // synchronises
-    if (s != PPO_OK) return s;
-    if (c->last_stat_slot >= 0) {
-        StepStats st;
-        HIPCHK(c, hipMemcpy(&st, c->step_stats + c->last_stat_slot, sizeof st, hipMemcpyDeviceToHost));
+    if (c->snap_count == 2) return fail(c, PPO_ERR_STATE, "two statistics snapshots are pending: read one (ppo_stats_snapshot_read) before taking a third");
+    const int slot = (c->snap_oldest + c->snap_count) & 1;
+    StatsSnap* h = c->snap + slot;
+    h->have_step = c->last_stat_slot >= 0;
+    h->have_ev = c->have_ev;
+    h->have_gstats = c->have_gstats;
+    h->world = c->world; h->B = c->B; h->global_step = c->global_step; h->opt_step = c->opt_step; h->updates = c->updates; h->lr = c->lr;
+    h->xchg_flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&h->error_flag, c->error_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (c->xchg && c->xchg->timeout_flag) HIPCHK(c, hipMemcpyAsync(&h->xchg_flag, c->xchg->timeout_flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (h->have_step) HIPCHK(c, hipMemcpyAsync(&h->st, c->step_stats + c->last_stat_slot, sizeof h->st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h->cf, c->clipfrac_accum, sizeof h->cf, hipMemcpyDeviceToHost, c->stream));
+    if (h->have_gstats) HIPCHK(c, hipMemcpyAsync(h->gstats, c->gstats, sizeof h->gstats, hipMemcpyDeviceToHost, c->stream));
+    else {
+        if (h->have_ev) HIPCHK(c, hipMemcpyAsync(h->ev, c->ev_sums, sizeof h->ev, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&h->ring, c->ring, sizeof h->ring, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->snap_ev[slot], c->stream));
+    c->snap_count += 1;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_stats_snapshot_read(ppo_ctx* c, ppo_stats* out) {
+    NEED(c, c && out, "null argument");
+    DeviceGuard dev_guard(c);
+    NEED(c, c->snap_count > 0, "no statistics snapshot is pending (ppo_stats_snapshot)");
+    std::memset(out, 0, sizeof *out);
+    const int slot = c->snap_oldest;
+    HIPCHK(c, hipEventSynchronize(c->snap_ev[slot]));
+    c->snap_oldest ^= 1;
+    c->snap_count -= 1;
+    const StatsSnap& h = c->snap[slot];
+    if (h.error_flag & 1) return fail(c, PPO_ERR_STATE, "CartPole reset-stream table exhausted (capacity %d resets per env)", c->reset_cap);
+    if (h.xchg_flag != 0)
+        return fail(c, PPO_ERR_COMM, "direct exchange: an all-reduce gave up waiting for a peer after %.1f s; its sums were incomplete, the replicas have "
+                                     "diverged and the communicator is dead (every later all-reduce returns at once)", c->xchg ? c->xchg->wait_seconds : 0.0);
+    if (h.have_step) {
+        const StepStats& st = h.st;
         out->pg_loss = st.pg_loss; out->v_loss = st.v_loss; out->entropy_loss = st.entropy_loss; out->approx_kl = st.approx_kl;
         out->loss = st.loss; out->clipfrac_last = st.clipfrac; out->total_norm = st.total_norm;
     }
-    double cf[2] = { 0, 0 };
-    HIPCHK(c, hipMemcpy(cf, c->clipfrac_accum, sizeof cf, hipMemcpyDeviceToHost));
-    out->clipfrac_mean = cf[1] > 0 ? cf[0] / cf[1] : 0.0;
-    if (c->have_gstats) {
+    out->clipfrac_mean = h.cf[1] > 0 ? h.cf[0] / h.cf[1] : 0.0;
+    if (h.have_gstats) {
         // sharded: the all-reduced block of the last ppo_update holds every rank's explained-variance sums and ring -- the same bytes on every rank
-        std::vector<double> g(PPO_GSTAT_DOUBLES);
-        HIPCHK(c, hipMemcpy(g.data(), c->gstats, g.size() * sizeof(double), hipMemcpyDeviceToHost));
-        const double n = (double)c->B * c->world;
+        const double* g = h.gstats;
+        const double n = (double)h.B * h.world;
         const double var_y = (g[1] - g[0] * g[0] / n) / (n - 1.0), var_d = (g[3] - g[2] * g[2] / n) / (n - 1.0);
         out->explained_variance = (double)(1.0f - (float)var_d / (float)var_y);  // :647-648 over the job's whole batch
         // the job's CircularBuffer(100): the newest 100 episodes of the union, in the reference's push order (step, then global env index)
         struct Ep { double key, len, rew; };
         std::vector<Ep> eps;
-        for (int r = 0; r < c->world; r++) {
-            const double* slot = g.data() + PPO_GSTAT_HEAD + (size_t)r * PPO_GSTAT_RANK;
+        double total = 0;
+        for (int r = 0; r < h.world; r++) {
+            const double* slot = g + PPO_GSTAT_HEAD + (size_t)r * PPO_GSTAT_RANK;
+            total += slot[0];
             const int size = (int)slot[1];
             for (int i = 0; i < size && i < 100; i++) eps.push_back({ slot[4 + 3 * i], slot[4 + 3 * i + 1], slot[4 + 3 * i + 2] });
         }
         std::sort(eps.begin(), eps.end(), [](const Ep& a, const Ep& b) { return a.key < b.key; });
         const size_t keep = std::min<size_t>(eps.size(), 100), first = eps.size() - keep;
         if (keep > 0) {
-            // the reference sums the ring from slot 0 upwards (Utils.h:72-78); a float sum depends on that order, so the merged episodes are laid
-            // out as the single ring would hold them: episode number j of the job sits in slot j % 100
-            double total = 0;
-            for (int r = 0; r < c->world; r++) total += g[PPO_GSTAT_HEAD + (size_t)r * PPO_GSTAT_RANK];
+            // the reference sums the ring from slot 0 upwards (Utils.h:72-78): lay the merged episodes out as the single ring would hold them --
+            // episode number j of the job sits in slot j % 100
             std::vector<Ep> ring_order(keep);
             for (size_t i = 0; i < keep; i++) {
                 const long long j = (long long)total - (long long)keep + (long long)i;   // 0-based episode number
@@ -1495,30 +1548,39 @@ extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
         }
         out->ep_count = (int32_t)keep;
     } else {
-    if (c->have_ev) {
-        static_assert(PPO_EV_BLOCKS * 4 * sizeof(double) <= 32768, "stack buffer");
-        double ev[PPO_EV_BLOCKS * 4];
-        HIPCHK(c, hipMemcpy(ev, c->ev_sums, sizeof ev, hipMemcpyDeviceToHost));
-        double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
-        for (int b = 0; b < PPO_EV_BLOCKS; b++) { sy += ev[b * 4]; sy2 += ev[b * 4 + 1]; sd += ev[b * 4 + 2]; sd2 += ev[b * 4 + 3]; }
-        const double n = (double)c->B;
-        const double var_y = (sy2 - sy * sy / n) / (n - 1.0), var_d = (sd2 - sd * sd / n) / (n - 1.0);
-        out->explained_variance = (double)(1.0f - (float)var_d / (float)var_y);  // :647-648 (float tensors)
+        if (h.have_ev) {
+            double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
+            for (int b = 0; b < PPO_EV_BLOCKS; b++) { sy += h.ev[b * 4]; sy2 += h.ev[b * 4 + 1]; sd += h.ev[b * 4 + 2]; sd2 += h.ev[b * 4 + 3]; }
+            const double n = (double)h.B;
+            const double var_y = (sy2 - sy * sy / n) / (n - 1.0), var_d = (sd2 - sd * sd / n) / (n - 1.0);
+            out->explained_variance = (double)(1.0f - (float)var_d / (float)var_y);  // :647-648 (float tensors)
+        }
+        const EpisodeRing& ring = h.ring;
+        if (ring.size > 0) {
+            double sl = 0, sr = 0;
+            for (int i = 0; i < ring.size; i++) { sl += ring.len[i]; sr += ring.rew[i]; }
+            out->ep_len_mean = sl / ring.size;                 // CircularBuffer::avgLength (Utils.h:76-78)
+            out->ep_rew_mean = (double)(float)(sr / ring.size); // avgReward returns float (Utils.h:72-74)
+        }
+        out->ep_count = ring.size;
     }
-    EpisodeRing ring;
-    HIPCHK(c, hipMemcpy(&ring, c->ring, sizeof ring, hipMemcpyDeviceToHost));
-    if (ring.size > 0) {
-        double sl = 0, sr = 0;
-        for (int i = 0; i < ring.size; i++) { sl += ring.len[i]; sr += ring.rew[i]; }
-        out->ep_len_mean = sl / ring.size;                 // CircularBuffer::avgLength (Utils.h:76-78)
-        out->ep_rew_mean = (double)(float)(sr / ring.size); // avgReward returns float (Utils.h:72-74)
-    }
-    out->ep_count = ring.size;
-    }
-    out->learning_rate = c->lr;
-    out->global_step = c->global_step;
-    out->optimizer_steps = c->opt_step;
-    out->updates = c->updates;
+    out->learning_rate = h.lr;
+    out->global_step = h.global_step;
+    out->optimizer_steps = h.opt_step;
+    out->updates = h.updates;
+    return PPO_OK;
+}
+
+extern "C" ppo_status ppo_read_stats(ppo_ctx* c, ppo_stats* out) {
+    NEED(c, c && out, "null argument");
+    NEED(c, c->snap_count == 0, "a statistics snapshot is pending: read it (ppo_stats_snapshot_read) before ppo_read_stats");
+    ppo_status s = ppo_stats_snapshot(c);
+    if (s != PPO_OK) return s;
+    s = ppo_stats_snapshot_read(c, out);
+    if (s != PPO_OK) return s;
+    // callers rely on ppo_read_stats leaving the stream idle (it always synchronised)
+    DeviceGuard dev_guard(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PPO_OK;
 }
 

@@ -206,17 +206,27 @@ void PPOAlgorithm::train() {
     const int64_t num_updates = (m_total_timesteps - static_cast<int64_t>(global_step)) / m_batch_size;   // :496
     ppo::check(ppo_env_reset(m_ctx), m_ctx, "initEnvs");
 
-    for (int64_t update = 1; update < num_updates + 1; update++) {
-        if (m_anneal_lr) {   // :514-518 (num_updates is recomputed from the remaining steps after a resume, like the reference)
+    // One iteration = LR anneal (:514-518), rollout (:524-548), advantages (:554), all epochs x minibatches (:567-644), explained variance (:647-648),
+    // and a statistics snapshot behind them.  Everything here is ENQUEUED: nothing waits for the GPU.
+    auto enqueue = [&](int64_t update) {
+        if (m_anneal_lr) {   // num_updates is recomputed from the remaining steps after a resume, like the reference
             const double frac = 1.0 - (update - 1.0) / num_updates;
             ppo::check(ppo_set_learning_rate(m_ctx, frac * m_learning_rate), m_ctx, "lr");
         }
-        // rollout (:524-548), advantages (:554), all epochs x minibatches (:567-644), explained variance (:647-648)
         ppo::check(ppo_rollout(m_ctx, nullptr), m_ctx, "rollout");
         ppo::check(ppo_calc_advantage(m_ctx), m_ctx, "calcAdvantage");
         ppo::check(ppo_update(m_ctx), m_ctx, "update");
-        ppo_stats st{};
-        ppo::check(ppo_read_stats(m_ctx, &st), m_ctx, "stats");   // synchronises: the wall clock below covers the whole iteration
+        ppo::check(ppo_stats_snapshot(m_ctx), m_ctx, "stats");
+    };
+    if (num_updates >= 1) enqueue(1);
+    for (int64_t update = 1; update < num_updates + 1; update++) {
+        // The reference's loop is serial: step, print, step.  Here the GPU starts iteration update + 1 while the host waits for, formats and prints
+        // the table of iteration `update` (the statistics were snapshotted behind its last kernel) -- except across a checkpoint, which must read
+        // the parameters iteration `update` left.
+        const bool checkpoint_due = update % m_checkpoint_updates == 0;
+        if (update < num_updates && !checkpoint_due) enqueue(update + 1);
+        ppo::check(ppo_stats_snapshot_read(m_ctx, &m_last_stats), m_ctx, "stats");   // waits for iteration `update` only
+        const ppo_stats& st = m_last_stats;
         global_step += static_cast<uint64_t>(m_batch_size);
         m_episode_stats->assign(st.ep_len_mean, static_cast<float>(st.ep_rew_mean), static_cast<size_t>(st.ep_count));
         m_clipfracs.assign(1, static_cast<float>(st.clipfrac_mean));
@@ -224,13 +234,15 @@ void PPOAlgorithm::train() {
         const auto end = std::chrono::steady_clock::now();
         const auto time_elapsed = std::chrono::duration_cast<std::chrono::milliseconds>(end - start_time);
         const auto fps = std::chrono::duration_cast<std::chrono::milliseconds>(end - update_time);
-        auto scalar = [&](double v) { return Tensor::from_host<float>(m_device, { static_cast<float>(v) }, { 1 }); };
+        auto scalar = [&](double v) { return Tensor::host_scalar(static_cast<float>(v)); };
         Tensor kl = scalar(st.approx_kl), ent = scalar(st.entropy_loss), ev = scalar(st.explained_variance), loss = scalar(st.loss),
                pg = scalar(st.pg_loss), vl = scalar(st.v_loss);
+        m_last_stats_valid = true;
         printPPOResults(update, static_cast<int64_t>(global_step), fps, time_elapsed, kl, ent, ev, loss, pg, vl);
+        m_last_stats_valid = false;
         update_time = std::chrono::steady_clock::now();
 
-        if (update % m_checkpoint_updates == 0) {   // :662-673
+        if (checkpoint_due) {   // :662-673
             fs::create_directories("./ModelCheckpoints/");
             fs::create_directories("./OptimizerCheckpoints/");
             const std::string a = "./ModelCheckpoints/PPO_Agent_" + std::to_string(global_step) + "_steps.pt";
@@ -238,6 +250,7 @@ void PPOAlgorithm::train() {
             std::cout << "Saving model checkpoint to " << a << "..." << std::endl;
             std::cout << "Saving optimizer checkpoint to " << o << "..." << std::endl;
             saveCheckpoint(a, o);
+            if (update < num_updates) enqueue(update + 1);
         }
     }
     fs::create_directories("./Models/");   // :678-685
@@ -380,8 +393,8 @@ void PPOAlgorithm::printPPOResults(int64_t update, int64_t global_step, std::chr
     row("time_elapsed"); printElement(static_cast<int64_t>(time_elapsed.count() / 1000.0), w);
     row("total_timesteps"); printElement(global_step, w);
     if (!first) {
-        ppo_stats st{};
-        ppo_read_stats(m_ctx, &st);
+        ppo_stats st = m_last_stats;
+        if (!m_last_stats_valid) ppo_read_stats(m_ctx, &st);
         std::cout << "| train/                  |              |\n" << std::setprecision(9);
         row("approx_kl"); printElement(approx_kl.item<float>(), w);
         row("clip_fraction"); printElement(PPOUtils::getVectorMean(m_clipfracs), w);

@@ -77,6 +77,8 @@ class PPOAlgorithm {
     ppo::Tensor m_obs, m_actions, m_logprobs, m_rewards, m_dones, m_values, m_action_masks;
 
     std::vector<float> m_clipfracs;
+    ppo_stats m_last_stats{};             // the statistics snapshot train() is printing (printPPOResults reads its learning rate from here, not from
+    bool m_last_stats_valid = false;      // the context, which may already be an iteration ahead); false outside train(): the context is asked
     std::unique_ptr<CircularBuffer> m_episode_stats;
     uint64_t m_global_step;
     std::shared_ptr<ThreadPool> m_threadPool;

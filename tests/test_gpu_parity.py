@@ -1001,3 +1001,40 @@ def test_orthogonal_init_statistics(P):
         np.testing.assert_allclose(gram, gain * gain * np.eye(min(r, c)), rtol=0, atol=2e-6 * gain * gain + 1e-12)
     assert off == p.size
     ctx.close()
+
+
+def test_stats_snapshots_are_read_in_order_without_draining(P):
+    """ppo_stats_snapshot / ppo_stats_snapshot_read (ppo_hip.h): a host that prints a table per update (printPPOResults, PPO_Discrete.cpp:700-774) runs one
+    iteration ahead -- snapshot k, enqueue iteration k + 1 and its snapshot, THEN read snapshot k.  Snapshot k must hold iteration k's statistics (not
+    k + 1's: learning rate, step counters, losses, episode means), two may be pending, a third is refused, and ppo_read_stats refuses to jump the queue."""
+    cfg = dict(num_envs=256, num_steps=64, num_minibatches=4, update_epochs=2, seed=7, max_episode_steps=30, total_timesteps=256 * 64 * 4)
+    ref = P.Context(P.make_config(**cfg))
+    ref.init_orthogonal(7)
+    ref.env_reset()
+    want = []
+    for _ in range(3):
+        ref.train_iteration()
+        want.append(ref.stats())
+    ref.close()
+    ctx = P.Context(P.make_config(**cfg))
+    ctx.init_orthogonal(7)
+    ctx.env_reset()
+    ctx.train_iteration()
+    ctx.stats_snapshot()
+    ctx.train_iteration()
+    ctx.stats_snapshot()
+    with pytest.raises(P.binding.PPOError, match="two statistics snapshots are pending"):
+        ctx.stats_snapshot()
+    with pytest.raises(P.binding.PPOError, match="snapshot is pending"):
+        ctx.stats()
+    got1 = ctx.stats_snapshot_read()
+    ctx.train_iteration()          # iteration 3 is enqueued before snapshot 2 is read
+    ctx.stats_snapshot()
+    got2 = ctx.stats_snapshot_read()
+    got3 = ctx.stats_snapshot_read()
+    assert [got1, got2, got3] == want
+    assert got1["updates"] == 1 and got2["updates"] == 2 and got1["learning_rate"] > got2["learning_rate"] > got3["learning_rate"]
+    with pytest.raises(P.binding.PPOError, match="no statistics snapshot is pending"):
+        ctx.stats_snapshot_read()
+    assert ctx.stats() == want[2]
+    ctx.close()
