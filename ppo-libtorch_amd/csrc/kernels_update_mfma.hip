@@ -45,6 +45,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MT = 32;              // samples per wave tile
 constexpr int LS = 68;              // padded row stride (floats) of an fp32 [sample][unit] image
@@ -94,6 +95,11 @@ __device__ __forceinline__ f32x16 mfma_x2(const u32x4 a1, const u32x4 a2, const 
     acc = mfma_f16(a1, b2, acc);
     acc = mfma_f16(a1, b1, acc);
     return acc;
+}
+// v_mfma_f32_16x16x32_f16: A lane (i = lane & 15, kg = lane >> 4) holds k = 8 kg .. 8 kg + 7 of row i, B the same for column j = lane & 15,
+// D lane (j = lane & 15, kg) holds rows 4 kg .. 4 kg + 3 of column j
+__device__ __forceinline__ f32x4 mfma16_f16(const u32x4 a, const u32x4 b, const f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 // ds_read_b64_tr_b16: per group of 16 lanes a 4-row x 16-column block of 16-bit elements is read and delivered column-major: lane
 // 4q + p of the group supplies the address of row q, columns 4p .. 4p+3; lane i receives column i of the four rows (row q in its
@@ -200,7 +206,14 @@ __device__ __forceinline__ float pow2i(int e) { return u2f((uint32_t)(127 + e) <
 // instructions may still move across it, LDS reads and MFMAs may not.
 #define MF_PIN() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400)
 
-template <int NET, int DIST, int OBS, int AMAX, bool EXACT, bool STAMP>
+// DW1M: the layer-1 weight gradient dW1[u][o] = sum_s dz1[s][u] x[s][o] (and db1, as the column of a constant 1) on the matrix cores too
+// (v_mfma_f32_16x16x32_f16: K = the tile's 32 samples in ONE instruction per 16 units and term product).  As vector work it was the phase that
+// read the most LDS of the tile -- 32 broadcast 16-byte reads of the observations beside the 32 reads of the dz1 image -- and 160 vector
+// instructions; now dz1 is cut into fp16 terms (64 instructions), leaves as two [sample][unit] term images like dz2 and comes back through 16
+// transposing reads.  dz1 carries dz2's factor 2^S times at most sum_n |c W2[n][k]|; a fixed 2^-7 keeps its terms inside fp16 (bound 2^14 x
+// 64 x |c W2| < 2^21 for |W2| < 0.7; larger weights saturate to inf and the update fails loudly like an oversized c W2 does).  Used where the
+// register file has room for the 16 accumulator registers (the reference's two shapes); the generic variants keep the vector form.
+template <int NET, int DIST, int OBS, int AMAX, bool EXACT, bool STAMP, bool DW1M>
 __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
     unsigned long long ph[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long t_prev = 0;
@@ -274,10 +287,15 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
             for (int r = 0; r < 16; r++) gW2[i][j][r] = 0.0f;
     float gW3[AMAX], gW1[OBS];     // lane = unit
+    f32x4 gW1m[4];                 // DW1M: [unit block b]: lane (j, kg) holds dW1[16 b + 4 kg + r][o = j] (j < OBS) and db1[16 b + 4 kg + r] (j == OBS)
 #pragma unroll
     for (int k = 0; k < AMAX; k++) gW3[k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < OBS; k++) gW1[k] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) gW1m[b][r] = 0.0f;
     float gb1 = 0.0f, gb2[2] = { 0.0f, 0.0f }, gb3[AMAX];   // gb2: lane (n, hi) holds the sum over ITS half of the samples
 #pragma unroll
     for (int k = 0; k < AMAX; k++) gb3[k] = 0.0f;
@@ -574,6 +592,12 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
                         for (int r = 0; r < 16; r++) gW2[i][j][r] *= f;
 #pragma unroll
                 for (int o = 0; o < OBS; o++) gW1[o] *= f;
+                if constexpr (DW1M) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) gW1m[b][r] *= f;
+                }
                 gb1 *= f; gb2[0] *= f; gb2[1] *= f;
                 S_w = S_new;
                 scaleS = pow2i(S_w);
@@ -587,24 +611,33 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             for (int k = 0; k < AMAX; k++) if (k < AOUT) sDo[k * MT + s] = dOut[k];
         }
         wave_lds_fence();
+        {
+            float accw3[AMAX];
 #pragma unroll
-        for (int k = 0; k < AMAX; k++) {
-            if (k < AOUT) {
-                float acc = 0.0f;
+            for (int k = 0; k < AMAX; k++) accw3[k] = 0.0f;
 #pragma unroll
-                for (int c0 = 0; c0 < MT; c0 += 16) {   // 16 image rows + 4 x 16-byte dOut reads in flight together
-                    float hv[16];
+            for (int c0 = 0; c0 < MT; c0 += 16) {   // 16 image rows, read ONCE for all logits, + 4 x 16-byte dOut reads per logit in flight together
+                float hv[16];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) hv[i] = img[(c0 + i) * LS + lane];
+                for (int i = 0; i < 16; i++) hv[i] = img[(c0 + i) * LS + lane];
 #pragma unroll
-                    for (int i = 0; i < 16; i += 4) {
-                        const float4 d = ld4(&sDo[k * MT + c0 + i]);
-                        acc = __builtin_fmaf(d.x, hv[i], acc); acc = __builtin_fmaf(d.y, hv[i + 1], acc);
-                        acc = __builtin_fmaf(d.z, hv[i + 2], acc); acc = __builtin_fmaf(d.w, hv[i + 3], acc);
+                for (int k = 0; k < AMAX; k++) {
+                    if (k < AOUT) {
+#pragma unroll
+                        for (int i = 0; i < 16; i += 4) {
+                            const float4 d = ld4(&sDo[k * MT + c0 + i]);
+                            accw3[k] = __builtin_fmaf(d.x, hv[i], accw3[k]); accw3[k] = __builtin_fmaf(d.y, hv[i + 1], accw3[k]);
+                            accw3[k] = __builtin_fmaf(d.z, hv[i + 2], accw3[k]); accw3[k] = __builtin_fmaf(d.w, hv[i + 3], accw3[k]);
+                        }
                     }
                 }
-                gW3[k] += acc;
-                gb3[k] += hi == 0 ? dOut[k] : 0.0f;   // summed over lanes at the end
+            }
+#pragma unroll
+            for (int k = 0; k < AMAX; k++) {
+                if (k < AOUT) {
+                    gW3[k] += accw3[k];
+                    gb3[k] += hi == 0 ? dOut[k] : 0.0f;   // summed over lanes at the end
+                }
             }
         }
 
@@ -626,7 +659,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             }
         }
 #pragma unroll
-        for (int e = 0; e < 32; e++) dz2[e] = dz2[e] * (1.0f - h2[e] * h2[e]);
+        for (int e = 0; e < 32; e++) dz2[e] = dz2[e] * __builtin_fmaf(-h2[e], h2[e], 1.0f);   // 1 - h^2 in one rounding (was mul, sub: 32 instructions more)
         // B operand of d(hidden 1): dz2 in place (D layout), cut into its fp16 terms -- the ONLY split of dz2: the same terms, written to
         // the wave's region as two [sample][unit] fp16 images and read back transposed, are the A operand of dW2
         uint32_t zp[2][16];
@@ -726,16 +759,65 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const float4 hb = ld4(&img[s * LS + 8 * qq + 4 * hi + 32 * t]);
-                        dz1[16 * t + 4 * qq + 0] = acc[4 * qq + 0] * (1.0f - hb.x * hb.x);
-                        dz1[16 * t + 4 * qq + 1] = acc[4 * qq + 1] * (1.0f - hb.y * hb.y);
-                        dz1[16 * t + 4 * qq + 2] = acc[4 * qq + 2] * (1.0f - hb.z * hb.z);
-                        dz1[16 * t + 4 * qq + 3] = acc[4 * qq + 3] * (1.0f - hb.w * hb.w);
+                        // (1 - h^2), DW1M: times 2^-7 (an exact scaling), as one multiply and one fused multiply-add
+                        constexpr float K7 = DW1M ? 0x1p-7f : 1.0f;
+                        dz1[16 * t + 4 * qq + 0] = acc[4 * qq + 0] * __builtin_fmaf(hb.x * -K7, hb.x, K7);
+                        dz1[16 * t + 4 * qq + 1] = acc[4 * qq + 1] * __builtin_fmaf(hb.y * -K7, hb.y, K7);
+                        dz1[16 * t + 4 * qq + 2] = acc[4 * qq + 2] * __builtin_fmaf(hb.z * -K7, hb.z, K7);
+                        dz1[16 * t + 4 * qq + 3] = acc[4 * qq + 3] * __builtin_fmaf(hb.w * -K7, hb.w, K7);
                     }
                 }
             }
         }
         MF_STAMP(8);   // dh1 MFMA + dz1
         wave_lds_fence();  // dW2's reads of the h1 image are done
+        if constexpr (DW1M) {
+            // ---------------- c 2^-7 dW1[u][o] += sum_s dz1[s][u] x[s][o], db1 as the column x[s][OBS] := 1: 12 MFMAs of 16 x 16 x 32 ----------------
+            {
+                uint32_t zq[2][16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) split2(dz1[2 * j], dz1[2 * j + 1], zq[0][j], zq[1][j]);
+#pragma unroll
+                for (int term = 0; term < 2; term++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            *reinterpret_cast<uint2*>(zimg + term * MT * NS + s * NS + 8 * q + 4 * hi + 32 * t) = make_uint2(zq[term][8 * t + 2 * q], zq[term][8 * t + 2 * q + 1]);
+            }
+            // B operand: lane (j = lane & 15, kg = lane >> 4) holds x[s = 8 kg + e][o = j], e = 0 .. 7; column OBS is the constant 1, the rest 0
+            const int j16 = lane & 15, kg = lane >> 4;
+            u32x4 b1, b2;
+            {
+                const int jo = j16 < OBS ? j16 : OBS - 1;
+                const float4 xa = ld4(&sX[jo * MT + 8 * kg]), xb = ld4(&sX[jo * MT + 8 * kg + 4]);
+                const float fill = j16 == OBS ? 1.0f : 0.0f;
+                const bool use = j16 < OBS;
+                float xv[8] = { use ? xa.x : fill, use ? xa.y : fill, use ? xa.z : fill, use ? xa.w : fill,
+                                use ? xb.x : fill, use ? xb.y : fill, use ? xb.z : fill, use ? xb.w : fill };
+#pragma unroll
+                for (int e = 0; e < 4; e++) { uint32_t p1, p2; split2(xv[2 * e], xv[2 * e + 1], p1, p2); b1[e] = p1; b2[e] = p2; }
+            }
+            wave_lds_fence();
+            // A operand of unit block b: the 16-lane group kg reads samples 8 kg .. + 3 (second read: + 4) x units 16 b .. + 15 and receives unit
+            // 16 b + (lane & 15) of the four samples
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                u32x4 A1, A2;
+                {
+                    const uint16_t* q = zimg + (8 * kg + tq) * NS + 16 * b + 4 * tp;
+                    const uint2 lo2 = lds_read_tr16(q), hi2 = lds_read_tr16(q + 4 * NS);
+                    const uint2 lo3 = lds_read_tr16(q + MT * NS), hi3 = lds_read_tr16(q + MT * NS + 4 * NS);
+                    A1 = u32x4{ lo2.x, lo2.y, hi2.x, hi2.y };
+                    A2 = u32x4{ lo3.x, lo3.y, hi3.x, hi3.y };
+                }
+                f32x4 acc4 = gW1m[b];
+                acc4 = mfma16_f16(A2, b1, acc4);
+                acc4 = mfma16_f16(A1, b2, acc4);
+                acc4 = mfma16_f16(A1, b1, acc4);
+                gW1m[b] = acc4;
+            }
+        } else {
         store_dlayout(img, dz1, s, hi);
         wave_lds_fence();
         // ---------------- c dW1[u = lane][o] += sum_s c dz1[s][u] x[s][o]; c db1 ----------------
@@ -762,6 +844,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             gb1 += accb;
 #pragma unroll
             for (int o = 0; o < OBS; o++) gW1[o] += accw[o];
+        }
         }
         wave_lds_fence();  // image and sX are rewritten by the next tile
         MF_STAMP(9);   // dz1 image + dW1
@@ -797,6 +880,13 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         gb1 *= invS;
 #pragma unroll
         for (int o = 0; o < OBS; o++) gW1[o] *= invS;
+        if constexpr (DW1M) {   // ... and the fixed 2^-7 of the dz1 terms
+            const float f = invS * 0x1p7f;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) gW1m[b][r] = (gW1m[b][r] * f) * TANH_C_INV;
+        }
     }
     gb1 *= TANH_C_INV;
 #pragma unroll
@@ -811,9 +901,21 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
             for (int r = 0; r < 16; r++) red[L.w2[NET] - base + umap(r, hi, tn) * 64 + s + 32 * tk] = gW2[tn][tk][r];
 #pragma unroll
     for (int k = 0; k < AMAX; k++) if (k < AOUT) red[L.w3[NET] - base + k * 64 + lane] = gW3[k];
+    if constexpr (DW1M) {
+        const int j16 = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int o = 0; o < OBS; o++) red[L.w1[NET] - base + lane * OBS + o] = gW1[o];
-    red[L.b1[NET] - base + lane] = gb1;
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int u = 16 * b + 4 * kg + r;
+                if (j16 < OBS) red[L.w1[NET] - base + u * OBS + j16] = gW1m[b][r];
+                else if (j16 == OBS) red[L.b1[NET] - base + u] = gW1m[b][r];
+            }
+    } else {
+#pragma unroll
+        for (int o = 0; o < OBS; o++) red[L.w1[NET] - base + lane * OBS + o] = gW1[o];
+        red[L.b1[NET] - base + lane] = gb1;
+    }
     if (hi == 0) { red[L.b2[NET] - base + s] = gb2[0]; red[L.b2[NET] - base + s + 32] = gb2[1]; }
 #pragma unroll
     for (int k = 0; k < AMAX; k++) if (k < AOUT) {
@@ -849,8 +951,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void fwd_bwd_mfma_kernel(UpdateArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor
     const int b = blockIdx.x;
-    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, true, STAMP>(a, smem, b, a.n_blocks[0]);
-    else mf_body<1, DIST, OBS, AMAX, EXACT, STAMP>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
+#ifdef MF_AB_NO_DW1M
+    constexpr bool DW1M = false;
+#else
+    constexpr bool DW1M = EXACT;   // the reference's two shapes: 234 / 237 vector registers leave room for 12 more; the generic variants (245 - 247) do not
+#endif
+    if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, true, STAMP, DW1M>(a, smem, b, a.n_blocks[0]);
+    else mf_body<1, DIST, OBS, AMAX, EXACT, STAMP, DW1M>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
 
 // One 32-byte record per sample and net for the update kernel's gather (K5): critic {obs[0..3], return, old value, 0, 0}, actor
