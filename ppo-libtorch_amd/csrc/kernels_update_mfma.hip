@@ -21,8 +21,9 @@
 //
 // Arithmetic: every fp32 operand x is carried as TWO fp16 terms, t1 = rn16(x), t2 = rn16(x - t1) (round to nearest even; x - t1 is
 // exact: one v_fma_mix_f32 with t1 read straight out of its packed pair), and every fp32 product a.b is issued as the three f16
-// products a1b1 + a1b2 + a2b1 on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  |x - t1 - t2| <= 2^-24 |x| and the dropped a2b2 is
-// <= 2^-24 |a||b| (|t2| <= 2^-12 |x|), so a product is off by <= 3 x 2^-24 |a||b|: fp32's own rounding.  fp16 has 5 exponent bits
+// products a1b1 + a1b2 + a2b1 on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  |x - t1 - t2| <= 2^-23 |x| (the residual x - t1 has up to 13
+// significant bits and fp16 keeps 11) and the dropped a2b2 is <= 2^-22 |a||b| (|t2| <= 2^-11 |x|), so a product is off by about 5 x 2^-24 |a||b|:
+// a few fp32 roundings.  fp16 has 5 exponent bits
 // where fp32 has 8; the range is handled per operand:
 //   * h1 (|h| <= 1) and c W2 are used as they are: below 2^-2 the second term runs into fp16's denormals and the representation error
 //     becomes absolute, <= 2^-25 -- a quarter of the rounding step of an fp32 number near 1, and h, W enter sums of O(1) terms.
@@ -80,7 +81,7 @@ __device__ __forceinline__ float resid_hi(uint32_t p, float x) {
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(x));
     return r;
 }
-// (x0, x1) -> two dwords of packed fp16 pairs (low half = x0's term): x = t1 + t2 + d, |d| <= max(2^-24 |x|, 2^-25) for |x| < 65520
+// (x0, x1) -> two dwords of packed fp16 pairs (low half = x0's term): x = t1 + t2 + d, |d| <= max(2^-23 |x|, 2^-25) for |x| < 65520
 // (four instructions per pair: the conversion packs, the residual reads its half of the pair directly)
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& p1, uint32_t& p2) {
     p1 = pk_f16(x0, x1);

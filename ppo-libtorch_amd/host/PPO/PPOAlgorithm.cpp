@@ -340,7 +340,7 @@ void PPOAlgorithm::loadPolicyFromCheckpoint() {
                 std::cout << "Continuing training from step " << m_global_step << std::endl;
                 ppo::check(ppo_params_set_h(m_ctx, p.data(), P), m_ctx, "load params");
             }
-        } catch (const std::runtime_error& ex) {   // not an archive, truncated, damaged: say why and start fresh
+        } catch (const std::exception& ex) {   // not an archive, truncated, damaged (any exception, bad_alloc / length_error included): say why and start fresh
             std::cout << ex.what() << "; ignoring it." << std::endl;
         }
     }
@@ -365,7 +365,7 @@ void PPOAlgorithm::loadPolicyFromCheckpoint() {
                     std::cout << "Checkpoint " << o << " was saved with AdamW options other than the reference's (betas 0.9/0.999, eps 1e-5, weight_decay 0.01);"
                               << " this build keeps the reference's." << std::endl;
             }
-        } catch (const std::runtime_error& ex) {
+        } catch (const std::exception& ex) {
             std::cout << ex.what() << "; ignoring it." << std::endl;
         }
     }

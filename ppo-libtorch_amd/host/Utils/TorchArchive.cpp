@@ -287,15 +287,25 @@ struct Archive {
             fail(file, name + ": unexpected storage record");
         if (st->items[1]->s != "torch FloatStorage") fail(file, name + ": storage type " + st->items[1]->s + " (float32 expected)");
         const auto rec = zip.record(stem + "/data/" + st->items[2]->s);
+        // every field below comes out of the file: check its kind before its value is read, and bound the element count by what the storage record
+        // can hold BEFORE anything is sized by it (a damaged or hostile archive must end in "ignored, because ...", not in bad_alloc or an overflow)
+        if (args->items[1]->kind != Value::INT || args->items[2]->kind != Value::TUPLE || args->items[3]->kind != Value::TUPLE)
+            fail(file, name + ": unexpected tensor record (offset / sizes / strides)");
         const int64_t storage_numel = (int64_t)(rec.second / 4), offset = args->items[1]->i;
         NamedTensor t;
         t.name = name;
         std::vector<int64_t> strides;
-        for (const V& d : args->items[2]->items) t.sizes.push_back(d->i);
-        for (const V& d : args->items[3]->items) strides.push_back(d->i);
+        for (const V& d : args->items[2]->items) { if (d->kind != Value::INT) fail(file, name + ": a size is not an integer"); t.sizes.push_back(d->i); }
+        for (const V& d : args->items[3]->items) { if (d->kind != Value::INT) fail(file, name + ": a stride is not an integer"); strides.push_back(d->i); }
         if (strides.size() != t.sizes.size()) fail(file, name + ": sizes and strides disagree");
+        if (t.sizes.size() > 8) fail(file, name + ": more than 8 dimensions");
         int64_t numel = 1;
-        for (int64_t d : t.sizes) { if (d < 0) fail(file, name + ": negative size"); numel *= d; }
+        for (int64_t d : t.sizes) {
+            if (d < 0) fail(file, name + ": negative size");
+            if (d != 0 && numel > storage_numel / d) fail(file, name + ": more elements than its storage record holds");   // also rules out overflow
+            numel *= d;
+        }
+        if (offset < 0 || numel > storage_numel) fail(file, name + ": more elements than its storage record holds");
         t.values.resize((size_t)numel);
         std::vector<int64_t> idx(t.sizes.size(), 0);
         for (int64_t e = 0; e < numel; e++) {
@@ -307,12 +317,13 @@ struct Archive {
         }
         return t;
     }
-    void collect(const V& obj, const std::string& prefix, std::vector<NamedTensor>& out) const {
+    void collect(const V& obj, const std::string& prefix, std::vector<NamedTensor>& out, int depth = 0) const {
+        if (depth > 32) fail(file, "module tree deeper than 32 levels (a memo self-reference?)");
         for (const auto& kv : obj->dict) {
             if (kv.first->kind != Value::STR) continue;
             const std::string name = prefix.empty() ? kv.first->s : prefix + "." + kv.first->s;
             if (isTensor(kv.second)) out.push_back(tensor(kv.second, name));
-            else if (kv.second->kind == Value::OBJECT) collect(kv.second, name, out);
+            else if (kv.second->kind == Value::OBJECT) collect(kv.second, name, out, depth + 1);
         }
     }
 };

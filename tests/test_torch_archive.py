@@ -159,3 +159,30 @@ def test_damaged_files_are_refused_with_a_reason(tool, tmp_path):
     # an agent archive is not an optimizer archive
     r = _run([tool, "dump-optimizer", os.path.join(G, "ref_discrete_agent.pt")], ok=False)
     assert r.returncode == 1 and "optimizer archive" in r.stderr
+
+
+def test_hostile_sizes_are_refused_not_allocated(tool, tmp_path):
+    """The reader trusts nothing the pickle says: a tensor whose sizes claim more elements than its storage record holds -- here
+    (2^31 - 1) x (2^31 - 1), which would also overflow the element count -- is refused with a reason before anything is sized by it, and a size that
+    is not an integer is refused too.  The archive is otherwise intact (re-packed with correct CRCs), so only the tensor record can be the reason."""
+    import zipfile
+    src = os.path.join(G, "ref_discrete_agent.pt")
+
+    def repack(dst, edit):
+        with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, "w", zipfile.ZIP_STORED) as zout:
+            for info in zin.infolist():
+                data = zin.read(info.filename)
+                if info.filename.endswith("/data.pkl"):
+                    data = edit(data)
+                zout.writestr(info.filename, data)
+
+    small = b"(K@K\x04t"                       # MARK, BININT1 64, BININT1 4, TUPLE: the sizes of criticInputLayer.weight
+    assert small in zipfile.ZipFile(src).read(next(n for n in zipfile.ZipFile(src).namelist() if n.endswith("/data.pkl")))
+    huge = tmp_path / "huge.pt"
+    repack(str(huge), lambda d: d.replace(small, b"(J\xff\xff\xff\x7fJ\xff\xff\xff\x7ft", 1))
+    r = _run([tool, "dump-agent", str(huge)], ok=False)
+    assert r.returncode == 1 and "more elements than its storage record holds" in r.stderr, r.stderr
+    odd = tmp_path / "odd.pt"
+    repack(str(odd), lambda d: d.replace(small, b"(K@Nt", 1))       # a size that is None
+    r = _run([tool, "dump-agent", str(odd)], ok=False)
+    assert r.returncode == 1 and ("not an integer" in r.stderr or "unexpected" in r.stderr), r.stderr
