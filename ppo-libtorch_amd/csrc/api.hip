@@ -1131,7 +1131,11 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
     float* grads = B_<float>(c, PPO_BUF_GRADS);
     {
         ProfScope ps(c, PROF_FWD_BWD);
+#ifdef GEN_AB_ONE_STREAM   // A/B build (tools/build_variant.sh): every kernel alone on the chip, for per-kernel durations
+        const bool two = false;
+#else
         const bool two = g.bf16 && c->stream2 != nullptr;   // the critic's passes on their own stream: a kernel of one net fills the CUs the other net's kernel is draining
+#endif
         auto gather = [&](const int32_t* rows, int64_t n, hipStream_t st) {
             return gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
                               B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), rows, n, g, st);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of several builds on one GPU's share of configs[4] inside ONE gpurun call:  tools/c4_ab.sh ROUNDS lib_A.so lib_B.so ...
+# A/B of libppo_hip.so builds on configs[4]'s share inside ONE gpurun call:  tools/c4_ab.sh ROUNDS lib_A.so lib_B.so ...
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 R=$1; shift
 cp ppo-libtorch_amd/libppo_hip.so /tmp/libppo_hip_orig.so
@@ -9,8 +9,7 @@ for i in $(seq 1 $R); do
         python3 tools/config4_bench.py 2>/dev/null | tail -n 1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-36s' % '$src', round(d['env_steps_per_s']/1e6,3), 'M env-steps/s', round(d['minibatch_step_ms'],4), 'ms/step', round(d.get('update_ms_per_step',0),4), 'ms all-in/step', round(d['rollout_ms'],3), 'ms rollout', round(d['optimizer_ms'],4), 'ms opt')"
-        python3 tools/fused_fwd_probe.py 2>/dev/null | tail -n 1
+print('%-40s' % '$src', round(d['env_steps_per_s']/1e6,3), 'M env-steps/s', round(d['minibatch_step_ms'],4), 'ms step', round(d['update_ms_per_step'],4), 'ms all-in')"
     done
 done
 cp /tmp/libppo_hip_orig.so ppo-libtorch_amd/libppo_hip.so
