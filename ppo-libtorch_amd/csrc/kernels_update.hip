@@ -671,17 +671,26 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_sumsq_kernel(Fuse
         const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
         double acc = 0.0;
         if (p < L.P) {
-            const int net = p >= L.net_off[1] ? 1 : 0;
-            const int nb = net ? a.nb1 : a.nb0;
-            const float* col = a.slab + (size_t)(net ? a.nb0 : 0) * Pmax + (p - L.net_off[net]);
+            // (selects between the two nets' constants, not L.net_off[net]: indexing the kernel-argument struct with a per-lane value is a VECTOR load
+            // from the argument segment -- a memory round trip in front of the slab loads)
+            const bool net1 = p >= L.net_off[1];
+            const int nb = net1 ? a.nb1 : a.nb0;
+            const float* col = a.slab + (size_t)(net1 ? a.nb0 : 0) * Pmax + (p - (net1 ? L.net_off[1] : L.net_off[0]));
             const int b0 = (nb * w) / RED_WAVES, b1 = (nb * (w + 1)) / RED_WAVES;
             int b = b0;
-            for (; b + 8 <= b1; b += 8) {
-                float v[8];
+            for (; b + 16 <= b1; b += 16) {   // a wave's 16 slabs of the 128-workgroup update kernel: ONE batch of loads, one round trip
+                float v[16];
 #pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = col[(size_t)(b + i) * Pmax];
+                for (int i = 0; i < 16; i++) v[i] = col[(size_t)(b + i) * Pmax];
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc += (double)v[i];
+                for (int i = 0; i < 16; i++) acc += (double)v[i];
+            }
+            for (; b + 4 <= b1; b += 4) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = col[(size_t)(b + i) * Pmax];
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc += (double)v[i];
             }
             for (; b < b1; b++) acc += (double)col[(size_t)b * Pmax];
         }
@@ -719,7 +728,8 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_sumsq_kernel(Fuse
             if (p < L.P) a.grads[p] = g;
             // sums of squares per tensor of this workgroup's 64 gradients (a workgroup touches at most a few tensors)
             int tl = 0;
-            for (int t = 0; t < L.n_tensors; t++) if (p >= L.tensor_off[t]) tl = t;
+#pragma unroll
+            for (int t = 0; t < 12; t++) if (t < L.n_tensors && p >= L.tensor_off[t]) tl = t;   // fixed bound: the offsets stay scalar constants
             const double g2 = p < L.P ? (double)g * (double)g : 0.0;
             for (int t = 0; t < 12; t++) {
                 double v = 0.0;
@@ -729,22 +739,31 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_sumsq_kernel(Fuse
             }
         }
     } else {
-        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor workgroups), [4]=value loss (critic workgroups)
-        for (int kk = 0; kk < 5; kk++) {
-            const int net = kk < 4 ? 1 : 0, col = kk < 4 ? kk : 0;
-            const int nb = net ? a.nb1 : a.nb0;
-            double v = 0.0;
-            for (int b = threadIdx.x; b < nb; b += 64 * RED_WAVES) v += a.stat_slab[((size_t)(net ? a.nb0 : 0) + b) * 8 + col];
-            v = wave_sum_d(v);
-            __syncthreads();
-            if (lane == 0) part[0][w] = v;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double sacc = 0.0;
-                for (int i = 0; i < RED_WAVES; i++) sacc += part[0][i];
-                a.sums_out[kk] = sacc;
-                part[1][kk] = sacc;
+        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor workgroups), [4]=value loss (critic workgroups).  All five columns are requested
+        // together and reduced together: one memory round trip and one barrier (they used to be five of each, one column after the other --
+        // this workgroup alone set the kernel's duration).  Fixed order: a thread's workgroups in index order, lanes on the DPP network, waves in order.
+        double v5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+        for (int b = threadIdx.x; b < a.nb0 || b < a.nb1; b += 64 * RED_WAVES) {
+            double t[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+            if (b < a.nb1) {
+                const double* r = a.stat_slab + ((size_t)a.nb0 + b) * 8;
+                t[0] = r[0]; t[1] = r[1]; t[2] = r[2]; t[3] = r[3];
             }
+            if (b < a.nb0) t[4] = a.stat_slab[(size_t)b * 8];
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) v5[kk] += t[kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) {
+            const double r = wave_sum_d_dpp(v5[kk]);
+            if (lane == 0) part[w][kk] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            double sacc = 0.0;
+            for (int i = 0; i < RED_WAVES; i++) sacc += part[i][threadIdx.x];
+            a.sums_out[threadIdx.x] = sacc;
+            part[RED_WAVES - 1][8 + threadIdx.x] = sacc;   // for the exchange below (a slot no wave's partial uses)
         }
         if (threadIdx.x >= 5 && threadIdx.x < 8) a.sums_out[threadIdx.x] = 0.0;
         if constexpr (XCHG) {
@@ -752,7 +771,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_sumsq_kernel(Fuse
             __syncthreads();
             if (threadIdx.x < 64) {
                 const int parity = (int)(a.seq & 1ull);
-                const float mine = threadIdx.x < 5 ? (float)part[1][threadIdx.x] : 0.0f;
+                const float mine = threadIdx.x < 5 ? (float)part[RED_WAVES - 1][8 + threadIdx.x] : 0.0f;
                 for (int r = 0; r < a.n_ranks; r++)
                     if (r != a.rank && threadIdx.x < 8)
                         __hip_atomic_store(reinterpret_cast<float*>(xchg_slot(a.peers[r], a.slot_bytes, parity, a.rank)) + L.P + threadIdx.x, mine, __ATOMIC_RELAXED,

@@ -405,9 +405,15 @@ __device__ __forceinline__ float opt_total_norm(const NetLayout& L, const double
         }
     }
     __syncthreads();
+    // total = || (||g_1||, ..., ||g_12||) ||_2 with float per-tensor norms (clip_grad.h:58-70).  Lane t forms tensor t's norm -- ONE binary64 square
+    // root per wave instead of twelve in a row on every lane (a binary64 sqrt is a ~40-instruction sequence) -- and the squares are added in tensor
+    // order through scalar registers: the same operations in the same order as before, every thread gets the same bits.
+    double sq = 0.0;
+    if (lane < 12) { const float nrm = (float)sqrt(n2s[lane]); sq = (double)nrm * nrm; }
     double tot = 0.0;
 #pragma unroll
-    for (int t = 0; t < 12; t++) { const float nrm = (float)sqrt(n2s[t]); tot += (double)nrm * nrm; }
+    for (int t = 0; t < 12; t++)
+        tot += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sq), t), __builtin_amdgcn_readlane(__double2loint(sq), t));
     return (float)sqrt(tot);
 }
 __device__ __forceinline__ float opt_clip_coef(float total, float max_norm) {   // clip_grad.h:76-78
