@@ -459,17 +459,24 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_kernel(const floa
         const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
         double acc = 0.0;
         if (p < L.P) {
-            const int net = p >= L.net_off[1] ? 1 : 0;
-            const int nb = net ? nb1 : nb0;
-            const float* col = slab + (size_t)(net ? nb0 : 0) * Pmax + (p - L.net_off[net]);
+            const bool net1 = p >= L.net_off[1];   // selects, not L.net_off[net]: see reduce_grads_sumsq_kernel
+            const int nb = net1 ? nb1 : nb0;
+            const float* col = slab + (size_t)(net1 ? nb0 : 0) * Pmax + (p - (net1 ? L.net_off[1] : L.net_off[0]));
             const int b0 = (nb * w) / RED_WAVES, b1 = (nb * (w + 1)) / RED_WAVES;
             int b = b0;
-            for (; b + 8 <= b1; b += 8) {
-                float v[8];
+            for (; b + 16 <= b1; b += 16) {
+                float v[16];
 #pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = col[(size_t)(b + i) * Pmax];
+                for (int i = 0; i < 16; i++) v[i] = col[(size_t)(b + i) * Pmax];
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc += (double)v[i];
+                for (int i = 0; i < 16; i++) acc += (double)v[i];
+            }
+            for (; b + 4 <= b1; b += 4) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = col[(size_t)(b + i) * Pmax];
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc += (double)v[i];
             }
             for (; b < b1; b++) acc += (double)col[(size_t)b * Pmax];
         }
@@ -482,22 +489,30 @@ __global__ __launch_bounds__(64 * RED_WAVES) void reduce_grads_kernel(const floa
             grads[p] = (float)s;
         }
     } else {
-        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor workgroups), [4]=value loss (critic workgroups)
-        for (int k = 0; k < 5; k++) {
-            const int net = k < 4 ? 1 : 0, col = k < 4 ? k : 0;
-            const int nb = net ? nb1 : nb0;
-            double v = 0.0;
-            for (int b = threadIdx.x; b < nb; b += 64 * RED_WAVES) v += stat_slab[((size_t)(net ? nb0 : 0) + b) * 8 + col];
-            v = wave_sum_d(v);
-            __syncthreads();
-            if (lane == 0) part[0][w] = v;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double s = 0.0;
-                for (int i = 0; i < RED_WAVES; i++) s += part[0][i];
-                sums_out[k] = s;
-                grads[L.P + k] = (float)s;   // float copies ride behind the gradient so ONE all-reduce carries both
+        // loss sums: [0]=pg [1]=entropy [2]=kl [3]=clip count (actor workgroups), [4]=value loss (critic workgroups): the five columns together, one
+        // round trip and one barrier, in the order reduce_grads_sumsq_kernel adds them (the fused and the step-by-step paths give the same bits)
+        double v5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+        for (int b = threadIdx.x; b < nb0 || b < nb1; b += 64 * RED_WAVES) {
+            double t[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+            if (b < nb1) {
+                const double* r = stat_slab + ((size_t)nb0 + b) * 8;
+                t[0] = r[0]; t[1] = r[1]; t[2] = r[2]; t[3] = r[3];
             }
+            if (b < nb0) t[4] = stat_slab[(size_t)b * 8];
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) v5[kk] += t[kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) {
+            const double r = wave_sum_d_dpp(v5[kk]);
+            if (lane == 0) part[w][kk] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            double sacc = 0.0;
+            for (int i = 0; i < RED_WAVES; i++) sacc += part[i][threadIdx.x];
+            sums_out[threadIdx.x] = sacc;
+            grads[L.P + threadIdx.x] = (float)sacc;   // float copies ride behind the gradient so ONE all-reduce carries both
         }
         if (threadIdx.x >= 5 && threadIdx.x < 8) { sums_out[threadIdx.x] = 0.0; grads[L.P + threadIdx.x] = 0.0f; }
     }
@@ -548,10 +563,20 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
         else { for (int i = 0; i < 5; i++) ls[i] = loss_sums[i]; }
         if (clipfrac_accum && do_step) { cf0 = clipfrac_accum[0]; cf1 = clipfrac_accum[1]; }
     }
-    // total_norm = || (||g_1||, ..., ||g_12||) ||_2 with float per-tensor norms (clip_grad.h:58-70); every thread forms the same bits
+    // total_norm = || (||g_1||, ..., ||g_12||) ||_2 with float per-tensor norms (clip_grad.h:58-70); every thread forms the same bits.  Lane t of a
+    // wave forms tensor t's norm (one binary64 sqrt per wave, not twelve in a row), the squares are added in tensor order through scalar registers.
+    double sq = 0.0;
+    {
+        const int ln = tid & 63;
+        double mine = 0.0;
+#pragma unroll
+        for (int t = 0; t < 12; t++) mine = ln == t ? n2[t] : mine;
+        if (ln < 12) { const float nrm = (float)sqrt(mine); sq = (double)nrm * nrm; }
+    }
     double tot = 0.0;
 #pragma unroll
-    for (int t = 0; t < 12; t++) { const float nrm = (float)sqrt(n2[t]); tot += (double)nrm * nrm; }
+    for (int t = 0; t < 12; t++)
+        tot += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sq), t), __builtin_amdgcn_readlane(__double2loint(sq), t));
     const float total = (float)sqrt(tot);
     float c = max_norm / (total + 1e-6f);   // clip_grad.h:76-78
     if (c > 1.0f) c = 1.0f;
