@@ -69,7 +69,7 @@ __device__ __forceinline__ float critic_head(const float* __restrict__ p, const 
 template <int DIST, int AMAX, int EXACTA = 0>
 __device__ __forceinline__ void heads_from_logits(float* z, const NetLayout& L, const uint8_t* mask_row, bool all_valid, bool sample, int64_t seed,
                                                   int64_t row_global, int64_t step_index, int* act, float& logprob, float& entropy,
-                                                  uint4* philox_cache = nullptr, bool* cache_valid = nullptr) {
+                                                  uint4* philox_cache = nullptr, bool* cache_valid = nullptr, bool cache_fresh = false) {
     const int A = EXACTA ? EXACTA : L.act;
     const int n_heads = EXACTA ? 1 : L.n_heads;
     float pr[AMAX];
@@ -113,7 +113,7 @@ __device__ __forceinline__ void heads_from_logits(float* z, const NetLayout& L, 
             // one Philox call feeds four consecutive steps: counter (row, step / 4, head, 0), word step % 4
             uint4 w;
             if (philox_cache && h == 0) {
-                if (!*cache_valid || (step_index & 3) == 0) {
+                if (!cache_fresh && (!*cache_valid || (step_index & 3) == 0)) {   // cache_fresh: the caller has refreshed the cache for this step already
                     *philox_cache = philox4x32_10((uint32_t)seed, (uint32_t)((uint64_t)seed >> 32), (uint32_t)row_global, (uint32_t)(step_index >> 2), 0u, 0u);
                     *cache_valid = true;
                 }
@@ -395,6 +395,302 @@ __global__ __launch_bounds__(64, 2) void rollout2_kernel(RolloutArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused rollout on the matrix cores, SIXTEEN envs per wave (the reference's single-head policies).  rollout2_kernel is bound by vector issue:
+// ~400 vector instructions per step and wave serve two envs, 128 of them the 64 x 64 matvec.  Here a wave owns a 16-env tile and the actor's two
+// layers are MFMA products with the envs as the 16 COLUMNS:
+//     layer 1   z1[u][e] = b1[u] + sum_o W1[u][o] x[e][o]    v_mfma_f32_16x16x4_f32 (exact fp32 operands), one per block of 16 units
+//     layer 2   z2[n][e] = b2[n] + sum_k W2[n][k] h1[e][k]   v_mfma_f32_16x16x32_f16, fp32 carried as two fp16 terms, three products per fp32 product
+//                                                            (kernels_update_mfma.hip: the same arithmetic as the update kernel and values_mfma_kernel)
+// A 16 x 16 result has lane (e = lane & 15, kg = lane >> 4) holding units 16 b + 4 kg + r of env e -- which is directly the B operand of the next
+// product when the weight fragments enumerate the contraction in that order (chunk c <-> unit blocks 2c, 2c + 1): no data crosses lanes between the
+// layers, no LDS, no barrier.  The four lanes of an env then hold 16 hidden units each: logits are 16 fused multiply-adds per lane and two
+// cross-lane steps.  Softmax, sampling, env physics and bookkeeping run per lane (the four lanes of an env redundantly: same bits), lane kg = 0
+// stores.  ~470 vector instructions per step serve sixteen envs (29 per env against 200).
+// Per-env arithmetic does not depend on the env's position in its tile (a column of an MFMA result is a sum over k only): a shard reproduces its
+// columns of the unsharded rollout bit for bit, as before.  Against rollout2_kernel / policy_act_kernel the logits agree to fp32 noise (~1e-7), not
+// bit for bit: sampled actions can differ where a uniform draw falls within that noise of a CDF edge.
+// ---------------------------------------------------------------------------------------------------------
+typedef float r16_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 r16_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int r16_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void r16_split2(float x0, float x1, uint32_t& p1, uint32_t& p2) {   // kernels_update_mfma.hip: split2
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x0), "v"(x1));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p1), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p1), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(r0), "v"(r1));
+}
+__device__ __forceinline__ r16_f32x4 r16_mfma(const r16_u32x4 a, const r16_u32x4 b, const r16_f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(r16_f16x8, a), __builtin_bit_cast(r16_f16x8, b), acc, 0, 0, 0);
+}
+
+// FIVE waves per 16-env tile.  One wave doing all 64 units measured 191 us per 128-step rollout (rollout2_kernel: 210), four waves sharing the
+// layers 181: a lone wave issues a dependent instruction every ~7 - 9 cycles and a step is ONE dependent chain -- layer 1, tanh, layer 2, tanh,
+// logits, softmax, sample, physics (binary64 sin / cos, three IEEE divisions), bookkeeping -- of which the policy is less than half.  So the chain is
+// cut where it can be:
+//   waves 0 - 3 (the policy): wave w owns units 16 w .. 16 w + 15 of both layers -- ONE 16 x 16 block per layer: 4 tanh, one split pair.  The layers'
+//       results cross waves through LDS in exactly the form the next product wants them (lane-aligned: lane (e, kg) of every wave needs what lane
+//       (e, kg) of waves 2c and 2c + 1 hold).
+//   wave 5 (trigonometry): the transition's cos / sin of the state (glibc's binary64 polynomials, ~40 % of a transition) depend on the state
+//       only: formed while layer 1 runs.  Wave 3 also draws the step's random words (they depend on (seed, env, step)).
+//   wave 4 (the envs): the rest of a transition depends on the state and on WHICH action is taken, not on the policy's output, so while layer 2
+//       runs it forms the transition of EVERY possible action, lane kg of an env taking action kg (same function, same inputs: the same bits as
+//       stepping after the fact); when the logits arrive it samples, SELECTS one (a lane shuffle), does the bookkeeping, publishes the next
+//       observation, and stores behind the barrier.  The reset row an env would restart from is requested every step, so an episode's end
+//       never waits for memory.
+// Three barriers per step (hidden layer + trigonometry, logits' partial sums, next observation); buffers alternate by step parity.
+// Measured per 128-step rollout at 4096 envs (A/B in one call, rollout + critic batch): rollout2_kernel 234 us; one wave per tile 216; four policy
+// waves that also step the envs 207; + env wave 196; + trigonometry off the env wave and reset prefetch 171 (cos and sin on two waves: 176).
+template <int ENV, int DIST, int OBS, int EXACTA>
+__global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_h1[2][2][2][64][4];      // [step parity][term][chunk c][lane][wave 2c: 2 dwords | wave 2c + 1: 2 dwords]
+    __shared__ __attribute__((aligned(16))) float s_part[2][EXACTA][16][16];    // [step parity][logit][env][4 w + kg]
+    __shared__ float s_x[2][4][16];                                             // [step parity][obs component][env]: the observation the policy sees next
+    __shared__ float s_tr[2][2][16];                                            // [step parity][cos | sin][env]: the transition's trigonometry (wave 5)
+    __shared__ uint4 s_rng[2][16];                                              // [step parity][env]: the Philox words serving this step (wave 3)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = lane & 15, kg = lane >> 4;
+    const bool envw = wave == 4, trigw = wave == 5;
+    const int mw = wave & 3;            // the env wave loads (and ignores) block 0's weights: every index stays in bounds
+    int tile = blockIdx.x;
+    {   // contiguous env ranges per XCD, as in rollout_kernel
+        const int nb = gridDim.x, q = nb / 8, r = nb % 8, x = blockIdx.x % 8, i = blockIdx.x / 8;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int N = a.N;
+    int env = 16 * tile + e;
+    const bool live = env < N;          // the last tile may be ragged: its idle columns compute on env N - 1 and store nothing
+    if (!live) env = N - 1;
+    const NetLayout& L = a.L;
+    constexpr int H = 1, A = EXACTA;
+    const int64_t env_global = a.env_offset + env;
+    const float* __restrict__ P = a.params;
+
+    // ---- a policy wave's block of the actor's weights as MFMA A operands, once per launch ----
+    // layer 1 (16x16x4 f32): lane (i = e, k = kg) holds W1[16 w + i][k]
+    const float a1 = kg < OBS ? P[L.w1[1] + (16 * mw + e) * OBS + kg] : 0.0f;
+    // layer 2 (16x16x32 f16): lane (i = e, kg) holds, for chunk c, the eight k = {32 c + 4 kg + 0..3, 32 c + 16 + 4 kg + 0..3} of row n = 16 w + i
+    // -- the order in which the 16 x 16 results of waves 2c and 2c + 1 present their units -- as two fp16 terms
+    r16_u32x4 w2a[2][2];   // [c][term]
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) w[q] = P[L.w2[1] + (16 * mw + e) * PPO_HIDDEN + 32 * c + 16 * (q >> 2) + 4 * kg + (q & 3)];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t p1, p2;
+            r16_split2(w[2 * q], w[2 * q + 1], p1, p2);
+            w2a[c][0][q] = p1; w2a[c][1][q] = p2;
+        }
+    }
+    // biases and the output layer in result layout: register r <-> unit 16 w + 4 kg + r
+    float b1d[4], b2d[4], w3d[A][4], b3[A];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int u = 16 * mw + 4 * kg + r;
+        b1d[r] = P[L.b1[1] + u];
+        b2d[r] = P[L.b2[1] + u];
+#pragma unroll
+        for (int aa = 0; aa < A; aa++) w3d[aa][r] = P[L.w3[1] + aa * PPO_HIDDEN + u];
+    }
+#pragma unroll
+    for (int aa = 0; aa < A; aa++) b3[aa] = P[L.b3[1] + aa];
+
+    // ---- the env wave's state (lanes kg = 0 .. 3 of an env hold identical copies; lane kg = 0 stores) ----
+    float st[OBS];
+#pragma unroll
+    for (int k = 0; k < OBS; k++) st[k] = a.env_state[(size_t)k * N + env];
+    int ep_len = a.ep_len[env];
+    float ep_rew = a.ep_rew[env];
+    int resets = a.reset_count[env];
+    int done = a.next_done[env];
+    uint4 philox_words = make_uint4(0u, 0u, 0u, 0u);
+    bool philox_valid = false;
+    const bool writer = live && envw;
+    if (envw && kg == 0) {
+#pragma unroll
+        for (int k = 0; k < OBS; k++) s_x[0][k][e] = st[k];
+    }
+    __syncthreads();
+
+#ifdef R16_STAMPS
+    unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
+#define R16_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph[i] += n_ - tp; tp = n_; } while (0)
+#else
+#define R16_STAMP(i) do { } while (0)
+#endif
+    for (int t = 0; t < a.T; t++) {
+        const size_t tn = (size_t)t * N + env;
+        const int par = t & 1;
+        float cst[1][OBS], crew[1], rrow[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        int cterm[1];
+        float s_reward = 0.0f, s_logprob = 0.0f, s_fin_rew = 0.0f;
+        int s_fin_len = 0, s_act = 0, s_done = 0;
+        if (wave < 4) {
+            // layer 1 + tanh: this wave's 16 units; B operand x[e][k = kg]
+            const float xk = s_x[par][kg & 3][e];
+            float h1[4];
+            {
+                r16_f32x4 acc = { b1d[0], b1d[1], b1d[2], b1d[3] };
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, kg < OBS ? xk : 0.0f, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) h1[r] = tanh_mufu(acc[r]);
+            }
+            // fp16 terms of the block -> this wave's half of chunk (w >> 1)'s B operand
+            uint32_t p1a, p2a, p1b, p2b;
+            r16_split2(h1[0], h1[1], p1a, p2a);
+            r16_split2(h1[2], h1[3], p1b, p2b);
+            *reinterpret_cast<uint2*>(&s_h1[par][0][wave >> 1][lane][2 * (wave & 1)]) = make_uint2(p1a, p1b);
+            *reinterpret_cast<uint2*>(&s_h1[par][1][wave >> 1][lane][2 * (wave & 1)]) = make_uint2(p2a, p2b);
+            // wave 3 also draws the step's random words (they depend on (seed, env, step) only; one Philox call feeds four steps: heads_from_logits)
+            if (wave == 3 && kg == 0 && a.forced_actions == nullptr && (((a.step_base + t) & 3) == 0 || t == 0))
+                s_rng[par][e] = philox4x32_10((uint32_t)a.seed, (uint32_t)((uint64_t)a.seed >> 32), (uint32_t)env_global, (uint32_t)((a.step_base + t) >> 2), 0u, 0u);
+        } else if (trigw) {
+            // wave 5: the trigonometry of the transition (binary64 sin / cos of the state the policy is looking at), for the env wave's tail
+            float xs[OBS], tr[2];
+#pragma unroll
+            for (int k = 0; k < OBS; k++) xs[k] = s_x[par][k][e];
+            env_step_pre<ENV>(xs, tr);
+            if (kg == 0) { s_tr[par][0][e] = tr[0]; s_tr[par][1][e] = tr[1]; }
+        } else {
+            // m_obs[step] = next_obs (PPO_Discrete.cpp:529): lane kg stores component kg
+            float xk = 0.0f;
+#pragma unroll
+            for (int k = 0; k < OBS; k++) xk = kg == k ? st[k] : xk;
+            if (writer && kg < OBS) a.obs[tn * OBS + kg] = xk;
+            // the row of the shared reset stream this env would restart from (CartPole.cpp:34-45), requested every step so that an episode's end
+            // never waits for it
+            if (ENV == PPO_ENV_CARTPOLE) {
+                const int k = resets < a.reset_cap ? resets : a.reset_cap - 1;
+                const float4 r = reinterpret_cast<const float4*>(a.reset_table)[k];
+                rrow[0] = r.x; rrow[1] = r.y; rrow[2] = r.z; rrow[3] = r.w;
+            }
+        }
+        R16_STAMP(0);
+        __syncthreads();   // the hidden layer, the trigonometry and the random words are in LDS
+        R16_STAMP(1);
+        if (envw) {
+            // the transition of every possible action, while the policy waves run layer 2: lane kg of an env runs the action-dependent tail for
+            // action kg -- the candidates are computed SIDE BY SIDE in one instruction stream (lanes kg >= A repeat the last action)
+            float tr[2] = { s_tr[par][0][e], s_tr[par][1][e] };
+#pragma unroll
+            for (int k = 0; k < OBS; k++) cst[0][k] = st[k];
+            crew[0] = env_step_tail<ENV>(cst[0], kg < A ? kg : A - 1, tr, cterm[0]);
+            if (a.forced_actions == nullptr && (((a.step_base + t) & 3) == 0 || t == 0)) { philox_words = s_rng[par][e]; philox_valid = true; }
+        }
+        if (wave < 4) {
+            // layer 2: rows 16 w .. + 15 over all 64 inputs
+            r16_u32x4 hb[2][2];   // [c][term]
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int term = 0; term < 2; term++) hb[c][term] = *reinterpret_cast<const r16_u32x4*>(&s_h1[par][term][c][lane][0]);
+            r16_f32x4 acc = { b2d[0], b2d[1], b2d[2], b2d[3] };
+#pragma unroll
+            for (int c = 0; c < 2; c++) {   // small terms first
+                acc = r16_mfma(w2a[c][1], hb[c][0], acc);
+                acc = r16_mfma(w2a[c][0], hb[c][1], acc);
+                acc = r16_mfma(w2a[c][0], hb[c][0], acc);
+            }
+            // logits: this lane's 4 units; the env's 16 partials (4 waves x 4 lanes) meet in LDS and are added in one fixed order
+#pragma unroll
+            for (int aa = 0; aa < A; aa++) {
+                float part = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) part = __builtin_fmaf(tanh_mufu(acc[r]), w3d[aa][r], part);
+                s_part[par][aa][e][4 * wave + kg] = part;
+            }
+        }
+        R16_STAMP(2);
+        __syncthreads();   // the partial sums of the logits are in LDS
+        R16_STAMP(3);
+        if (envw) {
+            float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int aa = 0; aa < A; aa++) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_part[par][aa][e][4 * q]);
+                    sum = (((sum + v.x) + v.y) + v.z) + v.w;
+                }
+                z[aa] = sum + b3[aa];
+            }
+            int act[PPO_MAX_HEADS];
+            const bool forced = a.forced_actions != nullptr;
+            if (forced) act[0] = (int)a.forced_actions[tn * H];
+            float logprob, entropy;
+            heads_from_logits<DIST, 4, EXACTA>(z, L, nullptr, true, !forced, a.seed, env_global, a.step_base + t, act, logprob, entropy,
+                                               &philox_words, &philox_valid, true);
+            // env step (the candidate of the action taken: it sits in lane kg = action of this env) + truncation + auto-reset (PPO_Discrete.cpp:440-458)
+            int term;
+            float reward;
+            if (act[0] >= 0 && act[0] < A) {
+                const int src = e + 16 * act[0];
+                term = __shfl(cterm[0], src, 64);
+                reward = __shfl(crew[0], src, 64);
+#pragma unroll
+                for (int k = 0; k < OBS; k++) st[k] = __shfl(cst[0][k], src, 64);
+            } else {
+                reward = env_step<ENV>(st, act[0], term);   // a forced action outside the head's range (tests): stepped as given
+            }
+            ep_len += 1;
+            ep_rew += reward;
+            if (ep_len == a.max_episode_steps) term = 1;
+            int fin_len = 0;
+            float fin_rew = 0.0f;
+            if (term) {
+                fin_len = ep_len;
+                fin_rew = ep_rew;
+                int k = resets++;
+                if (ENV == PPO_ENV_CARTPOLE && k >= a.reset_cap) { k = a.reset_cap - 1; if (kg == 0) atomicOr(a.error_flag, 1); }
+                if (ENV == PPO_ENV_CARTPOLE) { st[0] = rrow[0]; st[1] = rrow[1]; st[2] = rrow[2]; st[3] = rrow[3]; (void)k; }
+                else env_reset<ENV>(st, a.reset_table, k, a.seed, env_global);
+                ep_len = 0;
+                ep_rew = 0.0f;
+            }
+            if (kg == 0) {   // the observation the policy sees next
+#pragma unroll
+                for (int k = 0; k < OBS; k++) s_x[par ^ 1][k][e] = st[k];
+            }
+            s_reward = reward; s_logprob = logprob; s_fin_len = fin_len; s_fin_rew = fin_rew; s_act = act[0]; s_done = done;
+            done = term;
+        }
+        R16_STAMP(4);
+        __syncthreads();   // the next observation is in LDS
+        R16_STAMP(5);
+        // the step's stores leave behind the barrier: the policy waves are already on the next step
+        if (writer && kg == 0) {
+            a.dones[tn] = (float)s_done;
+            a.logprobs[tn] = s_logprob;
+            a.rewards[tn] = s_reward;
+            a.fin_len[tn] = s_fin_len;
+            a.fin_rew[tn] = s_fin_rew;
+            a.actions[tn * H] = s_act;
+        }
+        if (DIST == PPO_DIST_MASKED && a.masks && writer && kg < A) a.masks[tn * A + kg] = 1;
+    }
+#ifdef R16_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4 || wave == 5))
+        printf("R16 wave %d: work-before-B1 %llu wait-B1 %llu work-before-B2 %llu wait-B2 %llu work-before-B3 %llu wait-B3 %llu (cycles per step x T=%d)\n", wave,
+               ph[0] / a.T, ph[1] / a.T, ph[2] / a.T, ph[3] / a.T, ph[4] / a.T, ph[5] / a.T, a.T);
+#endif
+    if (writer && kg == 0) {
+        a.next_done[env] = done;
+        a.ep_len[env] = ep_len;
+        a.ep_rew[env] = ep_rew;
+        a.reset_count[env] = resets;
+    }
+    if (writer && kg < OBS) {
+        float xk = 0.0f;
+#pragma unroll
+        for (int k = 0; k < OBS; k++) xk = kg == k ? st[k] : xk;
+        a.next_obs[(size_t)env * OBS + kg] = xk;
+        a.env_state[(size_t)kg * N + env] = xk;
+    }
+}
+
 // Critic over rows [0, n0) of obs0 and rows [0, n1) of obs1 (m_values[step] = Critic(obs[step]), PPO_Discrete.cpp:534-536, and the
 // bootstrap next_value = Critic(next_obs), :280): one wave per row, grid-stride, critic rows resident in registers.
 template <int OBS>
@@ -655,10 +951,16 @@ __global__ void categorical_sample_kernel(const float* __restrict__ probs, int64
 hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.N), block(64);
     const dim3 grid2((unsigned)((a.N + 1) / 2));
+    const dim3 grid16((unsigned)((a.N + 15) / 16));
+#ifdef ROLLOUT_AB_VALU
+#define PPO_ROLLOUT_FAST(ENV, DIST, OBS, AA) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, AA>), grid2, block, 0, s, a)
+#else
+#define PPO_ROLLOUT_FAST(ENV, DIST, OBS, AA) hipLaunchKernelGGL((rollout16_kernel<ENV, DIST, OBS, AA>), grid16, dim3(384), 0, s, a)
+#endif
 #define PPO_LAUNCH_ROLLOUT(ENV, DIST, OBS)                                                                       \
     do {                                                                                                         \
-        if (a.L.n_heads == 1 && a.L.act == 2) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 2>), grid2, block, 0, s, a);      \
-        else if (a.L.n_heads == 1 && a.L.act == 3) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, 3>), grid2, block, 0, s, a); \
+        if (a.L.n_heads == 1 && a.L.act == 2) PPO_ROLLOUT_FAST(ENV, DIST, OBS, 2);                                \
+        else if (a.L.n_heads == 1 && a.L.act == 3) PPO_ROLLOUT_FAST(ENV, DIST, OBS, 3);                           \
         else if (a.L.act <= 4) hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, 4, 0>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((rollout_kernel<ENV, DIST, OBS, PPO_MAX_ACT, 0>), grid, block, 0, s, a);         \
     } while (0)
@@ -672,6 +974,7 @@ hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     }
 #undef PPO_LAUNCH_ROLLOUT
+#undef PPO_ROLLOUT_FAST
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // m_values and the bootstrap value in one batched launch (matrix cores for the reference's observation widths)

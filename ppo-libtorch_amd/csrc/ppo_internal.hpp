@@ -183,7 +183,9 @@ __device__ __forceinline__ float glibc_cosf(float y) {
 // Environment transitions
 // ---------------------------------------------------------------------------------------------------------
 // CartPole::step, reference Environments/CartPole.cpp:47-94 (constants :6-17).  st = {x, x_dot, theta, theta_dot}.
-__device__ __forceinline__ float cartpole_step(float* st, int action, int& terminated) {
+// The part of CartPole::step behind the trigonometry: everything that depends on the action.  cartpole_step = sin / cos of the state + this; the
+// fused rollout forms sin / cos ONCE per step and runs the tail for every possible action before the policy has chosen (kernels_rollout.hip).
+__device__ __forceinline__ float cartpole_tail(float* st, int action, float cos_theta, float sin_theta, int& terminated) {
     const float gravity = 9.8f, mass_pole = 0.1f, total_mass = 0.1f + 1.0f, length = 0.5f;
     const float polemass_length = 0.1f * 0.5f, force_mag = 10.0f, tau = 0.02f;
     const float theta_thr = 0x1.aceeap-3f; /* (float)(12*2*M_PI/360) = bits 0x3e567750, CartPole.cpp:16 */
@@ -191,7 +193,6 @@ __device__ __forceinline__ float cartpole_step(float* st, int action, int& termi
     float x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];
     float force = force_mag;
     if (action == 0) force = -force;
-    const float cos_theta = glibc_cosf(theta), sin_theta = glibc_sinf(theta);
     const float temp = (force + polemass_length * theta_dot * theta_dot * sin_theta) / total_mass;
     const float theta_acc = (gravity * sin_theta - cos_theta * temp) /
                             (length * (4.0f / 3.0f - mass_pole * cos_theta * cos_theta / total_mass));
@@ -204,13 +205,17 @@ __device__ __forceinline__ float cartpole_step(float* st, int action, int& termi
     terminated = (x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr) ? 1 : 0;
     return terminated ? -1.0f : 1.0f;
 }
+__device__ __forceinline__ float cartpole_step(float* st, int action, int& terminated) {
+    const float cos_theta = glibc_cosf(st[2]), sin_theta = glibc_sinf(st[2]);
+    return cartpole_tail(st, action, cos_theta, sin_theta, terminated);
+}
 
 // MountainCar::step, reference Environments/MountainCar.cpp:29-57 (constants :5-13).  st = {position, velocity}.
-__device__ __forceinline__ float mountaincar_step(float* st, int action, int& terminated) {
+__device__ __forceinline__ float mountaincar_tail(float* st, int action, float cos3p, int& terminated) {
     const float min_position = -1.2f, max_position = 0.6f, max_speed = 0.07f, goal_position = 0.5f, goal_velocity = 0.0f;
     const float force = 0.001f, gravity = 0.0025f;
     float position = st[0], velocity = st[1];
-    velocity += ((float)action - 1.0f) * force + glibc_cosf(3.0f * position) * (-gravity);
+    velocity += ((float)action - 1.0f) * force + cos3p * (-gravity);
     velocity = velocity < -max_speed ? -max_speed : (velocity > max_speed ? max_speed : velocity);
     position += velocity;
     position = position < min_position ? min_position : (position > max_position ? max_position : position);
@@ -219,11 +224,26 @@ __device__ __forceinline__ float mountaincar_step(float* st, int action, int& te
     st[0] = position; st[1] = velocity;
     return -1.0f;
 }
+__device__ __forceinline__ float mountaincar_step(float* st, int action, int& terminated) {
+    return mountaincar_tail(st, action, glibc_cosf(3.0f * st[0]), terminated);
+}
 
 template <int ENV>
 __device__ __forceinline__ float env_step(float* st, int action, int& terminated) {
     if constexpr (ENV == PPO_ENV_CARTPOLE) return cartpole_step(st, action, terminated);
     else return mountaincar_step(st, action, terminated);
+}
+// env_step in two halves: what depends on the state only (tr[0], tr[1]) ...
+template <int ENV>
+__device__ __forceinline__ void env_step_pre(const float* st, float* tr) {
+    if constexpr (ENV == PPO_ENV_CARTPOLE) { tr[0] = glibc_cosf(st[2]); tr[1] = glibc_sinf(st[2]); }
+    else { tr[0] = glibc_cosf(3.0f * st[0]); tr[1] = 0.0f; }
+}
+// ... and what depends on the action: env_step(st, a, t) == env_step_pre(st, tr) then env_step_tail(st, a, tr, t), bit for bit
+template <int ENV>
+__device__ __forceinline__ float env_step_tail(float* st, int action, const float* tr, int& terminated) {
+    if constexpr (ENV == PPO_ENV_CARTPOLE) return cartpole_tail(st, action, tr[0], tr[1], terminated);
+    else return mountaincar_tail(st, action, tr[0], terminated);
 }
 
 // CartPole::reset (CartPole.cpp:34-45): the k-th reset of ANY env reads words 4k..4k+3 of the one stream all envs share
