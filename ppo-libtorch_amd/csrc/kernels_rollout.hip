@@ -414,12 +414,22 @@ __global__ __launch_bounds__(64, 2) void rollout2_kernel(RolloutArgs a) {
 typedef float r16_f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 r16_f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int r16_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t r16_pk(float x0, float x1) {   // v_cvt_pk_f16_f32 from the compiler, NOT asm: it pads the 2 wait states an MFMA operand needs
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = { x0, x1 };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
+}
 __device__ __forceinline__ void r16_split2(float x0, float x1, uint32_t& p1, uint32_t& p2) {   // kernels_update_mfma.hip: split2
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x0), "v"(x1));
+    p1 = r16_pk(x0, x1);
     float r0, r1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p1), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p1), "v"(x1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(r0), "v"(r1));
+    p2 = r16_pk(r0, r1);
+}
+typedef _Float16 r16_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ r16_f32x4 r16_mfma16(const uint2 a, const uint2 b, const r16_f32x4 acc) {   // 16x16x16: lane (i, kg) holds k = 4 kg .. 4 kg + 3
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(r16_f16x4, a), __builtin_bit_cast(r16_f16x4, b), acc, 0, 0, 0);
 }
 __device__ __forceinline__ r16_f32x4 r16_mfma(const r16_u32x4 a, const r16_u32x4 b, const r16_f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(r16_f16x8, a), __builtin_bit_cast(r16_f16x8, b), acc, 0, 0, 0);
@@ -445,7 +455,7 @@ __device__ __forceinline__ r16_f32x4 r16_mfma(const r16_u32x4 a, const r16_u32x4
 template <int ENV, int DIST, int OBS, int EXACTA>
 __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_h1[2][2][2][64][4];      // [step parity][term][chunk c][lane][wave 2c: 2 dwords | wave 2c + 1: 2 dwords]
-    __shared__ __attribute__((aligned(16))) float s_part[2][EXACTA][16][16];    // [step parity][logit][env][4 w + kg]
+    __shared__ __attribute__((aligned(16))) float s_part[2][EXACTA][16][4];     // [step parity][logit][env][policy wave]: each wave's 16-unit share of a logit
     __shared__ float s_x[2][4][16];                                             // [step parity][obs component][env]: the observation the policy sees next
     __shared__ float s_tr[2][2][16];                                            // [step parity][cos | sin][env]: the transition's trigonometry (wave 5)
     __shared__ uint4 s_rng[2][16];                                              // [step parity][env]: the Philox words serving this step (wave 3)
@@ -484,15 +494,25 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
             w2a[c][0][q] = p1; w2a[c][1][q] = p2;
         }
     }
-    // biases and the output layer in result layout: register r <-> unit 16 w + 4 kg + r
-    float b1d[4], b2d[4], w3d[A][4], b3[A];
+    // biases in result layout: register r <-> unit 16 w + 4 kg + r
+    float b1d[4], b2d[4], b3[A];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int u = 16 * mw + 4 * kg + r;
         b1d[r] = P[L.b1[1] + u];
         b2d[r] = P[L.b2[1] + u];
+    }
+    // output layer (16x16x16 f16, K = this wave's 16 units): lane (i = e, kg) holds W3[a = i][16 w + 4 kg + 0..3] as two fp16 terms, rows a >= A zero,
+    // scaled by 2^8 (|W3| < 255 for fp16's range: an output layer three orders of magnitude past any trained policy)
+    uint2 w3a[2];   // [term]
+    {
+        float w[4];
 #pragma unroll
-        for (int aa = 0; aa < A; aa++) w3d[aa][r] = P[L.w3[1] + aa * PPO_HIDDEN + u];
+        for (int r = 0; r < 4; r++) w[r] = e < A ? 256.0f * P[L.w3[1] + e * PPO_HIDDEN + 16 * mw + 4 * kg + r] : 0.0f;   // x 2^8: keeps the small term of a ~1e-3 weight out of fp16's subnormals
+        uint32_t p1a, p2a, p1b, p2b;
+        r16_split2(w[0], w[1], p1a, p2a);
+        r16_split2(w[2], w[3], p1b, p2b);
+        w3a[0] = make_uint2(p1a, p1b); w3a[1] = make_uint2(p2a, p2b);
     }
 #pragma unroll
     for (int aa = 0; aa < A; aa++) b3[aa] = P[L.b3[1] + aa];
@@ -593,13 +613,22 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
                 acc = r16_mfma(w2a[c][0], hb[c][1], acc);
                 acc = r16_mfma(w2a[c][0], hb[c][0], acc);
             }
-            // logits: this lane's 4 units; the env's 16 partials (4 waves x 4 lanes) meet in LDS and are added in one fixed order
+            // logits: this wave's 16 units as ONE more product (16x16x16 f16, fp32 as two fp16 terms): z_w[a][e] = sum_u W3[a][u] h2[e][u] lands in
+            // lanes kg = 0 (rows a = 0 .. 3); the env wave adds the four waves' shares in wave order
+            float h2[4];
 #pragma unroll
-            for (int aa = 0; aa < A; aa++) {
-                float part = 0.0f;
+            for (int r = 0; r < 4; r++) h2[r] = tanh_mufu(acc[r]);
+            uint32_t q1a, q2a, q1b, q2b;
+            r16_split2(h2[0], h2[1], q1a, q2a);
+            r16_split2(h2[2], h2[3], q1b, q2b);
+            const uint2 hq1 = make_uint2(q1a, q1b), hq2 = make_uint2(q2a, q2b);
+            r16_f32x4 zacc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            zacc = r16_mfma16(w3a[1], hq1, zacc);
+            zacc = r16_mfma16(w3a[0], hq2, zacc);
+            zacc = r16_mfma16(w3a[0], hq1, zacc);
+            if (kg == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) part = __builtin_fmaf(tanh_mufu(acc[r]), w3d[aa][r], part);
-                s_part[par][aa][e][4 * wave + kg] = part;
+                for (int aa = 0; aa < A; aa++) s_part[par][aa][e][wave] = zacc[aa];
             }
         }
         R16_STAMP(2);
@@ -609,13 +638,8 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
             float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
             for (int aa = 0; aa < A; aa++) {
-                float sum = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_part[par][aa][e][4 * q]);
-                    sum = (((sum + v.x) + v.y) + v.z) + v.w;
-                }
-                z[aa] = sum + b3[aa];
+                const float4 v = *reinterpret_cast<const float4*>(&s_part[par][aa][e][0]);
+                z[aa] = __builtin_fmaf(((v.x + v.y) + v.z) + v.w, 0x1p-8f, b3[aa]);   // the weights' 2^8 comes off exactly
             }
             int act[PPO_MAX_HEADS];
             const bool forced = a.forced_actions != nullptr;

@@ -61,14 +61,16 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
-// (Inline asm: LLVM forms neither instruction from C for gfx950 -- x - (float)h becomes a conversion and a subtraction -- and its hazard
-// recognizer does not look into asm blocks; an MFMA that reads a register these instructions wrote in the slot right before it is handled by
-// the hardware: tools/probes/asm_mfma_hazard.hip, 0 differences against the same sequence padded with s_nop.)
-// two floats -> one dword of fp16 (low half = x0), round to nearest even (v_cvt_pk_f16_f32)
+// two floats -> one dword of fp16 (low half = x0), round to nearest even: v_cvt_pk_f16_f32, formed BY THE COMPILER from the vector conversion so
+// that its hazard recognizer sees the producer of an MFMA operand: a VGPR written by a VALU instruction needs 2 wait states before an MFMA
+// reads it as A/B, hipcc pads that pair only when both instructions are its own, and an MFMA that is not stalled on an accumulator chain reads
+// the OLD register otherwise (seen in rollout16_kernel: logits off by 1e-3 with the conversion in an asm string; tools/check_asm_hazards.py
+// scans the device assembly for the pair).  The residuals below stay asm (LLVM does not form v_fma_mix_f32 from x - (float)h): they never
+// feed an MFMA directly.
+typedef float f32x2_cv __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_f16(float x0, float x1) {
-    uint32_t p;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p) : "v"(x0), "v"(x1));
-    return p;
+    const f32x2_cv x = { x0, x1 };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
 }
 // x - (float)half(p): the residual of a rounding to fp16 is a float, so this fused multiply-add with an fp16 source is exact
 __device__ __forceinline__ float resid_lo(uint32_t p, float x) {

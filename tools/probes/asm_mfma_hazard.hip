@@ -2,6 +2,10 @@
 // (kernels_update_mfma.hip forms its fp16 terms with inline asm, which LLVM's hazard recognizer does not look into.)  Two kernels compute the
 // same 32x32x16 product; one issues conversion and MFMA back to back inside ONE asm block, the other puts s_nop 7 between them.  Equal bits on
 // every lane = the hardware interlocks (or needs no wait states).   hipcc --offload-arch=gfx950 -O3 -o asm_mfma_hazard asm_mfma_hazard.hip
+// ROUND 3: THIS PROBE'S CONCLUSION WAS WRONG.  Its MFMA sat in an accumulator chain (stalled at issue long enough for the operand to land); an
+// MFMA with nothing to wait for reads the OLD register: rollout16_kernel's logits were off by 1e-3 with one s_nop 0 between the asm conversion and
+// the MFMA.  The rule is 2 wait states (hipcc pads `s_nop 1` itself when the conversion is its own instruction: tools/probes/mfma16_split.hip,
+// tools/check_asm_hazards.py); pk_f16 / r16_pk are compiler-formed since.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
