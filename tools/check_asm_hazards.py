@@ -30,6 +30,10 @@ def scan(path, extra):
         cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + (["-fno-slp-vectorize"] if os.path.basename(path) in NOSLP else []) + extra + ["--cuda-device-only", "-S", "-o", f.name, path]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         lines = open(f.name).read().splitlines()
+    return scan_lines(lines, path)
+
+
+def scan_lines(lines, path="<asm>"):
     found, in_asm, func = [], False, "?"
     pending = []   # [written regs, states elapsed, text, line]
     for n, raw in enumerate(lines, 1):
