@@ -147,6 +147,7 @@ struct ppo_ctx {
     float* slab = nullptr;
     double* stat_slab = nullptr;
     double* loss_sums = nullptr;
+    float4* adv_norm = nullptr;         // [steps_per_update + 1] { mean, 1 / (std + 1e-8), std, 0 } per minibatch slot, from adv_stats once per update
     AdvStat* adv_stats = nullptr;       // [steps_per_update] + 1 scratch slot; sits right BEHIND gstats so that one all-reduce per update carries both
     double* gstats = nullptr;           // [PPO_GSTAT_DOUBLES] job-global statistics block of a sharded run (ppo_internal.hpp: PPO_GSTAT_*)
     bool have_gstats = false;           // the block holds the all-reduced statistics of the last ppo_update
@@ -503,6 +504,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         CK(dalloc(c, &blk, (size_t)PPO_GSTAT_DOUBLES + ((size_t)c->steps_per_update + 1) * PPO_ADV_PARTS * (sizeof(AdvStat) / sizeof(double))));
         c->gstats = blk;
         c->adv_stats = reinterpret_cast<AdvStat*>(blk + PPO_GSTAT_DOUBLES);
+        CK(dalloc(c, &c->adv_norm, (size_t)c->steps_per_update + 1));
     }
     CK(dalloc(c, &c->adam_coefs, (size_t)c->steps_per_update + 1));
     CK(hipHostMalloc(reinterpret_cast<void**>(&c->adam_coefs_h), 2 * ((size_t)c->steps_per_update + 1) * sizeof(AdamCoef)));
@@ -1256,6 +1258,7 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     a.inv_global_M = 1.0 / a.global_M;
     c->last_global_M = a.global_M;
     a.adv_stat = c->adv_stats + (size_t)slot * PPO_ADV_PARTS;
+    a.adv_norm = c->adv_norm + slot;
     a.slab = c->slab;
     a.stat_slab = c->stat_slab;
     a.stamps = c->stamping ? c->stamps : nullptr;
@@ -1300,6 +1303,7 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
         HIPCHK(c, launch_adv_stats(B_<float>(c, PPO_BUF_ADVANTAGES), idx, M, M, 1, c->adv_stats + (size_t)slot * PPO_ADV_PARTS, c->stream));
         ppo_status s = allreduce_sum(c, c->adv_stats + (size_t)slot * PPO_ADV_PARTS, 2 * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
+        HIPCHK(c, launch_adv_norm(c->adv_stats + (size_t)slot * PPO_ADV_PARTS, 1, 1, c->B, c->MB, M, c->world, c->adv_norm + slot, c->stream));
     }
     ppo_status s = fwd_bwd(c, idx, M, slot);
     if (s != PPO_OK) return s;
@@ -1375,6 +1379,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         if (sharded) s = allreduce_sum(c, c->gstats, (size_t)PPO_GSTAT_DOUBLES + (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         else s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
+        HIPCHK(c, launch_adv_norm(c->adv_stats, E * nmb, nmb, c->B, c->MB, 0, c->world, c->adv_norm, c->stream));
     } else {
         s = ppo_generate_permutations(c);
         if (s != PPO_OK) return s;

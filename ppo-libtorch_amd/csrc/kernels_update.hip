@@ -105,13 +105,9 @@ __device__ __forceinline__ void fwd_bwd_body(const UpdateArgs& a, float* smem) {
     const float invM = (float)a.inv_global_M;
     float mean_f = 0.0f, std_f = 0.0f;
     if (NET == 1 && a.hp.norm_adv) {
-        // (adv - mean) / (std + 1e-8) over the minibatch, std Bessel-corrected (PPO_Discrete.cpp:591-594)
-        double t1 = 0.0, t2 = 0.0;
-        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += a.adv_stat[i].s1; t2 += a.adv_stat[i].s2; }
-        const double mean = t1 / a.global_M;
-        const double var = (t2 - t1 * mean) / (a.global_M - 1.0);
-        mean_f = (float)mean;
-        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+        // (adv - mean) / (std + 1e-8) over the minibatch, std Bessel-corrected (PPO_Discrete.cpp:591-594): formed once per update by adv_norm_kernel
+        mean_f = a.adv_norm->x;
+        std_f = a.adv_norm->z;
     }
     __syncthreads();
 
@@ -1149,6 +1145,29 @@ hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* st
     hipLaunchKernelGGL(clip_adamw_sumsq_kernel, dim3((L.P + ADAM_THREADS - 1) / ADAM_THREADS), dim3(ADAM_THREADS), 0, s, a);
     return hipGetLastError();
 }
+// One thread per minibatch slot: the PPO_ADV_PARTS partial sums in order, then mean and Bessel std in binary64 as the update kernels used to do in
+// every launch (32 dependent scalar loads behind the weight loads: ~2 us of the actor's prologue, 40 times per update).
+__global__ void adv_norm_kernel(const AdvStat* __restrict__ stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world,
+                                float4* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += stats[(size_t)k * PPO_ADV_PARTS + i].s1; t2 += stats[(size_t)k * PPO_ADV_PARTS + i].s2; }
+    const int64_t start = (int64_t)(k % per_epoch) * MB;
+    const int64_t M = explicit_M > 0 ? explicit_M : (MB < B - start ? MB : B - start);
+    const double global_M = (double)M * world;
+    const double mean = t1 / global_M;
+    const double var = (t2 - t1 * mean) / (global_M - 1.0);
+    const float mean_f = (float)mean;
+    const float std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+    out[k] = make_float4(mean_f, 1.0f / (std_f + 1e-8f), std_f, 0.0f);
+}
+hipError_t launch_adv_norm(const AdvStat* stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world, float4* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adv_norm_kernel, dim3((n + 63) / 64), dim3(64), 0, s, stats, n, per_epoch > 0 ? per_epoch : 1, B, MB, explicit_M, world, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_t B, int64_t MB, int n_mb_total, AdvStat* out,
                             hipStream_t s) {
     const int per_epoch = (int)((B + MB - 1) / MB);

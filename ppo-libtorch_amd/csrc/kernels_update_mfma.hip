@@ -308,16 +308,13 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     const float clip = a.hp.clip_coef;
     const float lo = uniform_f(1 - clip), hi_c = uniform_f(1 + clip);
     const float invM = uniform_f((float)a.inv_global_M);
-    float mean_f = 0.0f, std_f = 0.0f;
+    // mean and 1 / (Bessel std + 1e-8) of the minibatch's advantages: two scalars formed once per update (adv_norm_kernel), one 16-byte scalar load here
+    float mean_f = 0.0f, inv_std = 0.0f;
     if (NET == 1 && a.hp.norm_adv) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += a.adv_stat[i].s1; t2 += a.adv_stat[i].s2; }
-        const double mean = t1 / a.global_M;
-        const double var = (t2 - t1 * mean) / (a.global_M - 1.0);
-        mean_f = uniform_f((float)mean);
-        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+        const float4 an = *a.adv_norm;
+        mean_f = uniform_f(an.x);
+        inv_std = uniform_f(an.y);
     }
-    const float inv_std = uniform_f(1.0f / (std_f + 1e-8f));
     __syncthreads();
     // Range of the fp16 terms of dz2 (gradients are ~1 / M): dz2 is formed already multiplied by 2^S, S a wave-uniform integer kept
     // such that the tile's largest possible |dz2| 2^S -- (sum_a |dOut[a]|) max|W3|, since |1 - h^2| <= 1 -- stays below 2^14.  S only

@@ -553,6 +553,7 @@ struct UpdateArgs {
     int M;                   // local minibatch rows
     double inv_global_M;     // 1 / (rows of the global minibatch)
     const AdvStat* adv_stat; // global sums for this minibatch (nullptr when !norm_adv)
+    const float4* adv_norm;  // { mean, 1 / (std + 1e-8), std (Bessel), 0 } of this minibatch's advantages, formed ONCE per update from adv_stat (launch_adv_norm)
     double global_M;
     float* slab;             // [n_blocks, P_net_max] partial gradients
     double* stat_slab;       // [n_blocks, 8] partial loss sums
@@ -604,6 +605,9 @@ hipError_t launch_adv_stats(const float* advantages, const int32_t* perm, int64_
                             hipStream_t s);
 hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, int64_t update_index, int64_t rank_salt, hipStream_t s);
 // the two above in one pass (ppo_update with norm_adv): perm[e][j] and the advantage sums of every minibatch of the update
+// { mean, 1 / (std + 1e-8), std, 0 } of the advantages of minibatch slots [0, n) from their PPO_ADV_PARTS partial sums (PPO_Discrete.cpp:591-594); slot k is
+// minibatch k % per_epoch of an epoch (rows min(MB, B - start) x world), or explicit_M x world rows when explicit_M > 0
+hipError_t launch_adv_norm(const AdvStat* stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world, float4* out, hipStream_t s);
 hipError_t launch_permutations_adv_stats(const float* advantages, int32_t* perm, int64_t B, int E, int64_t MB, int64_t seed, int64_t update_index,
                                          int64_t rank_salt, AdvStat* out, hipStream_t s);
 hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s);
