@@ -452,12 +452,20 @@ __device__ __forceinline__ r16_f32x4 r16_mfma(const r16_u32x4 a, const r16_u32x4
 // Three barriers per step (hidden layer + trigonometry, logits' partial sums, next observation); buffers alternate by step parity.
 // Measured per 128-step rollout at 4096 envs (A/B in one call, rollout + critic batch): rollout2_kernel 234 us; one wave per tile 216; four policy
 // waves that also step the envs 207; + env wave 196; + trigonometry off the env wave and reset prefetch 171 (cos and sin on two waves: 176).
+// Workgroup barrier for data handed over through LDS ONLY.  __syncthreads() is a release / acquire fence over every address space: hipcc puts
+// s_waitcnt vmcnt(0) in front of the s_barrier, and a wave that has just issued global stores then stands at the barrier until the memory side has
+// acknowledged them (~1 k cycles) -- with every other wave of the workgroup waiting for it.  The waves of the rollout exchange nothing through global
+// memory inside the step loop, so the barrier only has to wait for the wave's LDS operations (the asm's memory clobber keeps the compiler from moving
+// LDS accesses across it).
+__device__ __forceinline__ void r16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int ENV, int DIST, int OBS, int EXACTA>
 __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_h1[2][2][2][64][4];      // [step parity][term][chunk c][lane][wave 2c: 2 dwords | wave 2c + 1: 2 dwords]
     __shared__ __attribute__((aligned(16))) float s_part[2][EXACTA][16][4];     // [step parity][logit][env][policy wave]: each wave's 16-unit share of a logit
     __shared__ float s_x[2][4][16];                                             // [step parity][obs component][env]: the observation the policy sees next
     __shared__ float s_tr[2][2][16];                                            // [step parity][cos | sin][env]: the transition's trigonometry (wave 5)
+    __shared__ float s_rrow[2][4][16];                                          // [step parity][component][env]: CartPole, the reset row an env restarts from if this step ends its episode (wave 5)
     __shared__ uint4 s_rng[2][16];                                              // [step parity][env]: the Philox words serving this step (wave 3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e = lane & 15, kg = lane >> 4;
     const bool envw = wave == 4, trigw = wave == 5;
@@ -532,21 +540,46 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
 #pragma unroll
         for (int k = 0; k < OBS; k++) s_x[0][k][e] = st[k];
     }
+    // CartPole: the trigonometry runs a whole step AHEAD.  x and theta of the next state -- hence termination, truncation and the reset -- do not depend on
+    // the action (cartpole_next_pose), so while step t is in flight the trigonometry wave already forms sin / cos of theta(t + 1), keeping its own copies of
+    // the episode length and the reset count; nobody waits for it any more, and the env wave runs the candidate transitions beside the policy's layer 1.
+    constexpr bool AHEAD = ENV == PPO_ENV_CARTPOLE;
+    if (AHEAD && trigw) {
+        float tr[2];
+        env_step_pre<ENV>(st, tr);
+        if (kg == 0) { s_tr[0][0][e] = tr[0]; s_tr[0][1][e] = tr[1]; }
+    }
     __syncthreads();
 
 #ifdef R16_STAMPS
     unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
-#define R16_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph[i] += n_ - tp; tp = n_; } while (0)
+#define R16_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); ph[i] += n_ - tp; tp = n_; } while (0)   /* waits for the clock only, not for the wave's stores */
 #else
 #define R16_STAMP(i) do { } while (0)
 #endif
+    // what a step leaves in the rollout buffers, kept by the env wave until it has a free moment (AHEAD: the NEXT step's layer-2 phase; otherwise right
+    // behind the step's last barrier)
+    float s_reward = 0.0f, s_logprob = 0.0f, s_fin_rew = 0.0f;
+    int s_fin_len = 0, s_act = 0, s_done = 0;
+    auto store_step = [&](size_t at) {
+        if (writer && kg == 0) {
+            a.dones[at] = (float)s_done;
+            a.logprobs[at] = s_logprob;
+            a.rewards[at] = s_reward;
+            a.fin_len[at] = s_fin_len;
+            a.fin_rew[at] = s_fin_rew;
+            a.actions[at * H] = s_act;
+        }
+        if (DIST == PPO_DIST_MASKED && a.masks && writer && kg < A) a.masks[at * A + kg] = 1;
+    };
     for (int t = 0; t < a.T; t++) {
         const size_t tn = (size_t)t * N + env;
         const int par = t & 1;
-        float cst[1][OBS], crew[1], rrow[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        float cst[1][OBS], crew[1];
         int cterm[1];
-        float s_reward = 0.0f, s_logprob = 0.0f, s_fin_rew = 0.0f;
-        int s_fin_len = 0, s_act = 0, s_done = 0;
+        float theta_ahead = 0.0f;   // trigonometry wave, AHEAD
+        float4 row_ahead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int term_ahead = 0;
         if (wave < 4) {
             // layer 1 + tanh: this wave's 16 units; B operand x[e][k = kg]
             const float xk = s_x[par][kg & 3][e];
@@ -567,36 +600,68 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
             if (wave == 3 && kg == 0 && a.forced_actions == nullptr && (((a.step_base + t) & 3) == 0 || t == 0))
                 s_rng[par][e] = philox4x32_10((uint32_t)a.seed, (uint32_t)((uint64_t)a.seed >> 32), (uint32_t)env_global, (uint32_t)((a.step_base + t) >> 2), 0u, 0u);
         } else if (trigw) {
-            // wave 5: the trigonometry of the transition (binary64 sin / cos of the state the policy is looking at), for the env wave's tail
+            // wave 5: the trigonometry of the transition (binary64 sin / cos), for the env wave's tail
             float xs[OBS], tr[2];
 #pragma unroll
             for (int k = 0; k < OBS; k++) xs[k] = s_x[par][k][e];
-            env_step_pre<ENV>(xs, tr);
-            if (kg == 0) { s_tr[par][0][e] = tr[0]; s_tr[par][1][e] = tr[1]; }
+            if constexpr (AHEAD) {
+                // ... of the NEXT step's state: theta(t + 1) = theta + tau theta_dot, or the reset row's angle when this step ends the episode.  Every wave
+                // meets every barrier, so the work is cut in three: the angle here, its cosine behind barrier 1, its sine behind barrier 2 -- each piece
+                // shorter than the phase it sits in
+                const int kr = resets < a.reset_cap ? resets : a.reset_cap - 1;
+                row_ahead = reinterpret_cast<const float4*>(a.reset_table)[kr];   // this wave has no stores in flight: waiting for the row is waiting for the row
+                float x1;
+                cartpole_next_pose(xs, x1, theta_ahead, term_ahead);
+                ep_len += 1;
+                if (ep_len == a.max_episode_steps) term_ahead = 1;
+                if (term_ahead) { resets++; ep_len = 0; }
+                (void)tr;
+            } else {
+                env_step_pre<ENV>(xs, tr);   // of the state the policy is looking at
+                if (kg == 0) { s_tr[par][0][e] = tr[0]; s_tr[par][1][e] = tr[1]; }
+            }
         } else {
-            // m_obs[step] = next_obs (PPO_Discrete.cpp:529): lane kg stores component kg
-            float xk = 0.0f;
+            if constexpr (AHEAD) {   // sin / cos of this step's state arrived during the last step: the candidates run beside layer 1
+                float tr[2] = { s_tr[par][0][e], s_tr[par][1][e] };
 #pragma unroll
-            for (int k = 0; k < OBS; k++) xk = kg == k ? st[k] : xk;
-            if (writer && kg < OBS) a.obs[tn * OBS + kg] = xk;
-            // the row of the shared reset stream this env would restart from (CartPole.cpp:34-45), requested every step so that an episode's end
-            // never waits for it
-            if (ENV == PPO_ENV_CARTPOLE) {
-                const int k = resets < a.reset_cap ? resets : a.reset_cap - 1;
-                const float4 r = reinterpret_cast<const float4*>(a.reset_table)[k];
-                rrow[0] = r.x; rrow[1] = r.y; rrow[2] = r.z; rrow[3] = r.w;
+                for (int k = 0; k < OBS; k++) cst[0][k] = st[k];
+                crew[0] = env_step_tail<ENV>(cst[0], kg < A ? kg : A - 1, tr, cterm[0]);
+            }
+            if constexpr (!AHEAD) {
+                // m_obs[step] = next_obs (PPO_Discrete.cpp:529): lane kg stores component kg
+                float xk = 0.0f;
+#pragma unroll
+                for (int k = 0; k < OBS; k++) xk = kg == k ? st[k] : xk;
+                if (writer && kg < OBS) a.obs[tn * OBS + kg] = xk;
             }
         }
         R16_STAMP(0);
-        __syncthreads();   // the hidden layer, the trigonometry and the random words are in LDS
+        r16_lds_barrier();   // the hidden layer, the random words (and, not AHEAD, the trigonometry) are in LDS
         R16_STAMP(1);
+        if (AHEAD && trigw) {
+            // the reset row has had a phase to arrive: hand it to the env wave through LDS (a load of its own would make it wait for its own stores)
+            if (kg == 0) { s_rrow[par][0][e] = row_ahead.x; s_rrow[par][1][e] = row_ahead.y; s_rrow[par][2][e] = row_ahead.z; s_rrow[par][3][e] = row_ahead.w; }
+            if (term_ahead) theta_ahead = row_ahead.z;
+            const float c = glibc_cosf(theta_ahead);
+            if (kg == 0) s_tr[par ^ 1][0][e] = c;
+        }
         if (envw) {
-            // the transition of every possible action, while the policy waves run layer 2: lane kg of an env runs the action-dependent tail for
+            // the transition of every possible action, while the policy waves run the network: lane kg of an env runs the action-dependent tail for
             // action kg -- the candidates are computed SIDE BY SIDE in one instruction stream (lanes kg >= A repeat the last action)
-            float tr[2] = { s_tr[par][0][e], s_tr[par][1][e] };
+            if constexpr (!AHEAD) {
+                float tr[2] = { s_tr[par][0][e], s_tr[par][1][e] };
 #pragma unroll
-            for (int k = 0; k < OBS; k++) cst[0][k] = st[k];
-            crew[0] = env_step_tail<ENV>(cst[0], kg < A ? kg : A - 1, tr, cterm[0]);
+                for (int k = 0; k < OBS; k++) cst[0][k] = st[k];
+                crew[0] = env_step_tail<ENV>(cst[0], kg < A ? kg : A - 1, tr, cterm[0]);
+            } else {
+                // m_obs[step] = next_obs (PPO_Discrete.cpp:529), here: this wave has nothing else to do until the logits arrive, and whatever the compiler
+                // makes it wait for (the acknowledgements of the last step's stores) costs nobody anything in this phase
+                float xk = 0.0f;
+#pragma unroll
+                for (int k = 0; k < OBS; k++) xk = kg == k ? st[k] : xk;
+                if (writer && kg < OBS) a.obs[tn * OBS + kg] = xk;
+                if (t > 0) store_step(tn - N);   // ... and so do the last step's scalars
+            }
             if (a.forced_actions == nullptr && (((a.step_base + t) & 3) == 0 || t == 0)) { philox_words = s_rng[par][e]; philox_valid = true; }
         }
         if (wave < 4) {
@@ -632,8 +697,12 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
             }
         }
         R16_STAMP(2);
-        __syncthreads();   // the partial sums of the logits are in LDS
+        r16_lds_barrier();   // the partial sums of the logits are in LDS
         R16_STAMP(3);
+        if (AHEAD && trigw) {
+            const float sn = glibc_sinf(theta_ahead);
+            if (kg == 0) s_tr[par ^ 1][1][e] = sn;
+        }
         if (envw) {
             float z[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
@@ -669,7 +738,7 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
                 fin_rew = ep_rew;
                 int k = resets++;
                 if (ENV == PPO_ENV_CARTPOLE && k >= a.reset_cap) { k = a.reset_cap - 1; if (kg == 0) atomicOr(a.error_flag, 1); }
-                if (ENV == PPO_ENV_CARTPOLE) { st[0] = rrow[0]; st[1] = rrow[1]; st[2] = rrow[2]; st[3] = rrow[3]; (void)k; }
+                if (ENV == PPO_ENV_CARTPOLE) { st[0] = s_rrow[par][0][e]; st[1] = s_rrow[par][1][e]; st[2] = s_rrow[par][2][e]; st[3] = s_rrow[par][3][e]; (void)k; }   // the row of the shared reset stream (CartPole.cpp:34-45)
                 else env_reset<ENV>(st, a.reset_table, k, a.seed, env_global);
                 ep_len = 0;
                 ep_rew = 0.0f;
@@ -682,19 +751,12 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
             done = term;
         }
         R16_STAMP(4);
-        __syncthreads();   // the next observation is in LDS
+        r16_lds_barrier();   // the next observation is in LDS
         R16_STAMP(5);
         // the step's stores leave behind the barrier: the policy waves are already on the next step
-        if (writer && kg == 0) {
-            a.dones[tn] = (float)s_done;
-            a.logprobs[tn] = s_logprob;
-            a.rewards[tn] = s_reward;
-            a.fin_len[tn] = s_fin_len;
-            a.fin_rew[tn] = s_fin_rew;
-            a.actions[tn * H] = s_act;
-        }
-        if (DIST == PPO_DIST_MASKED && a.masks && writer && kg < A) a.masks[tn * A + kg] = 1;
+        if constexpr (!AHEAD) store_step(tn);
     }
+    if constexpr (AHEAD) { if (a.T > 0) store_step((size_t)(a.T - 1) * N + env); }
 #ifdef R16_STAMPS
     if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4 || wave == 5))
         printf("R16 wave %d: work-before-B1 %llu wait-B1 %llu work-before-B2 %llu wait-B2 %llu work-before-B3 %llu wait-B3 %llu (cycles per step x T=%d)\n", wave,

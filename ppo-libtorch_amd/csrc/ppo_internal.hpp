@@ -205,6 +205,15 @@ __device__ __forceinline__ float cartpole_tail(float* st, int action, float cos_
     terminated = (x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr) ? 1 : 0;
     return terminated ? -1.0f : 1.0f;
 }
+// Position and angle of CartPole's next state, and with them the termination test, do NOT depend on the action: the explicit Euler step advances x and theta
+// with the OLD velocities (CartPole.cpp:76-80; only x_dot and theta_dot see the force).  Same expressions as cartpole_tail, bit for bit; the fused rollout's
+// trigonometry wave uses this to form sin / cos of the NEXT state's angle a whole step ahead (kernels_rollout.hip).
+__device__ __forceinline__ void cartpole_next_pose(const float* st, float& x1, float& theta1, int& terminated) {
+    const float tau = 0.02f, theta_thr = 0x1.aceeap-3f, x_thr = 2.4f;
+    x1 = st[0] + tau * st[1];
+    theta1 = st[2] + tau * st[3];
+    terminated = (x1 < -x_thr || x1 > x_thr || theta1 < -theta_thr || theta1 > theta_thr) ? 1 : 0;
+}
 __device__ __forceinline__ float cartpole_step(float* st, int action, int& terminated) {
     const float cos_theta = glibc_cosf(st[2]), sin_theta = glibc_sinf(st[2]);
     return cartpole_tail(st, action, cos_theta, sin_theta, terminated);
