@@ -447,7 +447,7 @@ def main():
 
     # GAE scan back to back, outside the timed region: on the context's own buffers (this workload's size) and on fresh buffers of the three
     # sizes the roofline is quoted at -- wall time of 200 launches / 200: no event pair (~3 us on a 5 us launch), no foreign kernel in front
-    def gae_b2b(n_envs, bufs=None):
+    def gae_b2b(n_envs, bufs=None, fast=False):
         import numpy as np
         if bufs is None:
             rng = np.random.default_rng(n_envs)
@@ -457,11 +457,11 @@ def main():
                     ctx.empty((T, n_envs), np.float32), ctx.empty((T, n_envs), np.float32)]
         reps = 200
         for _ in range(3):
-            P.gae_launch(ctx, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], T, n_envs, 0.98, 0.95, bufs[5], bufs[6])
+            P.gae_launch(ctx, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], T, n_envs, 0.98, 0.95, bufs[5], bufs[6], fast=fast)
         ctx.sync()
         tg = time.perf_counter()
         for _ in range(reps):
-            P.gae_launch(ctx, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], T, n_envs, 0.98, 0.95, bufs[5], bufs[6])
+            P.gae_launch(ctx, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], T, n_envs, 0.98, 0.95, bufs[5], bufs[6], fast=fast)
         ctx.sync()
         ms = 1e3 * (time.perf_counter() - tg) / reps
         nbytes = 20 * n_envs * T + 8 * n_envs
@@ -470,11 +470,12 @@ def main():
     class _Ptr:
         def __init__(self, p):
             self.ptr = p
-    gae_rows = []
+    gae_rows, gae_fast_rows = [], []
     if rank == 0:
         own = [_Ptr(ctx.buffer_ptr(n)[0]) for n in ("REWARDS", "VALUES", "DONES", "NEXT_VALUE", "NEXT_DONE", "ADVANTAGES", "RETURNS")]
         gae_own = gae_b2b(N, own)
         gae_rows = [gae_b2b(n) for n in (4096, 8192, 32768)]
+        gae_fast_rows = [gae_b2b(n, fast=True) for n in (4096, 8192, 32768)]   # the associative scan (ppo_gae_fast): NOT what training runs
 
     if rank == 0:
         env_steps = args.steps * N * T * world
@@ -536,6 +537,10 @@ def main():
                                               "frac": gae_bytes / (gae_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gae_ms else None,
                                               "timing": "HIP events around the launch inside the iteration (the event pair adds ~3 us to a ~5 us launch)"},
                              "back_to_back_sizes": gae_rows,
+                             "fast_mode": {"what": "ppo_gae_fast: the recurrence as a segmented scan of affine maps (all 256 lanes busy, chain 2 x 31 instead of 2 x 128 "
+                                                   "operations); NOT bit-identical to the reference (<= 6 ulp of the largest advantage the chain carried, tests bound 16: profiles/r03_v4_gae_fast_report.jsonl), so training "
+                                                   "does not use it; timed here to state what giving up the reference's association order would buy",
+                                           "back_to_back_sizes": gae_fast_rows},
                              # the 40 % bar of BASELINE.json, stated in one place: the smallest measured size that clears it, what the headline's
                              # per-GPU size (configs[1] / [2]: 4096 envs) reaches, and the committed floor of a launch that moves the same bytes
                              "bar": {"target_frac": 0.40,

@@ -225,6 +225,13 @@ PPO_API ppo_status ppo_calc_advantage(ppo_ctx* ctx);
 PPO_API ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
                    const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages,
                    float* returns, void* stream);
+/* The same scan in FAST mode -- north_star's "segmented prefix sum": the recurrence as a scan of affine maps (c, d) o (c', d') = (c c', d + c d') over
+ * chunks of rows, all lanes busy, a done flag cuts the segment.  NOT bit-identical to PPO_Discrete.cpp:283-306 (the carry into a chunk is associated
+ * differently: <= 6 ULP of the largest advantage the chain has carried, measured); training (ppo_calc_advantage) never uses it.  Kept to state, with a number, what giving up the
+ * reference's association order would buy (profiles/NOTES.md). */
+PPO_API ppo_status ppo_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value,
+                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages,
+                        float* returns, void* stream);
 PPO_API ppo_status ppo_nstep_returns(const float* rewards, const float* values, const float* dones, const float* next_value,
                              const int32_t* next_done, int64_t T, int64_t N, float gamma, float* advantages, float* returns,
                              void* stream);

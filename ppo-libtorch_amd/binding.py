@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ppo_param_shapes", "ppo_params_init_orthogonal", "ppo_params_set_h", "ppo_params_get_h", "ppo_optimizer_set_h",
     "ppo_optimizer_get_h", "ppo_get_value", "ppo_policy_act", "ppo_categorical", "ppo_categorical_sample", "ppo_matmul", "ppo_env_transition",
     "ppo_cartpole_reset_stream_h", "ppo_env_reset", "ppo_env_step", "ppo_env_set_state_h", "ppo_env_get_state_h",
-    "ppo_rollout", "ppo_calc_advantage", "ppo_gae", "ppo_nstep_returns", "ppo_generate_permutations",
+    "ppo_rollout", "ppo_calc_advantage", "ppo_gae", "ppo_gae_fast", "ppo_nstep_returns", "ppo_generate_permutations",
     "ppo_minibatch_forward_backward", "ppo_allreduce_grads", "ppo_optimizer_step", "ppo_update", "ppo_train_iteration",
     "ppo_read_stats", "ppo_set_learning_rate", "ppo_profile_enable", "ppo_profile_read", "ppo_comm_unique_id", "ppo_comm_init",
     "ppo_comm_init_local", "ppo_comm_exchange_handle", "ppo_comm_init_exchange", "ppo_comm_exchange_timeouts",
@@ -407,8 +407,8 @@ def comm_unique_id():
 
 
 # ---- stateless entry points (need a context only for device memory plumbing)
-def gae(ctx, rewards, values, dones, next_value, next_done, gamma, gae_lambda, nstep=False):
-    """PPO_Discrete::calcAdvantage on caller buffers (reference PPO_Discrete.cpp:274-331)."""
+def gae(ctx, rewards, values, dones, next_value, next_done, gamma, gae_lambda, nstep=False, fast=False):
+    """PPO_Discrete::calcAdvantage on caller buffers (reference PPO_Discrete.cpp:274-331).  fast: the associative scan (ppo_gae_fast; not bit-identical)."""
     rewards = np.ascontiguousarray(rewards, np.float32)
     T, N = rewards.shape
     d = [ctx.dev(rewards), ctx.dev(values, np.float32), ctx.dev(dones, np.float32), ctx.dev(np.ravel(next_value), np.float32),
@@ -417,8 +417,8 @@ def gae(ctx, rewards, values, dones, next_value, next_done, gamma, gae_lambda, n
     if nstep:
         st = lib().ppo_nstep_returns(*(x.ptr for x in d), C.c_int64(T), C.c_int64(N), C.c_float(gamma), adv.ptr, ret.ptr, C.c_void_p(ctx.stream()))
     else:
-        st = lib().ppo_gae(*(x.ptr for x in d), C.c_int64(T), C.c_int64(N), C.c_float(gamma), C.c_float(gae_lambda), adv.ptr, ret.ptr,
-                           C.c_void_p(ctx.stream()))
+        fn = lib().ppo_gae_fast if fast else lib().ppo_gae
+        st = fn(*(x.ptr for x in d), C.c_int64(T), C.c_int64(N), C.c_float(gamma), C.c_float(gae_lambda), adv.ptr, ret.ptr, C.c_void_p(ctx.stream()))
     _check(st, ctx.h)
     ctx.sync()
     out = adv.download(), ret.download()
@@ -427,9 +427,9 @@ def gae(ctx, rewards, values, dones, next_value, next_done, gamma, gae_lambda, n
     return out
 
 
-def gae_launch(ctx, d_rewards, d_values, d_dones, d_next_value, d_next_done, T, N, gamma, gae_lambda, d_adv, d_ret):
+def gae_launch(ctx, d_rewards, d_values, d_dones, d_next_value, d_next_done, T, N, gamma, gae_lambda, d_adv, d_ret, fast=False):
     """Enqueues the scan on device arrays that already live in HBM (no copies, no synchronisation)."""
-    _check(lib().ppo_gae(d_rewards.ptr, d_values.ptr, d_dones.ptr, d_next_value.ptr, d_next_done.ptr, C.c_int64(T), C.c_int64(N), C.c_float(gamma),
+    _check((lib().ppo_gae_fast if fast else lib().ppo_gae)(d_rewards.ptr, d_values.ptr, d_dones.ptr, d_next_value.ptr, d_next_done.ptr, C.c_int64(T), C.c_int64(N), C.c_float(gamma),
                          C.c_float(gae_lambda), d_adv.ptr, d_ret.ptr, C.c_void_p(ctx.stream())), ctx.h)
 
 

@@ -1020,6 +1020,11 @@ extern "C" ppo_status ppo_gae(const float* rewards, const float* values, const f
     if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;
     return launch_gae(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, advantages, returns, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
 }
+extern "C" ppo_status ppo_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value, const int32_t* next_done,
+                                   int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
+    if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;
+    return launch_gae_fast(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, advantages, returns, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+}
 extern "C" ppo_status ppo_nstep_returns(const float* rewards, const float* values, const float* dones, const float* next_value,
                                         const int32_t* next_done, int64_t T, int64_t N, float gamma, float* advantages, float* returns, void* stream) {
     if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;

@@ -6,7 +6,7 @@
 //     A_t     = delta_t + ((gamma*lambda) * nnt_t) * A_{t+1}
 //     R_t     = A_t + v_t
 //
-// EXACT mode (the only one shipped): bit-identical to the reference needs its evaluation order along t and separately
+// EXACT mode (what training uses): bit-identical to the reference needs its evaluation order along t and separately
 // rounded mul/add (the library is built with -ffp-contract=off).  What is parallel without changing a single rounding:
 //   (i)  envs are independent                      -> a workgroup owns a strip of EPB env columns;
 //   (ii) delta_t and c_t = (gamma*lambda)*nnt_t are element-wise -> ALL 256 threads compute them while streaming
@@ -31,6 +31,16 @@
 // the pack is a job for B = T N threads, and inside the scan it has N / 16 workgroups of four waves to run on.  Not shipped.
 // Nor is a walk whose next 16 rows are pulled out of LDS (pinned by sched_barrier) before the current 16-step chain runs: 5.18 against 4.91 us
 // at 4 096 envs, 6.42 / 6.25, 19.06 / 18.6 -- the walk is bound by its 256 dependent mul / add per env, not by the LDS hand-overs.
+//
+// FAST mode (ppo_gae_fast; NOT what training uses -- bit-exactness is the bar): the recurrence as a segmented scan of affine maps.  A_t = delta_t + c_t A_{t+1} is
+// the map f_t(x) = delta_t + c_t x applied to A_{t+1}; maps compose associatively, (c, d) o (c', d') = (c c', d + c d'), and a done flag (c_t = 0) cuts
+// the segment by itself.  Phase B then is: every one of the 256 threads composes the maps of ITS chunk of rows of one env column (256 / EPB chunks per
+// column), the chunk maps meet in LDS, each thread runs the maps of the chunks above its own over the tile's carry (<= 15 steps) and replays its chunk
+// from that value.  The longest dependent chain falls from 2 x 128 operations on EPB lanes to 2 x (8 + 15 + 8) on all 256 -- and the answer is no longer
+// the reference's bit pattern: only the carry into a chunk is associated differently (inside a chunk the replay IS the reference's order), measured
+// <= 6 ULP of the largest |A| the chain has carried, 8 - 40 % of the elements differ at all (tests/test_gpu_parity.py::test_gae_fast_mode_stays_within_ulps,
+// profiles/r03_v4_gae_fast_report.jsonl).  What it buys: nothing at the sizes of BASELINE.json (4.9 / 6.0 / 18.8 us against 4.9 / 6.3 / 18.7 at 4096 / 8192 /
+// 32768 envs x 128 steps) -- the scan is launch + one memory round trip, not its chain; 16 % at T = 2048 x 32 envs, where the chain is long and the grid one workgroup.
 #include <cstdlib>
 
 #include "ppo_internal.hpp"
@@ -52,7 +62,7 @@ __device__ __forceinline__ int strip_of_block(int b, int grid) {
 }
 
 // MODE 0: GAE.  MODE 1: n-step returns (PPO_Discrete.cpp:309-329: ret_t = r_t + (gamma*nnt_t)*ret_{t+1}; adv = ret - v).
-template <int EPB, int MODE, bool VEC>
+template <int EPB, int MODE, bool VEC, bool FAST = false>
 __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
                                                            const float* __restrict__ dones, const float* __restrict__ next_value,
                                                            const int32_t* __restrict__ next_done, int T, int N, float gamma,
@@ -68,6 +78,14 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
     float carry = 0.0f;                                   // A_{t+1} (MODE 0) / ret_{t+1} (MODE 1) entering the tile
     const bool walker = tid < EPB && (n0 + tid) < N;
     if (MODE == 1 && walker) carry = next_value[n0 + tid];  // next_return = next_value at t = T-1 (:318)
+    // FAST: chunk maps [chunk][column] and the tile's carry per column (two copies: the one a tile reads, the one it leaves)
+    constexpr int NCH = GAE_THREADS / EPB, CH = GAE_TC / NCH;
+    __shared__ float sCk[FAST ? NCH * EPB : 1], sDk[FAST ? NCH * EPB : 1], sCarry[FAST ? 2 * EPB : 1];
+    int tile_par = 0;
+    if (FAST) {
+        if (tid < EPB) sCarry[tid] = carry;
+        __syncthreads();
+    }
 
     for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {        // tile covers rows [t_lo, t_hi)
         const int t_lo = t_hi > GAE_TC ? t_hi - GAE_TC : 0;
@@ -145,7 +163,35 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         // ---- phase B: the serial 2-op chain A_t = delta_t + c_t * A_{t+1}, one env per lane of wave 0, top row first.
         //      GAE_WALK rows are pulled into registers at a time so the LDS reads are in flight together and only the
         //      mul/add chain itself is serial. ----
-        if (walker) {
+        if constexpr (FAST) {
+            const int k = tid / EPB, c = tid % EPB;         // chunk k of column c: tile rows [k CH, (k + 1) CH), walked from the top
+            const int r_hi = (k + 1) * CH < rows ? (k + 1) * CH : rows, r_lo = k * CH < rows ? k * CH : rows;
+            float d[CH], cc[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int r = (k + 1) * CH - 1 - i;
+                const bool in = r < rows;
+                d[i] = in ? sA[r * EPB + c] : 0.0f;         // rows past a ragged tile: the identity map
+                cc[i] = in ? sC[r * EPB + c] : 1.0f;
+            }
+            float Ck = 1.0f, Dk = 0.0f;                     // this chunk as ONE map: A(r_lo) = Dk + Ck A(r_hi)
+#pragma unroll
+            for (int i = 0; i < CH; i++) { Dk = d[i] + cc[i] * Dk; Ck = cc[i] * Ck; }
+            sCk[k * EPB + c] = Ck;
+            sDk[k * EPB + c] = Dk;
+            __syncthreads();
+            float x = sCarry[tile_par * EPB + c];
+            for (int j = NCH - 1; j > k; j--) x = sDk[j * EPB + c] + sCk[j * EPB + c] * x;   // the value entering this chunk
+#pragma unroll
+            for (int i = 0; i < CH; i++) {                  // replay: inside the chunk this is the reference's own order
+                x = d[i] + cc[i] * x;
+                const int r = (k + 1) * CH - 1 - i;
+                if (r < rows) sA[r * EPB + c] = x;
+            }
+            if (k == 0) sCarry[(tile_par ^ 1) * EPB + c] = x;   // A of the tile's first row: the carry of the next (earlier) tile
+            tile_par ^= 1;
+            (void)r_hi; (void)r_lo;
+        } else if (walker) {
             float last = carry;
             int r = rows;
             // full chunks: unconditional code (16 + 16 LDS reads in flight, then the 16-step mul/add chain, then 16 writes);
@@ -207,7 +253,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
     }
 }
 
-template <int MODE>
+template <int MODE, bool FAST = false>
 hipError_t launch_scan(const float* rewards, const float* values, const float* dones, const float* next_value,
                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
                        hipStream_t s) {
@@ -224,10 +270,10 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     do {                                                                                                                      \
         const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \
         if (vec_ok && N % EPB == 0)                                                                                           \
-            hipLaunchKernelGGL((gae_kernel<EPB, MODE, true>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
+            hipLaunchKernelGGL((gae_kernel<EPB, MODE, true, FAST>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
                                (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
         else                                                                                                                  \
-            hipLaunchKernelGGL((gae_kernel<EPB, MODE, false>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
+            hipLaunchKernelGGL((gae_kernel<EPB, MODE, false, FAST>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
                                (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
     } while (0)
     if (epb == 64) PPO_GAE_LAUNCH(64);
@@ -243,6 +289,12 @@ hipError_t launch_gae(const float* rewards, const float* values, const float* do
                       const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
                       hipStream_t s) {
     return launch_scan<0>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, s);
+}
+
+hipError_t launch_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value,
+                           const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
+                           hipStream_t s) {
+    return launch_scan<0, true>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, s);
 }
 
 hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,

@@ -541,6 +541,9 @@ hipError_t launch_categorical_sample(const float* probs, int64_t n, int A, int64
 hipError_t launch_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
                       const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
                       hipStream_t s);
+hipError_t launch_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value,
+                           const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
+                           hipStream_t s);
 hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
                         const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s);
 

@@ -127,6 +127,30 @@ def test_gae_kernel_bit_exact_vs_oracle(P, util_ctx, T, N, p_done):
         assert np.array_equal(bits(ret), bits(o_ret)), (T, N, nstep)
 
 
+@pytest.mark.parametrize("T,N,p_done", [(128, 4096, 0.05), (128, 4096, 0.0), (300, 1024, 0.02), (5, 100, 0.3), (1, 4, 0.5), (129, 64, 0.0),
+                                        (2048, 32, 0.01), (128, 32768, 0.05), (7, 1, 0.0), (130, 20, 1.0), (128, 8192, 0.002)])
+def test_gae_fast_mode_stays_within_ulps(P, util_ctx, T, N, p_done):
+    """ppo_gae_fast (the scan of affine maps north_star names) is NOT the reference's bit pattern -- the carry into a chunk of rows is associated
+    differently -- but it stays within a few units in the last place of the quantity the chain carries: |fast - exact| <= 16 ulp(max |A| along the env's
+    segment) (measured: <= 6, tools/gae_fast_report.py).  With every step a terminal one (p_done = 1) no chain is left and the two modes agree bit for bit; so do rows that close
+    a chunk of the fast mode's decomposition right under a done flag."""
+    rng = np.random.default_rng(T * 7919 + N)
+    rewards = np.where(rng.random((T, N)) < 0.05, -1.0, 1.0).astype(np.float32)
+    values = rng.standard_normal((T, N)).astype(np.float32)
+    dones = (rng.random((T, N)) < p_done).astype(np.float32)
+    nv = rng.standard_normal(N).astype(np.float32)
+    nd = (rng.random(N) < p_done).astype(np.int32)
+    adv, ret = P.gae(util_ctx, rewards, values, dones, nv, nd, 0.98, 0.95)
+    f_adv, f_ret = P.gae(util_ctx, rewards, values, dones, nv, nd, 0.98, 0.95, fast=True)
+    scale = np.maximum.accumulate(np.abs(adv[::-1]).astype(np.float64), axis=0)[::-1]     # the largest |A| the chain has carried on its way down to row t (crosses done flags: an upper bound)
+    ulp = np.spacing(np.maximum(scale, 1e-30).astype(np.float32)).astype(np.float64)
+    err = np.abs(f_adv.astype(np.float64) - adv.astype(np.float64))
+    assert np.all(err <= 16 * ulp), (T, N, float((err / ulp).max()))
+    assert np.array_equal(bits(f_ret), bits((f_adv + values).astype(np.float32)))            # R = A + v, one rounding, as in the exact mode
+    if p_done == 1.0:
+        assert np.array_equal(bits(f_adv), bits(adv))
+
+
 def test_gae_segments_are_independent(P, util_ctx):
     """Size-independent property: a done at t+1 cuts the chain, so changing anything above the cut leaves rows <= t unchanged."""
     rng = np.random.default_rng(5)
