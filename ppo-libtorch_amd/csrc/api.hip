@@ -494,6 +494,11 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
     CK(dalloc(c, &c->error_flag, 1));
     c->use_mfma = A <= 4;   // the matrix-core update kernel folds heads of up to 4 logits; wider policies (2 x 64 nets) run the vector kernel
+    {   // diagnostic switch: PPO_UPDATE_KERNEL=valu runs the vector kernel for every shape (A/B; and rehearsals of more than two ranks on ONE GPU, where a
+        // matrix-core workgroup -- a CU's whole register file -- cannot start beside the waiting waves of the other ranks' exchanges: tests/test_gpu_exchange.py)
+        const char* k = getenv("PPO_UPDATE_KERNEL");
+        if (k && std::strcmp(k, "valu") == 0) c->use_mfma = false;
+    }
     c->max_blocks_per_net = 512;
     const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
     CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));

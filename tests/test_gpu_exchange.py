@@ -69,6 +69,12 @@ def test_exchange_ranks_equal_single_context(tmp_path, world):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world > 2:
+            # More than two ranks on ONE GPU can deadlock for a reason no deployment has (one rank per GPU): the ranks that reach the exchange first
+            # spin in 145 workgroups each, 3 x 145 > 256 CUs puts a waiting wave on every CU, and the matrix-core update kernel of the rank they are
+            # waiting for needs a CU's WHOLE register file per workgroup -- it can never start, and the waits run out (seen: 30 s, PPO_ERR_COMM).
+            # The vector update kernel shares a CU with the waiting waves; the two-rank case keeps the matrix-core kernel under the exchange.
+            env["PPO_UPDATE_KERNEL"] = "valu"
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
