@@ -544,6 +544,7 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
     // the action (cartpole_next_pose), so while step t is in flight the trigonometry wave already forms sin / cos of theta(t + 1), keeping its own copies of
     // the episode length and the reset count; nobody waits for it any more, and the env wave runs the candidate transitions beside the policy's layer 1.
     constexpr bool AHEAD = ENV == PPO_ENV_CARTPOLE;
+    constexpr bool PAIRED = AHEAD && EXACTA == 2 && OBS == 4;   // lane groups (0, 1) and (2, 3) of an env hold the candidates of actions (0, 1)
     if (AHEAD && trigw) {
         float tr[2];
         env_step_pre<ENV>(st, tr);
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
         const int par = t & 1;
         float cst[1][OBS], crew[1];
         int cterm[1];
+        float oth_xd = 0.0f, oth_td = 0.0f;   // env wave, PAIRED: the other action's x_dot, theta_dot
         float theta_ahead = 0.0f;   // trigonometry wave, AHEAD
         float4 row_ahead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         int term_ahead = 0;
@@ -625,7 +627,11 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
                 float tr[2] = { s_tr[par][0][e], s_tr[par][1][e] };
 #pragma unroll
                 for (int k = 0; k < OBS; k++) cst[0][k] = st[k];
-                crew[0] = env_step_tail<ENV>(cst[0], kg < A ? kg : A - 1, tr, cterm[0]);
+                crew[0] = env_step_tail<ENV>(cst[0], PAIRED ? (kg & 1) : (kg < A ? kg : A - 1), tr, cterm[0]);
+                if constexpr (PAIRED) {   // two actions: every lane fetches the OTHER action's velocities now, so that the choice later is a select, not a shuffle
+                    oth_xd = __shfl_xor(cst[0][1], 16, 64);
+                    oth_td = __shfl_xor(cst[0][3], 16, 64);
+                }
             }
             if constexpr (!AHEAD) {
                 // m_obs[step] = next_obs (PPO_Discrete.cpp:529): lane kg stores component kg
@@ -719,7 +725,15 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
             // env step (the candidate of the action taken: it sits in lane kg = action of this env) + truncation + auto-reset (PPO_Discrete.cpp:440-458)
             int term;
             float reward;
-            if (act[0] >= 0 && act[0] < A) {
+            if (PAIRED && act[0] >= 0 && act[0] < A) {
+                // position, angle, termination and reward are the same for both actions (cartpole_next_pose); the velocities are this lane's or its partner's
+                const bool mine = act[0] == (kg & 1);
+                term = cterm[0];
+                reward = crew[0];
+                st[0] = cst[0][0]; st[2] = cst[0][2];
+                st[1] = mine ? cst[0][1] : oth_xd;
+                st[3] = mine ? cst[0][3] : oth_td;
+            } else if (act[0] >= 0 && act[0] < A) {
                 const int src = e + 16 * act[0];
                 term = __shfl(cterm[0], src, 64);
                 reward = __shfl(crew[0], src, 64);
