@@ -435,23 +435,28 @@ __device__ __forceinline__ r16_f32x4 r16_mfma(const r16_u32x4 a, const r16_u32x4
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(r16_f16x8, a), __builtin_bit_cast(r16_f16x8, b), acc, 0, 0, 0);
 }
 
-// FIVE waves per 16-env tile.  One wave doing all 64 units measured 191 us per 128-step rollout (rollout2_kernel: 210), four waves sharing the
+// SIX waves per 16-env tile.  One wave doing all 64 units measured 191 us per 128-step rollout (rollout2_kernel: 210), four waves sharing the
 // layers 181: a lone wave issues a dependent instruction every ~7 - 9 cycles and a step is ONE dependent chain -- layer 1, tanh, layer 2, tanh,
 // logits, softmax, sample, physics (binary64 sin / cos, three IEEE divisions), bookkeeping -- of which the policy is less than half.  So the chain is
 // cut where it can be:
-//   waves 0 - 3 (the policy): wave w owns units 16 w .. 16 w + 15 of both layers -- ONE 16 x 16 block per layer: 4 tanh, one split pair.  The layers'
-//       results cross waves through LDS in exactly the form the next product wants them (lane-aligned: lane (e, kg) of every wave needs what lane
-//       (e, kg) of waves 2c and 2c + 1 hold).
-//   wave 5 (trigonometry): the transition's cos / sin of the state (glibc's binary64 polynomials, ~40 % of a transition) depend on the state
-//       only: formed while layer 1 runs.  Wave 3 also draws the step's random words (they depend on (seed, env, step)).
-//   wave 4 (the envs): the rest of a transition depends on the state and on WHICH action is taken, not on the policy's output, so while layer 2
-//       runs it forms the transition of EVERY possible action, lane kg of an env taking action kg (same function, same inputs: the same bits as
-//       stepping after the fact); when the logits arrive it samples, SELECTS one (a lane shuffle), does the bookkeeping, publishes the next
-//       observation, and stores behind the barrier.  The reset row an env would restart from is requested every step, so an episode's end
-//       never waits for memory.
-// Three barriers per step (hidden layer + trigonometry, logits' partial sums, next observation); buffers alternate by step parity.
-// Measured per 128-step rollout at 4096 envs (A/B in one call, rollout + critic batch): rollout2_kernel 234 us; one wave per tile 216; four policy
-// waves that also step the envs 207; + env wave 196; + trigonometry off the env wave and reset prefetch 171 (cos and sin on two waves: 176).
+//   waves 0 - 3 (the policy): wave w owns units 16 w .. 16 w + 15 of both layers -- ONE 16 x 16 block per layer: 4 tanh, one split pair -- and its
+//       16-unit share of every logit as one more product (16x16x16).  The layers' results cross waves through LDS in exactly the form the next
+//       product wants them (lane-aligned: lane (e, kg) of every wave needs what lane (e, kg) of waves 2c and 2c + 1 hold).  Wave 3 also draws the
+//       step's random words (they depend on (seed, env, step) only).
+//   wave 5 (trigonometry): the transition's cos / sin (glibc's binary64 polynomials, ~40 % of a transition) depend on the state only.  CartPole
+//       (AHEAD): the NEXT state's position and angle -- hence termination, truncation, reset -- do not depend on the action (cartpole_next_pose), so
+//       this wave works a whole step ahead, one piece per phase (angle + the reset row's load / cosine / sine), keeps its own episode length and
+//       reset count, and hands the reset row to the env wave through LDS.  MountainCar: cos(3 p) of the current state, while layer 1 runs.
+//   wave 4 (the envs): the rest of a transition depends on the state and on WHICH action is taken, not on the policy's output, so it forms the
+//       transition of EVERY possible action before the policy has spoken (AHEAD: beside layer 1; otherwise beside layer 2), one candidate per
+//       lane group (same function, same inputs: the same bits as stepping after the fact); when the logits arrive it samples, takes the
+//       candidate of the action drawn (two actions: a select between its own and its partner's velocities, fetched beforehand; otherwise a lane
+//       shuffle), does the bookkeeping and publishes the next observation.  Its global stores sit where it would otherwise idle (AHEAD: in the
+//       next step's layer-2 phase) and it has no global load in the loop: a load would make it wait for its own stores' acknowledgements.
+// Three LDS-only barriers per step (hidden layer [+ trigonometry], the logits' shares, next observation); buffers alternate by step parity.
+// Measured per 128-step rollout at 4096 envs (A/B in one call each, rollout + critic batch): rollout2_kernel 234 us; one wave per tile 216; four
+// policy waves that also step the envs 207; + env wave 196; + trigonometry off the env wave 171 (cos and sin on two waves: 176); logits as a
+// 16x16x16 product 167; trigonometry a step ahead, stores in the idle phase 161; select instead of shuffles 153 (profiles/NOTES.md).
 // Workgroup barrier for data handed over through LDS ONLY.  __syncthreads() is a release / acquire fence over every address space: hipcc puts
 // s_waitcnt vmcnt(0) in front of the s_barrier, and a wave that has just issued global stores then stands at the barrier until the memory side has
 // acknowledged them (~1 k cycles) -- with every other wave of the workgroup waiting for it.  The waves of the rollout exchange nothing through global
