@@ -682,6 +682,38 @@ def test_fused_rollout_equals_stepwise_api(P, N):
     b.close()
 
 
+@pytest.mark.parametrize("T,limit", [(1, 500), (2, 1), (5, 1), (7, 2), (64, 3), (33, 500)])
+def test_fused_rollout_at_constant_resets_and_short_horizons(P, T, limit):
+    """The fused rollout forms the NEXT step's sin / cos a step ahead of the action (CartPole's next pose does not depend on it) with its own copy of
+    the episode length and the reset count, hands reset rows over through LDS and defers a step's stores into the next step: drive exactly those
+    corners -- every step (or every second / third) ends an episode by truncation, one- and two-step rollouts, two rollouts back to back (the
+    counters persist) -- and compare the env side bit for bit with the stand-alone step kernel driven by the rollout's own actions."""
+    N = 40
+    cfg = dict(num_envs=N, num_steps=T, num_minibatches=1, update_epochs=1, seed=9, max_episode_steps=limit)
+    a, b = P.Context(P.make_config(**cfg)), P.Context(P.make_config(**cfg))
+    a.init_orthogonal(3)
+    b.set_params(a.get_params())
+    a.env_reset()
+    obs = b.env_reset()
+    done = np.zeros(N, np.float32)
+    for rollout in range(2):
+        a.rollout()
+        r_obs, r_act, r_rew, r_done = a.read("OBS", (T, N, 4)), a.read("ACTIONS", (T, N)), a.read("REWARDS", (T, N)), a.read("DONES", (T, N))
+        fin_len = a.read("FIN_LEN", (T, N))
+        for t in range(T):
+            assert np.array_equal(bits(obs), bits(r_obs[t])) and np.array_equal(done, r_done[t]), (rollout, t)
+            obs, rew, d = b.env_step(r_act[t].reshape(N, 1).astype(np.int64))
+            assert np.array_equal(rew, r_rew[t])
+            done = d.astype(np.float32)
+            if limit <= 3:
+                assert np.all(fin_len[t][d != 0] <= limit) and np.all(fin_len[t][d == 0] == 0)
+        assert np.array_equal(bits(obs), bits(a.read("NEXT_OBS", (N, 4)))) and np.array_equal(done, a.read("NEXT_DONE").astype(np.float32))
+    if limit == 1:
+        assert r_done[1:].min() == 1.0 if T > 1 else True     # every step ends an episode
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("kind", ["cartpole", "mountaincar", "nstep", "odd_envs"])
 def test_train_iteration_equals_rollout_scan_update(P, kind):
     """ppo_train_iteration against its three parts called one after the other (rollout, calc_advantage, update): same seeds, same arithmetic --
