@@ -241,6 +241,20 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     float* sDo = wbase + m.s_do;
     const float* __restrict__ P = a.params;
 
+    // ---- the first tile's batch rows: requested before anything else (see the gather pipeline below) ----
+    const int n_tiles = (a.M + MT - 1) / MT;
+    const int tile_step = nblk * MF_WAVES;
+    int tile = blk * MF_WAVES + wave;
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(NET == 0 ? a.rec_critic : a.rec_actor);
+    auto fetch_row = [&](int tl) -> int {
+        const int j = tl * MT + s;
+        const bool ok = tl < n_tiles && j < a.M;
+        const int v = a.idx[ok ? j : 0];
+        return ok ? v : -1;
+    };
+    int row_n = fetch_row(tile);
+    int row_nn = fetch_row(tile + tile_step);
+
     // ---- weights of this net -> LDS (once per launch) ----
     // Every element this thread brings in is a slot: 4096 / threads of W2, then its share of W1, W3, b1, b2, b3.  ALL loads are issued
     // before anything is used: one memory round trip for the prologue.  W1, b1, W2, b2 are stored multiplied by c (tanh_scaled).
@@ -260,6 +274,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     float wv[NS_];
 #pragma unroll
     for (int i = 0; i < NS_; i++) wv[i] = P[se[i] < 0 ? 0 : se[i]];
+    float4 x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];   // behind the weight loads: its wait for the index overlaps theirs.  Row 0 stands in for a missing row; zeroed at the point of use
     {
         // 4096 weights, 8 per thread: each is scaled, cut into its two fp16 terms once per launch and stored at its natural [n][k] place
         uint16_t* wn = reinterpret_cast<uint16_t*>(smem + m.w2);
@@ -333,25 +348,14 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
 
     MF_STAMP(0);   // prologue: weights -> LDS
 
-    const int n_tiles = (a.M + MT - 1) / MT;
-    const int tile_step = nblk * MF_WAVES;
-    int tile = blk * MF_WAVES + wave;
     // Gather (K5) from the packed sample records (pack_records_kernel): ONE 32-byte record per sample and net, so a permuted row
     // costs one memory line instead of one per field.  Software pipeline: batch-row indices are fetched TWO tiles ahead and the
     // record's first half (the observation) ONE tile ahead, so neither of the two dependent round trips is ever waited for inside a tile;
     // the second half (loss scalars) is requested at the top of its own tile and first used after layer 2.
     // Every load of the pipeline is UNCONDITIONAL (clamped address, value selected afterwards): a load inside a branch makes the
     // compiler's wait-count bookkeeping give up at the join and emit s_waitcnt vmcnt(0) at the next use of ANY loaded value.
-    const float4* __restrict__ rec = reinterpret_cast<const float4*>(NET == 0 ? a.rec_critic : a.rec_actor);
-    auto fetch_row = [&](int tl) -> int {
-        const int j = tl * MT + s;
-        const bool ok = tl < n_tiles && j < a.M;
-        const int v = a.idx[ok ? j : 0];
-        return ok ? v : -1;
-    };
-    int row_n = fetch_row(tile);
-    int row_nn = fetch_row(tile + tile_step);
-    float4 x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];   // row 0 stands in for a missing row; zeroed at the point of use
+    // (The first two index fetches and the first record fetch are issued at the very TOP of the kernel, in front of the weight staging: the two dependent
+    // round trips of the first tile then run under the prologue instead of in front of the first tile -- 42.5 -> 41.9 us per launch, A/B in one call.)
     const int wave_half = __builtin_amdgcn_readfirstlane(wave >> 2) & 1;   // SIMD partners are waves w and w + 4
     for (int it = 0; tile < n_tiles; tile += tile_step, it++) {
         // issue priority alternates between the two waves of a SIMD tile by tile: with equal priorities the older wave wins every
