@@ -522,19 +522,27 @@ void goldMultiHeadAgent(const std::string& outPath) {
     g.save(outPath);
 }
 
-int benchReference(int64_t numEnvs, int64_t numSteps, int64_t updates) {
+int benchReference(int64_t numEnvs, int64_t numSteps, int64_t updates, int64_t threads) {
     RunCfg c;
     c.num_envs = numEnvs; c.num_steps = numSteps; c.updates = updates;
     enterScratchWithConfig(c, "bench");
     PPO_Discrete algo;
+    unsigned poolThreads = std::thread::hardware_concurrency();
+    if (threads > 0) {
+        // the pool is a public member built in the constructor with hardware_concurrency() threads (PPO_Discrete.cpp:40) and started by
+        // train() (:488): a narrower pool of the reference's own class, and LibTorch's intra-op threads capped to match
+        algo.m_threadPool = std::make_shared<ThreadPool>(threads);
+        at::set_num_threads(static_cast<int>(threads));
+        poolThreads = static_cast<unsigned>(threads);
+    }
     auto t0 = std::chrono::steady_clock::now();
     algo.train();
     auto t1 = std::chrono::steady_clock::now();
     double sec = std::chrono::duration<double>(t1 - t0).count();
     double steps = static_cast<double>(updates) * numEnvs * numSteps;
     std::printf("REF_BENCH {\"num_envs\": %ld, \"num_steps\": %ld, \"updates\": %ld, \"seconds\": %.6f, "
-                "\"env_steps_per_sec\": %.3f, \"threads\": %u}\n",
-                (long)numEnvs, (long)numSteps, (long)updates, sec, steps / sec, std::thread::hardware_concurrency());
+                "\"env_steps_per_sec\": %.3f, \"threads\": %u, \"hardware_concurrency\": %u, \"torch_threads\": %d}\n",
+                (long)numEnvs, (long)numSteps, (long)updates, sec, steps / sec, poolThreads, std::thread::hardware_concurrency(), at::get_num_threads());
     return 0;
 }
 
@@ -765,6 +773,51 @@ void loadCheckpointFiles(const std::string& agentFile, const std::string& optimi
     g.save(outFile);
 }
 
+// (10) Learning curves: the reference's own acceptance test is "run ./PPO and watch ep_len_mean" (README.md:169-178).  The UNMODIFIED train()
+// (PPO_Discrete.cpp:485-690) runs to total_timesteps with the recommended hyper-parameters; the table it prints per update
+// (printPPOResults, :700-774) is captured and parsed into one JSON object per seed: exactly the numbers a user of the reference sees
+// (ep_len_mean with the table's 2 decimals).  tests/golden/curves_*.json = these objects for several seeds (oracle/make_curves.py).
+template <class Algo>
+int curvesReference(const RunCfg& c, const std::string& outFile) {
+    enterScratchWithConfig(c, "curves");
+    std::stringstream ss;
+    std::cout.copyfmt(std::ios(nullptr));
+    std::streambuf* old = std::cout.rdbuf(ss.rdbuf());
+    try { Algo algo; algo.train(); } catch (...) { std::cout.rdbuf(old); throw; }
+    std::cout.rdbuf(old);
+    const char* keys[] = { "ep_len_mean", "ep_rew_mean", "total_timesteps", "approx_kl", "clip_fraction", "explained_variance", "learning_rate",
+                           "loss", "policy_gradient_loss", "value_loss", "entropy_loss" };
+    constexpr int NK = sizeof keys / sizeof keys[0];
+    std::vector<std::array<std::string, NK>> rows;   // one per printed table; "null" where the table has no such row (first update, no finished episode)
+    std::array<std::string, NK> cur; cur.fill("null");
+    bool open = false;
+    std::istringstream is(ss.str());
+    std::string l;
+    while (std::getline(is, l)) {
+        if (!l.empty() && l[0] == '-') {   // a rule line opens or closes a table
+            if (open) { rows.push_back(cur); cur.fill("null"); }
+            open = !open;
+            continue;
+        }
+        if (!open || l.size() < 6 || l[0] != '|') continue;
+        const size_t bar = l.find('|', 1);
+        if (bar == std::string::npos) continue;
+        std::string k = l.substr(1, bar - 1), v = l.substr(bar + 1);
+        auto trim = [](std::string s) { size_t a = s.find_first_not_of(" |"), b = s.find_last_not_of(" |"); return a == std::string::npos ? std::string() : s.substr(a, b - a + 1); };
+        k = trim(k); v = trim(v);
+        for (int i = 0; i < NK; i++) if (k == keys[i] && !v.empty()) cur[i] = (v == "nan" || v == "-nan" || v == "inf") ? "null" : v;
+    }
+    std::ofstream f(outFile, std::ios::binary);
+    f << "{\"seed\": " << c.seed << ", \"updates\": " << rows.size();
+    for (int i = 0; i < NK; i++) {
+        f << ", \"" << keys[i] << "\": [";
+        for (size_t r = 0; r < rows.size(); r++) f << (r ? ", " : "") << rows[r][i];
+        f << "]";
+    }
+    f << "}\n";
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -854,8 +907,18 @@ int main(int argc, char** argv) {
             loadCheckpointFiles(argv[2], argv[3], std::atol(argv[4]), std::atol(argv[5]), argv[6]);
             return 0;
         }
-        if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]));
-        std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | ptgold <outdir> | ptload <agent.pt> <optimizer.pt> <obs> <act> <out.pgld> | bench <num_envs> <num_steps> <updates>\n";
+        if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]), argc > 5 ? std::atol(argv[5]) : 0);
+        if (mode == "curves" && argc > 6) {
+            // CartPoleRecommendedSettings.toml's hyper-parameters (RunCfg's defaults) with action_size = 2, as BASELINE.json configs[0] runs them
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            RunCfg c;
+            c.num_envs = std::atol(argv[3]); c.num_steps = std::atol(argv[4]); c.total_timesteps = std::atol(argv[5]); c.seed = std::atol(argv[6]);
+            return curvesReference<PPO_Discrete>(c, out);
+        }
+        std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | ptgold <outdir> | ptload <agent.pt> <optimizer.pt> <obs> <act> <out.pgld> | "
+                     "bench <num_envs> <num_steps> <updates> [threads] | curves <out.json> <num_envs> <num_steps> <total_timesteps> <seed>\n";
         return 2;
     } catch (const std::exception& ex) {
         std::cerr << "[ref_harness] error: " << ex.what() << std::endl;

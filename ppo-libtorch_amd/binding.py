@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppo_hip.so")
+# PPO_HIP_LIBRARY: another build of the SAME C-ABI (tools/ab.sh times variant builds side by side without copying over the shipped file);
+# it must export every symbol of include/ppo_hip.h like the shipped library or lib() raises
+LIB_PATH = os.environ.get("PPO_HIP_LIBRARY") or os.path.join(_HERE, "libppo_hip.so")
 
 MAX_HEADS = 8
 ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_SYNTHETIC = 0, 1, 2

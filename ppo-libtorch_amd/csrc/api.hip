@@ -167,6 +167,7 @@ struct ppo_ctx {
     float* scratch_obs = nullptr;       // [N,O] staging for AoS<->SoA conversions
     int max_blocks_per_net = 0;
     bool use_mfma = true;
+    bool update_single_wave = false;   // the one-wave-per-tile matrix-core update kernel instead of the wave-specialised one (A/B)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
     GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
     uint8_t* cur_mask = nullptr;     // generic path: action mask of the observation in NEXT_OBS, [N, A]
@@ -498,6 +499,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         // matrix-core workgroup -- a CU's whole register file -- cannot start beside the waiting waves of the other ranks' exchanges: tests/test_gpu_exchange.py)
         const char* k = getenv("PPO_UPDATE_KERNEL");
         if (k && std::strcmp(k, "valu") == 0) c->use_mfma = false;
+        if (k && std::strcmp(k, "mfma1") == 0) c->update_single_wave = true;
     }
     c->max_blocks_per_net = 512;
     const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
@@ -1272,6 +1274,8 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     a.slab = c->slab;
     a.stat_slab = c->stat_slab;
     a.stamps = c->stamping ? c->stamps : nullptr;
+    a.error_flag = c->error_flag;
+    a.single_wave = c->update_single_wave ? 1 : 0;
     if (c->use_mfma) update_blocks_mfma((int)M, a.n_blocks);
     else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
@@ -1525,6 +1529,7 @@ extern "C" ppo_status ppo_stats_snapshot_read(ppo_ctx* c, ppo_stats* out) {
     c->snap_count -= 1;
     const StatsSnap& h = c->snap[slot];
     if (h.error_flag & 1) return fail(c, PPO_ERR_STATE, "CartPole reset-stream table exhausted (capacity %d resets per env)", c->reset_cap);
+    if (h.error_flag & PPO_ERRFLAG_UPDATE_PROTOCOL) return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out (gradients of that step are incomplete)");
     if (h.xchg_flag != 0)
         return fail(c, PPO_ERR_COMM, "direct exchange: an all-reduce gave up waiting for a peer after %.1f s; its sums were incomplete, the replicas have "
                                      "diverged and the communicator is dead (every later all-reduce returns at once)", c->xchg ? c->xchg->wait_seconds : 0.0);

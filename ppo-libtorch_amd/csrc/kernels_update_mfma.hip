@@ -964,6 +964,794 @@ __global__ __launch_bounds__(MF_THREADS, 1) void fwd_bwd_mfma_kernel(UpdateArgs 
     else mf_body<1, DIST, OBS, AMAX, EXACT, STAMP, DW1M>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
 
+
+// =========================================================================================================
+// Wave-specialised form of the same step for the reference's two shapes (CartPole 4 -> 2, MountainCar 2 -> 3 masked).
+//
+// mf_body above gives one wave everything from gather to weight gradient; its 80 gradient accumulators pin it at 234 - 250 registers (two
+// waves per SIMD, nothing to spare), and every product that contracts over SAMPLES (dW3, dW2, dW1, the biases) makes the wave wait on its own
+// LDS round trips.  Here a workgroup is TWELVE waves with two jobs (round 3 did the same to the rollout):
+//   * waves 0-7  ("F": forward, loss, d(activation)): everything whose natural layout is lane = sample -- gather, layer 1, layer 2, head, PPO
+//     loss, dz2, d(hidden 1), dz1.  They only WRITE the sample-major images: h1 (fp16 terms, formed for layer 2 anyway -- no third split), h2
+//     (fp32), dz2 and dz1 (fp16 terms), the observation's terms, dOut.  ~130 registers, no gradient accumulator.
+//   * waves 8-11 ("G": gradients): everything that contracts over samples, i.e. needs lane = unit -- dW3 / db3 on the vector ALU from the h2
+//     image, dW2 / db2 and dW1 / db1 on the matrix cores from transposing reads of the term images.  Wave 8 + g serves F waves g and g + 4
+//     (its own SIMD's), holds the 80 accumulators for both, and is otherwise asleep.
+// Hand-over is through two LDS regions per F wave and two counters per F wave (events produced / consumed), polled with s_sleep: no barrier
+// inside the tile loop, so no wave waits for a slower one.  Per tile an F wave produces three events
+//   E0: RB = h2 image, sDo = dOut            -> G: dW3, db3
+//   E1: RA = h1 terms + x terms, RB = dz2 terms, SEV = the tile's power-of-two scale S  -> G: dW2, db2
+//   E2: RB = dz1 terms                        -> G: dW1, db1 (x terms from RA)
+// and before it overwrites a region it waits for the count of consumed events that frees it (RA: everything of the previous tile; RB: the
+// previous event).  G acknowledges an event as soon as its LDS reads have returned, before it issues the MFMAs.  Every wait is bounded: a
+// protocol error raises the context's error flag instead of hanging the GPU.
+// The scale S (see "Arithmetic" at the top) is each F wave's own -- a function of its own tiles only, quantised to multiples of four so that the two
+// F waves of a G wave mostly agree; an event carries it, and G moves the accumulators it adds to by the power of two between their scale and the
+// event's (exact).  With the fixed service order (a, b, a, b ...) the result does not depend on timing: same inputs, same bits.
+// =========================================================================================================
+constexpr int MG_FW = 8, MG_GW = 4, MG_WAVES = MG_FW + MG_GW, MG_THREADS = 64 * MG_WAVES;
+enum { MG_PROD = 0, MG_CONS = 8, MG_SEV = 16, MG_ONE = 32, MG_ZERO = 34, MG_FLAG_WORDS = 64 };
+
+struct MgSmem {
+    int w2, w1, b1, b2, w3, b3, flags, wave0, wave_stride, ra, rb, s_do, dred, total;  // offsets in floats
+};
+__host__ __device__ inline MgSmem mg_smem(int obs, int aout) {
+    MgSmem m;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.w2 = take(2 * 64 * NS / 2);
+    m.w1 = take(64 * obs);
+    m.b1 = take(64);
+    m.b2 = take(64);
+    m.w3 = take(aout * 64);
+    m.b3 = take(aout);
+    m.flags = take(MG_FLAG_WORDS);
+    m.wave0 = o;
+    int w = 0;
+    auto takew = [&](int n) { int r = w; w += (n + 3) & ~3; return r; };
+    m.ra = takew(MT * NS);       // two fp16 term images [term][sample][NS]; columns 64 .. 67 of a row carry the sample's observation terms
+    m.rb = takew(MF_REGION);     // h2 as fp32 [sample][LS], then dz2 terms, then dz1 terms
+    m.s_do = takew(aout * MT);   // [a][sample]
+    m.wave_stride = w;
+    o += MG_FW * w;
+    m.dred = take(4 * 2 * MG_FW);  // loss sums of the F waves (doubles), beyond everything the epilogue reuses
+    m.total = o;
+    return m;
+}
+
+// wave-uniform wait for a workgroup-shared LDS counter to reach `want`; false when the bound runs out (protocol error)
+typedef __attribute__((address_space(3))) volatile uint32_t lds_flag_t;
+__device__ __forceinline__ bool mg_wait_ge(const lds_flag_t* flag, uint32_t want) {
+#ifdef MG_DIAG_NOWAIT
+    return true;
+#endif
+    for (int spin = 0; spin < (1 << 21); spin++) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)*flag);
+        if (v >= want) { asm volatile("" ::: "memory"); return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+// The counter moves BEHIND this wave's LDS accesses so far.  No s_waitcnt: a wave's LDS instructions are executed by the LDS unit in the order they
+// were issued (that is what makes lgkmcnt a counter), so whoever reads the new count afterwards finds the data written / the region already read.
+// The asm is the compiler-side fence.  (-DMG_POST_WAIT restores the explicit wait for an A/B.)
+__device__ __forceinline__ void mg_post(lds_flag_t* flag, uint32_t v, int lane) {
+#ifdef MG_POST_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+    if (lane == 0) *flag = v;
+    asm volatile("" ::: "memory");
+}
+
+template <int NET, int DIST, int OBS, int AMAX>
+__device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
+    const NetLayout& L = a.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 31, hi = lane >> 5;
+    constexpr int AOUT = NET == 0 ? 1 : AMAX;
+    const MgSmem m = mg_smem(OBS, AOUT);
+    const uint16_t* sW2p = reinterpret_cast<const uint16_t*>(smem + m.w2);
+    float* sW1 = smem + m.w1;
+    float* sB1 = smem + m.b1;
+    float* sB2 = smem + m.b2;
+    float* sW3 = smem + m.w3;
+    float* sB3 = smem + m.b3;
+    lds_flag_t* flags = (lds_flag_t*)(smem + m.flags);   // explicit LDS address space: a generic volatile access is a FLAT instruction and waits for vmcnt too
+    const float* __restrict__ P = a.params;
+    const int n_tiles = (a.M + MT - 1) / MT;
+    const int tile_step = nblk * MG_FW;
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(NET == 0 ? a.rec_critic : a.rec_actor);
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tb = (lane >> 4) & 1;
+    bool proto_ok = true;
+
+    // ---- an F wave requests its first tile's batch rows before anything else (see mf_body) ----
+    int tile = blk * MG_FW + (wave < MG_FW ? wave : 0);
+    auto fetch_row = [&](int tl) -> int {
+        const int j = tl * MT + s;
+        const bool ok = tl < n_tiles && j < a.M;
+        const int v = a.idx[ok ? j : 0];
+        return ok ? v : -1;
+    };
+    int row_n = -1, row_nn = -1;
+    if (wave < MG_FW) { row_n = fetch_row(tile); row_nn = fetch_row(tile + tile_step); }
+
+    // ---- weights of this net -> LDS (once per launch, all twelve waves; W1, b1, W2, b2 multiplied by c = 2 log2(e), W2 cut into its fp16 terms) ----
+    constexpr int NW2 = (4096 + MG_THREADS - 1) / MG_THREADS;
+    {
+        float wv[NW2 + 5];
+#pragma unroll
+        for (int i = 0; i < NW2; i++) { const int e = tid + i * MG_THREADS; wv[i] = P[L.w2[NET] + (e < 4096 ? e : 0)]; }
+        wv[NW2] = P[L.w1[NET] + (tid < 64 * OBS ? tid : 0)];
+        wv[NW2 + 1] = P[L.w3[NET] + (tid < AOUT * 64 ? tid : 0)];
+        wv[NW2 + 2] = P[L.b1[NET] + (tid & 63)];
+        wv[NW2 + 3] = P[L.b2[NET] + (tid & 63)];
+        wv[NW2 + 4] = P[L.b3[NET] + (tid < AOUT ? tid : 0)];
+        uint16_t* wn = reinterpret_cast<uint16_t*>(smem + m.w2);
+#pragma unroll
+        for (int i = 0; i < NW2; i++) {
+            const int e = tid + i * MG_THREADS;
+            const int n = e >> 6, k = e & 63;
+            uint32_t p1, p2;
+            split2(wv[i] * TANH_C, 0.0f, p1, p2);
+            if (e < 4096) { wn[n * NS + k] = (uint16_t)p1; wn[64 * NS + n * NS + k] = (uint16_t)p2; }
+        }
+        static_assert(64 * OBS <= MG_THREADS && AMAX * 64 <= MG_THREADS, "one staging slot per thread");
+        if (tid < 64 * OBS) sW1[tid] = wv[NW2] * TANH_C;
+        if (tid < AOUT * 64) sW3[tid] = wv[NW2 + 1];
+        if (tid < 64) { sB1[tid] = wv[NW2 + 2] * TANH_C; sB2[tid] = wv[NW2 + 3] * TANH_C; }
+        if (tid < AOUT) sB3[tid] = wv[NW2 + 4];
+        if (tid < MG_FLAG_WORDS) flags[tid] = tid == MG_ONE ? 0x3c00u : 0u;   // MG_ONE: the fp16 cell {1, 0, 0, 0}
+    }
+    float4 x_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (wave < MG_FW) x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];
+    __syncthreads();
+
+    const int base = L.net_off[NET];
+    const int nsz = L.net_size[NET];
+    const int rstride = (nsz + 3) & ~3;
+    double* dred = reinterpret_cast<double*>(smem + m.dred);
+
+#ifdef MG_DIAG_NO_F
+    if (false) {
+#else
+    if (wave < MG_FW) {
+#endif
+        // =================================================== F: forward, loss, d(activation) ===================================================
+        float* wbase = smem + m.wave0 + wave * m.wave_stride;
+        uint16_t* ra16 = reinterpret_cast<uint16_t*>(wbase + m.ra);
+        float* img = wbase + m.rb;
+        uint16_t* zimg = reinterpret_cast<uint16_t*>(img);
+        float* sDo = wbase + m.s_do;
+        lds_flag_t* prod = flags + MG_PROD + wave;
+        const lds_flag_t* cons = flags + MG_CONS + wave;
+        float st0 = 0.0f, st1 = 0.0f, st2 = 0.0f, st3 = 0.0f;
+        const float clip = a.hp.clip_coef;
+        const float lo = uniform_f(1 - clip), hi_c = uniform_f(1 + clip);
+        const float invM = uniform_f((float)a.inv_global_M);
+        float mean_f = 0.0f, inv_std = 0.0f;
+        if (NET == 1 && a.hp.norm_adv) {
+            const float4 an = *a.adv_norm;
+            mean_f = uniform_f(an.x);
+            inv_std = uniform_f(an.y);
+        }
+        float w3max;
+        {
+            uint32_t mb = 0u;
+#pragma unroll
+            for (int k = 0; k < AOUT; k++) mb = max(mb, f2u(fabsf(sW3[k * 64 + lane])));
+            w3max = u2f(wave_max_u(mb));
+        }
+        int S_w = 100;
+        // Operands that stay in registers for the whole launch (an F wave has ~45 registers to spare; LDS is the busy pipe).  Each is a complete MFMA
+        // operand (four dwords, zeros included): assembling one from single dwords costs three moves per use.  Lanes hi = 1 (k = 8 .. 15) hold zeros in
+        // every A operand below, so whatever the B operand carries there drops out.
+        //   * layer 1 on the f16 matrix cores like the rest, K = 16 with the bias as one more input: row u = s + 32 t of [c W1 | c b1] as fp16 terms at
+        //     k = 0 .. OBS (B: the observation's terms and the constant 1).  Replaces 8 x 16-byte bias reads + 4 weight reads per tile, and the fp32
+        //     MFMAs that exclude every other vector instruction of the SIMD while they run;
+        //   * c b2: ONE product in front of layer 2's twelve, both terms side by side at k = 0, 1 against the constants 1, 1: 8 x 16-byte reads less;
+        //   * W3 transposed for dz2 = W3^T dOut on the matrix cores (K = the logits).  Up to two logits the three term products sit side by side in ONE
+        //     instruction: A = [w1 w1 w2] at k = 0 .. 5, B = [d1 d2 d1]; otherwise three instructions.
+        // The scale 2^S bounds dz2 = W3^T dOut, not dOut: with a small W3 (the actor's head starts at gain 0.01) dOut 2^S alone overruns fp16.  W3 enters
+        // its operand divided by P3 = the power of two just above max|W3| (|W3 / P3| <= 1) and dOut multiplied by 2^S P3 (<= 2^15): exact, the product is the same.
+        const int e3 = w3max > 0.0f ? (int)((f2u(w3max) >> 23) & 0xffu) - 126 : 0;   // max|W3| < 2^e3
+        const float w3norm = pow2i(e3 < -100 ? 100 : (e3 > 100 ? -100 : -e3));
+        const float p3 = pow2i(e3 < -100 ? -100 : (e3 > 100 ? 100 : e3));
+        constexpr int WR = AOUT <= 2 ? 1 : 2;  // dwords of one term of a lane's W3^T / dOut operand
+        u32x4 w1a[2][2];                       // [t][term]
+        u32x4 b2a[2];                          // [t]
+        u32x4 w3a[2][WR == 1 ? 1 : 2];         // [t][term] (one combined operand up to two logits)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int u = s + 32 * t;
+            float wrow[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int o = 0; o < OBS; o++) wrow[o] = sW1[u * OBS + o];
+            uint32_t p1[3], p2[3];
+            if constexpr (OBS == 4) { split2(wrow[0], wrow[1], p1[0], p2[0]); split2(wrow[2], wrow[3], p1[1], p2[1]); split2(sB1[u], 0.0f, p1[2], p2[2]); }
+            else { split2(wrow[0], wrow[1], p1[0], p2[0]); split2(sB1[u], 0.0f, p1[1], p2[1]); p1[2] = 0u; p2[2] = 0u; }
+            w1a[t][0] = u32x4{ hi ? 0u : p1[0], hi ? 0u : p1[1], hi ? 0u : p1[2], 0u };
+            w1a[t][1] = u32x4{ hi ? 0u : p2[0], hi ? 0u : p2[1], hi ? 0u : p2[2], 0u };
+            uint32_t q1, q2;
+            split2(sB2[u], 0.0f, q1, q2);   // low halves: the two terms
+            b2a[t] = u32x4{ hi ? 0u : ((q1 & 0xffffu) | (q2 << 16)), 0u, 0u, 0u };
+            float w3c[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int k = 0; k < AOUT; k++) w3c[k] = sW3[k * 64 + u] * w3norm;
+            uint32_t r1[2], r2[2];
+            split2(w3c[0], w3c[1], r1[0], r2[0]);
+            split2(w3c[2], w3c[3], r1[1], r2[1]);
+            if constexpr (WR == 1) w3a[t][0] = u32x4{ hi ? 0u : r1[0], hi ? 0u : r1[0], hi ? 0u : r2[0], 0u };
+            else { w3a[t][0] = u32x4{ hi ? 0u : r1[0], hi ? 0u : r1[1], 0u, 0u }; w3a[t][WR == 1 ? 0 : 1] = u32x4{ hi ? 0u : r2[0], hi ? 0u : r2[1], 0u, 0u }; }
+        }
+        const u32x4 ones2 = { 0x3c003c00u, 0u, 0u, 0u };   // B operand of the bias product: the constant 1 at k = 0 and k = 1
+        const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        const int wave_half = (wave >> 2) & 1;
+        uint32_t ev = 0;   // events produced so far (3 per tile)
+        for (int it = 0; tile < n_tiles; tile += tile_step, it++) {
+            if ((it ^ wave_half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            // ---------------- gather (K5) ----------------
+            const bool valid = row_n >= 0;
+            const int row = valid ? row_n : 0;
+            // four scalars, not an array: a select between array elements by `hi` (layer 1's B operand) sends an array to scratch memory
+            const float x0 = valid ? x_n.x : 0.0f, x1 = valid ? x_n.y : 0.0f, x2 = valid ? x_n.z : 0.0f, x3 = valid ? x_n.w : 0.0f;
+            const float4 sc = rec[2 * (size_t)row + 1];
+            float s_f0 = sc.x, s_f1 = sc.y;
+            uint32_t s_actbits = f2u(sc.z), s_maskbits = f2u(sc.w);
+            {
+                row_n = row_nn;
+                x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];
+                row_nn = fetch_row(tile + 2 * tile_step);
+            }
+            // ---------------- layer 1 (f16 MFMA on terms, K = 16: observation + the constant 1 that carries the bias) ----------------
+            // observation terms: also what G gets for dW1 (columns 64 .. 67 of the sample's row in each h1 term image; column OBS is the constant 1 of db1
+            // when it fits the 4-column cell)
+            uint32_t xq[2][2];
+            if constexpr (OBS == 4) { split2(x0, x1, xq[0][0], xq[1][0]); split2(x2, x3, xq[0][1], xq[1][1]); }
+            else { split2(x0, x1, xq[0][0], xq[1][0]); split2(1.0f, 0.0f, xq[0][1], xq[1][1]); }
+            float h1[32];
+            {
+                // k = 0 .. OBS: the observation's terms and the constant 1 (first term only); what lanes hi = 1 carry meets zeros in A
+                u32x4 xb1, xb2;
+                if constexpr (OBS == 4) { xb1 = u32x4{ xq[0][0], xq[0][1], 0x00003c00u, 0u }; xb2 = u32x4{ xq[1][0], xq[1][1], 0u, 0u }; }
+                else { xb1 = u32x4{ xq[0][0], xq[0][1], 0u, 0u }; xb2 = u32x4{ xq[1][0], xq[1][1], 0u, 0u }; }
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const f32x16 acc = mfma_x2(w1a[t][0], w1a[t][1], xb1, xb2, zero16);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) h1[16 * t + r] = tanh_scaled(acc[r]);
+                }
+            }
+            // ---------------- layer 2 forward; h1's terms (and the observation's) leave for G on the way ----------------
+            float h2[32];
+            {
+                uint32_t hp[2][16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) split2(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j]);
+                if (it > 0) proto_ok &= mg_wait_ge(cons, ev);   // G has read everything of the previous tile: RA is free
+#pragma unroll
+                for (int term = 0; term < 2; term++) {
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            *reinterpret_cast<uint2*>(ra16 + term * MT * NS + s * NS + 8 * q + 4 * hi + 32 * t) = make_uint2(hp[term][8 * t + 2 * q], hp[term][8 * t + 2 * q + 1]);
+                    if (hi == 0) *reinterpret_cast<uint2*>(ra16 + term * MT * NS + s * NS + 64) = make_uint2(xq[term][0], xq[term][1]);
+                }
+                auto afrag = [&](int g, int term) -> u32x4 {
+                    const uint16_t* q = sW2p + term * 64 * NS + (s + 32 * (g >> 2)) * NS + (g & 3) * 16 + hi * 4;
+                    const uint2 lo2 = *reinterpret_cast<const uint2*>(q), hi2 = *reinterpret_cast<const uint2*>(q + 8);
+                    const u32x4 r = { lo2.x, lo2.y, hi2.x, hi2.y };
+                    return r;
+                };
+                f32x16 acc;
+                u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1);
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const int t = g >> 2, c = g & 3;
+                    if (c == 0) {   // c b2 enters as a product: row n of A carries the bias's two terms at k = 0, 1, every column of B the constant 1 there
+                        acc = mfma_f16(b2a[t], ones2, zero16);
+                    }
+                    const u32x4 a1 = an1, a2 = an2;
+                    if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); }
+                    MF_PIN();
+                    const u32x4 b1 = { hp[0][4 * c], hp[0][4 * c + 1], hp[0][4 * c + 2], hp[0][4 * c + 3] };
+                    const u32x4 b2 = { hp[1][4 * c], hp[1][4 * c + 1], hp[1][4 * c + 2], hp[1][4 * c + 3] };
+                    acc = mfma_x2(a1, a2, b1, b2, acc);
+                    if (c == 3) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) h2[16 * t + r] = tanh_scaled(acc[r]);
+                    }
+                }
+            }
+            asm volatile("" : "+v"(s_f0), "+v"(s_f1), "+v"(s_actbits), "+v"(s_maskbits));
+            // ---------------- head + loss (K6, K7): as mf_body ----------------
+            float dOut[AMAX];
+#pragma unroll
+            for (int k = 0; k < AMAX; k++) dOut[k] = 0.0f;
+            if (NET == 0) {
+                float part = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const float4 w = ld4(&sW3[8 * (g & 3) + 4 * hi + 32 * (g >> 2)]);
+                    part = __builtin_fmaf(h2[4 * g], w.x, part); part = __builtin_fmaf(h2[4 * g + 1], w.y, part);
+                    part = __builtin_fmaf(h2[4 * g + 2], w.z, part); part = __builtin_fmaf(h2[4 * g + 3], w.w, part);
+                }
+                const float other = __shfl_xor(part, 32, 64);
+                const float v = ((hi == 0 ? part : other) + (hi == 0 ? other : part)) + sB3[0];
+                const float R = s_f0, vold = s_f1;
+                const float un = (v - R) * (v - R);
+                float g_v, lossv;
+                if (a.hp.clip_vloss) {   // PPO_Discrete.cpp:603-620
+                    const float dv = v - vold;
+                    const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+                    const float vc = vold + dvc;
+                    const float cl = (vc - R) * (vc - R);
+                    lossv = un > cl ? un : cl;
+                    const bool vin = (dv >= -clip && dv <= clip);
+                    const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+                    const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);
+                    g_v = a.hp.vf_coef * 0.5f * invM * d;
+                } else {                 // :622-625
+                    lossv = un;
+                    g_v = a.hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+                }
+                if (valid && hi == 0) st0 += lossv;
+                dOut[0] = valid ? g_v : 0.0f;
+            } else {
+                const float s_oldlp = s_f0, s_adv = s_f1;
+                float z[AMAX], pr[AMAX];
+                bool ok[AMAX];
+#pragma unroll
+                for (int k = 0; k < AMAX; k++) {
+                    float part = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        const float4 w = ld4(&sW3[k * 64 + 8 * (g & 3) + 4 * hi + 32 * (g >> 2)]);
+                        part = __builtin_fmaf(h2[4 * g], w.x, part); part = __builtin_fmaf(h2[4 * g + 1], w.y, part);
+                        part = __builtin_fmaf(h2[4 * g + 2], w.z, part); part = __builtin_fmaf(h2[4 * g + 3], w.w, part);
+                    }
+                    const float other = __shfl_xor(part, 32, 64);
+                    z[k] = ((hi == 0 ? part : other) + (hi == 0 ? other : part)) + sB3[k];
+                    ok[k] = true;
+                    if (DIST == PPO_DIST_MASKED) ok[k] = ((s_maskbits >> k) & 1u) != 0u;
+                    if (DIST == PPO_DIST_MASKED && !ok[k]) z[k] = -1e8f;
+                }
+                const int act_h = (int)(s_actbits & 0xffu);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < AMAX; k++) mx = z[k] > mx ? z[k] : mx;
+                float se = 0.0f;
+#pragma unroll
+                for (int k = 0; k < AMAX; k++) { pr[k] = fast_exp(z[k] - mx); se += pr[k]; }
+                const float lse = fast_log(se) + mx;
+                const float rse = __builtin_amdgcn_rcpf(se);
+                float e1 = 0.0f, nlp = 0.0f;
+#pragma unroll
+                for (int k = 0; k < AMAX; k++) {
+                    z[k] = z[k] - lse;
+                    pr[k] = pr[k] * rse;
+                    if (DIST == PPO_DIST_CATEGORICAL) {
+                        const float l = z[k] > 1.17549435e-38f ? z[k] : 1.17549435e-38f;   // the reference's clamp (Categorical.cpp:112-119)
+                        e1 += l * pr[k];
+                    } else {
+                        e1 += ok[k] ? z[k] * pr[k] : 0.0f;
+                    }
+                    if (k == act_h) nlp = z[k];
+                }
+                const float ent = -e1;
+                const float logratio = nlp - s_oldlp;           // :585
+                const float ratio = fast_exp(logratio);         // :586
+                float adv = s_adv;
+                if (a.hp.norm_adv) adv = (adv - mean_f) * inv_std;           // :593
+                const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
+                const float l1 = -adv * ratio, l2 = -adv * rc;  // :597-598
+                const bool inside = (ratio >= lo && ratio <= hi_c);
+                float d_ratio;
+                if (l1 > l2) d_ratio = -adv;
+                else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+                else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half/half
+                const float g_nlp = invM * d_ratio * ratio;
+                const float g_ent = -a.hp.ent_coef * invM;
+                if (valid && hi == 0) {
+                    st0 += l1 > l2 ? l1 : l2;
+                    st1 += ent;
+                    st2 += (ratio - 1.0f) - logratio;
+                    st3 += (fabsf(ratio - 1.0f) > clip) ? 1.0f : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < AMAX; k++) {
+                    float d = g_nlp * ((k == act_h ? 1.0f : 0.0f) - pr[k]);
+                    if (DIST == PPO_DIST_MASKED) d += g_ent * (-pr[k] * (z[k] + ent));
+                    dOut[k] = (valid && ok[k]) ? d : 0.0f;
+                }
+            }
+            // ---------------- E0: h2 image + dOut -> G (dW3, db3).  RB is free: everything of the previous tile was consumed (waited for above) ----------------
+            store_dlayout(img, h2, s, hi);
+            if (hi == 0) {
+#pragma unroll
+                for (int k = 0; k < AOUT; k++) sDo[k * MT + s] = dOut[k];
+            }
+            mg_post(prod, ++ev, lane);
+            // ---------------- the tile's power-of-two scale S: this wave's own (a function of ITS tiles only: results do not depend on timing), moved
+            //                  down when a tile's bound (sum_a |dOut[a]|) max|W3| 2^S would pass 2^13, and then to a multiple of 4 with the bound at
+            //                  2^8 .. 2^11, so that the two F waves of a G wave mostly agree and G seldom has to move its accumulators ----------------
+            {
+                float dsum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < AOUT; k++) dsum += fabsf(dOut[k]);
+                const float tmax = u2f(wave_max_u(f2u(dsum))) * w3max;
+                const int e = (int)((f2u(tmax) >> 23) & 0xffu) - 127;
+                if (e + S_w > 13) {
+                    int S_new = (11 - e) & ~3;
+                    S_w = S_new < -100 ? -100 : S_new;
+                }
+            }
+            const float scaleS = pow2i(S_w);
+            // ---------------- dz2 = (sum_a dOut[a] W3[a][u]) (1 - h2^2) 2^S, D layout ----------------
+            float dz2[32];
+            {
+                // B operand: dOut[s][.] 2^S as terms at the k slots of A's W3 terms
+                uint32_t d1[2], d2[2];
+                const float sc3 = scaleS * p3;
+                split2(dOut[0] * sc3, (AOUT > 1 ? dOut[AOUT > 1 ? 1 : 0] : 0.0f) * sc3, d1[0], d2[0]);
+                if constexpr (WR == 2) split2(dOut[AOUT > 2 ? 2 : 0] * sc3, (AOUT > 3 ? dOut[AOUT > 3 ? 3 : 0] : 0.0f) * sc3, d1[1], d2[1]);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    f32x16 acc;
+                    if constexpr (WR == 1) acc = mfma_f16(w3a[t][0], u32x4{ d1[0], d2[0], d1[0], 0u }, zero16);   // [w1 w1 w2] . [d1 d2 d1]
+                    else acc = mfma_x2(w3a[t][0], w3a[t][WR == 1 ? 0 : 1], u32x4{ d1[0], d1[1], 0u, 0u }, u32x4{ d2[0], d2[1], 0u, 0u }, zero16);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) dz2[16 * t + r] = acc[r] * __builtin_fmaf(-h2[16 * t + r], h2[16 * t + r], 1.0f);
+                }
+            }
+            uint32_t zp[2][16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) split2(dz2[2 * j], dz2[2 * j + 1], zp[0][j], zp[1][j]);
+            // ---------------- E1: dz2 terms -> RB once G has read the h2 image ----------------
+            if (lane == 0) flags[MG_SEV + wave] = (uint32_t)S_w;
+            proto_ok &= mg_wait_ge(cons, ev);
+#pragma unroll
+            for (int term = 0; term < 2; term++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        *reinterpret_cast<uint2*>(zimg + term * MT * NS + s * NS + 8 * q + 4 * hi + 32 * t) = make_uint2(zp[term][8 * t + 2 * q], zp[term][8 * t + 2 * q + 1]);
+            mg_post(prod, ++ev, lane);
+            // ---------------- c dh1^T[k][s] = sum_n c W2[n][k] dz2[s][n];  c 2^-7 dz1 = c dh1 (1 - h1^2) 2^-7, h1 rebuilt from its own terms in RA ----------------
+            float dz1[32];
+            {
+                auto afrag = [&](int g, int term) -> u32x4 {
+                    const uint16_t* q = sW2p + term * 64 * NS + (16 * (g & 3) + 4 * hi + tq) * NS + 32 * (g >> 2) + 16 * tb + 4 * tp;
+                    const uint2 lo2 = lds_read_tr16(q), hi2 = lds_read_tr16(q + 8 * NS);
+                    const u32x4 r = { lo2.x, lo2.y, hi2.x, hi2.y };
+                    return r;
+                };
+                f32x16 acc;
+                u32x4 an1 = afrag(0, 0), an2 = afrag(0, 1);
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const int t = g >> 2, c = g & 3;
+                    if (c == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+                    }
+                    const u32x4 a1 = an1, a2 = an2;
+                    if (g + 1 < 8) { an1 = afrag(g + 1, 0); an2 = afrag(g + 1, 1); }
+                    MF_PIN();
+                    const u32x4 b1 = { zp[0][4 * c], zp[0][4 * c + 1], zp[0][4 * c + 2], zp[0][4 * c + 3] };
+                    const u32x4 b2 = { zp[1][4 * c], zp[1][4 * c + 1], zp[1][4 * c + 2], zp[1][4 * c + 3] };
+                    acc = mfma_x2(a1, a2, b1, b2, acc);
+                    if (c == 3) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            // h1 = t1 + t2 (one v_fma_mix_f32 per value: exact, the terms were cut from h1)
+                            const uint2 u1 = *reinterpret_cast<const uint2*>(ra16 + s * NS + 8 * qq + 4 * hi + 32 * t);
+                            const uint2 u2 = *reinterpret_cast<const uint2*>(ra16 + MT * NS + s * NS + 8 * qq + 4 * hi + 32 * t);
+                            float hb[4];
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(hb[0]) : "v"(u1.x), "v"(u2.x));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hb[1]) : "v"(u1.x), "v"(u2.x));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(hb[2]) : "v"(u1.y), "v"(u2.y));
+                            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hb[3]) : "v"(u1.y), "v"(u2.y));
+#pragma unroll
+                            for (int j = 0; j < 4; j++) dz1[16 * t + 4 * qq + j] = acc[4 * qq + j] * __builtin_fmaf(hb[j] * -0x1p-7f, hb[j], 0x1p-7f);
+                        }
+                    }
+                }
+            }
+            // ---------------- E2: dz1 terms -> RB once G has read the dz2 terms ----------------
+            {
+                uint32_t zq[2][16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) split2(dz1[2 * j], dz1[2 * j + 1], zq[0][j], zq[1][j]);
+                proto_ok &= mg_wait_ge(cons, ev);
+#pragma unroll
+                for (int term = 0; term < 2; term++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            *reinterpret_cast<uint2*>(zimg + term * MT * NS + s * NS + 8 * q + 4 * hi + 32 * t) = make_uint2(zq[term][8 * t + 2 * q], zq[term][8 * t + 2 * q + 1]);
+                mg_post(prod, ++ev, lane);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // loss sums: a lane added a handful of samples in fp32; lanes, waves and workgroups are added in binary64
+        const double sd0 = wave_sum_d_dpp((double)st0), sd1 = wave_sum_d_dpp((double)st1), sd2 = wave_sum_d_dpp((double)st2), sd3 = wave_sum_d_dpp((double)st3);
+        if (lane == 0) { dred[wave * 4 + 0] = sd0; dred[wave * 4 + 1] = sd1; dred[wave * 4 + 2] = sd2; dred[wave * 4 + 3] = sd3; }
+        if (!proto_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
+        __syncthreads();   // tile loops done everywhere: LDS is reused by the gradient images
+        __syncthreads();   // gradient images parked
+#ifdef MG_DIAG_NO_G
+    } else if (false) {
+#else
+    } else {
+#endif
+        // =================================================== G: the products that contract over samples ===================================================
+        const int g = wave - MG_FW;
+        f32x16 gW2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) gW2[i][j][r] = 0.0f;
+        f32x4 gW1m[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) gW1m[b][r] = 0.0f;
+        float gW3[AMAX], gb3[AMAX], gb2[2] = { 0.0f, 0.0f };
+#pragma unroll
+        for (int k = 0; k < AMAX; k++) { gW3[k] = 0.0f; gb3[k] = 0.0f; }
+        int S_g2 = 100, S_g1 = 100;   // scale of (dW2, db2) / of (dW1, db1)
+        const int j16 = lane & 15, kg = lane >> 4;
+        // The two F waves are served in a FIXED cyclic order, the second a good event behind the first:
+        //     E0(a, i)  E0(b, i)  E1(a, i)  E1(b, i)  E2(a, i)  E2(b, i)
+        // (straight-line code per round: with a data-dependent order, or with conditions inside the round, the register allocator duplicates the 80
+        // accumulators across the branches and spills; the SIMD partners a = g, b = g + 4 advance at the same pace anyway).
+        auto tiles_of = [&](int fw) -> int {
+            const int t0 = blk * MG_FW + fw;
+            return t0 < n_tiles ? (n_tiles - 1 - t0) / tile_step + 1 : 0;
+        };
+        // the two F waves of a G wave sit on DIFFERENT SIMDs (waves w and w + 4 share one): the fixed order keeps a G wave's pair in step, and SIMD
+        // partners in step would want the same pipe at the same time
+        const int fw_b = MG_GW + ((g + 1) & (MG_GW - 1));
+        const int nt_a = tiles_of(g), nt_b = tiles_of(fw_b);
+        bool g_ok = true;
+#define MG_REGION_PTRS(fw)                                                                         \
+        float* wbase = smem + m.wave0 + (fw) * m.wave_stride;                                      \
+        const uint16_t* ra16 = reinterpret_cast<const uint16_t*>(wbase + m.ra);                    \
+        const float* img = wbase + m.rb;                                                           \
+        const uint16_t* zimg = reinterpret_cast<const uint16_t*>(img);                             \
+        const float* sDo = wbase + m.s_do;                                                         \
+        lds_flag_t* cons = flags + MG_CONS + (fw);                                                 \
+        (void)ra16; (void)zimg; (void)sDo; (void)img
+        // E1 / E2 carry the tile's scale S: the accumulators the event adds to move to it first (powers of two: exact, whichever way)
+        auto factor_to = [&](const int S_ev, int& S_acc) __attribute__((always_inline)) -> float {
+            int d = S_ev - S_acc;
+            d = d < -126 ? -126 : (d > 126 ? 126 : d);
+            S_acc = S_ev;
+            return pow2i(d);
+        };
+        // ---- E0: dW3[a][u = lane] += sum_s dOut[s][a] h2[s][u]; db3[a] += sum_s dOut[s][a] (every lane forms the same sum) ----
+        auto serve_e0 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
+            MG_REGION_PTRS(fw);
+            g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno);
+            // the image's 32 rows into registers, then the acknowledgement (RB is what the F wave is waiting for; dOut is not rewritten before the
+            // next tile's E0, which comes behind everything of this tile), then the products
+            float hv[MT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) hv[i] = img[i * LS + lane];
+            mg_post(cons, evno, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < AOUT; k++) {
+                float accw3 = 0.0f, accb3 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MT; i += 4) {
+                    const float4 d = ld4(&sDo[k * MT + i]);
+                    accw3 = __builtin_fmaf(d.x, hv[i], accw3); accw3 = __builtin_fmaf(d.y, hv[i + 1], accw3);
+                    accw3 = __builtin_fmaf(d.z, hv[i + 2], accw3); accw3 = __builtin_fmaf(d.w, hv[i + 3], accw3);
+                    accb3 += (d.x + d.y) + (d.z + d.w);
+                }
+                gW3[k] += accw3; gb3[k] += accb3;
+            }
+        };
+        // ---- E1: dW2[n][k] += sum_s dz2[s][n] h1[s][k], db2[n] += sum_s dz2[s][n]: both operands by transposing reads of the term images.
+        //      Lane (n | k = lane & 31, hi) holds the terms of samples 16 c + 8 hi + 0..7 of unit (lane & 31) + 32 t ----
+        auto serve_e1 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
+            MG_REGION_PTRS(fw);
+            g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno);
+            {
+                const int S_ev = __builtin_amdgcn_readfirstlane((int)flags[MG_SEV + fw]);
+                if (S_ev != S_g2) {
+                    const float f = factor_to(S_ev, S_g2);
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                            for (int r = 0; r < 16; r++) gW2[i][jj][r] *= f;
+                    gb2[0] *= f; gb2[1] *= f;
+                }
+            }
+            auto trf = [&](const uint16_t* im, int c, int t, int term) __attribute__((always_inline)) -> u32x4 {
+                const int off = term * MT * NS + (16 * c + 8 * hi + tq) * NS + 32 * t + 16 * tb + 4 * tp;
+                const uint2 l2 = lds_read_tr16(im + off), h2_ = lds_read_tr16(im + off + 4 * NS);
+                return u32x4{ l2.x, l2.y, h2_.x, h2_.y };
+            };
+            u32x4 A[2][2][2];   // [chunk][tn][term]: dz2, from RB -- the region the F wave wants back: read whole, acknowledged, and only then h1
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int term = 0; term < 2; term++) A[c][t][term] = trf(zimg, c, t, term);
+            mg_post(cons, evno, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                u32x4 B[2][2];   // [tk][term]: h1, from RA (held until E2 anyway)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int term = 0; term < 2; term++) B[t][term] = trf(ra16, c, t, term);
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++) {
+                    float cacc = 0.0f;
+#pragma unroll
+                    for (int term = 1; term >= 0; term--)
+#pragma unroll
+                        for (int d = 0; d < 4; d++) cacc = add_pair(A[c][tn][term][d], cacc);
+                    gb2[tn] += cacc;
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+                    for (int tk = 0; tk < 2; tk++)
+                        gW2[tn][tk] = mfma_x2(A[c][tn][0], A[c][tn][1], B[tk][0], B[tk][1], gW2[tn][tk]);
+                __builtin_amdgcn_sched_barrier(0);   // the second chunk's h1 reads are issued behind the first chunk's MFMAs, not hoisted above them (16 more registers)
+            }
+        };
+        // ---- E2: c 2^-7 dW1[u][o] += sum_s dz1[s][u] x[s][o], db1 as the column of the constant 1: 12 MFMAs of 16 x 16 x 32.
+        //      B operand: lane (j = lane & 15, kg) holds the x terms of samples 8 kg + 0..7, column j.  The 16-lane group reads a 4-sample x 16-column
+        //      block: the lanes of column cell 0 point at the row's observation cell (columns 64 .. 67 of the h1 term image), cell 1 at the constant
+        //      {1, 0, 0, 0} (first term, OBS == 4 only: with OBS == 2 the 1 sits in the observation cell), the others at zeros ----
+        auto serve_e2 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
+            MG_REGION_PTRS(fw);
+            g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno);
+            {
+                const int S_ev = __builtin_amdgcn_readfirstlane((int)flags[MG_SEV + fw]);
+                if (S_ev != S_g1) {
+                    const float f = factor_to(S_ev, S_g1);
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) gW1m[b][r] *= f;
+                }
+            }
+            u32x4 xb[2];
+#pragma unroll
+            for (int term = 0; term < 2; term++) {
+                const uint16_t* cell = reinterpret_cast<const uint16_t*>(smem + m.flags) + 2 * ((OBS == 4 && tp == 1 && term == 0) ? MG_ONE : MG_ZERO);
+                const uint16_t* q0 = tp == 0 ? ra16 + term * MT * NS + (8 * kg + tq) * NS + 64 : cell;
+                const uint16_t* q1 = tp == 0 ? ra16 + term * MT * NS + (8 * kg + tq + 4) * NS + 64 : cell;
+                const uint2 lo2 = lds_read_tr16(q0), hi2 = lds_read_tr16(q1);
+                xb[term] = u32x4{ lo2.x, lo2.y, hi2.x, hi2.y };
+            }
+            u32x4 A1[4], A2[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint16_t* q = zimg + (8 * kg + tq) * NS + 16 * b + 4 * tp;
+                const uint2 lo2 = lds_read_tr16(q), hi2 = lds_read_tr16(q + 4 * NS);
+                const uint2 lo3 = lds_read_tr16(q + MT * NS), hi3 = lds_read_tr16(q + MT * NS + 4 * NS);
+                A1[b] = u32x4{ lo2.x, lo2.y, hi2.x, hi2.y };
+                A2[b] = u32x4{ lo3.x, lo3.y, hi3.x, hi3.y };
+            }
+            mg_post(cons, evno, lane);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                f32x4 acc4 = gW1m[b];
+                acc4 = mfma16_f16(A2[b], xb[0], acc4);
+                acc4 = mfma16_f16(A1[b], xb[1], acc4);
+                acc4 = mfma16_f16(A1[b], xb[0], acc4);
+                gW1m[b] = acc4;
+            }
+        };
+        __builtin_amdgcn_s_setprio(2);
+#ifdef MG_DIAG_G_IDLE
+        for (int i = 0; i < 0; i++) {
+#else
+        for (int i = 0; i < nt_a; i++) {   // nt_a >= nt_b (wave a's first tile comes first); nt_a - nt_b is 0 or 1
+#endif
+            const int nj = i < nt_b ? 2 : 1;
+#ifndef MG_DIAG_NO_E0
+#pragma nounroll
+            for (int j = 0; j < nj; j++) serve_e0(j ? fw_b : g, 3u * i + 1u);
+#endif
+#ifndef MG_DIAG_NO_E1
+#pragma nounroll
+            for (int j = 0; j < nj; j++) serve_e1(j ? fw_b : g, 3u * i + 2u);
+#endif
+#ifndef MG_DIAG_NO_E2
+#pragma nounroll
+            for (int j = 0; j < nj; j++) serve_e2(j ? fw_b : g, 3u * i + 3u);
+#endif
+        }
+#undef MG_REGION_PTRS
+        __builtin_amdgcn_s_setprio(0);
+        if (!g_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
+        // ---- the factors leave: 2^S (dW2, db2, dW1, db1), the fixed 2^-7 of the dz1 terms and the c of the scaled W2 (dW1, db1) ----
+        gb2[0] += __shfl_xor(gb2[0], 32, 64); gb2[1] += __shfl_xor(gb2[1], 32, 64);
+        {
+            const float invS = pow2i(-S_g2);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) gW2[i][j][r] *= invS;
+            gb2[0] *= invS; gb2[1] *= invS;
+            const float f = pow2i(-S_g1) * 0x1p7f;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) gW1m[b][r] = (gW1m[b][r] * f) * TANH_C_INV;
+        }
+        __syncthreads();   // tile loops done everywhere: weights and images are dead
+        float* red = smem + g * rstride;
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int tk = 0; tk < 2; tk++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[L.w2[NET] - base + umap(r, hi, tn) * 64 + s + 32 * tk] = gW2[tn][tk][r];
+#pragma unroll
+        for (int k = 0; k < AOUT; k++) red[L.w3[NET] - base + k * 64 + lane] = gW3[k];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int u = 16 * b + 4 * kg + r;
+                if (j16 < OBS) red[L.w1[NET] - base + u * OBS + j16] = gW1m[b][r];
+                else if (j16 == OBS) red[L.b1[NET] - base + u] = gW1m[b][r];
+            }
+        if (hi == 0) { red[L.b2[NET] - base + s] = gb2[0]; red[L.b2[NET] - base + s + 32] = gb2[1]; }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < AOUT; k++) red[L.b3[NET] - base + k] = gb3[k];
+        }
+        __syncthreads();
+    }
+    // ---- every thread adds the four gradient images in a fixed order into the workgroup's slab ----
+    const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
+    float* slab = a.slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * Pmax;
+    for (int e = tid; e < nsz; e += MG_THREADS) {
+        float t = smem[e];
+#pragma unroll
+        for (int w = 1; w < MG_GW; w++) t += smem[w * rstride + e];
+        slab[e] = t;
+    }
+    if (tid < 4) {
+        double* o = a.stat_slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * 8;
+        double t = dred[tid];
+#pragma unroll
+        for (int w = 1; w < MG_FW; w++) t += dred[4 * w + tid];
+        o[tid] = t;
+    }
+}
+
+template <int DIST, int OBS, int AMAX>
+__global__ __launch_bounds__(MG_THREADS, 1) void fwd_bwd_mfma_ws_kernel(UpdateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;   // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor
+    if (b < a.n_blocks[0]) mg_body<0, DIST, OBS, 1>(a, smem, b, a.n_blocks[0]);
+    else mg_body<1, DIST, OBS, AMAX>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
+}
+
 // One 32-byte record per sample and net for the update kernel's gather (K5): critic {obs[0..3], return, old value, 0, 0}, actor
 // {obs[0..3], old log-prob, advantage, actions (8 bits per head), mask bits} (obs zero-padded to 4).  The flattened rollout buffers
 // stay what the C-ABI exposes (PPO_Discrete.cpp:557-562); this is the layout the 40 permuted passes of an update read.  The kernel
@@ -1153,6 +1941,27 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
     // the reference's two shapes get fully folded head code: CartPole (obs 4, one head of 2) and MountainCar (obs 2, one masked
     // head of 3); anything else with <= 4 logits runs the generic variant
     const bool one = a.L.n_heads == 1;
+    // the reference's two shapes: the wave-specialised kernel (twelve waves, 160 KB of LDS)
+    if (!a.single_wave && !a.stamps && one) {
+        const bool cart = a.L.obs == 4 && a.L.act == 2 && a.hp.dist_kind == PPO_DIST_CATEGORICAL;
+        const bool mcar = a.L.obs == 2 && a.L.act == 3 && a.hp.dist_kind == PPO_DIST_MASKED;
+        if (cart || mcar) {
+            const size_t ws_shmem = (size_t)mg_smem(a.L.obs, a.L.act).total * sizeof(float);
+            if (ws_shmem > 160 * 1024) return hipErrorNotSupported;
+            const dim3 ws_block(MG_THREADS);
+            static std::atomic<unsigned long long> ws_ok_c{0}, ws_ok_m{0};
+            if (cart) {
+                hipError_t e = allow_dynamic_lds(ws_ok_c, reinterpret_cast<const void*>(&fwd_bwd_mfma_ws_kernel<PPO_DIST_CATEGORICAL, 4, 2>));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((fwd_bwd_mfma_ws_kernel<PPO_DIST_CATEGORICAL, 4, 2>), grid, ws_block, ws_shmem, s, a);
+            } else {
+                hipError_t e = allow_dynamic_lds(ws_ok_m, reinterpret_cast<const void*>(&fwd_bwd_mfma_ws_kernel<PPO_DIST_MASKED, 2, 3>));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((fwd_bwd_mfma_ws_kernel<PPO_DIST_MASKED, 2, 3>), grid, ws_block, ws_shmem, s, a);
+            }
+            return hipGetLastError();
+        }
+    }
     if (a.L.obs == 4) {
         if (a.hp.dist_kind == PPO_DIST_CATEGORICAL) {
             if (one && a.L.act == 2) PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 4, 2, true); else PPO_LAUNCH_MF(PPO_DIST_CATEGORICAL, 4, 4, false);

@@ -571,7 +571,10 @@ struct UpdateArgs {
     double* stat_slab;       // [n_blocks, 8] partial loss sums
     int n_blocks[2];         // workgroups of the critic / of the actor; slab row = (net ? n_blocks[0] : 0) + workgroup
     unsigned long long* stamps;  // diagnostic build only: [2 nets][12 phases] cycle sums of wave 0 / workgroup 0
+    int32_t* error_flag;     // the context's device error word (bit 0: reset table exhausted; PPO_ERRFLAG_UPDATE_PROTOCOL: a bounded wait of the wave-specialised update kernel ran out)
+    int single_wave;         // 1: the one-wave-per-tile matrix-core kernel even for the reference's two shapes (A/B; ppo_config.kernel_flags)
 };
+constexpr int32_t PPO_ERRFLAG_UPDATE_PROTOCOL = 2;
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
 // matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}: fp32 carried as two fp16 terms, three

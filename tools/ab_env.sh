@@ -1,0 +1,15 @@
+#!/bin/bash
+# A/B of two settings of an environment variable on the SAME library inside one gpurun call:  tools/ab_env.sh ROUNDS VAR valueA valueB ...
+# ("-" = unset).  Prints what tools/ab.sh prints.
+set -e
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+R=$1; VAR=$2; shift 2
+for i in $(seq 1 $R); do
+    for val in "$@"; do
+        if [ "$val" == "-" ]; then unset $VAR; else export $VAR="$val"; fi
+        python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile 1 2>/dev/null | tail -n 1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('%-24s' % '$VAR=$val', round(d['value']/1e6,2), 'M env-steps/s', round(d['ms_per_step'],3), 'ms', round(1e3*d['roofline']['avg_launch_ms'],2), 'us/update launch', round(1e3*d['phase_ms_per_step']['rollout'],1), 'us rollout+values', round(25*((d['phase_ms_per_step']['clip_adamw'] or 0)+(d['phase_ms_per_step']['grad_reduce'] or 0)),2), 'us/optimizer step')"
+    done
+done
