@@ -1045,6 +1045,12 @@ __device__ __forceinline__ void mg_post(lds_flag_t* flag, uint32_t v, int lane) 
     asm volatile("" ::: "memory");
 }
 
+// -DMG_STAMP (diagnostic build, tools/ws_stamps.py): cycles F wave 0 / G wave 8 of workgroup 0 spend inside their waits and services
+#ifdef MG_STAMP
+#define MG_TIMED(slot, expr) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); expr; tstamp[slot] += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define MG_TIMED(slot, expr) do { expr; } while (0)
+#endif
 template <int NET, int DIST, int OBS, int AMAX>
 __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
     const NetLayout& L = a.L;
@@ -1065,6 +1071,10 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(NET == 0 ? a.rec_critic : a.rec_actor);
     const int tq = (lane & 15) >> 2, tp = lane & 3, tb = (lane >> 4) & 1;
     bool proto_ok = true;
+#ifdef MG_STAMP
+    unsigned long long tstamp[6] = { 0, 0, 0, 0, 0, 0 };
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- an F wave requests its first tile's batch rows before anything else (see mf_body) ----
     int tile = blk * MG_FW + (wave < MG_FW ? wave : 0);
@@ -1229,7 +1239,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 uint32_t hp[2][16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) split2(h1[2 * j], h1[2 * j + 1], hp[0][j], hp[1][j]);
-                if (it > 0) proto_ok &= mg_wait_ge(cons, ev);   // G has read everything of the previous tile: RA is free
+                if (it > 0) MG_TIMED(1, proto_ok &= mg_wait_ge(cons, ev));   // G has read everything of the previous tile: RA is free
 #pragma unroll
                 for (int term = 0; term < 2; term++) {
 #pragma unroll
@@ -1411,7 +1421,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
             for (int j = 0; j < 16; j++) split2(dz2[2 * j], dz2[2 * j + 1], zp[0][j], zp[1][j]);
             // ---------------- E1: dz2 terms -> RB once G has read the h2 image ----------------
             if (lane == 0) flags[MG_SEV + wave] = (uint32_t)S_w;
-            proto_ok &= mg_wait_ge(cons, ev);
+            MG_TIMED(2, proto_ok &= mg_wait_ge(cons, ev));
 #pragma unroll
             for (int term = 0; term < 2; term++)
 #pragma unroll
@@ -1466,7 +1476,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 uint32_t zq[2][16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) split2(dz1[2 * j], dz1[2 * j + 1], zq[0][j], zq[1][j]);
-                proto_ok &= mg_wait_ge(cons, ev);
+                MG_TIMED(3, proto_ok &= mg_wait_ge(cons, ev));
 #pragma unroll
                 for (int term = 0; term < 2; term++)
 #pragma unroll
@@ -1482,6 +1492,12 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         const double sd0 = wave_sum_d_dpp((double)st0), sd1 = wave_sum_d_dpp((double)st1), sd2 = wave_sum_d_dpp((double)st2), sd3 = wave_sum_d_dpp((double)st3);
         if (lane == 0) { dred[wave * 4 + 0] = sd0; dred[wave * 4 + 1] = sd1; dred[wave * 4 + 2] = sd2; dred[wave * 4 + 3] = sd3; }
         if (!proto_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
+#ifdef MG_STAMP
+        if (blk == 0 && tid == 0 && a.stamps) {
+            a.stamps[NET * 12 + 0] += __builtin_amdgcn_s_memtime() - t_begin;
+            for (int i = 1; i < 4; i++) a.stamps[NET * 12 + i] += tstamp[i];
+        }
+#endif
         __syncthreads();   // tile loops done everywhere: LDS is reused by the gradient images
         __syncthreads();   // gradient images parked
 #ifdef MG_DIAG_NO_G
@@ -1539,7 +1555,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         // ---- E0: dW3[a][u = lane] += sum_s dOut[s][a] h2[s][u]; db3[a] += sum_s dOut[s][a] (every lane forms the same sum) ----
         auto serve_e0 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
             MG_REGION_PTRS(fw);
-            g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno);
+            MG_TIMED(0, g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno));
             // the image's 32 rows into registers, then the acknowledgement (RB is what the F wave is waiting for; dOut is not rewritten before the
             // next tile's E0, which comes behind everything of this tile), then the products
             float hv[MT];
@@ -1564,7 +1580,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         //      Lane (n | k = lane & 31, hi) holds the terms of samples 16 c + 8 hi + 0..7 of unit (lane & 31) + 32 t ----
         auto serve_e1 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
             MG_REGION_PTRS(fw);
-            g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno);
+            MG_TIMED(0, g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno));
             {
                 const int S_ev = __builtin_amdgcn_readfirstlane((int)flags[MG_SEV + fw]);
                 if (S_ev != S_g2) {
@@ -1622,7 +1638,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         //      {1, 0, 0, 0} (first term, OBS == 4 only: with OBS == 2 the 1 sits in the observation cell), the others at zeros ----
         auto serve_e2 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
             MG_REGION_PTRS(fw);
-            g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno);
+            MG_TIMED(0, g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno));
             {
                 const int S_ev = __builtin_amdgcn_readfirstlane((int)flags[MG_SEV + fw]);
                 if (S_ev != S_g1) {
@@ -1684,6 +1700,12 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
 #undef MG_REGION_PTRS
         __builtin_amdgcn_s_setprio(0);
         if (!g_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
+#ifdef MG_STAMP
+        if (blk == 0 && tid == MG_FW * 64 && a.stamps) {
+            a.stamps[NET * 12 + 5] += __builtin_amdgcn_s_memtime() - t_begin;
+            a.stamps[NET * 12 + 6] += tstamp[0];
+        }
+#endif
         // ---- the factors leave: 2^S (dW2, db2, dW1, db1), the fixed 2^-7 of the dz1 terms and the c of the scaled W2 (dW1, db1) ----
         gb2[0] += __shfl_xor(gb2[0], 32, 64); gb2[1] += __shfl_xor(gb2[1], 32, 64);
         {
@@ -1942,7 +1964,11 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
     // head of 3); anything else with <= 4 logits runs the generic variant
     const bool one = a.L.n_heads == 1;
     // the reference's two shapes: the wave-specialised kernel (twelve waves, 160 KB of LDS)
+#ifdef MG_STAMP
+    if (!a.single_wave && one) {
+#else
     if (!a.single_wave && !a.stamps && one) {
+#endif
         const bool cart = a.L.obs == 4 && a.L.act == 2 && a.hp.dist_kind == PPO_DIST_CATEGORICAL;
         const bool mcar = a.L.obs == 2 && a.L.act == 3 && a.hp.dist_kind == PPO_DIST_MASKED;
         if (cart || mcar) {
