@@ -95,6 +95,26 @@ def rocprof_kernel_us(prefix):
     return None
 
 
+def curve_parity_summary():
+    """The committed measurement of tests/test_gpu_curves.py (profiles/r*_curves.json): the free-running build against the unmodified reference's
+    learning curves (ten seeds each, tests/golden/curves_*.json), two lines per scenario."""
+    f = newest_profile("_curves.json")
+    if not f:
+        return None
+    try:
+        with open(f) as fh:
+            rows = json.load(fh)
+        return {"source": "profiles/" + os.path.basename(f) + " (python tests/test_gpu_curves.py)",
+                "scenarios": [{"scenario": r["scenario"],
+                               "steps_to_ep_len_195": "build median %.0f, reference median %.0f [min %.0f, max %.0f], Mann-Whitney p = %.2f"
+                                                      % (r["steps_to_195"]["build_median"], r["steps_to_195"]["ref_median"], r["steps_to_195"]["ref_min"], r["steps_to_195"]["ref_max"], r["steps_to_195"]["mannwhitney_p"]),
+                               "plateau_ep_len": "build median %.1f, reference median %.1f [min %.1f, max %.1f], Mann-Whitney p = %.2f"
+                                                 % (r["plateau"]["build_median"], r["plateau"]["ref_median"], r["plateau"]["ref_min"], r["plateau"]["ref_max"], r["plateau"]["mannwhitney_p"])}
+                              for r in rows]}
+    except Exception:
+        return None
+
+
 def committed_jsonl(suffix):
     f = newest_profile(suffix)
     if not f:
@@ -117,12 +137,12 @@ def gae_floor_us():
     return None
 
 
-def run_reference(num_envs, num_steps, updates, timeout=900):
+def run_reference(num_envs, num_steps, updates, threads=0, timeout=900):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if not os.path.exists(ref):
         return None
     try:
-        out = subprocess.run([ref, "bench", str(num_envs), str(num_steps), str(updates)], capture_output=True, text=True, timeout=timeout).stdout
+        out = subprocess.run([ref, "bench", str(num_envs), str(num_steps), str(updates), str(threads)], capture_output=True, text=True, timeout=timeout).stdout
         m = re.search(r"REF_BENCH (\{.*\})", out)
         return json.loads(m.group(1)) if m else None
     except Exception as ex:
@@ -131,16 +151,21 @@ def run_reference(num_envs, num_steps, updates, timeout=900):
 
 
 def cpu_baseline(num_envs, num_steps, obs, act):
-    # bounded sample (~15 s on the GPU box's host cores): ONE full update iteration of the headline workload on a quarter of its envs
-    # (1024 of 4096); the ThreadPool path's cost is per env-step, so the rate carries to the full workload (measured 7.0k at 4096 x 2)
-    sample_envs = min(num_envs, 1024)
-    r = run_reference(sample_envs, num_steps, 1)
+    # ONE full update iteration (rollout + GAE + 40 optimizer steps) of the unmodified reference's PPO_Discrete::train() on the FULL headline workload
+    # (4096 envs x 128 steps), twice: with the pool the reference builds itself -- ThreadPool(hardware_concurrency) (PPO_Discrete.cpp:40), oversubscribed on
+    # a many-core host: one job per env per step, the queue lock dominates -- and with the same pool class at 16 threads (+ LibTorch's intra-op threads capped
+    # to match), a width at which the number is not an artefact of lock contention.  ~1 min + ~10 s of CPU work.
+    r = run_reference(num_envs, num_steps, 1)
     if r:
+        what = "1 full update iteration (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch CPU, %d envs x %d steps (the full headline workload)" % (num_envs, num_steps)
         out = {"value": r["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(r["threads"]), "kind": "reference",
-               "sample": "1 full update iteration (rollout+GAE+update) of the unmodified reference's PPO_Discrete::train() on LibTorch CPU, "
-                         "ThreadPool(hardware_concurrency), %d envs x %d steps (the headline workload has %d envs: bounded sample)" % (sample_envs, num_steps, num_envs),
-               "note": "%d-thread ThreadPool, oversubscribed (one job per env per step: the pool's queue lock dominates); %d-env sample of the %d-env workload; "
-                       "a reported baseline -- the GPU/CPU ratio says nothing about kernel quality" % (int(r["threads"]), sample_envs, num_envs)}
+               "sample": what + ", ThreadPool(hardware_concurrency) as the reference builds it",
+               "note": "a reported baseline -- the GPU/CPU ratio says nothing about kernel quality; with %d threads the reference's pool is oversubscribed "
+                       "(one job per env per step: its queue lock dominates), see `capped_pool` for a sane width" % int(r["threads"])}
+        c = run_reference(num_envs, num_steps, 1, threads=16)
+        if c:
+            out["capped_pool"] = {"value": c["env_steps_per_sec"], "unit": "env-steps/s", "cores": int(c["threads"]),
+                                  "sample": what + ", the reference's ThreadPool class at 16 threads (public member replaced before train()), at::set_num_threads(16)"}
         # BASELINE.json configs[0]: the reference's own CPU-runnable case, 8 envs x 128 steps
         c1 = run_reference(8, 128, 20)
         if c1:
@@ -488,7 +513,7 @@ def main():
         fb_ms, gae_ms = per_launch("fwd_bwd"), per_launch("gae")
         gae_bytes = 20 * N * T + 8 * N
         generic = args.workload == "config4"
-        fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma_kernel"
+        fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma"
         fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, pmc_traffic("gae_kernel") if args.workload == "cartpole" else None
         if generic:
             roof = {"kernel": "one minibatch step of the generic path (gather, 10 forward + 18 backward layer products on gemm_kernel with fused bias / tanh / tanh' / "
@@ -496,27 +521,34 @@ def main():
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None, "traffic": None}
         else:
-            # what the matrix cores execute: per 32-sample tile and net 72 v_mfma_f32_32x32x16_f16 (three f16 products per fp32 product)
-            f16_fl = 2 * ((M + 31) // 32) * 72 * (2 * 32 * 32 * 16)
-            roof = {"kernel": "fwd_bwd_mfma_kernel (gather+forward+PPO loss+backward; fp32 carried as two fp16 terms, three f16 MFMA products per fp32 product)",
-                    # the roofline of the instruction stream the kernel issues: executed f16 MFMA FLOP/s against the dense f16 matrix peak.  It cannot
-                    # pass 1 and it shows the headroom; the kernel is held below it by the LDS pipe and the vector work around each MFMA (`limiter`).
-                    "bound": "mfma", "limiter": "lds+valu (LDS pipe ~55 % busy, ~18 vector instructions per MFMA: DESIGN.md section 4)",
-                    "achieved": f16_fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": f16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
+            # what the matrix cores execute per 32-sample tile and net in fwd_bwd_mfma_ws_kernel: 82 v_mfma_f32_32x32x16_f16 (layer 1 with
+            # its bias 6, the layer-2 bias 2, layer 2 / d(hidden) / dW2 24 each -- three f16 products per fp32 product --, dz2 2 [6 beyond two logits]) and
+            # 12 v_mfma_f32_16x16x32_f16 (dW1, db1)
+            tiles = (M + 31) // 32
+            f16_fl = 2 * tiles * ((82 if act <= 2 else 86) * (2 * 32 * 32 * 16) + 12 * (2 * 16 * 16 * 32))
+            roof = {"kernel": "fwd_bwd_mfma_ws_kernel (gather+forward+PPO loss+backward, wave-specialised: 8 forward + 4 gradient waves per workgroup; fp32 carried "
+                              "as two fp16 terms, three f16 MFMA products per fp32 product)",
+                    # `frac` = ALGORITHMIC work (53 376 FLOP per sample, forward + backward of both nets) / launch duration / the dense f16
+                    # matrix peak, i.e. the peak of the pipe the kernel issues on.  `frac_executed` counts what that pipe executes (the three-product
+                    # emulation of fp32: 2.9 x the algorithmic FLOP) -- the pipe's utilisation, not a roofline fraction.
+                    "bound": "mfma", "limiter": "lds+valu (LDS pipe ~55 % busy, ~15 vector instructions per MFMA: DESIGN.md section 4)",
+                    "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
+                    "achieved_executed": f16_fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None,
+                    "frac_executed": f16_fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
                     "executed_flops_per_launch": f16_fl,
-                    # the arithmetic the path DELIVERS (algorithmic fp32 FLOP of forward + backward of both nets), for comparison with an fp32 implementation:
-                    # 157.3 TFLOP/s is the peak of the fp32 matrix instruction, which this kernel does not issue -- a yardstick, not this kernel's roofline
-                    "achieved_fp32_equiv": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "fp32_mfma_peak": F32_PEAK_TFLOPS,
+                    # yardstick only: 157.3 TFLOP/s is the peak of the fp32 matrix instruction, which this kernel does not issue
+                    "fp32_mfma_peak": F32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if fb_ms else None,
                     "traffic": (fb_tr or {}).get("bytes"), "traffic_detail": fb_tr,
-                    "rocprof": rocprof_kernel_us("fwd_bwd_mfma_kernel") if args.workload == "cartpole" else None}
+                    "rocprof": rocprof_kernel_us("fwd_bwd_mfma") if args.workload == "cartpole" else None}
         roof.update({"flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
                      "sampling": "HIP events on the context's stream around 1 launch in %s (--profile %d)" % ({1: "1", 2: "8", 4: "41"}.get(args.profile, "?"), args.profile)})
         phases = {"rollout": "rollout", "gae": "gae", "grad_reduce": "reduce", "clip_adamw": "optimizer"}
         out = {
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if generic else "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if generic else "f32 (update GEMMs: two-term f16 split on f16 MFMA, fp32 accumulate; everything else IEEE f32)",
             # the gradient all-reduce that ran (N > 1), what was asked for, and why they differ if they do
             "transport": transport, "transport_requested": requested if world > 1 else None, "transport_fallback_reason": fallback_reason,
             "comm_ranks": world, "transport_ab": transport_ab,
@@ -553,7 +585,8 @@ def main():
             # HIP-event time per iteration of the phases that were bracketed (--profile 1 brackets all of them); null = not sampled in this run
             "phase_ms_per_step": dict({k: (prof[v + "_ms"] / args.steps if prof[v + "_launches"] > 0 else None) for k, v in phases.items()},
                                       fwd_bwd=40 * fb_ms if fb_ms else None),
-            "train_stats": {k: st[k] for k in ("loss", "ep_len_mean", "ep_rew_mean", "explained_variance", "global_step")},
+            "train_stats": dict({k: st[k] for k in ("loss", "ep_len_mean", "ep_rew_mean", "explained_variance", "global_step")},
+                                learning_curve_parity=curve_parity_summary()),
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cartpole":
             out["cpu_baseline"] = cpu_baseline(N, T, obs, act)

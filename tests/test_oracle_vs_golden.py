@@ -245,3 +245,22 @@ def test_full_update_tracks_reference(name):
     assert np.abs(p - g[U + "params_after"]).max() <= 2e-5
     ev = O.explained_variance(g[U + "gae_returns"], g[U + "values"])
     assert abs(ev - float(g[U + "explained_var"][0])) <= 1e-5
+
+
+@pytest.mark.parametrize("name,envs,updates", [("curves_config0_8x128", 8, 150), ("curves_64x128", 64, 80)])
+def test_reference_curve_fixtures(name, envs, updates):
+    """tests/golden/curves_*.json (the unmodified reference's own table per update, ten seeds: oracle/make_curves.py) are what
+    tests/test_gpu_curves.py compares the free-running build with: well-formed, complete, and the reference does learn in them
+    (README.md:169-178: ep_len_mean climbs; every seed passes 195 and ends far above its start)."""
+    import json
+    with open(os.path.join(G, name + ".json")) as f:
+        doc = json.load(f)
+    cfg = doc["config"]
+    assert cfg["num_envs"] == envs and cfg["num_steps"] == 128 and cfg["action_size"] == 2 and cfg["total_timesteps"] == updates * envs * 128
+    assert [r["seed"] for r in doc["runs"]] == list(range(1, 11))
+    for r in doc["runs"]:
+        assert r["updates"] == updates and all(len(r[k]) == updates for k in ("ep_len_mean", "total_timesteps", "loss", "value_loss", "approx_kl"))
+        assert r["total_timesteps"] == [envs * 128 * (u + 1) for u in range(updates)]
+        el = [v for v in r["ep_len_mean"] if v is not None]
+        assert max(el) >= 195 and el[-1] > 5 * el[1]
+        assert r["loss"][0] is None and all(v is not None and np.isfinite(v) for v in r["loss"][1:])   # the first update's table has no train/ block
