@@ -773,6 +773,199 @@ void loadCheckpointFiles(const std::string& agentFile, const std::string& optimi
     g.save(outFile);
 }
 
+// (11) Headline-size pin: BASELINE.json configs[1] (CartPole, 4096 envs x 128 steps) and configs[3] (MountainCar, 8192 x 128, masked) driven through
+// the reference's own components in train()'s order (PPO_Discrete.cpp:524-548, 274-306, 554-648) with everything random INJECTED from a counter hash
+// both sides can regenerate (tests/test_gpu_headline_ref.py): the actions of the rollout, the permutations of the update, MountainCar's initial
+// positions.  Tensors of this size cannot be committed, so the fixture carries
+//   * CRC-32s of what must match bit for bit: obs / rewards / dones / next_obs / next_done of the rollout, and advantages / returns of calcAdvantage
+//     on SYNTHETIC values (hash-made floats in m_values; the critic's head zeroed with bias 0.25, so next_value is exactly 0.25 on both sides);
+//   * what matches within fp32 noise: binary64 sums and a strided sample of logprobs / values / the real advantages, the 40 x 7 per-step scalars of the
+//     update, parameters before and after.
+namespace hl {
+inline uint64_t mix64(uint64_t x) {   // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+inline float unit24(uint64_t h) { return static_cast<float>(static_cast<uint32_t>(h >> 40)) * 5.9604644775390625e-8f; }   // [0, 1), 24 bits: exact
+uint32_t crc32(const void* data, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+uint32_t crcOf(const torch::Tensor& t) { torch::Tensor c = t.detach().cpu().contiguous(); return crc32(c.data_ptr(), static_cast<size_t>(c.nbytes())); }
+constexpr uint64_t SEED_ACT = 0x1111ull << 32, SEED_PERM = 0x2222ull << 32, SEED_VAL = 0x3333ull << 32, SEED_POS = 0x4444ull << 32;
+}  // namespace hl
+
+template <class Algo, bool Masked>
+void goldHeadline(RunCfg cfg, const std::string& tag, const std::string& outPath) {
+    GoldWriter g;
+    cfg.updates = 1;
+    enterScratchWithConfig(cfg, "headline_" + tag);
+    auto algoPtr = std::make_unique<Algo>();
+    Algo& algo = *algoPtr;
+    const int64_t T = algo.m_num_steps, N = algo.m_num_envs, B = algo.m_batch_size, MB = algo.m_minibatch_size, A = algo.m_action_size;
+    std::vector<torch::Tensor> params = algo.m_agent->parameters();
+    {
+        std::vector<int64_t> meta = { T, N, algo.m_obs_size, A, algo.m_num_minibatches, algo.m_update_epochs, algo.m_max_episode_steps, algo.m_seed, 1,
+                                      algo.m_anneal_lr, algo.m_use_gae, algo.m_norm_adv, algo.m_clip_vloss, Masked };
+        g.addI64("meta", meta, { static_cast<int64_t>(meta.size()) });
+        std::vector<float> hp = { algo.m_learning_rate, algo.m_gamma, algo.m_gae_lambda, algo.m_clip_coef, algo.m_ent_coef, algo.m_vf_coef, algo.m_max_grad_norm };
+        g.addF32("hparams", hp, { static_cast<int64_t>(hp.size()) });
+    }
+    g.add("params_before", flatParams(params));
+    algo.m_threadPool->start();
+    torch::Tensor next_obs, next_done = torch::zeros({ N });
+    torch::Tensor next_mask;
+    if constexpr (Masked) {
+        next_mask = torch::ones({ N, 3 }, torch::kBool);
+        next_obs = algo.initEnvs(next_mask);
+        // MountainCar::reset draws from std::random_device (MountainCar.cpp:79-88): the initial positions are injected (hash-made, the reference's range)
+        next_obs = next_obs.clone();
+        for (int64_t n = 0; n < N; n++) {
+            const float a = hl::unit24(hl::mix64(hl::SEED_POS + static_cast<uint64_t>(n)));
+            const float b = 0.2f * a;
+            const float p0 = -0.6f + b;
+            algo.m_envs[n]->state = { p0, 0.0f };
+            algo.m_envs[n]->episode_length = 0;
+            algo.m_envs[n]->episode_reward = 0.0f;
+            next_obs[n][0] = p0; next_obs[n][1] = 0.0f;
+        }
+    } else {
+        next_obs = algo.initEnvs();
+    }
+    g.addI64("crc_init_obs", { hl::crcOf(next_obs) }, { 1 });
+
+    // ---- rollout with injected actions (PPO_Discrete.cpp:524-548) ----
+    torch::Tensor reward, done;
+    {
+        torch::NoGradGuard ng;
+        for (int64_t step = 0; step < T; step++) {
+            algo.m_obs[step] = next_obs;
+            algo.m_dones[step] = next_done;
+            std::vector<int64_t> av(N);
+            for (int64_t n = 0; n < N; n++) av[n] = static_cast<int64_t>(hl::mix64(hl::SEED_ACT + static_cast<uint64_t>(step * N + n)) % static_cast<uint64_t>(A));
+            torch::Tensor action = torch::from_blob(av.data(), { N }, torch::kInt64).clone();
+            AgentOutput out;
+            if constexpr (Masked) {
+                algo.m_action_masks[step] = next_mask;
+                out = algo.m_agent->getActionAndValueMasked(next_obs, next_mask, action.unsqueeze(0));   // [heads = 1, N]
+                algo.m_actions[step] = out.action;                                                       // [N, 1] broadcast into [N, action_size] (:93, :562)
+            } else {
+                out = algo.m_agent->getActionAndValueDiscrete(next_obs, action);
+                algo.m_actions[step] = action.unsqueeze(1);
+            }
+            algo.m_values[step] = out.value.flatten();
+            algo.m_logprobs[step] = out.logprob;
+            std::tie(next_obs, reward, done) = algo.stepEnvs(Masked ? out.action.cpu() : action);
+            algo.m_rewards[step] = reward.view(-1);
+            next_done = done.squeeze();
+        }
+    }
+    g.addI64("crc_obs", { hl::crcOf(algo.m_obs) }, { 1 });
+    g.addI64("crc_rewards", { hl::crcOf(algo.m_rewards) }, { 1 });
+    g.addI64("crc_dones", { hl::crcOf(algo.m_dones) }, { 1 });
+    g.addI64("crc_next_obs", { hl::crcOf(next_obs) }, { 1 });
+    g.addI64("crc_next_done", { hl::crcOf(next_done.to(torch::kInt32)) }, { 1 });
+    {
+        const torch::Tensor dones_sum = algo.m_dones.sum(), next_done_sum = next_done.to(torch::kFloat64).sum();
+        g.addF64("count_done", { dones_sum.item<double>(), next_done_sum.item<double>() }, { 2 });
+    }
+    auto sample = [&](const torch::Tensor& t) { return t.reshape(-1).index({ torch::indexing::Slice(0, torch::indexing::None, 4099) }).clone(); };
+    auto sums = [&](const torch::Tensor& t) { torch::Tensor d = t.to(torch::kFloat64); return std::vector<double>{ d.sum().item<double>(), (d * d).sum().item<double>() }; };
+    g.add("sample_logprobs", sample(algo.m_logprobs));
+    g.add("sample_values", sample(algo.m_values));
+    g.addF64("sums_logprobs", sums(algo.m_logprobs), { 2 });
+    g.addF64("sums_values", sums(algo.m_values), { 2 });
+
+    // ---- calcAdvantage on synthetic values: bit-exact target (PPO_Discrete.cpp:274-306) ----
+    {
+        torch::NoGradGuard ng;
+        torch::Tensor real_values = algo.m_values.clone();
+        std::vector<float> sv(static_cast<size_t>(T * N));
+        for (int64_t i = 0; i < T * N; i++) sv[i] = hl::unit24(hl::mix64(hl::SEED_VAL + static_cast<uint64_t>(i))) * 4.0f - 2.0f;
+        algo.m_values = torch::from_blob(sv.data(), { T, N }, torch::kFloat32).clone();
+        // critic head: weight 0, bias 0.25 -> getValue(next_obs) is exactly 0.25 whatever the hidden layers hold (params[4], params[5]: criticOutputLayer)
+        torch::Tensor w_keep = params[4].detach().clone(), b_keep = params[5].detach().clone();
+        params[4].zero_(); params[5].fill_(0.25f);
+        auto gae = algo.calcAdvantage(next_obs, next_done);
+        g.addI64("crc_syn_returns", { hl::crcOf(gae[0]) }, { 1 });
+        g.addI64("crc_syn_advantages", { hl::crcOf(gae[1]) }, { 1 });
+        g.add("sample_syn_advantages", sample(gae[1]));
+        params[4].copy_(w_keep); params[5].copy_(b_keep);
+        algo.m_values = real_values;
+    }
+    // ---- the real advantages, then the update with injected permutations (PPO_Discrete.cpp:554-648) ----
+    auto gae = algo.calcAdvantage(next_obs, next_done);
+    torch::Tensor returns = gae[0], advantages = gae[1];
+    g.add("sample_advantages", sample(advantages));
+    g.addF64("sums_advantages", sums(advantages), { 2 });
+    g.addF64("sums_returns", sums(returns), { 2 });
+    torch::Tensor b_obs = algo.m_obs.reshape({ B, algo.m_obs_size });
+    torch::Tensor b_logprobs = algo.m_logprobs.reshape(-1);
+    torch::Tensor b_actions = Masked ? algo.m_actions.reshape({ B, A }) : algo.m_actions.reshape(-1);
+    torch::Tensor b_advantages = advantages.reshape(-1), b_returns = returns.reshape(-1), b_values = algo.m_values.reshape(-1);
+    torch::Tensor b_masks;
+    if constexpr (Masked) b_masks = algo.m_action_masks.reshape({ -1, algo.m_action_masks.sizes().back() });
+    std::vector<float>().swap(algo.m_clipfracs);
+    std::vector<double> scal;
+    for (int64_t epoch = 0; epoch < algo.m_update_epochs; epoch++) {
+        std::vector<std::pair<uint64_t, int64_t>> keys(static_cast<size_t>(B));
+        for (int64_t i = 0; i < B; i++) keys[i] = { hl::mix64(hl::SEED_PERM + static_cast<uint64_t>(epoch * B + i)), i };
+        std::sort(keys.begin(), keys.end());
+        std::vector<int64_t> pv(static_cast<size_t>(B));
+        for (int64_t i = 0; i < B; i++) pv[i] = keys[i].second;
+        torch::Tensor b_inds = torch::from_blob(pv.data(), { B }, torch::kInt64).clone();
+        for (int64_t start = 0; start < B; start += MB) {
+            torch::Tensor mb = b_inds.index({ torch::indexing::Slice(start, start + MB) });
+            AgentOutput o;
+            if constexpr (Masked) o = algo.m_agent->getActionAndValueMasked(b_obs.index({ mb }), b_masks.index({ mb }), b_actions.to(torch::kLong).index({ mb }).t());
+            else o = algo.m_agent->getActionAndValueDiscrete(b_obs.index({ mb }), b_actions.to(torch::kLong).index({ mb }));
+            torch::Tensor logratio = o.logprob - b_logprobs.index({ mb });
+            torch::Tensor ratio = logratio.exp();
+            torch::Tensor approx_kl = algo.getApproxKLAndClippedObj(ratio, logratio);
+            torch::Tensor adv = b_advantages.index({ mb });
+            if (algo.m_norm_adv) adv = (adv - adv.mean()) / (adv.std() + 1e-8f);
+            torch::Tensor l1 = -adv * ratio;
+            torch::Tensor l2 = -adv * torch::clamp(ratio, 1 - algo.m_clip_coef, 1 + algo.m_clip_coef);
+            torch::Tensor pg_loss = torch::max(l1, l2).mean();
+            torch::Tensor nv = o.value.view(-1);
+            torch::Tensor ret = b_returns.index({ mb });
+            torch::Tensor v_loss;
+            if (algo.m_clip_vloss) {
+                torch::Tensor un = (nv - ret) * (nv - ret);
+                torch::Tensor vold = b_values.index({ mb });
+                torch::Tensor vc = vold + torch::clamp(nv - vold, -algo.m_clip_coef, algo.m_clip_coef);
+                torch::Tensor cl = (vc - ret) * (vc - ret);
+                v_loss = 0.5f * torch::max(un, cl).mean();
+            } else {
+                v_loss = 0.5f * ((nv - ret) * (nv - ret)).mean();
+            }
+            torch::Tensor entropy_loss = o.entropy.mean();
+            torch::Tensor loss = pg_loss - algo.m_ent_coef * entropy_loss + v_loss * algo.m_vf_coef;
+            algo.m_optimizer->zero_grad();
+            loss.backward();
+            double total_norm = torch::nn::utils::clip_grad_norm_(params, algo.m_max_grad_norm);
+            algo.m_optimizer->step();
+            scal.insert(scal.end(), { pg_loss.item<double>(), v_loss.item<double>(), entropy_loss.item<double>(), approx_kl.item<double>(),
+                                      static_cast<double>(algo.m_clipfracs.back()), loss.item<double>(), total_norm });
+        }
+    }
+    g.addF64("step_scalars", scal, { static_cast<int64_t>(scal.size() / 7), 7 });
+    g.add("params_after", flatParams(params));
+    g.addF64("lr", { static_cast<torch::optim::AdamWOptions&>(algo.m_optimizer->param_groups()[0].options()).lr() }, { 1 });
+    algo.m_threadPool->stop();
+    g.save(outPath);
+}
+
 // (10) Learning curves: the reference's own acceptance test is "run ./PPO and watch ep_len_mean" (README.md:169-178).  The UNMODIFIED train()
 // (PPO_Discrete.cpp:485-690) runs to total_timesteps with the recommended hyper-parameters; the table it prints per update
 // (printPPOResults, :700-774) is captured and parsed into one JSON object per seed: exactly the numbers a user of the reference sees
@@ -908,6 +1101,22 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (mode == "bench" && argc > 4) return benchReference(std::atol(argv[2]), std::atol(argv[3]), std::atol(argv[4]), argc > 5 ? std::atol(argv[5]) : 0);
+        if (mode == "headline" && argc > 2) {
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            {
+                RunCfg c;   // BASELINE.json configs[1]: CartPole-v1, 4096 envs x 128 steps, the recommended settings with action_size = 2
+                c.num_envs = 4096; c.num_steps = 128; c.seed = 2;
+                goldHeadline<PPO_Discrete, false>(c, "cartpole", out + "/headline_cartpole_4096x128.pgld");
+            }
+            {
+                RunCfg c;   // BASELINE.json configs[3]: MountainCar, 8192 envs, CategoricalMasked path
+                c.obs_size = 2; c.action_size = 3; c.max_episode_steps = 200; c.seed = 1; c.num_envs = 8192; c.num_steps = 128; c.ent_coef = 0.01; c.gamma = 0.99;
+                goldHeadline<PPO_MultiDiscrete, true>(c, "mountaincar", out + "/headline_mountaincar_8192x128.pgld");
+            }
+            return 0;
+        }
         if (mode == "curves" && argc > 6) {
             // CartPoleRecommendedSettings.toml's hyper-parameters (RunCfg's defaults) with action_size = 2, as BASELINE.json configs[0] runs them
             char buf[4096];
@@ -918,7 +1127,7 @@ int main(int argc, char** argv) {
             return curvesReference<PPO_Discrete>(c, out);
         }
         std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | ptgold <outdir> | ptload <agent.pt> <optimizer.pt> <obs> <act> <out.pgld> | "
-                     "bench <num_envs> <num_steps> <updates> [threads] | curves <out.json> <num_envs> <num_steps> <total_timesteps> <seed>\n";
+                     "bench <num_envs> <num_steps> <updates> [threads] | curves <out.json> <num_envs> <num_steps> <total_timesteps> <seed> | headline <outdir>\n";
         return 2;
     } catch (const std::exception& ex) {
         std::cerr << "[ref_harness] error: " << ex.what() << std::endl;

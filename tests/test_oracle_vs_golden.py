@@ -264,3 +264,51 @@ def test_reference_curve_fixtures(name, envs, updates):
         el = [v for v in r["ep_len_mean"] if v is not None]
         assert max(el) >= 195 and el[-1] > 5 * el[1]
         assert r["loss"][0] is None and all(v is not None and np.isfinite(v) for v in r["loss"][1:])   # the first update's table has no train/ block
+
+
+@pytest.mark.parametrize("name", ["headline_cartpole_4096x128", "headline_mountaincar_8192x128"])
+def test_oracle_at_headline_size_against_the_compiled_reference(name):
+    """The C restatement at BASELINE.json configs[1] / configs[3] FULL size against the compiled reference (oracle/ref_harness.cpp `headline`: the
+    reference's components driven in train()'s order with hash-made actions; tests/test_gpu_headline_ref.py is the device's twin of this test):
+    the whole rollout's env side (obs / rewards / dones / next_obs / next_done: 4096 x 128 and 8192 x 128 transitions, auto-resets included) and
+    calcAdvantage on hash-made values -- CRC-32 for CRC-32; log-probs / values on the fixture's strided sample within fp32 noise."""
+    import zlib
+    g = O.read_pgld(os.path.join(G, name + ".pgld"))
+    m, h = g["meta"], g["hparams"]
+    T, N, obs_dim, A, max_steps, seed, masked = int(m[0]), int(m[1]), int(m[2]), int(m[3]), int(m[6]), int(m[7]), int(m[13])
+    B = T * N
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+    def mix64(x):
+        with np.errstate(over="ignore"):
+            x = x + np.uint64(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return x ^ (x >> np.uint64(31))
+    unit24 = lambda hh: (hh >> np.uint64(40)).astype(np.float32) * np.float32(5.9604644775390625e-8)
+    env = O.VecEnv(O.ENV_MOUNTAINCAR if masked else O.ENV_CARTPOLE, N, seed, max_steps)
+    x = env.init()
+    if masked:
+        p0 = np.float32(-0.6) + np.float32(0.2) * unit24(mix64(np.uint64(0x4444 << 32) + np.arange(N, dtype=np.uint64)))
+        x = np.stack([p0, np.zeros(N, np.float32)], 1).astype(np.float32)
+        env.set_state(state=x, ep_len=np.zeros(N, np.int32), ep_rew=np.zeros(N, np.float32))
+    assert crc(x) == int(g["crc_init_obs"][0])
+    actions = (mix64(np.uint64(0x1111 << 32) + np.arange(B, dtype=np.uint64)) % np.uint64(A)).astype(np.int64).reshape(T, N)
+    obs, rew, dones = np.empty((T, N, obs_dim), np.float32), np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    done = np.zeros(N, np.float32)
+    for t in range(T):
+        obs[t], dones[t] = x, done
+        x, r, d = env.step(actions[t])
+        rew[t], done = r, d.astype(np.float32)
+    assert crc(obs) == int(g["crc_obs"][0]) and crc(rew) == int(g["crc_rewards"][0]) and crc(dones) == int(g["crc_dones"][0])
+    assert crc(x) == int(g["crc_next_obs"][0]) and crc(done.astype(np.int32)) == int(g["crc_next_done"][0])
+    assert dones.sum() == g["count_done"][0]
+    syn = (unit24(mix64(np.uint64(0x3333 << 32) + np.arange(B, dtype=np.uint64))) * np.float32(4.0) - np.float32(2.0)).reshape(T, N)
+    adv, ret = O.gae(rew, syn, dones, np.full(N, 0.25, np.float32), done.astype(np.int32), float(h[1]), float(h[2]))
+    assert crc(ret) == int(g["crc_syn_returns"][0]) and crc(adv) == int(g["crc_syn_advantages"][0])
+    net = O.Net.make(obs_dim, [A], dist_kind=O.DIST_MASKED if masked else O.DIST_CATEGORICAL)
+    rows = np.arange(0, B, 4099)
+    mask = np.ones((rows.size, A), np.uint8) if masked else None
+    lp, _, v = O.evaluate(net, g["params_before"], obs.reshape(B, obs_dim)[rows], actions.reshape(B)[rows], mask)
+    np.testing.assert_allclose(lp, g["sample_logprobs"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(v, g["sample_values"], rtol=0, atol=3e-6)
