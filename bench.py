@@ -225,6 +225,8 @@ def parse_args(argv=None):
                     "exchange only if RCCL cannot be brought up (with --same-device: the exchange, RCCL refuses two ranks on one device); both = RCCL timed as "
                     "`value`, then the exchange timed beside it (`transport_ab`)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (exchange transport only)")
+    ap.add_argument("--kernel-flags", type=int, default=0, help="ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*: 1 vector rollout, 2 vector update, "
+                    "4 one-wave matrix-core update): A/B runs of the hand-written kernels; 0 = the defaults")
     ap.add_argument("--profile", type=int, default=-1, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel (1 launch in 8) + GAE, "
                     "4 the same with 1 launch in 41; default: 4 from 20 steps up (>= 20 samples), 2 below")
     ap.add_argument("--bringup-timeout", type=float, default=300.0, help="N > 1: seconds a rank may spend between start and the end of the warm-up before it gives up "
@@ -343,7 +345,12 @@ def main():
                               max_episode_steps=W["max_steps"], seed=2, total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98,
                               gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True,
                               device=0 if args.same_device else local_rank,
-                              compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32)
+                              compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32,
+                              # ppo_config.kernel_flags: which kernel runs a stage (A/B runs); --same-device with more than two ranks: the vector update
+                              # kernel (ranks waiting in the exchange sit on every CU, and a matrix-core update workgroup needs a CU's whole register
+                              # file: tests/test_gpu_exchange.py); --comm-selftest: a real one-rank RCCL communicator
+                              kernel_flags=args.kernel_flags | (P.KERNEL_UPDATE_VECTOR if args.same_device and world > 2 else 0)
+                                           | (P.KERNEL_COMM_SELFTEST if args.comm_selftest and world == 1 else 0))
     def warm(c):
         try:
             c.init_orthogonal(2)   # same seed on every rank: replicated weights
@@ -364,9 +371,7 @@ def main():
         try:
             c = P.Context(cfg)
             if args.comm_selftest and world == 1:
-                os.environ["PPO_COMM_SELFTEST"] = "1"
                 c.comm_init(P.comm_unique_id(), 0, 1)
-                del os.environ["PPO_COMM_SELFTEST"]
         except Exception as ex:
             err = ex
         if world > 1:
@@ -530,7 +535,7 @@ def main():
                               "as two fp16 terms, three f16 MFMA products per fp32 product)",
                     # `frac` = ALGORITHMIC work (53 376 FLOP per sample, forward + backward of both nets) / launch duration / the dense f16
                     # matrix peak, i.e. the peak of the pipe the kernel issues on.  `frac_executed` counts what that pipe executes (the three-product
-                    # emulation of fp32: 2.9 x the algorithmic FLOP) -- the pipe's utilisation, not a roofline fraction.
+                    # emulation of fp32 plus the zero padding of the small products: 3.4 x the algorithmic FLOP) -- the pipe's utilisation, not a roofline fraction.
                     "bound": "mfma", "limiter": "lds+valu (LDS pipe ~55 % busy, ~15 vector instructions per MFMA: DESIGN.md section 4)",
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,

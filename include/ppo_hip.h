@@ -28,7 +28,7 @@ extern "C" {
 
 #define PPO_MAX_HEADS 8
 #define PPO_API __attribute__((visibility("default")))
-#define PPO_ABI_VERSION 3
+#define PPO_ABI_VERSION 4
 
 typedef int32_t ppo_status;
 enum { PPO_OK = 0, PPO_ERR_INVALID = 1, PPO_ERR_HIP = 2, PPO_ERR_STATE = 3, PPO_ERR_COMM = 4, PPO_ERR_UNSUPPORTED = 5 };
@@ -67,7 +67,24 @@ typedef struct ppo_config {
     int64_t global_num_envs;    /* 0 or num_envs when not sharded */
     float learning_rate, gamma, gae_lambda, clip_coef, ent_coef, vf_coef, max_grad_norm;
     int32_t compute_dtype;      /* PPO_DTYPE_*: arithmetic of the layer GEMMs of a PPO_ENV_SYNTHETIC network; the 2 x 64 paths are always f32 */
+    int32_t kernel_flags;       /* PPO_KERNEL_* (0 = the defaults): which hand-written kernel runs a stage, for A/B runs and for bit-exact replays */
 } ppo_config;
+
+/* ppo_config.kernel_flags.  The defaults put the reference's two shapes on the matrix cores; every alternative computes the same function.
+ *   PPO_KERNEL_ROLLOUT_VECTOR   the fused rollout on the vector ALU (rollout2_kernel): logits formed by the same fp32 multiply-adds, in the same order, as
+ *                               ppo_policy_act.  The default rollout16_kernel forms layer 2 and the logits as two-term fp16 products on the matrix cores:
+ *                               its logits agree with ppo_policy_act's to fp32 noise (~1e-7), NOT bit for bit, so an action sampled where the uniform
+ *                               sits within ~1e-6 of a bin edge can differ (measured: <= 2 of 8 192), and its output-layer operand is pre-scaled by 2^8:
+ *                               |W3| >= 255 does not fit fp16 -- the kernel raises the context's error word and ppo_read_stats / ppo_stats_snapshot_read fail with
+ *                               PPO_ERR_STATE (no silent inf / NaN logits).  Use this flag for golden / bit-exact replays and for such weights.
+ *   PPO_KERNEL_UPDATE_VECTOR    the update's forward / backward on the vector ALU (fwd_bwd_kernel) for every shape: plain fp32 arithmetic; also for
+ *                               rehearsals of more than two ranks on ONE GPU (tests/test_gpu_exchange.py).
+ *   PPO_KERNEL_UPDATE_ONE_WAVE  the one-wave-per-tile matrix-core kernel (fwd_bwd_mfma_kernel) instead of the wave-specialised one
+ *                               (fwd_bwd_mfma_ws_kernel) for the reference's two shapes: the A/B partner of the default.
+ *   PPO_KERNEL_COMM_SELFTEST    ppo_comm_init(..., rank 0, nranks 1) really creates a ONE-rank RCCL communicator and every collective of the multi-rank
+ *                               path is really issued (sums over one rank = identity): the only way to drive the RCCL calls -- library lookup,
+ *                               datatype / op enums, stream ordering, the three-kernel optimizer path -- on a box with a single GPU. */
+enum { PPO_KERNEL_ROLLOUT_VECTOR = 1, PPO_KERNEL_UPDATE_VECTOR = 2, PPO_KERNEL_UPDATE_ONE_WAVE = 4, PPO_KERNEL_COMM_SELFTEST = 8 };
 
 /* Scalars the reference prints per update (PPO_Discrete.cpp:700-774) plus per-step diagnostics. */
 typedef struct ppo_stats {

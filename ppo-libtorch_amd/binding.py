@@ -20,7 +20,8 @@ MM_EPI_NONE, MM_EPI_BIAS, MM_EPI_BIAS_TANH, MM_EPI_DTANH = 0, 1, 2, 3
 MM_F32X3, MM_BF16 = 0, 1
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
-ABI_VERSION = 3
+KERNEL_ROLLOUT_VECTOR, KERNEL_UPDATE_VECTOR, KERNEL_UPDATE_ONE_WAVE, KERNEL_COMM_SELFTEST = 1, 2, 4, 8   # ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*)
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 COMM_HANDLE_BYTES = 64
 
@@ -57,7 +58,7 @@ class Config(C.Structure):
                 ("clip_vloss", C.c_int32), ("anneal_lr", C.c_int32), ("seed", C.c_int64), ("total_timesteps", C.c_int64),
                 ("env_offset", C.c_int64), ("global_num_envs", C.c_int64), ("learning_rate", C.c_float), ("gamma", C.c_float),
                 ("gae_lambda", C.c_float), ("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float),
-                ("max_grad_norm", C.c_float), ("compute_dtype", C.c_int32)]
+                ("max_grad_norm", C.c_float), ("compute_dtype", C.c_int32), ("kernel_flags", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -86,7 +87,7 @@ def make_config(env_kind=ENV_CARTPOLE, dist_kind=DIST_CATEGORICAL, obs_size=4, h
                 num_minibatches=4, update_epochs=10, max_episode_steps=500, use_gae=True, norm_adv=True, clip_vloss=True,
                 anneal_lr=True, seed=2, total_timesteps=100000, env_offset=0, global_num_envs=0, learning_rate=1e-3, gamma=0.98,
                 gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, device=0, hidden=64, n_hidden=2,
-                compute_dtype=0):
+                compute_dtype=0, kernel_flags=0):
     """Defaults = Environments/CartPoleRecommendedSettings.toml of the reference with action_size = 2."""
     c = Config()
     c.struct_size = C.sizeof(Config)
@@ -102,6 +103,7 @@ def make_config(env_kind=ENV_CARTPOLE, dist_kind=DIST_CATEGORICAL, obs_size=4, h
     c.learning_rate, c.gamma, c.gae_lambda, c.clip_coef = learning_rate, gamma, gae_lambda, clip_coef
     c.ent_coef, c.vf_coef, c.max_grad_norm = ent_coef, vf_coef, max_grad_norm
     c.compute_dtype = compute_dtype
+    c.kernel_flags = kernel_flags   # KERNEL_*: include/ppo_hip.h PPO_KERNEL_*
     return c
 
 

@@ -167,7 +167,8 @@ struct ppo_ctx {
     float* scratch_obs = nullptr;       // [N,O] staging for AoS<->SoA conversions
     int max_blocks_per_net = 0;
     bool use_mfma = true;
-    bool update_single_wave = false;   // the one-wave-per-tile matrix-core update kernel instead of the wave-specialised one (A/B)
+    bool update_single_wave = false;   // PPO_KERNEL_UPDATE_ONE_WAVE
+    bool rollout_vector = false;       // PPO_KERNEL_ROLLOUT_VECTOR
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
     GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
     uint8_t* cur_mask = nullptr;     // generic path: action mask of the observation in NEXT_OBS, [N, A]
@@ -408,6 +409,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     if (cfg->dist_kind != PPO_DIST_CATEGORICAL && cfg->dist_kind != PPO_DIST_MASKED) return fail(nullptr, PPO_ERR_INVALID, "unknown dist_kind %d", cfg->dist_kind);
     if (cfg->compute_dtype != PPO_DTYPE_F32 && cfg->compute_dtype != PPO_DTYPE_BF16) return fail(nullptr, PPO_ERR_INVALID, "unknown compute_dtype %d", cfg->compute_dtype);
+    if (cfg->kernel_flags & ~(PPO_KERNEL_ROLLOUT_VECTOR | PPO_KERNEL_UPDATE_VECTOR | PPO_KERNEL_UPDATE_ONE_WAVE | PPO_KERNEL_COMM_SELFTEST)) return fail(nullptr, PPO_ERR_INVALID, "unknown bits in kernel_flags 0x%x", cfg->kernel_flags);
     if (cfg->compute_dtype == PPO_DTYPE_BF16 && !generic)
         return fail(nullptr, PPO_ERR_UNSUPPORTED, "compute_dtype = PPO_DTYPE_BF16 applies to networks whose layers are GEMMs (env_kind = PPO_ENV_SYNTHETIC); the reference's "
                     "2 x 64 networks always compute in f32");
@@ -495,12 +497,10 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
     CK(dalloc(c, &c->error_flag, 1));
     c->use_mfma = A <= 4;   // the matrix-core update kernel folds heads of up to 4 logits; wider policies (2 x 64 nets) run the vector kernel
-    {   // diagnostic switch: PPO_UPDATE_KERNEL=valu runs the vector kernel for every shape (A/B; and rehearsals of more than two ranks on ONE GPU, where a
-        // matrix-core workgroup -- a CU's whole register file -- cannot start beside the waiting waves of the other ranks' exchanges: tests/test_gpu_exchange.py)
-        const char* k = getenv("PPO_UPDATE_KERNEL");
-        if (k && std::strcmp(k, "valu") == 0) c->use_mfma = false;
-        if (k && std::strcmp(k, "mfma1") == 0) c->update_single_wave = true;
-    }
+    // ppo_config.kernel_flags (include/ppo_hip.h): the only switch between kernels; nothing is read from the environment
+    if (cfg->kernel_flags & PPO_KERNEL_UPDATE_VECTOR) c->use_mfma = false;
+    c->update_single_wave = (cfg->kernel_flags & PPO_KERNEL_UPDATE_ONE_WAVE) != 0;
+    c->rollout_vector = (cfg->kernel_flags & PPO_KERNEL_ROLLOUT_VECTOR) != 0;
     c->max_blocks_per_net = 512;
     const int Pmax = std::max(c->L.net_size[0], c->L.net_size[1]);
     CK(dalloc(c, &c->slab, (size_t)2 * c->max_blocks_per_net * Pmax));
@@ -990,6 +990,7 @@ extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     a.ep_rew = B_<float>(c, PPO_BUF_EP_REW);
     a.reset_count = B_<int32_t>(c, PPO_BUF_RESET_COUNT);
     a.reset_table = c->reset_table; a.reset_cap = c->reset_cap; a.error_flag = c->error_flag;
+    a.vector_kernel = c->rollout_vector ? 1 : 0;
     a.obs = B_<float>(c, PPO_BUF_OBS);
     a.actions = B_<int32_t>(c, PPO_BUF_ACTIONS);
     a.logprobs = B_<float>(c, PPO_BUF_LOGPROBS);
@@ -1529,6 +1530,9 @@ extern "C" ppo_status ppo_stats_snapshot_read(ppo_ctx* c, ppo_stats* out) {
     c->snap_count -= 1;
     const StatsSnap& h = c->snap[slot];
     if (h.error_flag & 1) return fail(c, PPO_ERR_STATE, "CartPole reset-stream table exhausted (capacity %d resets per env)", c->reset_cap);
+    if (h.error_flag & PPO_ERRFLAG_ROLLOUT_RANGE)
+        return fail(c, PPO_ERR_STATE, "rollout: an output-layer weight of the actor is >= 255 in magnitude and does not fit the fp16 operand of the matrix-core rollout "
+                                      "(its logits are invalid): create the context with PPO_KERNEL_ROLLOUT_VECTOR in ppo_config.kernel_flags");
     if (h.error_flag & PPO_ERRFLAG_UPDATE_PROTOCOL) return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out (gradients of that step are incomplete)");
     if (h.xchg_flag != 0)
         return fail(c, PPO_ERR_COMM, "direct exchange: an all-reduce gave up waiting for a peer after %.1f s; its sums were incomplete, the replicas have "
@@ -1680,11 +1684,9 @@ extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, 
     DeviceGuard dev_guard(c);
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
     NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
-    // PPO_COMM_SELFTEST=1: a ONE-rank communicator is really created and every collective of the multi-rank path is really issued
-    // (sums over one rank = identity).  The only way to drive the RCCL calls -- library lookup, datatype / op enums, stream
-    // ordering, the three-kernel optimizer path -- on a box with a single GPU.
-    const char* st = getenv("PPO_COMM_SELFTEST");
-    const bool selftest = nranks == 1 && st && std::strcmp(st, "1") == 0;
+    // ppo_config.kernel_flags & PPO_KERNEL_COMM_SELFTEST: a ONE-rank communicator is really created and every collective of the multi-rank path is
+    // really issued (sums over one rank = identity): the RCCL calls on a box with a single GPU
+    const bool selftest = nranks == 1 && (c->cfg.kernel_flags & PPO_KERNEL_COMM_SELFTEST) != 0;
     if (nranks == 1 && !selftest) { c->world = 1; c->rank = 0; return PPO_OK; }
     std::string err;
     if (!rccl::load(err)) return fail(c, PPO_ERR_COMM, "%s", err.c_str());

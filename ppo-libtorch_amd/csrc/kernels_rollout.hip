@@ -522,6 +522,9 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
         float w[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) w[r] = e < A ? 256.0f * P[L.w3[1] + e * PPO_HIDDEN + 16 * mw + 4 * kg + r] : 0.0f;   // x 2^8: keeps the small term of a ~1e-3 weight out of fp16's subnormals
+        // the range is checked, not assumed: a weight that does not fit raises the context's error word (reported by ppo_read_stats: the
+        // rollout's logits are then invalid; PPO_KERNEL_ROLLOUT_VECTOR has no such limit)
+        if (fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3]))) >= 65280.0f && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_ROLLOUT_RANGE);
         uint32_t p1a, p2a, p1b, p2b;
         r16_split2(w[0], w[1], p1a, p2a);
         r16_split2(w[2], w[3], p1b, p2b);
@@ -1057,11 +1060,12 @@ hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.N), block(64);
     const dim3 grid2((unsigned)((a.N + 1) / 2));
     const dim3 grid16((unsigned)((a.N + 15) / 16));
-#ifdef ROLLOUT_AB_VALU
-#define PPO_ROLLOUT_FAST(ENV, DIST, OBS, AA) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, AA>), grid2, block, 0, s, a)
-#else
-#define PPO_ROLLOUT_FAST(ENV, DIST, OBS, AA) hipLaunchKernelGGL((rollout16_kernel<ENV, DIST, OBS, AA>), grid16, dim3(384), 0, s, a)
-#endif
+    // ppo_config.kernel_flags & PPO_KERNEL_ROLLOUT_VECTOR: the vector-ALU rollout, whose logits are ppo_policy_act's bit for bit
+#define PPO_ROLLOUT_FAST(ENV, DIST, OBS, AA)                                                                                  \
+    do {                                                                                                                      \
+        if (a.vector_kernel) hipLaunchKernelGGL((rollout2_kernel<ENV, DIST, OBS, AA>), grid2, block, 0, s, a);                \
+        else hipLaunchKernelGGL((rollout16_kernel<ENV, DIST, OBS, AA>), grid16, dim3(384), 0, s, a);                          \
+    } while (0)
 #define PPO_LAUNCH_ROLLOUT(ENV, DIST, OBS)                                                                       \
     do {                                                                                                         \
         if (a.L.n_heads == 1 && a.L.act == 2) PPO_ROLLOUT_FAST(ENV, DIST, OBS, 2);                                \

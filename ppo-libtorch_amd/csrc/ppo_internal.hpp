@@ -514,6 +514,7 @@ struct RolloutArgs {
     int32_t* next_done;    // [N]
     float* next_value;     // [N]
     const int64_t* forced_actions;  // [T,N,H] or null
+    int vector_kernel;     // PPO_KERNEL_ROLLOUT_VECTOR: rollout2_kernel for the single-head shapes
 };
 
 hipError_t launch_rollout(const RolloutArgs& a, hipStream_t s);
@@ -575,6 +576,7 @@ struct UpdateArgs {
     int single_wave;         // 1: the one-wave-per-tile matrix-core kernel even for the reference's two shapes (A/B; ppo_config.kernel_flags)
 };
 constexpr int32_t PPO_ERRFLAG_UPDATE_PROTOCOL = 2;
+constexpr int32_t PPO_ERRFLAG_ROLLOUT_RANGE = 4;   // rollout16_kernel: |W3| does not fit the fp16 operand (pre-scaled by 2^8)
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
 // matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}: fp32 carried as two fp16 terms, three

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(P):
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
     assert [e for e in exported if e.startswith("ppo_")] == decl
     assert all(e.startswith("ppo_") or e.startswith("_") for e in exported)  # nothing else leaks from the C-ABI
-    assert lib.ppo_abi_version() == P.binding.ABI_VERSION == 3
+    assert lib.ppo_abi_version() == P.binding.ABI_VERSION == 4
 
 
 def test_struct_mirrors_match_header(P):
@@ -80,3 +80,18 @@ def test_context_creation_fails_loudly_without_gpu(P):
         pytest.skip("a GPU is present")
     with pytest.raises(P.binding.PPOError):
         P.Context(P.make_config())
+
+
+def test_no_environment_switches_in_product():
+    """Which kernel runs a stage is ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*): the library reads nothing from the environment, and the
+    Python layer only PPO_HIP_LIBRARY (binding.py: which build of the same C-ABI to load) and the rendezvous variables of torch.distributed (dist.py)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "ppo-libtorch_amd", "csrc", "*")) + glob.glob(os.path.join(root, "ppo-libtorch_amd", "host", "**", "*.*"), recursive=True):
+        if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+            assert "getenv" not in open(f).read(), f
+    names = set()
+    for f in ("binding.py", "dist.py", "__init__.py"):
+        names |= set(re.findall(r"environ(?:\.get\(|\[)\s*[\"']([A-Z_0-9]+)", open(os.path.join(root, "ppo-libtorch_amd", f)).read()))
+    assert names <= {"PPO_HIP_LIBRARY", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"}, names

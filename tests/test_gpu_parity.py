@@ -682,6 +682,55 @@ def test_fused_rollout_equals_stepwise_api(P, N):
     b.close()
 
 
+@pytest.mark.parametrize("N", [96, 33])
+def test_vector_rollout_flag_is_bit_exact_with_policy_act(P, N):
+    """ppo_config.kernel_flags & PPO_KERNEL_ROLLOUT_VECTOR (include/ppo_hip.h): the fused rollout on the vector ALU forms its logits with ppo_policy_act's
+    own multiply-adds -- log-probs BIT FOR BIT, and every action the stand-alone sampler draws from the same Philox word is the rollout's (no flips).
+    This is the rollout for golden / bit-exact replays; the default matrix-core rollout agrees to fp32 noise (the test above)."""
+    cfg = dict(num_envs=N, num_steps=40, num_minibatches=1, update_epochs=1, seed=5, max_episode_steps=30)
+    a = P.Context(P.make_config(kernel_flags=P.KERNEL_ROLLOUT_VECTOR, **cfg))
+    b = P.Context(P.make_config(**cfg))
+    a.init_orthogonal(11)
+    params = a.get_params()
+    params[-130:] *= 30.0
+    a.set_params(params)
+    b.set_params(params)
+    a.env_reset()
+    obs = b.env_reset()
+    a.rollout()
+    T = 40
+    r_obs, r_act, r_lp, r_v = a.read("OBS", (T, N, 4)), a.read("ACTIONS", (T, N)), a.read("LOGPROBS", (T, N)), a.read("VALUES", (T, N))
+    for t in range(T):
+        assert np.array_equal(bits(obs), bits(r_obs[t]))
+        act, lp, en, v = b.policy_act(obs, step_index=t)
+        assert np.array_equal(act.ravel(), r_act[t]) and np.array_equal(bits(lp), bits(r_lp[t])) and np.array_equal(bits(v), bits(r_v[t]))
+        obs, _, _ = b.env_step(act)
+    a.close()
+    b.close()
+
+
+def test_matrix_core_rollout_reports_weights_beyond_fp16(P):
+    """The matrix-core rollout's output-layer operand is pre-scaled by 2^8 and cut into fp16 terms: |W3| >= 255 does not fit.  The reference has no such
+    limit, so the kernel checks: such a weight raises the context's error word and the next statistics read fails (PPO_ERR_STATE) instead of sampling
+    from inf / NaN logits; with PPO_KERNEL_ROLLOUT_VECTOR the same weights run."""
+    cfg = dict(num_envs=64, num_steps=8, num_minibatches=1, update_epochs=1, seed=5)
+    for flags, ok in ((0, False), (P.KERNEL_ROLLOUT_VECTOR, True)):
+        ctx = P.Context(P.make_config(kernel_flags=flags, **cfg))
+        ctx.init_orthogonal(3)
+        params = ctx.get_params()
+        params[-130] = 300.0          # one actor output-layer weight (the last 130 floats: actorOutputLayer.weight [2, 64] + bias [2])
+        ctx.set_params(params)
+        ctx.env_reset()
+        ctx.rollout()
+        if ok:
+            assert np.isfinite(ctx.read("LOGPROBS", (8, 64))).all()
+            ctx.stats()
+        else:
+            with pytest.raises(P.binding.PPOError, match="PPO_KERNEL_ROLLOUT_VECTOR"):
+                ctx.stats()
+        ctx.close()
+
+
 @pytest.mark.parametrize("T,limit", [(1, 500), (2, 1), (5, 1), (7, 2), (64, 3), (33, 500)])
 def test_fused_rollout_at_constant_resets_and_short_horizons(P, T, limit):
     """The fused rollout forms the NEXT step's sin / cos a step ahead of the action (CartPole's next pose does not depend on it) with its own copy of
@@ -963,17 +1012,15 @@ def test_sharded_job_statistics_equal_single_context(P, world, N, T, max_steps):
 
 
 def _rccl_selftest_ctx(P, monkeypatch, cfg, selftest):
-    ctx = P.Context(P.make_config(**cfg))
+    ctx = P.Context(P.make_config(kernel_flags=P.KERNEL_COMM_SELFTEST if selftest else 0, **cfg))
     if selftest:
-        monkeypatch.setenv("PPO_COMM_SELFTEST", "1")
         ctx.comm_init(P.comm_unique_id(), 0, 1)
-        monkeypatch.delenv("PPO_COMM_SELFTEST")
     return ctx
 
 
 @pytest.mark.parametrize("epochs,nmb,iters", [(1, 1, 1), (2, 4, 2)])
 def test_rccl_single_rank_selftest(P, monkeypatch, epochs, nmb, iters):
-    """The RCCL calls of the multi-rank path on ONE GPU: with PPO_COMM_SELFTEST=1 a one-rank communicator is really created
+    """The RCCL calls of the multi-rank path on ONE GPU: with PPO_KERNEL_COMM_SELFTEST in ppo_config.kernel_flags a one-rank communicator is really created
     (ncclGetUniqueId / ncclCommInitRank from the dlopen'ed librccl) and every collective of an update really goes through
     ncclAllReduce (f32 gradient + loss-sum tail per optimizer step, f64 statistics block + advantage sums per update), followed by the
     three-kernel optimizer path the ranks of a multi-GPU job take.  Sums over one rank are the identity, so the run must reproduce the

@@ -1,3 +1,4 @@
+"""Diagnostic: distance of the 40 optimizer steps of the headline fixture from the compiled reference, per update kernel (DIAG_KERNEL = ws | mfma1 | valu)."""
 import os, sys, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import test_gpu_headline_ref as H
@@ -6,7 +7,8 @@ P = H.load_package()
 name = "headline_cartpole_4096x128"
 g, meta = H.load(name)
 T, N, O_, A = meta["T"], meta["N"], meta["obs"], meta["act"]; B = T*N; MB = B//meta["nmb"]
-ctx = P.Context(P.make_config(num_envs=N, num_steps=T, num_minibatches=4, update_epochs=10, seed=2, total_timesteps=B, learning_rate=meta["lr"], gamma=meta["gamma"], gae_lambda=meta["lam"]))
+KF = {"ws": 0, "mfma1": P.KERNEL_UPDATE_ONE_WAVE, "valu": P.KERNEL_UPDATE_VECTOR}[os.environ.get("DIAG_KERNEL", "ws")]   # which update kernel: ppo_config.kernel_flags
+ctx = P.Context(P.make_config(num_envs=N, num_steps=T, num_minibatches=4, update_epochs=10, seed=2, total_timesteps=B, learning_rate=meta["lr"], gamma=meta["gamma"], gae_lambda=meta["lam"], kernel_flags=KF))
 ctx.set_params(g["params_before"]); ctx.env_reset()
 actions = (H.mix64(H.SEED_ACT + np.arange(B, dtype=np.uint64)) % np.uint64(A)).astype(np.int64).reshape(T, N, 1)
 ctx.rollout(actions); ctx.calc_advantage(); ctx.set_learning_rate(float(g["lr"][0]))
