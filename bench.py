@@ -225,6 +225,9 @@ def parse_args(argv=None):
                     "exchange only if RCCL cannot be brought up (with --same-device: the exchange, RCCL refuses two ranks on one device); both = RCCL timed as "
                     "`value`, then the exchange timed beside it (`transport_ab`)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses device 0 (exchange transport only)")
+    ap.add_argument("--preflight", action="store_true", help="N > 1: fresh rank processes only create a small context each, bring the RCCL communicator up and run five "
+                    "all-reduces of small integers (checked exactly), then exit: the first minute of a multi-GPU lease says whether the transport works at all, "
+                    "with a reason, before any warm-up is spent")
     ap.add_argument("--kernel-flags", type=int, default=0, help="ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*: 1 vector rollout, 2 vector update, "
                     "4 one-wave matrix-core update): A/B runs of the hand-written kernels; 0 = the defaults")
     ap.add_argument("--profile", type=int, default=-1, help="HIP-event timing inside the timed region: 0 off, 1 every kernel, 2 dominant kernel (1 launch in 8) + GAE, "
@@ -302,6 +305,68 @@ def self_launch(args, argv):
     return rc if rc != 0 else (0 if line is not None else 1)
 
 
+def preflight(P, dist, rank, world, local_rank, args, watchdog):
+    """RCCL first contact, nothing else: a 64-env context per rank, ncclGetUniqueId / ncclCommInitRank, five all-reduces of small integers through the
+    library's own gradient all-reduce (ppo_allreduce_grads: the call a training step makes), each checked exactly, one JSON line from rank 0.  Every
+    stage is agreed over the ranks (gloo), so a failure names its stage and rank instead of hanging its peers; the watchdog covers a hang."""
+    import numpy as np
+    stage, err, ctx = "context", None, None
+    t0 = time.perf_counter()
+
+    def agree(ok_here, what):
+        ok = True if dist is None else P.dist.all_ranks_agree(dist, ok_here)
+        if not ok_here:
+            sys.stderr.write("preflight rank %d: %s failed: %r\n" % (rank, what, err))
+        return ok
+    try:
+        cfg = P.dist.shard_config(P.make_config, rank, world, 64 * world, num_steps=8, num_minibatches=1, update_epochs=1, device=0 if args.same_device else local_rank)
+        ctx = P.Context(cfg)
+    except Exception as ex:
+        err = ex
+    if not agree(err is None, stage):
+        return 5
+    stage = "ncclGetUniqueId / ncclCommInitRank"
+    ident = None
+    if rank == 0:
+        try:
+            ident = P.comm_unique_id()
+        except Exception as ex:
+            err = ex
+    if dist is not None:
+        ident = P.dist.broadcast_bytes(dist, ident, src=0)
+    if err is None:
+        try:
+            if ident is None:
+                raise RuntimeError("rank 0 could not make an RCCL unique id")
+            ctx.comm_init(ident, rank, world)
+        except Exception as ex:
+            err = ex
+    if not agree(err is None, stage):
+        return 6
+    t_up = time.perf_counter() - t0
+    stage = "all-reduce"
+    pattern = (np.arange(ctx.P) % 97).astype(np.float32)
+    try:
+        for rep in range(5):
+            ctx.write("GRADS", pattern * (rank + 1) * (rep + 1))
+            P.binding._check(P.binding.lib().ppo_allreduce_grads(ctx.h), ctx.h)
+            got = ctx.read("GRADS")
+            if not np.array_equal(got, pattern * (rep + 1) * (world * (world + 1) // 2)):
+                raise RuntimeError("all-reduce %d returned wrong sums on rank %d" % (rep, rank))
+    except Exception as ex:
+        err = ex
+    if not agree(err is None, stage):
+        return 7
+    watchdog.disarm()
+    if rank == 0:
+        print(json.dumps({"preflight": "ok", "n_gpus": world, "transport": "rccl" if world > 1 else "none", "bringup_s": t_up,
+                          "allreduces_checked": 5, "payload_floats": int(ctx.P)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+    ctx.close()
+    return 0
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -318,23 +383,39 @@ def main():
 
     # N > 1: nothing between here and the end of the warm-up may hang the job -- a rank that is still bringing its communicator up after
     # --bringup-timeout seconds exits non-zero (torch.distributed.run then ends the other ranks)
-    watchdog = None
-    if world > 1 and args.bringup_timeout > 0:
-        import threading
+    class Watchdog:
+        """Ends this rank (exit code 3) when a bring-up stage is still running after --bringup-timeout seconds; armed around EVERY bring-up -- the
+        first transport's and, with --transport both, the second one's -- and disarmed only while the timed regions run."""
+        def __init__(self):
+            self.t = None
 
-        def give_up():
-            sys.stderr.write("bench.py rank %d: communicator bring-up / warm-up still running after %.0f s -- giving up\n" % (rank, args.bringup_timeout))
-            sys.stderr.flush()
-            os._exit(3)
-        watchdog = threading.Timer(args.bringup_timeout, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        def arm(self, what):
+            self.disarm()
+            if world > 1 and args.bringup_timeout > 0:
+                import threading
+
+                def give_up():
+                    sys.stderr.write("bench.py rank %d: %s still running after %.0f s -- giving up\n" % (rank, what, args.bringup_timeout))
+                    sys.stderr.flush()
+                    os._exit(3)
+                self.t = threading.Timer(args.bringup_timeout, give_up)
+                self.t.daemon = True
+                self.t.start()
+
+        def disarm(self):
+            if self.t is not None:
+                self.t.cancel()
+                self.t = None
+    watchdog = Watchdog()
+    watchdog.arm("communicator bring-up / warm-up")
 
     from __graft_entry__ import load_package
     P = load_package()
     dist = None
     if world > 1:
         dist, rank, world = P.dist.init_process_group("gloo")  # plumbing only: rendezvous, id broadcast, barrier, max over ranks
+    if args.preflight:
+        sys.exit(preflight(P, dist, rank, world, local_rank, args, watchdog))
     obs, heads = W["obs"], W["heads"]
     act = sum(heads)
     N, T = args.envs or W["envs"], args.num_steps
@@ -375,6 +456,14 @@ def main():
         except Exception as ex:
             err = ex
         if world > 1:
+            # stage 1: every rank has its context (device, buffers) before anyone enters ncclCommInitRank -- a rank that failed here would leave its
+            # peers blocked inside it until the watchdog fires
+            if not P.dist.all_ranks_agree(dist, err is None):
+                if err is not None:
+                    sys.stderr.write("rank %d: context creation failed (%r)\n" % (rank, err))
+                if c is not None:
+                    c.close()
+                return None, repr(err) if err is not None else "a peer failed to create its context"
             ident = None
             if rank == 0 and err is None:
                 try:
@@ -416,8 +505,13 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             c.train_iteration()
-        barrier()
+        c.sync()
+        dt_own = time.perf_counter() - t0      # this rank's own K steps, before it waits for the others
+        if dist is not None:
+            dist.barrier()
+        c.sync()
         dt = time.perf_counter() - t0
+        rank_times.append(dt_own)
         if dist is not None:
             dt = P.dist.max_over_ranks(dist, dt)
             if not P.dist.all_ranks_agree(dist, c.comm_exchange_timeouts() == 0):
@@ -426,6 +520,7 @@ def main():
                 os._exit(4)
         return dt
 
+    rank_times = []   # this rank's own seconds for the K steps of each timed() call
     requested = args.transport
     fallback_reason = args.fallback_reason
     if world == 1:
@@ -449,8 +544,7 @@ def main():
             ctx = start_exchange()
             if ctx is None:
                 sys.exit("direct-exchange transport failed its start-up checks")
-    if watchdog is not None:
-        watchdog.cancel()
+    watchdog.disarm()
 
     if args.profile < 0:
         args.profile = 4 if args.steps >= 20 else 2
@@ -459,12 +553,26 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(0)
     st = ctx.stats()
+    # N > 1: what every rank measured by itself, so that a scaling record can be read in one pass -- its own time for the K steps (min / max show a
+    # straggler) and the device time of its gradient all-reduces (HIP events around the collective on the context's stream: the wait for the slowest
+    # peer is inside)
+    per_rank = None
+    if dist is not None:
+        ar_n = prof["allreduce_launches"]
+        rows = P.dist.values_of_ranks(dist, [1e3 * rank_times[0] / args.steps, (1e3 * prof["allreduce_ms"] / ar_n) if ar_n else -1.0, float(ar_n)])
+        per_rank = {"rank_ms_per_step": [r[0] for r in rows], "rank_ms_per_step_min": min(r[0] for r in rows), "rank_ms_per_step_max": max(r[0] for r in rows),
+                    "allreduce_us_per_call": [r[1] if r[1] >= 0 else None for r in rows], "allreduce_calls_sampled": [int(r[2]) for r in rows],
+                    "allreduce_us_per_step": [(40 * r[1]) if r[1] >= 0 else None for r in rows],
+                    "note": "allreduce_us_per_call: HIP events around one gradient all-reduce in 41 (every optimizer step has one; x 40 = per bench step); the "
+                            "statistics all-reduce (one per update) is not in it"}
 
     # opt-in A/B: the same K steps on the one-shot direct exchange, in a second context, after the RCCL number is in hand
     transport_ab = None
     if world > 1 and requested == "both":
         try:
+            watchdog.arm("the second transport's bring-up (--transport both)")
             cx = start_exchange()
+            watchdog.disarm()
             if cx is None:
                 transport_ab = {"transport": "exchange", "failed": "start-up checks"}
             else:
@@ -556,7 +664,7 @@ def main():
             "dtype": "bf16" if generic else "f32 (update GEMMs: two-term f16 split on f16 MFMA, fp32 accumulate; everything else IEEE f32)",
             # the gradient all-reduce that ran (N > 1), what was asked for, and why they differ if they do
             "transport": transport, "transport_requested": requested if world > 1 else None, "transport_fallback_reason": fallback_reason,
-            "comm_ranks": world, "transport_ab": transport_ab,
+            "comm_ranks": world, "transport_ab": transport_ab, "per_rank": per_rank,
             "data": "synthetic (counter-based env, random-init 4x256 actor/critic)" if generic else "synthetic (fixed-seed %s, random-init 2x64 actor/critic)" % ("CartPole-v1" if args.workload == "cartpole" else "MountainCar"),
             "config": {"workload": (W["label"] % (N, T)) + " (BASELINE.json configs[%d]%s)" % (W["cfg1"] if world == 1 else W["cfg8"], ", one GPU's share" if generic and world == 1 else ""),
                        "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,

@@ -297,6 +297,8 @@ typedef struct ppo_profile {
     int64_t fwd_bwd_launches, gae_launches, rollout_launches, optimizer_launches, reduce_launches;
     double fwd_bwd_ms, gae_ms, rollout_ms, optimizer_ms, reduce_ms;   /* summed over the launches since enable/read */
     double phase_cycles[24];  /* mode 3: [critic, actor][12 phases] shader cycles of one wave of the dominant kernel */
+    int64_t allreduce_launches;   /* N > 1: gradient / statistics all-reduces bracketed (every one in mode 1; in modes 2 and 4 the one behind a bracketed */
+    double allreduce_ms;          /* dominant-kernel launch): the collective's device time on THIS rank, waiting for the slowest peer included */
 } ppo_profile;
 /* on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fused forward/backward; ONE launch in 8 is bracketed: an
  * event pair costs the stream ~3 us, 40 pairs per update were 8 % of the run) and the GAE scan,

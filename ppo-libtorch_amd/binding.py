@@ -75,7 +75,8 @@ class Stats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("fwd_bwd_launches", C.c_int64), ("gae_launches", C.c_int64), ("rollout_launches", C.c_int64),
                 ("optimizer_launches", C.c_int64), ("reduce_launches", C.c_int64), ("fwd_bwd_ms", C.c_double), ("gae_ms", C.c_double),
-                ("rollout_ms", C.c_double), ("optimizer_ms", C.c_double), ("reduce_ms", C.c_double), ("phase_cycles", C.c_double * 24)]
+                ("rollout_ms", C.c_double), ("optimizer_ms", C.c_double), ("reduce_ms", C.c_double), ("phase_cycles", C.c_double * 24),
+                ("allreduce_launches", C.c_int64), ("allreduce_ms", C.c_double)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "phase_cycles"}

@@ -177,6 +177,7 @@ struct ppo_ctx {
     int last_n_blocks[2] = { 0, 0 };
     int prof_every = 1;              // mode 2: bracket one update-kernel launch in prof_every (an event pair costs the stream ~3 us)
     int64_t prof_count = 0;
+    bool prof_last_sampled = false;   // the last update launch was bracketed: so is the all-reduce that follows it
     bool stamping = false;           // diagnostic flavour of the update kernel (in-kernel phase stamps)
 
     // host-side training state
@@ -205,7 +206,7 @@ struct ppo_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 
-enum { PROF_FWD_BWD = 0, PROF_GAE, PROF_ROLLOUT, PROF_OPT, PROF_REDUCE, PROF_KINDS_ };
+enum { PROF_FWD_BWD = 0, PROF_GAE, PROF_ROLLOUT, PROF_OPT, PROF_REDUCE, PROF_ALLREDUCE, PROF_KINDS_ };
 
 struct ProfScope {
     ppo_ctx* c;
@@ -1086,6 +1087,9 @@ static AdamCoef adam_coef(double lr, int64_t t) {
 
 static ppo_status allreduce_sum(ppo_ctx* c, void* buf, size_t count, bool f64) {
     if (c->world <= 1 && !c->force_collectives) return PPO_OK;
+    // bracketed like the dominant kernel: every call in mode 1, otherwise the one that follows a bracketed update launch
+    ProfScope ps(c, PROF_ALLREDUCE, c->prof_every <= 1 || c->prof_last_sampled);
+    c->prof_last_sampled = false;
     if (c->xchg) {
         ExchangeComm& x = *c->xchg;
         const size_t bytes = count * (f64 ? 8 : 4);
@@ -1280,7 +1284,8 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     if (c->use_mfma) update_blocks_mfma((int)M, a.n_blocks);
     else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
-        ProfScope ps(c, PROF_FWD_BWD, c->prof_every <= 1 || (c->prof_count++ % c->prof_every) == c->prof_every / 2);
+        c->prof_last_sampled = c->prof_every <= 1 || (c->prof_count++ % c->prof_every) == c->prof_every / 2;
+        ProfScope ps(c, PROF_FWD_BWD, c->prof_last_sampled);
         if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
         else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
@@ -1622,7 +1627,7 @@ extern "C" ppo_status ppo_profile_enable(ppo_ctx* c, int32_t on) {
     //     3 = in-kernel phase stamps of the dominant kernel (diagnostic variant: read its SHARES, never its run time),
     //     4 = as 2 with one launch in 41 (about one per update, a different step of the update every time)
     const bool sampled = on == 2 || on == 4;
-    c->profiling = (on == 0 || on == 3) ? 0u : (sampled ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE)) : 0xffffffffu);
+    c->profiling = (on == 0 || on == 3) ? 0u : (sampled ? ((1u << PROF_FWD_BWD) | (1u << PROF_GAE) | (1u << PROF_ALLREDUCE)) : 0xffffffffu);
     c->prof_every = on == 2 ? 8 : (on == 4 ? 41 : 1);   // modes 2 / 4 sample the update kernel (5 / ~1 of an update's 40 launches), every GAE launch
     c->prof_count = 0;
     c->stamping = on == 3;
@@ -1646,8 +1651,8 @@ extern "C" ppo_status ppo_profile_read(ppo_ctx* c, ppo_profile* out) {
         const ppo_status hs = comm_health(c);
         if (hs != PPO_OK) return hs;
     }
-    int64_t* cnt[PROF_KINDS_] = { &out->fwd_bwd_launches, &out->gae_launches, &out->rollout_launches, &out->optimizer_launches, &out->reduce_launches };
-    double* ms[PROF_KINDS_] = { &out->fwd_bwd_ms, &out->gae_ms, &out->rollout_ms, &out->optimizer_ms, &out->reduce_ms };
+    int64_t* cnt[PROF_KINDS_] = { &out->fwd_bwd_launches, &out->gae_launches, &out->rollout_launches, &out->optimizer_launches, &out->reduce_launches, &out->allreduce_launches };
+    double* ms[PROF_KINDS_] = { &out->fwd_bwd_ms, &out->gae_ms, &out->rollout_ms, &out->optimizer_ms, &out->reduce_ms, &out->allreduce_ms };
     for (auto& sp : c->spans) {
         float t = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&t, sp.a, sp.b));

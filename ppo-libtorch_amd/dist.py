@@ -8,10 +8,13 @@ id, barriers and the max-over-ranks of the timing.
 """
 import os
 
-# HIP IPC between processes (RCCL's intra-node transport and the direct exchange's peer buffers) needs dmabuf IPC on hosts whose driver supports
-# nothing else; without it hipIpcGetMemHandle / ncclCommInitRank fail with "invalid argument".  It must be in the environment before the process's
-# first HIP call, which is why it is set where the multi-process path is imported, not where a communicator is made.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+def enable_dmabuf_ipc():
+    """HIP IPC between processes (RCCL's intra-node transport and the direct exchange's peer buffers) needs dmabuf IPC on hosts whose driver supports
+    nothing else; without it hipIpcGetMemHandle / ncclCommInitRank fail with "invalid argument".  It must be in the environment before the process's
+    first HIP call: init_process_group() sets it for world > 1 (the multi-rank path only -- importing this module changes nothing for a single-GPU
+    user), and a launcher should put it into the ranks' environment itself (bench.py does)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def shard_envs(global_num_envs, rank, world):
@@ -55,6 +58,8 @@ def init_process_group(backend="gloo"):
     os.environ.setdefault("MASTER_PORT", "29500")
     if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.exists("/sys/class/net/lo"):
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: gloo must not depend on the host name resolving
+    if world > 1:
+        enable_dmabuf_ipc()
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist, rank, world
@@ -97,6 +102,15 @@ def all_ranks_agree(dist, ok):
     t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(t.item() > 0.5)
+
+
+def values_of_ranks(dist, values):
+    """A short list of floats from every rank, in rank order, on every rank (per-rank timings of a bench line)."""
+    import torch
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.tolist()] for t in out]
 
 
 def max_over_ranks(dist, value):
