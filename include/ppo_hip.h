@@ -277,7 +277,12 @@ PPO_API ppo_status ppo_train_iteration(ppo_ctx* ctx);
  * (pg / value / entropy loss, approx-KL, clipfrac, grad norm) ride the gradient all-reduce; the explained-variance sums (:647-648) and every
  * rank's ring of finished episodes, each episode tagged with its position in the reference's push order (step, then global env index; :474-480),
  * ride the per-update all-reduce of the advantage sums, and the host rebuilds the job's CircularBuffer(100) from the union: ep_rew_mean /
- * ep_len_mean / ep_count are what ONE context over all envs would report.  They describe the state at the last ppo_update. */
+ * ep_len_mean / ep_count are what ONE context over all envs would report.  They describe the state at the last ppo_update: episodes that end in
+ * a rollout taken AFTER it are not in them yet -- unlike a single context (one rank), whose episode ring is read as it stands.  ppo_comm_init
+ * refuses more than 8 ranks (the block holds 8 slots: one node).  While a snapshot is pending (ppo_stats_snapshot) ppo_read_stats fails: read it first.
+ * Device-side error words (reset table exhausted, fp16 range of the matrix-core rollout, a bounded wait of the update kernel) surface here and in
+ * ppo_stats_snapshot_read as PPO_ERR_STATE; a host that runs an iteration ahead of its snapshots (the facade's train()) learns of them one
+ * iteration late and must check the snapshot before it writes a checkpoint (it does). */
 PPO_API ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
 /* The same read in two steps, for a host that prints a table per update (printPPOResults, :700-774) and must not drain the GPU to do it:
  * ppo_stats_snapshot enqueues, behind the work enqueued so far, asynchronous copies of everything the statistics are made of into one pinned block

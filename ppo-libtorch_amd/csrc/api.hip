@@ -1688,6 +1688,7 @@ extern "C" ppo_status ppo_comm_init(ppo_ctx* c, const void* id_h, int32_t rank, 
     NEED(c, c && id_h, "null argument");
     DeviceGuard dev_guard(c);
     NEED(c, nranks >= 1 && rank >= 0 && rank < nranks, "bad rank / nranks");
+    NEED(c, nranks <= 8, "more than 8 ranks: the job-global statistics block (ppo_read_stats) and the transports serve the 8 GPUs of one node");
     NEED(c, c->cfg.global_num_envs == (int64_t)c->cfg.num_envs * nranks, "global_num_envs must equal num_envs * nranks (equal shards)");
     // ppo_config.kernel_flags & PPO_KERNEL_COMM_SELFTEST: a ONE-rank communicator is really created and every collective of the multi-rank path is
     // really issued (sums over one rank = identity): the RCCL calls on a box with a single GPU

@@ -306,6 +306,10 @@ struct Archive {
             numel *= d;
         }
         if (offset < 0 || numel > storage_numel) fail(file, name + ": more elements than its storage record holds");
+        // a stride no honest view needs (every index x stride product then stays far inside int64: the element loop cannot overflow before its bound check)
+        for (int64_t st : strides)
+            if (st < -storage_numel || st > storage_numel) fail(file, name + ": stride outside its storage");
+        if (offset > storage_numel) fail(file, name + ": offset outside its storage");
         t.values.resize((size_t)numel);
         std::vector<int64_t> idx(t.sizes.size(), 0);
         for (int64_t e = 0; e < numel; e++) {
