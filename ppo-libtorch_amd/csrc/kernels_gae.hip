@@ -61,6 +61,9 @@ __device__ __forceinline__ int strip_of_block(int b, int grid) {
     return (((k >> 1) << 3) + xcd) * 2 + (k & 1);
 }
 
+#ifndef GAE_NO_PIPELINE
+#define GAE_NO_PIPELINE 0   /* -DGAE_NO_PIPELINE=1: the walk without software-pipelined LDS reads (A/B) */
+#endif
 // MODE 0: GAE.  MODE 1: n-step returns (PPO_Discrete.cpp:309-329: ret_t = r_t + (gamma*nnt_t)*ret_{t+1}; adv = ret - v).
 template <int EPB, int MODE, bool VEC, bool FAST = false>
 __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
@@ -191,6 +194,29 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
             if (k == 0) sCarry[(tile_par ^ 1) * EPB + c] = x;   // A of the tile's first row: the carry of the next (earlier) tile
             tile_par ^= 1;
             (void)r_hi; (void)r_lo;
+        } else if (walker && rows == GAE_TC && !GAE_NO_PIPELINE) {
+            // full tile: the chunks' LDS reads are software-pipelined -- chunk k + 1's 32 reads are in flight while chunk k's 16-step chain runs, so
+            // only the chain itself (2 dependent operations per row) and the first chunk's read latency are serial
+            float last = carry;
+            float d[2][GAE_WALK], cc[2][GAE_WALK];
+#pragma unroll
+            for (int i = 0; i < GAE_WALK; i++) { d[0][i] = sA[(GAE_TC - 1 - i) * EPB + tid]; cc[0][i] = sC[(GAE_TC - 1 - i) * EPB + tid]; }
+#pragma unroll
+            for (int k = 0; k < GAE_TC / GAE_WALK; k++) {
+                const int cur = k & 1, nxt = cur ^ 1, r = GAE_TC - k * GAE_WALK;
+                if (k + 1 < GAE_TC / GAE_WALK) {
+#pragma unroll
+                    for (int i = 0; i < GAE_WALK; i++) { d[nxt][i] = sA[(r - GAE_WALK - 1 - i) * EPB + tid]; cc[nxt][i] = sC[(r - GAE_WALK - 1 - i) * EPB + tid]; }
+                }
+#pragma unroll
+                for (int i = 0; i < GAE_WALK; i++) {
+                    last = d[cur][i] + cc[cur][i] * last;
+                    d[cur][i] = last;
+                }
+#pragma unroll
+                for (int i = 0; i < GAE_WALK; i++) sA[(r - 1 - i) * EPB + tid] = d[cur][i];
+            }
+            carry = last;
         } else if (walker) {
             float last = carry;
             int r = rows;

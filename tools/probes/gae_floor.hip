@@ -59,6 +59,42 @@ __global__ __launch_bounds__(256) void column_kernel(const float* __restrict__ r
     }
 }
 
+// chain_kernel: the scan's strip decomposition with NO global traffic -- the tile's delta / coefficient rows are made in LDS by the workgroup itself,
+// then one lane per env column walks the 128-step chain A_t = d_t + c_t * A_{t+1} exactly as kernels_gae.hip does (two separately rounded operations
+// per row, LDS reads of the next 16 rows in flight while a chunk's chain runs), then one store per column keeps the result alive.
+// chain_us - empty_us = what the serial walk costs when nothing else is in its way: the part of the scan no overlap can remove besides the memory
+// round trip of its FIRST rows and the drain of its LAST ones (column_us is that round trip + drain).
+template <int EPB>
+__global__ __launch_bounds__(256) void chain_kernel(float* __restrict__ o1, int N, float seed) {
+    __shared__ __attribute__((aligned(16))) float sA[128 * EPB], sC[128 * EPB];
+    const int tid = threadIdx.x, n0 = blockIdx.x * EPB;
+    for (int e = tid; e < 128 * EPB; e += 256) { sA[e] = seed + (float)(e & 7); sC[e] = (e & 31) ? 0.931f : 0.0f; }
+    __syncthreads();
+    if (tid < EPB) {
+        float last = 0.0f;
+        float d[2][16], cc[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { d[0][i] = sA[(127 - i) * EPB + tid]; cc[0][i] = sC[(127 - i) * EPB + tid]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int cur = k & 1, nxt = cur ^ 1, r = 128 - k * 16;
+            if (k + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) { d[nxt][i] = sA[(r - 17 - i) * EPB + tid]; cc[nxt][i] = sC[(r - 17 - i) * EPB + tid]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float m = cc[cur][i] * last;          // separately rounded, like the reference's tensor expression (-ffp-contract=off)
+                last = d[cur][i] + m;
+                d[cur][i] = last;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) sA[(r - 1 - i) * EPB + tid] = d[cur][i];
+        }
+        o1[n0 + tid] = last;
+    }
+}
+
 int main(int argc, char** argv) {
     std::vector<int> sizes;
     for (int i = 1; i < argc; i++) sizes.push_back(atoi(argv[i]));
@@ -90,9 +126,12 @@ int main(int argc, char** argv) {
         const double t_stream = timeit([&] { hipLaunchKernelGGL(stream_kernel, dim3(g_stream), dim3(256), 0, s, (const float4*)r, (const float4*)v, (const float4*)d, (float4*)o1, (float4*)o2, n / 4); });
         const double t_col = N >= 8192 ? timeit([&] { hipLaunchKernelGGL(column_kernel<32>, dim3(N / 32), dim3(256), 0, s, r, v, d, o1, o2, T, N); })
                                        : timeit([&] { hipLaunchKernelGGL(column_kernel<16>, dim3(N / 16), dim3(256), 0, s, r, v, d, o1, o2, T, N); });
+        const double t_chain = N >= 8192 ? timeit([&] { hipLaunchKernelGGL(chain_kernel<32>, dim3(N / 32), dim3(256), 0, s, o1, N, 0.5f); })
+                                         : timeit([&] { hipLaunchKernelGGL(chain_kernel<16>, dim3(N / 16), dim3(256), 0, s, o1, N, 0.5f); });
         const double bytes = 20.0 * n;
         printf("{\"N\": %d, \"T\": %d, \"bytes\": %.0f, \"empty_us\": %.2f, \"stream_us\": %.2f, \"stream_GBs\": %.0f, \"column_us\": %.2f, \"column_GBs\": %.0f, "
-               "\"us_at_40pct_of_8TBs\": %.2f}\n", N, T, bytes, t_empty, t_stream, bytes / t_stream / 1e3, t_col, bytes / t_col / 1e3, bytes / 3.2e12 * 1e6);
+               "\"chain_us\": %.2f, \"chain_minus_empty_us\": %.2f, \"column_plus_chain_us\": %.2f, \"us_at_40pct_of_8TBs\": %.2f}\n", N, T, bytes, t_empty, t_stream,
+               bytes / t_stream / 1e3, t_col, bytes / t_col / 1e3, t_chain, t_chain - t_empty, t_col + (t_chain - t_empty), bytes / 3.2e12 * 1e6);
         CK(hipFree(r)); CK(hipFree(v)); CK(hipFree(d)); CK(hipFree(o1)); CK(hipFree(o2));
     }
     return 0;
