@@ -115,6 +115,18 @@ def curve_parity_summary():
         return None
 
 
+def c4_traffic():
+    f = newest_profile("_config4_traffic.json")
+    if not f:
+        return None
+    try:
+        with open(f) as fh:
+            d = json.load(fh)
+        return {"bytes_per_minibatch_step": d["bytes_per_minibatch_step"], "read": d["read_per_step"], "write": d["write_per_step"], "source": "profiles/" + os.path.basename(f)}
+    except Exception:
+        return None
+
+
 def committed_jsonl(suffix):
     f = newest_profile(suffix)
     if not f:
@@ -640,7 +652,9 @@ def main():
             roof = {"kernel": "one minibatch step of the generic path (gather, 10 forward + 18 backward layer products on gemm_kernel with fused bias / tanh / tanh' / "
                               "bias-gradient epilogues, heads + PPO loss): bf16 operands and activations, f32 accumulation", "bound": "mfma",
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None, "traffic": None}
+                    "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
+                    # HBM bytes of one minibatch step: the committed --pmc measurement of this workload (tools/collect_profiles.sh, tools/c4_traffic.py)
+                    "traffic": (c4_traffic() or {}).get("bytes_per_minibatch_step"), "traffic_detail": c4_traffic()}
         else:
             # what the matrix cores execute per 32-sample tile and net in fwd_bwd_mfma_ws_kernel: 82 v_mfma_f32_32x32x16_f16 (layer 1 with
             # its bias 6, the layer-2 bias 2, layer 2 / d(hidden) / dW2 24 each -- three f16 products per fp32 product --, dz2 2 [6 beyond two logits]) and

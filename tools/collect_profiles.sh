@@ -47,5 +47,17 @@ fi
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/c4_trace" -o run -- python3 $ROOT/tools/config4_bench.py > "$OUT/c4_bench.json" 2> "$OUT/c4_trace.log"
 cp "$(find "$OUT/c4_trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_config4_kernel_stats.csv"
 tail -n 1 "$OUT/c4_bench.json" > "$ROOT/profiles/${TAG}_config4_bench.json"
+# the same share under the memory counters (separate passes, counters only): HBM bytes per minibatch step of the generic path = the sum over its
+# kernels of bytes per dispatch x dispatches per step (tools/c4_traffic.py) -> bench.py --workload config4 reports it as roofline.traffic
+j=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+    j=$((j + 1))
+    rocprofv3 --pmc $set -f csv -d "$OUT/c4_pmc$j" -o run -- python3 $ROOT/tools/config4_bench.py > "$OUT/c4_pmc$j.log" 2>&1 || echo "config4 pmc pass $j FAILED"
+done
+python3 $ROOT/tools/pmc_summary.py "$OUT/c4_pmc_per_dispatch.json" "$OUT"/c4_pmc* > "$OUT/c4_pmc_summary.txt"
+python3 $ROOT/tools/c4_traffic.py "$OUT/c4_pmc_per_dispatch.json" "$ROOT/profiles/${TAG}_config4_kernel_stats.csv" > "$ROOT/profiles/${TAG}_config4_traffic.json"
+# the wave-specialised update kernel's wait shares (diagnostic build, if present) and the learning-curve comparison
+if [ -f $ROOT/build_ab/libppo_hip_ws_stamp.so ]; then PPO_HIP_LIBRARY=$ROOT/build_ab/libppo_hip_ws_stamp.so python3 $ROOT/tools/ws_stamps.py > "$ROOT/profiles/${TAG}_ws_stamps.txt" 2>&1 || true; fi
+python3 $ROOT/tests/test_gpu_curves.py > "$ROOT/profiles/${TAG}_curves.json" 2> "$OUT/curves.err" || echo "curves FAILED"
 cp "$ROOT"/profiles/${TAG}_* "$OUT/"
 echo done

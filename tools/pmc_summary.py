@@ -11,7 +11,7 @@ coalesced 64 MiB stream reports exactly half (x2 confirmed), the gather reports 
 64-byte sectors (8.4 MB useful) -- one 64-byte request per record, counted at its size -- so gather kernels get x1, and both
 readings are kept in the JSON (`hbm_read_bytes_x1`, `hbm_read_bytes_x2`).
 """
-GATHER_KERNELS = ("fwd_bwd_mfma_kernel", "gather_read")
+GATHER_KERNELS = ("fwd_bwd_mfma_kernel", "fwd_bwd_mfma_ws_kernel", "gather_read")
 import csv
 import glob
 import json
