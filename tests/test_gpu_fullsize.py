@@ -123,3 +123,28 @@ def test_config3_mountaincar_masked_8192x128(P):
     # max_episode_steps 100 instead of the env's 200: a random policy never reaches the flag inside 128 steps, and the time-limit
     # truncation + auto-reset path should be part of the run
     _run(P, P.ENV_MOUNTAINCAR, P.DIST_MASKED, 2, 3, 8192, 128, 100, O.mountaincar_step, 0.99, 0.95, 1)
+
+
+@pytest.mark.parametrize("mountaincar", [False, True])
+def test_update_is_a_function_of_its_inputs_at_full_size(P, mountaincar):
+    """The wave-specialised update kernel hands tiles from forward waves to gradient waves through LDS event counters (no sanitizer exists for the GPU
+    side).  Two contexts with identical state train side by side at the headline size -- their kernels interleave differently on the chip every time --
+    and after every iteration their parameters agree BIT FOR BIT: a race in the hand-over would show as a difference, and the fixed summation orders make
+    the result a function of the inputs alone (tools/soak_ws.py is the long version: 400 iterations)."""
+    kw = dict(num_steps=128, num_minibatches=4, update_epochs=10, seed=2, total_timesteps=30 * 4096 * 128, learning_rate=1e-3, gamma=0.98, gae_lambda=0.95)
+    if mountaincar:
+        kw.update(env_kind=P.ENV_MOUNTAINCAR, dist_kind=P.DIST_MASKED, obs_size=2, head_dims=(3,), num_envs=8192, max_episode_steps=200, ent_coef=0.01)
+    else:
+        kw.update(num_envs=4096, max_episode_steps=500)
+    a, b = P.Context(P.make_config(**kw)), P.Context(P.make_config(**kw))
+    for x in (a, b):
+        x.init_orthogonal(2)
+        x.env_reset()
+    for i in range(12):
+        a.train_iteration()
+        b.train_iteration()
+        pa, pb = a.get_params(), b.get_params()
+        assert np.array_equal(bits(pa), bits(pb)), (i, int((pa != pb).sum()))
+    assert np.isfinite(a.stats()["loss"])
+    a.close()
+    b.close()
