@@ -556,8 +556,9 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
                 CK(dalloc(c, &g.dz_bf[1][i], RB * g.ld_h));
                 CK(dalloc(c, &g.dout_bf[i], RB * 128));
             }
-            CK(dalloc(c, &g.cs_part[0], (R / 128 + 1) * g.ld_h));
-            CK(dalloc(c, &g.cs_part[1], (R / 128 + 1) * g.ld_h));
+            g.cs_layer_stride = (int64_t)(R / 128 + 1) * g.ld_h;
+            CK(dalloc(c, &g.cs_part[0], (size_t)GL.n_layers * g.cs_layer_stride));
+            CK(dalloc(c, &g.cs_part[1], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.head_db_part, (size_t)GEN_LOSS_BLOCKS * (GL.act + 1)));
         } else {
             for (int net = 0; net < 2; net++)
@@ -579,9 +580,12 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             int64_t mx = 0;
             for (int l = 0; l < GL.n_layers; l++) mx = std::max<int64_t>(mx, (int64_t)std::max(GL.out_dim[0][l], GL.out_dim[1][l]) * (GL.in_dim[l] + 1));
             g.wslab_stride = (mx + 3) & ~3ll;
-            CK(dalloc(c, &g.wslab, (size_t)(GEN_SPLIT_MFMA + 1) * g.wslab_stride));
+            // bf16 storage: a block of slabs per layer (a net's slab sums are ONE launch behind its backward pass: 10 launches less per minibatch step);
+            // 5 layers x 129 slabs x 386 KB x 2 nets = 0.5 GB of 288
+            g.wslab_layer_stride = (int64_t)(GEN_SPLIT_MFMA + 1) * g.wslab_stride;
+            CK(dalloc(c, &g.wslab, (size_t)(g.bf16 ? GL.n_layers : 1) * g.wslab_layer_stride));
             if (g.bf16) {
-                CK(dalloc(c, &g.wslab1, (size_t)(GEN_SPLIT_MFMA + 1) * g.wslab_stride));
+                CK(dalloc(c, &g.wslab1, (size_t)GL.n_layers * g.wslab_layer_stride));
                 CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
                 CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
                 CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));

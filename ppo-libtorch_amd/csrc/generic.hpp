@@ -72,7 +72,9 @@ struct GenericCtx {
     uint8_t* row_mask = nullptr;   // gathered masks [rows_max, act]
     double* loss_part = nullptr;   // [GEN_LOSS_BLOCKS, 8] partial loss sums
     float* wslab = nullptr;        // [GEN_SPLIT + 1][max over layers of out * in + out]: row-chunk partials of one layer's dW | db
-    float* wslab1 = nullptr;       // bf16 storage: the actor's own slab set (its backward pass runs beside the critic's)
+    float* wslab1 = nullptr;       // bf16 storage: the actor's own slab set (its backward pass runs beside the critic's); with bf16 storage a slab set holds
+                                   // one block of (GEN_SPLIT_MFMA + 1) slabs PER LAYER (wslab_layer_stride apart)
+    int64_t wslab_layer_stride = 0;
     int64_t wslab_stride = 0;
     float* db_part = nullptr;      // [GEN_DB_CHUNKS][max out]: row-chunk partials of one layer's bias gradient
     // ---- bf16 storage (ppo_config.compute_dtype = PPO_DTYPE_BF16): layer inputs, hidden activations and back-propagated gradients live in HBM
@@ -84,7 +86,9 @@ struct GenericCtx {
     uint16_t* tmp_bf[2] = {};      // [.][ld_h] ping-pong activations of a forward pass that keeps nothing (rollout step, critic batch)
     uint16_t* dz_bf[2][2] = {};    // [net][.] [.][ld_h] ping-pong d(pre-activation); one pair per net: the two backward passes run on two streams
     uint16_t* dout_bf[2] = {};     // [net] [.][128] d(loss)/d(value), d(loss)/d(logits); zero beyond the head's width
-    float* cs_part[2] = {};        // [net] [rows_max / 128][ld_h] per-m-tile column sums of a d(pre-activation) (the next bias gradient)
+    float* cs_part[2] = {};        // [net] [layer][rows_max / 128 + 1][ld_h] per-m-tile column sums of a d(pre-activation) (the next bias gradient); one block per layer,
+                                   // so that a net's slab sums can run as ONE launch behind its backward pass
+    int64_t cs_layer_stride = 0;   // floats between two layers' blocks
     float* head_db_part = nullptr; // [GEN_LOSS_BLOCKS][act + 1] block sums of d(loss)/d(logits) | d(value) (the head layers' bias gradients)
     int64_t* act64 = nullptr;      // [N, n_heads] actions of the current rollout step (int64, the stand-alone API's type)
     float* step_lp = nullptr;      // [N] log-prob / entropy of the current rollout step

@@ -546,6 +546,40 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     }
 }
 
+// The same sums for every layer of a net in ONE launch (bf16 storage: each layer has its own slab block): blockIdx.y = layer.
+struct SlabJob { const float* slab; const float* db_part; float* gw; float* gb; int64_t n_w, n_b, db_stride; int S, db_chunks; };
+struct SlabJobs { SlabJob j[GEN_MAX_LAYERS]; int64_t slab_stride; };
+__global__ __launch_bounds__(256) void slab_sum_layers_kernel(SlabJobs jobs) {
+    __shared__ float red[4][64];
+    const SlabJob& J = jobs.j[blockIdx.y];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
+    if ((int64_t)blockIdx.x * 64 >= J.n_w + J.n_b) return;   // whole block past this layer's elements (uniform: no barrier is skipped by part of a block)
+    float acc = 0.0f;
+    if (i < J.n_w + J.n_b) {
+        const bool w = i < J.n_w;
+        const float* src = w ? J.slab + i : J.db_part + (i - J.n_w);
+        const int64_t stride = w ? jobs.slab_stride : J.db_stride;
+        const int n = w ? J.S : J.db_chunks;
+        const int per = (n + 3) / 4, k0 = q * per, k1 = k0 + per < n ? k0 + per : n;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = src[(size_t)(k + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += v[j];
+        }
+        for (; k < k1; k++) acc += src[(size_t)k * stride];
+    }
+    red[q][e] = acc;
+    __syncthreads();
+    if (q == 0 && i < J.n_w + J.n_b) {
+        const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        if (i < J.n_w) J.gw[i] = t; else J.gb[i - J.n_w] = t;
+    }
+}
+
 inline unsigned grid_for(int64_t n, int per_block) { const int64_t g = (n + per_block - 1) / per_block; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace
@@ -683,6 +717,11 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
                 if (i == net && hipMemsetAsync(g.dout_bf[i] + rows * 128, 0, (size_t)tail * 128 * 2, s) != hipSuccess) return hipErrorUnknown;
             }
         }
+        // every layer's partial slabs (and the column sums that are the next bias gradient) go to the layer's OWN block; the fixed-order sums of all layers
+        // are ONE launch at the end of the pass (they are needed by the norm / AdamW only): 2 launches per minibatch step instead of 10
+        SlabJobs jobs{};
+        jobs.slab_stride = g.wslab_stride;
+        int64_t most = 0;
         for (int l = L.n_layers - 1; l >= 0; l--) {
             const int K = L.in_dim[l], N = L.out_dim[net][l];
             const bool head = l == L.n_layers - 1;
@@ -690,22 +729,28 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
             const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
             const int64_t n_w = (int64_t)N * K;
             const int S = ranges(N, K);
-            hipError_t e = launch_matmul_bf16(true, true, N, K, rows, d, ldd, in, ldi, wslab, K, false, PPO_MM_EPI_NONE, nullptr, 0, S, g.wslab_stride, nullptr, 0, s);
+            float* lslab = wslab + (size_t)l * g.wslab_layer_stride;
+            hipError_t e = launch_matmul_bf16(true, true, N, K, rows, d, ldd, in, ldi, lslab, K, false, PPO_MM_EPI_NONE, nullptr, 0, S, g.wslab_stride, nullptr, 0, s);
             if (e != hipSuccess) return e;
-            const float* dbp = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part[net];
-            const int dbc = head ? GEN_LOSS_BLOCKS : (int)((rows + 127) / 128);
-            const int64_t dbs = head ? L.act + 1 : g.ld_h;
-            hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n_w + N + 63) / 64)), dim3(256), 0, s, wslab, g.wslab_stride, S, n_w, dbp, dbc, dbs, (int64_t)N,
-                               grads + L.w_off[net][l], grads + L.b_off[net][l]);
+            // the bias gradient of layer l: block sums of the head gradient (loss kernel), or the column sums the d(input) product of layer l + 1 left
+            // in block l + 1 of cs_part (written below, one iteration ago)
+            SlabJob& J = jobs.j[l];
+            J.slab = lslab; J.S = S; J.n_w = n_w; J.n_b = N;
+            J.db_part = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part[net] + (size_t)(l + 1) * g.cs_layer_stride;
+            J.db_chunks = head ? GEN_LOSS_BLOCKS : (int)((rows + 127) / 128);
+            J.db_stride = head ? L.act + 1 : g.ld_h;
+            J.gw = grads + L.w_off[net][l]; J.gb = grads + L.b_off[net][l];
+            most = std::max<int64_t>(most, n_w + N);
             if (l > 0) {
                 uint16_t* nd = g.dz_bf[net][l & 1];
-                // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2), stored bf16; its column sums per 128-row tile -> cs_part
+                // dH[rows, K] = d[rows, N] . W[N, K], then d(pre-activation) = dH (1 - h^2), stored bf16; its column sums per 128-row tile -> cs_part block l
                 e = launch_matmul_bf16(false, true, rows, K, N, d, ldd, g.wplanes + g.wp_off[net][l], g.wp_kpad[l], nd, g.ld_h, true, PPO_MM_EPI_DTANH,
-                                       g.acts_bf[net][l - 1], g.ld_h, 1, 0, g.cs_part[net], g.ld_h, s);
+                                       g.acts_bf[net][l - 1], g.ld_h, 1, 0, g.cs_part[net] + (size_t)l * g.cs_layer_stride, g.ld_h, s);
                 if (e != hipSuccess) return e;
                 d = nd; ldd = g.ld_h;
             }
         }
+        hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)L.n_layers), dim3(256), 0, s, jobs);
         return hipGetLastError();
     }
     const float* d = dout;
