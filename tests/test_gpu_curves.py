@@ -114,6 +114,6 @@ def test_learning_curves_match_reference_band(P, name):
     assert all(np.isfinite(v) for v in r["build_steps_to_195"]), (name, "a seed of the build never reached ep_len_mean 195", r)
 
 
-if __name__ == "__main__":   # python tests/test_gpu_curves.py -> the numbers the test compares (profiles/r04_v1_curves.json)
+if __name__ == "__main__":   # python tests/test_gpu_curves.py -> the numbers the test compares (profiles/r04_v2_curves.json)
     P_ = load_package()
     print(json.dumps([summarize(P_, n) for n in ("curves_config0_8x128", "curves_64x128")], indent=1))
