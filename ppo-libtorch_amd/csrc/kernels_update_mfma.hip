@@ -171,6 +171,8 @@ __device__ __forceinline__ float tanh_scaled(float cz) {
     const float e = __builtin_amdgcn_exp2f(cz);
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
+// (Packed fp32 arithmetic -- v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32 for the additions, fmas and products around the two transcendentals and in
+// the (1 - h^2) factors, 229 scalar instructions of a tile as 133 packed ones -- was built and measured in round 4: + 1.0 us per launch.  Not used.)
 // acc + lo(p) + hi(p) for a packed fp16 pair (v_dot2c_f32_f16 against (1, 1))
 __device__ __forceinline__ float add_pair(uint32_t p, float acc) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, p), __builtin_bit_cast(f16x2, 0x3c003c00u), acc, false);
@@ -1019,6 +1021,11 @@ __host__ __device__ inline MgSmem mg_smem(int obs, int aout) {
     return m;
 }
 
+// Region slot of F wave fw: the two F waves a G wave serves (g and MG_GW + ((g + 1) & 3), on different SIMDs) own ADJACENT regions 2g, 2g + 1 --
+// once it has served their last events nobody else touches that pair, and its gradient image (net_size floats <= 2 regions) can be parked there
+// without waiting for the rest of the workgroup.
+__host__ __device__ constexpr int mg_slot(int fw) { return fw < MG_GW ? 2 * fw : 2 * ((fw - MG_GW + MG_GW - 1) & (MG_GW - 1)) + 1; }
+
 // wave-uniform wait for a workgroup-shared LDS counter to reach `want`; false when the bound runs out (protocol error)
 typedef __attribute__((address_space(3))) volatile uint32_t lds_flag_t;
 __device__ __forceinline__ bool mg_wait_ge(const lds_flag_t* flag, uint32_t want) {
@@ -1117,10 +1124,12 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
     float4 x_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (wave < MG_FW) x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];
     __syncthreads();
+#ifdef MG_STAMP
+    const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
+    if (blk == 0 && tid == 0 && a.stamps) atomicAdd(a.stamps + NET * 12 + 7, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));   // prologue: weights -> LDS
+#endif
 
     const int base = L.net_off[NET];
-    const int nsz = L.net_size[NET];
-    const int rstride = (nsz + 3) & ~3;
     double* dred = reinterpret_cast<double*>(smem + m.dred);
 
 #ifdef MG_DIAG_NO_F
@@ -1129,7 +1138,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
     if (wave < MG_FW) {
 #endif
         // =================================================== F: forward, loss, d(activation) ===================================================
-        float* wbase = smem + m.wave0 + wave * m.wave_stride;
+        float* wbase = smem + m.wave0 + mg_slot(wave) * m.wave_stride;
         uint16_t* ra16 = reinterpret_cast<uint16_t*>(wbase + m.ra);
         float* img = wbase + m.rb;
         uint16_t* zimg = reinterpret_cast<uint16_t*>(img);
@@ -1413,7 +1422,11 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                     if constexpr (WR == 1) acc = mfma_f16(w3a[t][0], u32x4{ d1[0], d2[0], d1[0], 0u }, zero16);   // [w1 w1 w2] . [d1 d2 d1]
                     else acc = mfma_x2(w3a[t][0], w3a[t][WR == 1 ? 0 : 1], u32x4{ d1[0], d1[1], 0u, 0u }, u32x4{ d2[0], d2[1], 0u, 0u }, zero16);
 #pragma unroll
+#ifdef MG_DIAG_CHEAP_DZ2   // timing only (results wrong): 64 vector instructions less per tile
+                    for (int r = 0; r < 16; r++) dz2[16 * t + r] = acc[r];
+#else
                     for (int r = 0; r < 16; r++) dz2[16 * t + r] = acc[r] * __builtin_fmaf(-h2[16 * t + r], h2[16 * t + r], 1.0f);
+#endif
                 }
             }
             uint32_t zp[2][16];
@@ -1494,12 +1507,11 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         if (!proto_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
 #ifdef MG_STAMP
         if (blk == 0 && tid == 0 && a.stamps) {
-            a.stamps[NET * 12 + 0] += __builtin_amdgcn_s_memtime() - t_begin;
-            for (int i = 1; i < 4; i++) a.stamps[NET * 12 + i] += tstamp[i];
+            atomicAdd(a.stamps + NET * 12 + 0, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+            for (int i = 1; i < 4; i++) atomicAdd(a.stamps + NET * 12 + i, (unsigned long long)(tstamp[i]));
         }
 #endif
-        __syncthreads();   // tile loops done everywhere: LDS is reused by the gradient images
-        __syncthreads();   // gradient images parked
+        __syncthreads();   // gradient images parked (each G wave in the regions of its own two F waves: no barrier in front of that)
 #ifdef MG_DIAG_NO_G
     } else if (false) {
 #else
@@ -1538,7 +1550,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         const int nt_a = tiles_of(g), nt_b = tiles_of(fw_b);
         bool g_ok = true;
 #define MG_REGION_PTRS(fw)                                                                         \
-        float* wbase = smem + m.wave0 + (fw) * m.wave_stride;                                      \
+        float* wbase = smem + m.wave0 + mg_slot(fw) * m.wave_stride;                                    \
         const uint16_t* ra16 = reinterpret_cast<const uint16_t*>(wbase + m.ra);                    \
         const float* img = wbase + m.rb;                                                           \
         const uint16_t* zimg = reinterpret_cast<const uint16_t*>(img);                             \
@@ -1702,8 +1714,8 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         if (!g_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
 #ifdef MG_STAMP
         if (blk == 0 && tid == MG_FW * 64 && a.stamps) {
-            a.stamps[NET * 12 + 5] += __builtin_amdgcn_s_memtime() - t_begin;
-            a.stamps[NET * 12 + 6] += tstamp[0];
+            atomicAdd(a.stamps + NET * 12 + 5, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+            atomicAdd(a.stamps + NET * 12 + 6, (unsigned long long)(tstamp[0]));
         }
 #endif
         // ---- the factors leave: 2^S (dW2, db2, dW1, db1), the fixed 2^-7 of the dz1 terms and the c of the scaled W2 (dW1, db1) ----
@@ -1723,8 +1735,8 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
                 for (int r = 0; r < 4; r++) gW1m[b][r] = (gW1m[b][r] * f) * TANH_C_INV;
         }
-        __syncthreads();   // tile loops done everywhere: weights and images are dead
-        float* red = smem + g * rstride;
+        // this wave has served the last events of its two F waves: their regions (adjacent: mg_slot) are dead and nobody else's business
+        float* red = smem + m.wave0 + 2 * g * m.wave_stride;
 #pragma unroll
         for (int tn = 0; tn < 2; tn++)
 #pragma unroll
@@ -1733,29 +1745,51 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 for (int r = 0; r < 16; r++) red[L.w2[NET] - base + umap(r, hi, tn) * 64 + s + 32 * tk] = gW2[tn][tk][r];
 #pragma unroll
         for (int k = 0; k < AOUT; k++) red[L.w3[NET] - base + k * 64 + lane] = gW3[k];
+        {   // column j16 of the [dW1 | db1] block: one address and one stride per lane, ONE predicate for the sixteen stores
+            const int col0 = j16 < OBS ? L.w1[NET] - base + j16 : L.b1[NET] - base;
+            const int ustride = j16 < OBS ? OBS : 1;
+            if (j16 <= OBS) {
 #pragma unroll
-        for (int b = 0; b < 4; b++)
+                for (int b = 0; b < 4; b++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int u = 16 * b + 4 * kg + r;
-                if (j16 < OBS) red[L.w1[NET] - base + u * OBS + j16] = gW1m[b][r];
-                else if (j16 == OBS) red[L.b1[NET] - base + u] = gW1m[b][r];
+                    for (int r = 0; r < 4; r++) red[col0 + (16 * b + 4 * kg + r) * ustride] = gW1m[b][r];
             }
+        }
         if (hi == 0) { red[L.b2[NET] - base + s] = gb2[0]; red[L.b2[NET] - base + s + 32] = gb2[1]; }
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < AOUT; k++) red[L.b3[NET] - base + k] = gb3[k];
         }
+#ifdef MG_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (blk == 0 && tid == MG_FW * 64 && a.stamps) atomicAdd(a.stamps + NET * 12 + 10, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));   // own image stored
+#endif
         __syncthreads();
+#ifdef MG_STAMP
+        if (blk == 0 && tid == MG_FW * 64 && a.stamps) atomicAdd(a.stamps + NET * 12 + 11, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+#endif
     }
     // ---- every thread adds the four gradient images in a fixed order into the workgroup's slab ----
     const int Pmax = L.net_size[0] > L.net_size[1] ? L.net_size[0] : L.net_size[1];
     float* slab = a.slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * Pmax;
-    for (int e = tid; e < nsz; e += MG_THREADS) {
-        float t = smem[e];
+    {
+        constexpr int NSZ = 64 * OBS + 64 + 4096 + 64 + 64 * AOUT + AOUT;   // = L.net_size[NET] (checked by the launcher)
+        constexpr int NE = (NSZ + MG_THREADS - 1) / MG_THREADS;
+        float t[NE][MG_GW];
 #pragma unroll
-        for (int w = 1; w < MG_GW; w++) t += smem[w * rstride + e];
-        slab[e] = t;
+        for (int i = 0; i < NE; i++) {   // every read of a thread in flight before the first addition
+            const int e = tid + i * MG_THREADS;
+#pragma unroll
+            for (int w = 0; w < MG_GW; w++) t[i][w] = smem[m.wave0 + 2 * w * m.wave_stride + (e < NSZ ? e : 0)];
+        }
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int e = tid + i * MG_THREADS;
+            float acc = t[i][0];
+#pragma unroll
+            for (int w = 1; w < MG_GW; w++) acc += t[i][w];
+            if (e < NSZ) slab[e] = acc;
+        }
     }
     if (tid < 4) {
         double* o = a.stat_slab + ((size_t)(NET == 0 ? 0 : a.n_blocks[0]) + blk) * 8;
@@ -1764,6 +1798,12 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         for (int w = 1; w < MG_FW; w++) t += dred[4 * w + tid];
         o[tid] = t;
     }
+#ifdef MG_STAMP
+    if (blk == 0 && tid == 0 && a.stamps) {
+        atomicAdd(a.stamps + NET * 12 + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));          // the whole workgroup, first instruction to last
+        atomicAdd(a.stamps + NET * 12 + 9, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t_real0));      // the same from the prologue's barrier on, in 100 MHz ticks (clock calibration)
+    }
+#endif
 }
 
 template <int DIST, int OBS, int AMAX>
@@ -1971,7 +2011,11 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
 #endif
         const bool cart = a.L.obs == 4 && a.L.act == 2 && a.hp.dist_kind == PPO_DIST_CATEGORICAL;
         const bool mcar = a.L.obs == 2 && a.L.act == 3 && a.hp.dist_kind == PPO_DIST_MASKED;
-        if (cart || mcar) {
+        const int body = 64 * a.L.obs + 64 + 4096 + 64;   // the kernel's epilogue has the two nets' sizes as compile-time constants
+        // ... and a G wave parks its gradient image in the two regions of its F waves
+        const bool sizes = a.L.net_size[0] == body + 64 + 1 && a.L.net_size[1] == body + 64 * a.L.act + a.L.act &&
+                           2 * mg_smem(a.L.obs, a.L.act).wave_stride >= a.L.net_size[1] && 2 * mg_smem(a.L.obs, 1).wave_stride >= a.L.net_size[0];
+        if ((cart || mcar) && sizes) {
             const size_t ws_shmem = (size_t)mg_smem(a.L.obs, a.L.act).total * sizeof(float);
             if (ws_shmem > 160 * 1024) return hipErrorNotSupported;
             const dim3 ws_block(MG_THREADS);
