@@ -1059,6 +1059,23 @@ __device__ __forceinline__ void mg_post(lds_flag_t* flag, uint32_t v, int lane) 
 #define MG_TIMED(slot, expr) do { expr; } while (0)
 #endif
 template <int NET, int DIST, int OBS, int AMAX>
+// -DMG_TRACE (diagnostic build, tools/ws_trace.py; implies MG_STAMP's buffer): the hand-over timeline of ONE tile round (the third) of the actor's
+// workgroup 0 -- F wave 0 ("a" of G wave 8), F wave 5 (its "b") and G wave 8 -- as cycles since the wave's first instruction, summed over launches.
+#ifdef MG_TRACE
+#define MG_ST_ADD(slot, v) do { } while (0)   // the trace owns the 24 slots
+#else
+#define MG_ST_ADD(slot, v) atomicAdd(a.stamps + NET * 12 + (slot), (v))
+#endif
+#ifdef MG_TRACE
+#define MG_TR_F(slot_a, slot_b) do { if (NET == 1 && blk == 0 && it == 2 && lane == 0 && a.stamps) {                         \
+        if (wave == 0 && (slot_a) >= 0) atomicAdd(a.stamps + (slot_a), (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));     \
+        if (wave == 5 && (slot_b) >= 0) atomicAdd(a.stamps + (slot_b), (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin)); } } while (0)
+#define MG_TR_G(slot) do { if (NET == 1 && blk == 0 && tr_round && wave == MG_FW && lane == 0 && a.stamps)                      \
+        atomicAdd(a.stamps + (slot), (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin)); } while (0)
+#else
+#define MG_TR_F(slot_a, slot_b) do { } while (0)
+#define MG_TR_G(slot) do { } while (0)
+#endif
 __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
     const NetLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1126,7 +1143,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
     __syncthreads();
 #ifdef MG_STAMP
     const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
-    if (blk == 0 && tid == 0 && a.stamps) atomicAdd(a.stamps + NET * 12 + 7, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));   // prologue: weights -> LDS
+    if (blk == 0 && tid == 0 && a.stamps) MG_ST_ADD(7, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));   // prologue: weights -> LDS
 #endif
 
     const int base = L.net_off[NET];
@@ -1210,6 +1227,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         uint32_t ev = 0;   // events produced so far (3 per tile)
         for (int it = 0; tile < n_tiles; tile += tile_step, it++) {
             if ((it ^ wave_half) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            MG_TR_F(0, 8);
             // ---------------- gather (K5) ----------------
             const bool valid = row_n >= 0;
             const int row = valid ? row_n : 0;
@@ -1393,6 +1411,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 for (int k = 0; k < AOUT; k++) sDo[k * MT + s] = dOut[k];
             }
             mg_post(prod, ++ev, lane);
+            MG_TR_F(1, 9);
             // ---------------- the tile's power-of-two scale S: this wave's own (a function of ITS tiles only: results do not depend on timing), moved
             //                  down when a tile's bound (sum_a |dOut[a]|) max|W3| 2^S would pass 2^13, and then to a multiple of 4 with the bound at
             //                  2^8 .. 2^11, so that the two F waves of a G wave mostly agree and G seldom has to move its accumulators ----------------
@@ -1434,7 +1453,9 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
             for (int j = 0; j < 16; j++) split2(dz2[2 * j], dz2[2 * j + 1], zp[0][j], zp[1][j]);
             // ---------------- E1: dz2 terms -> RB once G has read the h2 image ----------------
             if (lane == 0) flags[MG_SEV + wave] = (uint32_t)S_w;
+            MG_TR_F(2, -1);
             MG_TIMED(2, proto_ok &= mg_wait_ge(cons, ev));
+            MG_TR_F(3, -1);
 #pragma unroll
             for (int term = 0; term < 2; term++)
 #pragma unroll
@@ -1443,6 +1464,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                     for (int q = 0; q < 4; q++)
                         *reinterpret_cast<uint2*>(zimg + term * MT * NS + s * NS + 8 * q + 4 * hi + 32 * t) = make_uint2(zp[term][8 * t + 2 * q], zp[term][8 * t + 2 * q + 1]);
             mg_post(prod, ++ev, lane);
+            MG_TR_F(4, 10);
             // ---------------- c dh1^T[k][s] = sum_n c W2[n][k] dz2[s][n];  c 2^-7 dz1 = c dh1 (1 - h1^2) 2^-7, h1 rebuilt from its own terms in RA ----------------
             float dz1[32];
             {
@@ -1489,7 +1511,9 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 uint32_t zq[2][16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) split2(dz1[2 * j], dz1[2 * j + 1], zq[0][j], zq[1][j]);
+                MG_TR_F(5, -1);
                 MG_TIMED(3, proto_ok &= mg_wait_ge(cons, ev));
+                MG_TR_F(6, -1);
 #pragma unroll
                 for (int term = 0; term < 2; term++)
 #pragma unroll
@@ -1498,6 +1522,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                         for (int q = 0; q < 4; q++)
                             *reinterpret_cast<uint2*>(zimg + term * MT * NS + s * NS + 8 * q + 4 * hi + 32 * t) = make_uint2(zq[term][8 * t + 2 * q], zq[term][8 * t + 2 * q + 1]);
                 mg_post(prod, ++ev, lane);
+                MG_TR_F(7, 11);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1507,8 +1532,8 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         if (!proto_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
 #ifdef MG_STAMP
         if (blk == 0 && tid == 0 && a.stamps) {
-            atomicAdd(a.stamps + NET * 12 + 0, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
-            for (int i = 1; i < 4; i++) atomicAdd(a.stamps + NET * 12 + i, (unsigned long long)(tstamp[i]));
+            MG_ST_ADD(0, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+            for (int i = 1; i < 4; i++) MG_ST_ADD(i, (unsigned long long)(tstamp[i]));
         }
 #endif
         __syncthreads();   // gradient images parked (each G wave in the regions of its own two F waves: no barrier in front of that)
@@ -1549,8 +1574,11 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         const int fw_b = MG_GW + ((g + 1) & (MG_GW - 1));
         const int nt_a = tiles_of(g), nt_b = tiles_of(fw_b);
         bool g_ok = true;
+#ifdef MG_TRACE
+        bool tr_round = false;
+#endif
 #define MG_REGION_PTRS(fw)                                                                         \
-        float* wbase = smem + m.wave0 + mg_slot(fw) * m.wave_stride;                                    \
+        float* wbase = smem + m.wave0 + mg_slot(fw) * m.wave_stride;                               \
         const uint16_t* ra16 = reinterpret_cast<const uint16_t*>(wbase + m.ra);                    \
         const float* img = wbase + m.rb;                                                           \
         const uint16_t* zimg = reinterpret_cast<const uint16_t*>(img);                             \
@@ -1567,7 +1595,9 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         // ---- E0: dW3[a][u = lane] += sum_s dOut[s][a] h2[s][u]; db3[a] += sum_s dOut[s][a] (every lane forms the same sum) ----
         auto serve_e0 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
             MG_REGION_PTRS(fw);
+            if (fw == g) MG_TR_G(12);
             MG_TIMED(0, g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno));
+            MG_TR_G(fw == g ? 13 : 15);
             // the image's 32 rows into registers, then the acknowledgement (RB is what the F wave is waiting for; dOut is not rewritten before the
             // next tile's E0, which comes behind everything of this tile), then the products
             float hv[MT];
@@ -1587,12 +1617,14 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 }
                 gW3[k] += accw3; gb3[k] += accb3;
             }
+            MG_TR_G(fw == g ? 14 : 16);
         };
         // ---- E1: dW2[n][k] += sum_s dz2[s][n] h1[s][k], db2[n] += sum_s dz2[s][n]: both operands by transposing reads of the term images.
         //      Lane (n | k = lane & 31, hi) holds the terms of samples 16 c + 8 hi + 0..7 of unit (lane & 31) + 32 t ----
         auto serve_e1 = [&](const int fw, const uint32_t evno) __attribute__((always_inline)) {
             MG_REGION_PTRS(fw);
             MG_TIMED(0, g_ok &= mg_wait_ge(flags + MG_PROD + fw, evno));
+            MG_TR_G(fw == g ? 17 : 20);
             {
                 const int S_ev = __builtin_amdgcn_readfirstlane((int)flags[MG_SEV + fw]);
                 if (S_ev != S_g2) {
@@ -1619,6 +1651,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
 #pragma unroll
                     for (int term = 0; term < 2; term++) A[c][t][term] = trf(zimg, c, t, term);
             mg_post(cons, evno, lane);
+            MG_TR_G(fw == g ? 18 : 21);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -1643,6 +1676,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                         gW2[tn][tk] = mfma_x2(A[c][tn][0], A[c][tn][1], B[tk][0], B[tk][1], gW2[tn][tk]);
                 __builtin_amdgcn_sched_barrier(0);   // the second chunk's h1 reads are issued behind the first chunk's MFMAs, not hoisted above them (16 more registers)
             }
+            MG_TR_G(fw == g ? 19 : 22);
         };
         // ---- E2: c 2^-7 dW1[u][o] += sum_s dz1[s][u] x[s][o], db1 as the column of the constant 1: 12 MFMAs of 16 x 16 x 32.
         //      B operand: lane (j = lane & 15, kg) holds the x terms of samples 8 kg + 0..7, column j.  The 16-lane group reads a 4-sample x 16-column
@@ -1688,6 +1722,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                 acc4 = mfma16_f16(A1[b], xb[0], acc4);
                 gW1m[b] = acc4;
             }
+            if (fw != g) MG_TR_G(23);
         };
         __builtin_amdgcn_s_setprio(2);
 #ifdef MG_DIAG_G_IDLE
@@ -1696,6 +1731,9 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         for (int i = 0; i < nt_a; i++) {   // nt_a >= nt_b (wave a's first tile comes first); nt_a - nt_b is 0 or 1
 #endif
             const int nj = i < nt_b ? 2 : 1;
+#ifdef MG_TRACE
+            tr_round = i == 2;
+#endif
 #ifndef MG_DIAG_NO_E0
 #pragma nounroll
             for (int j = 0; j < nj; j++) serve_e0(j ? fw_b : g, 3u * i + 1u);
@@ -1714,8 +1752,8 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         if (!g_ok && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_UPDATE_PROTOCOL);
 #ifdef MG_STAMP
         if (blk == 0 && tid == MG_FW * 64 && a.stamps) {
-            atomicAdd(a.stamps + NET * 12 + 5, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
-            atomicAdd(a.stamps + NET * 12 + 6, (unsigned long long)(tstamp[0]));
+            MG_ST_ADD(5, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+            MG_ST_ADD(6, (unsigned long long)(tstamp[0]));
         }
 #endif
         // ---- the factors leave: 2^S (dW2, db2, dW1, db1), the fixed 2^-7 of the dz1 terms and the c of the scaled W2 (dW1, db1) ----
@@ -1762,11 +1800,11 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         }
 #ifdef MG_STAMP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (blk == 0 && tid == MG_FW * 64 && a.stamps) atomicAdd(a.stamps + NET * 12 + 10, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));   // own image stored
+        if (blk == 0 && tid == MG_FW * 64 && a.stamps) MG_ST_ADD(10, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));   // own image stored
 #endif
         __syncthreads();
 #ifdef MG_STAMP
-        if (blk == 0 && tid == MG_FW * 64 && a.stamps) atomicAdd(a.stamps + NET * 12 + 11, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+        if (blk == 0 && tid == MG_FW * 64 && a.stamps) MG_ST_ADD(11, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
 #endif
     }
     // ---- every thread adds the four gradient images in a fixed order into the workgroup's slab ----
@@ -1800,8 +1838,8 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
     }
 #ifdef MG_STAMP
     if (blk == 0 && tid == 0 && a.stamps) {
-        atomicAdd(a.stamps + NET * 12 + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));          // the whole workgroup, first instruction to last
-        atomicAdd(a.stamps + NET * 12 + 9, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t_real0));      // the same from the prologue's barrier on, in 100 MHz ticks (clock calibration)
+        MG_ST_ADD(8, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));          // the whole workgroup, first instruction to last
+        MG_ST_ADD(9, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t_real0));      // the same from the prologue's barrier on, in 100 MHz ticks (clock calibration)
     }
 #endif
 }
