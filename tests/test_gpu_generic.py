@@ -29,8 +29,9 @@ def P():
 # tanh (hardware exp2 against tanhf), which now and then tips a value across a bf16 rounding boundary (one part in 256 of that activation).
 # Measured at configs[4]'s shape (tools/bf16_dev_report.py): log-prob 6e-4 max / 4e-6 mean, value 2e-3 max / 2e-5 mean, losses 2e-6, gradient 2e-4
 # of its largest element -- against 0.38 / 1e-2 / 1e-2 between the bf16 and the f32 arithmetic themselves.
-# PARITY UNPINNED for every shape in this file: the reference hard-wires 2 x 64 networks (Agent.cpp:25-59), so nothing the reference holds can pin a
+# PARITY UNPINNED for every shape of _check_shape: the reference hard-wires 2 x 64 networks (Agent.cpp:25-59), so nothing the reference holds can pin a
 # 4 x 256 network or bf16 arithmetic; the yardstick is the oracle's own generic / bf16 mode (ORC_DTYPE_BF16), whose f32 2 x 64 case IS pinned.
+# What the reference CAN pin is this file's code at the reference's own shape: the tests at the end of the file.
 # bf16 bars = ~3x the measured values above (log-prob 6e-4 -> 2e-3, value 2e-3 -> 4e-3 (2x), losses 2e-6 -> 6e-6, gradient 2e-4 -> 6e-4 of max).
 TOL = {0: dict(fwd=5e-6, fwd_v=5e-6, agree=0.995, loss=1e-5, grad=1e-4, same=1e-6), 1: dict(fwd=2e-3, fwd_v=4e-3, agree=0.98, loss=6e-6, grad=6e-4, same=1e-6)}
 
@@ -272,3 +273,120 @@ def test_generic_two_rank_shards_equal_single_context(P):
         assert np.abs(p2 - p_ref).max() <= 2e-5, r
     assert np.array_equal(bits(out[0][2]), bits(out[1][2]))   # replicas stay bit-identical
     whole.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The generic kernels AT THE REFERENCE'S OWN SHAPE, against the compiled reference: what pins this file's CODE (not its shapes).
+# The reference cannot build a 4 x 256 network, but the generic path can build the reference's 2 x 64 one: env_kind SYNTHETIC selects the GEMM-based
+# kernels (kernels_gemm.hip, kernels_generic*.hip) whatever the widths; the reference's rollout batch is written into the context's buffers and the
+# 40 optimizer steps of its first update are driven with its own permutations -- the fixtures, loop and bars of
+# tests/test_gpu_parity.py::test_full_update_tracks_reference (losses 1e-5: north_star; parameters after the update 2e-6), on the other kernels.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REFERENCE_UPDATES = ["discrete_t32_n8_seed2", "discrete_t64_n16_seed3_trunc", "discrete_t128_n64_seed1", "discrete_shipped_toml_t32_n8_act1",
+                     "discrete_config0_t128_n8_seed2", "multidiscrete_mountaincar_t32_n16"]
+
+
+def _load_reference_update(name):
+    g = O.read_pgld(os.path.join(G, name + ".pgld"))
+    m, h = g["meta"], g["hparams"]
+    meta = dict(T=int(m[0]), N=int(m[1]), obs=int(m[2]), act=int(m[3]), nmb=int(m[4]), epochs=int(m[5]), max_steps=int(m[6]), seed=int(m[7]), updates=int(m[8]),
+                anneal=int(m[9]), norm_adv=int(m[11]), clip_vloss=int(m[12]), masked=int(m[13]),
+                lr=float(h[0]), gamma=float(h[1]), lam=float(h[2]), clip=float(h[3]), ent=float(h[4]), vf=float(h[5]), mgn=float(h[6]))
+    return g, meta
+
+
+def _generic_ctx_at_reference_shape(P, meta, dtype):
+    return P.Context(P.make_config(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED if meta["masked"] else P.DIST_CATEGORICAL, obs_size=meta["obs"],
+                                   head_dims=(meta["act"],), hidden=64, n_hidden=2, num_envs=meta["N"], num_steps=meta["T"], num_minibatches=meta["nmb"],
+                                   update_epochs=meta["epochs"], max_episode_steps=meta["max_steps"], use_gae=True, norm_adv=bool(meta["norm_adv"]),
+                                   clip_vloss=bool(meta["clip_vloss"]), anneal_lr=bool(meta["anneal"]), seed=meta["seed"],
+                                   total_timesteps=meta["updates"] * meta["T"] * meta["N"], learning_rate=meta["lr"], gamma=meta["gamma"], gae_lambda=meta["lam"],
+                                   clip_coef=meta["clip"], ent_coef=meta["ent"], vf_coef=meta["vf"], max_grad_norm=meta["mgn"], compute_dtype=dtype))
+
+
+def _write_reference_batch(ctx, g, U, meta):
+    T, N = meta["T"], meta["N"]
+    ctx.write("OBS", g[U + "obs"])
+    ctx.write("ACTIONS", g[U + "actions"].reshape(T, N, -1)[:, :, :1].astype(np.int32))
+    for buf, key in (("LOGPROBS", "logprobs"), ("REWARDS", "rewards"), ("DONES", "dones"), ("VALUES", "values"), ("ADVANTAGES", "gae_advantages"), ("RETURNS", "gae_returns")):
+        ctx.write(buf, g[U + key])
+    if meta["masked"]:
+        ctx.write("MASKS", g[U + "action_masks"].astype(np.uint8))
+
+
+@pytest.mark.parametrize("name", REFERENCE_UPDATES)
+def test_generic_kernels_track_the_reference_update_at_its_own_shape(P, name):
+    g, meta = _load_reference_update(name)
+    ctx = _generic_ctx_at_reference_shape(P, meta, 0)
+    assert ctx.P == g["u1/params_before"].size
+    U = "u1/"
+    MB = meta["T"] * meta["N"] // meta["nmb"]
+    _write_reference_batch(ctx, g, U, meta)
+    ctx.set_params(g[U + "params_before"])
+    ctx.set_learning_rate(float(g[U + "lr"][0]))
+    scal = g[U + "step_scalars"]
+    k = 0
+    for e in range(meta["epochs"]):
+        for s in range(meta["nmb"]):
+            ctx.minibatch_forward_backward(g[U + "perms"][e, s * MB:(s + 1) * MB])
+            st = ctx.stats()
+            for i, key in enumerate(("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "loss")):
+                assert abs(st[key] - scal[k, i]) <= 1e-5 * max(1.0, abs(scal[k, i])), (name, k, key, st[key], scal[k, i])
+            ctx.optimizer_step()
+            k += 1
+    assert np.abs(ctx.get_params() - g[U + "params_after"]).max() <= 2e-6
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", REFERENCE_UPDATES)
+def test_generic_forward_kernels_against_the_reference_at_its_own_shape(P, name):
+    """tests/test_gpu_parity.py::test_policy_forward_teacher_forced on the generic forward kernels: the reference's own log-probs, entropies and values of its
+    rollout, and its bootstrap value, within 3e-6; then the generic scan on the reference's rewards / values / dones bit for bit."""
+    g, meta = _load_reference_update(name)
+    ctx = _generic_ctx_at_reference_shape(P, meta, 0)
+    U = "u1/"
+    T, N = meta["T"], meta["N"]
+    B = T * N
+    ctx.set_params(g[U + "params_before"])
+    obs = g[U + "obs"].reshape(B, meta["obs"])
+    acts = g[U + "actions"].reshape(B, -1)[:, :1].astype(np.int64)
+    mask = g[U + "action_masks"].reshape(B, -1).astype(np.uint8) if meta["masked"] else None
+    a, lp, en, v = ctx.policy_act(obs, mask=mask, action=acts)
+    assert np.array_equal(a, acts)
+    np.testing.assert_allclose(lp, g[U + "logprobs"].ravel(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(v, g[U + "values"].ravel(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(en, g[U + "rollout_entropy"].ravel(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(ctx.get_value(g[U + "next_obs"]), g[U + "next_value"].ravel(), rtol=0, atol=3e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["discrete_t128_n64_seed1", "multidiscrete_mountaincar_t32_n16"])
+def test_generic_bf16_arithmetic_against_the_reference_update(P, name):
+    """The bf16 mode (BASELINE configs[4]'s arithmetic) on the reference's own batch: how far bf16 operands and activations move the reference's fp32
+    scalars over the 40 steps of an update.  Not a parity claim (the reference has no bf16 mode) -- a measured distance with a bar at ~3x of it (2e-4)."""
+    g, meta = _load_reference_update(name)
+    ctx = _generic_ctx_at_reference_shape(P, meta, 1)
+    U = "u1/"
+    MB = meta["T"] * meta["N"] // meta["nmb"]
+    _write_reference_batch(ctx, g, U, meta)
+    ctx.set_params(g[U + "params_before"])
+    ctx.set_learning_rate(float(g[U + "lr"][0]))
+    scal = g[U + "step_scalars"]
+    worst = {}
+    k = 0
+    for e in range(meta["epochs"]):
+        for s in range(meta["nmb"]):
+            ctx.minibatch_forward_backward(g[U + "perms"][e, s * MB:(s + 1) * MB])
+            st = ctx.stats()
+            for i, key in enumerate(("pg_loss", "v_loss", "entropy_loss", "approx_kl", "loss")):
+                d = abs(st[key] - scal[k, [0, 1, 2, 3, 5][i]]) / max(1.0, abs(scal[k, [0, 1, 2, 3, 5][i]]))
+                worst[key] = max(worst.get(key, 0.0), d)
+            ctx.optimizer_step()
+            k += 1
+    print(name, "bf16 against the reference's fp32 scalars, worst relative distance over", k, "steps:", {a: "%.2e" % b for a, b in worst.items()})
+    assert all(np.isfinite(v) for v in worst.values())
+    assert max(worst.values()) <= 2e-4, worst    # measured 5.5e-5 (v_loss, MountainCar fixture), 3.7e-5 (CartPole)
+    ctx.close()
