@@ -390,3 +390,26 @@ def test_generic_bf16_arithmetic_against_the_reference_update(P, name):
     assert all(np.isfinite(v) for v in worst.values())
     assert max(worst.values()) <= 2e-4, worst    # measured 5.5e-5 (v_loss, MountainCar fixture), 3.7e-5 (CartPole)
     ctx.close()
+
+
+def test_generic_forward_kernels_on_the_reference_multihead_agent(P):
+    """configs[4]'s head list [3, 3, 3, 2] is the one head list the reference was ALSO run with (Agent::getActionAndValueMasked with m_actionSpace = {3,3,3,2},
+    tests/golden/multihead_agent.pgld: Agent.cpp:137-170 with its 2 x 64 bodies): the generic forward kernels against that fixture -- log-probs and entropies
+    summed over heads, masks with disabled actions, teacher-forced actions (the bars of tests/test_gpu_parity.py::test_multihead_masked_agent)."""
+    g = O.read_pgld(os.path.join(G, "multihead_agent.pgld"))
+    heads = tuple(int(h) for h in g["heads"])
+    obs_dim = g["x"].shape[1]
+    for dtype, tol in ((0, 3e-6), (1, 2e-2)):
+        ctx = P.Context(P.make_config(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=obs_dim, head_dims=heads, hidden=64, n_hidden=2, num_envs=8, num_steps=4,
+                                      num_minibatches=1, update_epochs=1, compute_dtype=dtype))
+        assert ctx.P == g["params"].size
+        ctx.set_params(g["params"])
+        a, lp, en, v = ctx.policy_act(g["x"], mask=g["mask"].astype(np.uint8), action=g["action_hn"].T)
+        assert np.array_equal(a, g["action_out"])
+        np.testing.assert_allclose(lp, g["logprob"], rtol=1e-5 if dtype == 0 else 0, atol=tol)
+        np.testing.assert_allclose(en, g["entropy"], rtol=1e-5 if dtype == 0 else 0, atol=tol)
+        np.testing.assert_allclose(v, g["value"].ravel(), rtol=1e-5 if dtype == 0 else 0, atol=tol)
+        if dtype == 1:
+            print("bf16 against the reference's multi-head agent: log-prob %.1e, entropy %.1e, value %.1e (max abs)" %
+                  (np.abs(lp - g["logprob"]).max(), np.abs(en - g["entropy"]).max(), np.abs(v - g["value"].ravel()).max()))
+        ctx.close()
