@@ -1058,7 +1058,6 @@ __device__ __forceinline__ void mg_post(lds_flag_t* flag, uint32_t v, int lane) 
 #else
 #define MG_TIMED(slot, expr) do { expr; } while (0)
 #endif
-template <int NET, int DIST, int OBS, int AMAX>
 // -DMG_TRACE (diagnostic build, tools/ws_trace.py; implies MG_STAMP's buffer): the hand-over timeline of ONE tile round (the third) of the actor's
 // workgroup 0 -- F wave 0 ("a" of G wave 8), F wave 5 (its "b") and G wave 8 -- as cycles since the wave's first instruction, summed over launches.
 #ifdef MG_TRACE
@@ -1076,6 +1075,7 @@ template <int NET, int DIST, int OBS, int AMAX>
 #define MG_TR_F(slot_a, slot_b) do { } while (0)
 #define MG_TR_G(slot) do { } while (0)
 #endif
+template <int NET, int DIST, int OBS, int AMAX>
 __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const int blk, const int nblk) {
     const NetLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
