@@ -148,3 +148,54 @@ def test_update_is_a_function_of_its_inputs_at_full_size(P, mountaincar):
     assert np.isfinite(a.stats()["loss"])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("mountaincar", [False, True])
+def test_update_kernels_agree_on_awkward_minibatch_sizes(P, mountaincar):
+    """The wave-specialised update kernel hands tiles to waves round-robin (tile = workgroup x 8 + wave, step = workgroups x 8): minibatch sizes that leave
+    partial tiles, waves without a tile, and -- beyond 1024 x 32 rows -- the two forward waves of a gradient wave with DIFFERENT tile counts (the ragged last
+    round of its service loop).  Explicit minibatches of such sizes through ppo_minibatch_forward_backward on the three kernels ppo_config.kernel_flags
+    selects; the vector kernel (plain fp32, pinned against the compiled reference by tests/test_gpu_parity.py) is the yardstick: losses 2e-6, gradients 5e-6
+    of the largest element (measured 5e-7 at 131 072 rows, tools/headline_grad_diag.py)."""
+    N, T = 1024, 64
+    B = N * T
+    kw = dict(num_envs=N, num_steps=T, num_minibatches=1, update_epochs=1, seed=4, total_timesteps=4 * B)
+    if mountaincar:
+        kw.update(env_kind=P.ENV_MOUNTAINCAR, dist_kind=P.DIST_MASKED, obs_size=2, head_dims=(3,), max_episode_steps=200, ent_coef=0.01)
+    ctxs = {flags: P.Context(P.make_config(kernel_flags=flags, **kw)) for flags in (P.KERNEL_UPDATE_VECTOR, P.KERNEL_UPDATE_ONE_WAVE, 0)}
+    ref = ctxs[P.KERNEL_UPDATE_VECTOR]
+    ref.init_orthogonal(4)
+    params = ref.get_params()
+    params[-(64 * (3 if mountaincar else 2) + (3 if mountaincar else 2)):] *= 20.0    # a policy that is not uniform: ratios away from 1 after a step
+    ref.set_params(params)
+    ref.env_reset()
+    ref.rollout()
+    ref.calc_advantage()
+    names = ["OBS", "ACTIONS", "LOGPROBS", "REWARDS", "DONES", "VALUES", "ADVANTAGES", "RETURNS"] + (["MASKS"] if mountaincar else [])
+    O_ = 2 if mountaincar else 4
+    shapes = {"OBS": (T, N, O_), "ACTIONS": (T, N, 1), "MASKS": (T, N, 3)}
+    data = {n: ref.read(n, shapes.get(n, (T, N))) for n in names}
+    # old log-probs that differ from the new ones (ratio != 1, some samples clipped): shift them a little
+    rng = np.random.default_rng(3)
+    data["LOGPROBS"] = (data["LOGPROBS"] + rng.normal(0, 0.15, (T, N))).astype(np.float32)
+    for c in ctxs.values():
+        c.set_params(params)
+        for n in names:
+            c.write(n, data[n])
+    perm = rng.permutation(B).astype(np.int32)
+    for M in (2, 31, 32, 33, 257, 8 * 32 + 1, 1024 * 32, 1024 * 32 + 1, 1025 * 32, 1300 * 32 + 7, B):
+        idx = perm[:M]
+        out = {}
+        for flags, c in ctxs.items():
+            g = c.minibatch_forward_backward(idx)
+            out[flags] = (g, c.stats())
+        g0, s0 = out[P.KERNEL_UPDATE_VECTOR]
+        assert np.isfinite(g0).all() and np.abs(g0).max() > 0, M
+        for flags in (P.KERNEL_UPDATE_ONE_WAVE, 0):
+            g, s = out[flags]
+            for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "loss"):
+                assert abs(s[key] - s0[key]) <= 2e-6 * max(1.0, abs(s0[key])), (M, flags, key, s[key], s0[key])
+            assert abs(s["clipfrac_last"] - s0["clipfrac_last"]) <= 2.0 / M + 1e-7, (M, flags)       # a count: samples on the clip threshold fall either way
+            assert np.abs(g - g0).max() <= 5e-6 * np.abs(g0).max(), (M, flags, np.abs(g - g0).max() / np.abs(g0).max())
+    for c in ctxs.values():
+        c.close()
