@@ -74,9 +74,17 @@ typedef struct ppo_config {
  *   PPO_KERNEL_ROLLOUT_VECTOR   the fused rollout on the vector ALU (rollout2_kernel): logits formed by the same fp32 multiply-adds, in the same order, as
  *                               ppo_policy_act.  The default rollout16_kernel forms layer 2 and the logits as two-term fp16 products on the matrix cores:
  *                               its logits agree with ppo_policy_act's to fp32 noise (~1e-7), NOT bit for bit, so an action sampled where the uniform
- *                               sits within ~1e-6 of a bin edge can differ (measured: <= 2 of 8 192), and its output-layer operand is pre-scaled by 2^8:
- *                               |W3| >= 255 does not fit fp16 -- the kernel raises the context's error word and ppo_read_stats / ppo_stats_snapshot_read fail with
- *                               PPO_ERR_STATE (no silent inf / NaN logits).  Use this flag for golden / bit-exact replays and for such weights.
+ *                               sits within ~1e-6 of a bin edge can differ (measured: <= 2 of 8 192).  Use this flag for golden / bit-exact replays.
+ *   fp16 ranges                 The matrix-core kernels carry some operands as fp16 terms: rollout16_kernel 2^8 W3 (|W3| < 255), the update kernels c W2 and
+ *                               the products through its columns (sum |W2[:, k]| < ~350), c W1 / c b1 / c b2 (< 22 700) and the observation (< 65 504).  The
+ *                               reference has none of these limits and a caller never meets the weight limits: the optimizer kernels keep the running
+ *                               maximum of |parameter| per class, the host reads a pinned mirror of it without synchronising (thresholds at half the
+ *                               limits: max |W3| >= 128, max |W2| >= 4, anything else >= 8192), and a launch whose weights do not fit takes the vector
+ *                               kernel (plain fp32, the same function) -- for that launch only, with the default flags.  An OBSERVATION beyond fp16 written
+ *                               into PPO_BUF_OBS cannot be foreseen: the update then raises the context's error word, the optimizer step is NOT applied
+ *                               (parameters and moments keep their last good values) and ppo_read_stats / ppo_stats_snapshot_read fail with
+ *                               PPO_ERR_STATE; PPO_KERNEL_UPDATE_VECTOR has no such limit.  The same holds for a hand-over wait of the update kernel that
+ *                               runs out (a protocol error, never observed): the step is skipped and reported, never applied.
  *   PPO_KERNEL_UPDATE_VECTOR    the update's forward / backward on the vector ALU (fwd_bwd_kernel) for every shape: plain fp32 arithmetic; also for
  *                               rehearsals of more than two ranks on ONE GPU (tests/test_gpu_exchange.py).
  *   PPO_KERNEL_UPDATE_ONE_WAVE  the one-wave-per-tile matrix-core kernel (fwd_bwd_mfma_kernel) instead of the wave-specialised one

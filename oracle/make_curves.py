@@ -6,7 +6,7 @@ CartPoleRecommendedSettings.toml's hyper-parameters and `action_size = 2`, and p
 (printPPOResults, :700-774) -- the reference's de-facto acceptance test (README.md:169-178).  Runs only in the build container
 (needs /root/reference compiled into oracle/_ref); the JSON travels, the reference does not.
 
-    python oracle/make_curves.py            # writes tests/golden/curves_config0_8x128.json, curves_64x128.json
+    python oracle/make_curves.py [name ...]   # writes tests/golden/<name>.json for every (or the named) scenario below
 """
 import concurrent.futures as cf
 import json
@@ -23,6 +23,7 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 SCENARIOS = {
     "curves_config0_8x128": (8, 128, 150 * 8 * 128, list(range(1, 11))),     # BASELINE.json configs[0] shape, 150 updates
     "curves_64x128": (64, 128, 80 * 64 * 128, list(range(1, 11))),           # 80 updates of 8192 steps
+    "curves_4096x128": (4096, 128, 30 * 4096 * 128, list(range(1, 6))),      # BASELINE.json configs[1] shape: 30 updates of 524 288 steps (~10 s each here)
 }
 
 
@@ -37,7 +38,9 @@ def one(num_envs, num_steps, total, seed):
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the build container")
-    for name, (n, t, total, seeds) in SCENARIOS.items():
+    wanted = sys.argv[1:] or list(SCENARIOS)
+    for name in wanted:
+        n, t, total, seeds = SCENARIOS[name]
         with cf.ThreadPoolExecutor(max_workers=1) as ex:
             runs = list(ex.map(lambda s: one(n, t, total, s), seeds))
         doc = {

@@ -145,6 +145,48 @@ std::array<torch::Tensor, 2> flatAdamState(Optim& opt, const std::vector<torch::
     return { torch::cat(m).clone(), torch::cat(v).clone() };
 }
 
+// One minibatch of train()'s update loop up to and including backward() -- the expressions of PPO_Discrete.cpp:576-638 /
+// PPO_MultiDiscrete.cpp:602-665 in their order, through the reference's own Agent / distributions / getApproxKLAndClippedObj and LibTorch autograd.
+// Every re-drive of this file (goldTrainScenario, goldHeadline, goldConfig4) goes through THIS function, and goldTrainScenario certifies it
+// bit-identical to the reference's real train() ("certified_bitwise").  The caller clips and steps (:640-641), so it can record in between.
+struct MinibatchOut {
+    AgentOutput o;
+    torch::Tensor pg_loss, v_loss, entropy_loss, approx_kl, loss;
+};
+template <class Algo, bool Masked>
+MinibatchOut minibatchLossBackward(Algo& algo, const torch::Tensor& mb, const torch::Tensor& b_obs, const torch::Tensor& b_masks, const torch::Tensor& b_actions,
+                                   const torch::Tensor& b_logprobs, const torch::Tensor& b_advantages, const torch::Tensor& b_returns, const torch::Tensor& b_values) {
+    MinibatchOut r;
+    if constexpr (Masked)
+        r.o = algo.m_agent->getActionAndValueMasked(b_obs.index({ mb }), b_masks.index({ mb }), b_actions.to(torch::kLong).index({ mb }).t());
+    else
+        r.o = algo.m_agent->getActionAndValueDiscrete(b_obs.index({ mb }), b_actions.to(torch::kLong).index({ mb }));
+    torch::Tensor logratio = r.o.logprob - b_logprobs.index({ mb });
+    torch::Tensor ratio = logratio.exp();
+    r.approx_kl = algo.getApproxKLAndClippedObj(ratio, logratio);
+    torch::Tensor adv = b_advantages.index({ mb });
+    if (algo.m_norm_adv) adv = (adv - adv.mean()) / (adv.std() + 1e-8f);
+    torch::Tensor l1 = -adv * ratio;
+    torch::Tensor l2 = -adv * torch::clamp(ratio, 1 - algo.m_clip_coef, 1 + algo.m_clip_coef);
+    r.pg_loss = torch::max(l1, l2).mean();
+    torch::Tensor nv = r.o.value.view(-1);
+    torch::Tensor ret = b_returns.index({ mb });
+    if (algo.m_clip_vloss) {
+        torch::Tensor un = (nv - ret) * (nv - ret);
+        torch::Tensor vold = b_values.index({ mb });
+        torch::Tensor vc = vold + torch::clamp(nv - vold, -algo.m_clip_coef, algo.m_clip_coef);
+        torch::Tensor cl = (vc - ret) * (vc - ret);
+        r.v_loss = 0.5f * torch::max(un, cl).mean();
+    } else {
+        r.v_loss = 0.5f * ((nv - ret) * (nv - ret)).mean();
+    }
+    r.entropy_loss = r.o.entropy.mean();
+    r.loss = r.pg_loss - algo.m_ent_coef * r.entropy_loss + r.v_loss * algo.m_vf_coef;
+    algo.m_optimizer->zero_grad();
+    r.loss.backward();
+    return r;
+}
+
 // Re-drive of one or more updates through the reference's public methods, recording everything.
 template <class Algo, bool Masked>
 void goldTrainScenario(const RunCfg& cfg, const std::string& tag, const std::string& outPath) {
@@ -278,35 +320,10 @@ void goldTrainScenario(const RunCfg& cfg, const std::string& tag, const std::str
             perms.push_back(b_inds.clone());
             for (int64_t start = 0; start < B; start += MB) {
                 torch::Tensor mb = b_inds.index({ torch::indexing::Slice(start, start + MB) });
-                AgentOutput o;
-                if constexpr (Masked)
-                    o = algo.m_agent->getActionAndValueMasked(b_obs.index({ mb }), b_masks.index({ mb }),
-                                                              b_actions.to(torch::kLong).index({ mb }).t());
-                else
-                    o = algo.m_agent->getActionAndValueDiscrete(b_obs.index({ mb }), b_actions.to(torch::kLong).index({ mb }));
-                torch::Tensor logratio = o.logprob - b_logprobs.index({ mb });
-                torch::Tensor ratio = logratio.exp();
-                approx_kl = algo.getApproxKLAndClippedObj(ratio, logratio);
-                torch::Tensor adv = b_advantages.index({ mb });
-                if (algo.m_norm_adv) adv = (adv - adv.mean()) / (adv.std() + 1e-8f);
-                torch::Tensor l1 = -adv * ratio;
-                torch::Tensor l2 = -adv * torch::clamp(ratio, 1 - algo.m_clip_coef, 1 + algo.m_clip_coef);
-                pg_loss = torch::max(l1, l2).mean();
+                MinibatchOut r = minibatchLossBackward<Algo, Masked>(algo, mb, b_obs, b_masks, b_actions, b_logprobs, b_advantages, b_returns, b_values);
+                AgentOutput& o = r.o;
+                pg_loss = r.pg_loss; v_loss = r.v_loss; entropy_loss = r.entropy_loss; loss = r.loss; approx_kl = r.approx_kl;
                 torch::Tensor nv = o.value.view(-1);
-                torch::Tensor ret = b_returns.index({ mb });
-                if (algo.m_clip_vloss) {
-                    torch::Tensor un = (nv - ret) * (nv - ret);
-                    torch::Tensor vold = b_values.index({ mb });
-                    torch::Tensor vc = vold + torch::clamp(nv - vold, -algo.m_clip_coef, algo.m_clip_coef);
-                    torch::Tensor cl = (vc - ret) * (vc - ret);
-                    v_loss = 0.5f * torch::max(un, cl).mean();
-                } else {
-                    v_loss = 0.5f * ((nv - ret) * (nv - ret)).mean();
-                }
-                entropy_loss = o.entropy.mean();
-                loss = pg_loss - algo.m_ent_coef * entropy_loss + v_loss * algo.m_vf_coef;
-                algo.m_optimizer->zero_grad();
-                loss.backward();
                 const bool dump = (update == 1) && (k == 0 || k == 1 || k == stepsPerUpdate - 1);
                 const std::string K = U + "k" + std::to_string(k) + "/";
                 if (dump) {
@@ -926,33 +943,8 @@ void goldHeadline(RunCfg cfg, const std::string& tag, const std::string& outPath
         torch::Tensor b_inds = torch::from_blob(pv.data(), { B }, torch::kInt64).clone();
         for (int64_t start = 0; start < B; start += MB) {
             torch::Tensor mb = b_inds.index({ torch::indexing::Slice(start, start + MB) });
-            AgentOutput o;
-            if constexpr (Masked) o = algo.m_agent->getActionAndValueMasked(b_obs.index({ mb }), b_masks.index({ mb }), b_actions.to(torch::kLong).index({ mb }).t());
-            else o = algo.m_agent->getActionAndValueDiscrete(b_obs.index({ mb }), b_actions.to(torch::kLong).index({ mb }));
-            torch::Tensor logratio = o.logprob - b_logprobs.index({ mb });
-            torch::Tensor ratio = logratio.exp();
-            torch::Tensor approx_kl = algo.getApproxKLAndClippedObj(ratio, logratio);
-            torch::Tensor adv = b_advantages.index({ mb });
-            if (algo.m_norm_adv) adv = (adv - adv.mean()) / (adv.std() + 1e-8f);
-            torch::Tensor l1 = -adv * ratio;
-            torch::Tensor l2 = -adv * torch::clamp(ratio, 1 - algo.m_clip_coef, 1 + algo.m_clip_coef);
-            torch::Tensor pg_loss = torch::max(l1, l2).mean();
-            torch::Tensor nv = o.value.view(-1);
-            torch::Tensor ret = b_returns.index({ mb });
-            torch::Tensor v_loss;
-            if (algo.m_clip_vloss) {
-                torch::Tensor un = (nv - ret) * (nv - ret);
-                torch::Tensor vold = b_values.index({ mb });
-                torch::Tensor vc = vold + torch::clamp(nv - vold, -algo.m_clip_coef, algo.m_clip_coef);
-                torch::Tensor cl = (vc - ret) * (vc - ret);
-                v_loss = 0.5f * torch::max(un, cl).mean();
-            } else {
-                v_loss = 0.5f * ((nv - ret) * (nv - ret)).mean();
-            }
-            torch::Tensor entropy_loss = o.entropy.mean();
-            torch::Tensor loss = pg_loss - algo.m_ent_coef * entropy_loss + v_loss * algo.m_vf_coef;
-            algo.m_optimizer->zero_grad();
-            loss.backward();
+            MinibatchOut r = minibatchLossBackward<Algo, Masked>(algo, mb, b_obs, b_masks, b_actions, b_logprobs, b_advantages, b_returns, b_values);
+            torch::Tensor pg_loss = r.pg_loss, v_loss = r.v_loss, entropy_loss = r.entropy_loss, approx_kl = r.approx_kl, loss = r.loss;
             double total_norm = torch::nn::utils::clip_grad_norm_(params, algo.m_max_grad_norm);
             algo.m_optimizer->step();
             scal.insert(scal.end(), { pg_loss.item<double>(), v_loss.item<double>(), entropy_loss.item<double>(), approx_kl.item<double>(),
@@ -964,6 +956,208 @@ void goldHeadline(RunCfg cfg, const std::string& tag, const std::string& outPath
     g.addF64("lr", { static_cast<torch::optim::AdamWOptions&>(algo.m_optimizer->param_groups()[0].options()).lr() }, { 1 });
     algo.m_threadPool->stop();
     g.save(outPath);
+}
+
+// (12) BASELINE.json configs[4]'s OWN SHAPE -- obs 376, heads [3, 3, 3, 2], 4 x 256 tanh bodies -- on the UNMODIFIED reference classes.  The reference's Agent
+// hard-wires 2 x 64 bodies in its constructor (Agent.cpp:25-59; the 256-wide third layer is there as comments, :27,32,45-46), but m_Critic, m_Actor,
+// m_actionSpace and m_actionSpaceSum are PUBLIC members (Agent.h:44-50), replace_module is public LibTorch API, ppoLayerInit is a public method
+// (Agent.cpp:91-99) and getActionAndValueMasked / getValue (Agent.cpp:107-170) are shape-agnostic.  So: a PPO_MultiDiscrete built by its own constructor,
+// its agent's two Sequentials swapped for 376 -> 256 x 4 -> {11 | 1} ones initialised by the reference's own ppoLayerInit with the reference's gains, the
+// optimizer rebuilt by the constructor's expression (PPO_MultiDiscrete.cpp:78-80), and then the certified minibatch re-drive (minibatchLossBackward above)
+// + clip_grad_norm_ + AdamW on a batch whose every input is a counter hash both sides regenerate (tests/test_gpu_config4_ref.py): observations, masks (at least
+// one valid action per head), actions (valid under the mask), rewards, done flags, the permutations.  Old log-probs / values are the agent's own on that batch
+// (NoGrad, as the rollout computes them, PPO_MultiDiscrete.cpp:559), advantages / returns are calcAdvantage's (:289-346) on them.
+// One file carries the initial parameters in full (2.4 MB, shared by both sizes); per size: what is small in full, what is large as a strided sample +
+// binary64 sums, the 7 scalars of every optimizer step, per-tensor norms of the first gradient and of the final parameters.
+namespace c4 {
+constexpr uint64_t SEED_OBS = 0x5101ull << 32, SEED_MASK = 0x5202ull << 32, SEED_KEEP = 0x5303ull << 32, SEED_START = 0x5404ull << 32, SEED_REW = 0x5505ull << 32,
+                   SEED_DONE = 0x5606ull << 32, SEED_NOBS = 0x5707ull << 32, SEED_NDONE = 0x5808ull << 32, SEED_PERM = 0x5909ull << 32;
+inline float obsOf(uint64_t seed, uint64_t i) { return (hl::unit24(hl::mix64(seed + i)) * 2.0f - 1.0f) * 1.7320508f; }   // uniform, mean 0, variance 1; one rounding
+}  // namespace c4
+
+struct Config4Run {   // what a second run of the same scenario, started one ulp away, contributes to the fixture
+    std::vector<double> scal;
+    torch::Tensor paramsAfterSample, lastGradSample;
+    uint32_t crcParamsBefore = 0;
+};
+Config4Run goldConfig4(int64_t N, int64_t T, int64_t nmb, int64_t epochs, bool full, const std::string& paramsPath, const std::string& outPath, bool ulpTwin = false,
+                       const Config4Run* other = nullptr) {
+    const std::vector<int64_t> heads = { 3, 3, 3, 2 };
+    const int64_t O = 376, A = 11, H = 4, W = 256;
+    RunCfg cfg;
+    cfg.obs_size = O; cfg.action_size = A; cfg.max_episode_steps = 200; cfg.seed = 1; cfg.num_envs = N; cfg.num_steps = T; cfg.num_minibatches = nmb;
+    cfg.update_epochs = epochs; cfg.ent_coef = 0.01; cfg.gamma = 0.99; cfg.updates = 1;
+    enterScratchWithConfig(cfg, "config4");
+    auto algoPtr = std::make_unique<PPO_MultiDiscrete>();
+    PPO_MultiDiscrete& algo = *algoPtr;
+    Agent& agent = *algo.m_agent;
+    {   // the swap: same layer names as the constructor's (and its commented third layer's), same gains (Agent.cpp:25-37)
+        auto lin = [&](int64_t in, int64_t out, double gain) { return agent.ppoLayerInit(torch::nn::Linear(in, out), gain); };
+        const double g2 = sqrt(2);
+        torch::nn::Sequential critic({ { "criticInputLayer", lin(O, W, g2) }, { "Tanh1", torch::nn::Tanh() }, { "criticMiddleLayer", lin(W, W, g2) }, { "Tanh2", torch::nn::Tanh() },
+                                       { "criticMiddleLayer2", lin(W, W, g2) }, { "Tanh3", torch::nn::Tanh() }, { "criticMiddleLayer3", lin(W, W, g2) }, { "Tanh4", torch::nn::Tanh() },
+                                       { "criticOutputLayer", lin(W, 1, 1.0) } });
+        torch::nn::Sequential actor({ { "actorInputLayer", lin(O, W, g2) }, { "Tanh1", torch::nn::Tanh() }, { "actorMiddleLayer", lin(W, W, g2) }, { "Tanh2", torch::nn::Tanh() },
+                                      { "actorMiddleLayer2", lin(W, W, g2) }, { "Tanh3", torch::nn::Tanh() }, { "actorMiddleLayer3", lin(W, W, g2) }, { "Tanh4", torch::nn::Tanh() },
+                                      { "actorOutputLayer", lin(W, A, 0.01) } });
+        agent.m_Critic = torch::nn::Sequential(agent.replace_module("m_Critic", critic));
+        agent.m_Actor = torch::nn::Sequential(agent.replace_module("m_Actor", actor));
+        agent.m_actionSpace = heads;
+        agent.m_actionSpaceSum = A;
+        algo.m_optimizer = std::make_shared<torch::optim::AdamW>(algo.m_agent->parameters(), torch::optim::AdamWOptions(algo.m_learning_rate).eps(1e-5f));
+    }
+    std::vector<torch::Tensor> params = agent.parameters();
+    if (params.size() != 20) throw std::runtime_error("config4: expected 20 parameter tensors (critic first, then actor)");
+    const int64_t B = algo.m_batch_size, MB = algo.m_minibatch_size;
+    GoldWriter g;
+    {
+        std::vector<int64_t> meta = { T, N, O, A, algo.m_num_minibatches, algo.m_update_epochs, algo.m_max_episode_steps, algo.m_seed, 1,
+                                      algo.m_anneal_lr, algo.m_use_gae, algo.m_norm_adv, algo.m_clip_vloss, 1, W, 4 };
+        g.addI64("meta", meta, { static_cast<int64_t>(meta.size()) });
+        g.addI64("heads", heads, { H });
+        std::vector<float> hp = { algo.m_learning_rate, algo.m_gamma, algo.m_gae_lambda, algo.m_clip_coef, algo.m_ent_coef, algo.m_vf_coef, algo.m_max_grad_norm };
+        g.addF32("hparams", hp, { static_cast<int64_t>(hp.size()) });
+        std::vector<int64_t> shapes;
+        for (const auto& p : params) { shapes.push_back(p.dim() > 0 ? p.size(0) : 1); shapes.push_back(p.dim() > 1 ? p.size(1) : 1); }
+        g.addI64("param_shapes", shapes, { static_cast<int64_t>(params.size()), 2 });
+    }
+    torch::Tensor params0 = flatParams(params);
+    g.addI64("crc_params_before", { hl::crcOf(params0) }, { 1 });
+    if (ulpTwin) {
+        // THE REFERENCE'S OWN SENSITIVITY: the same scenario started from parameters that differ from params0 in the LAST BIT of every element (up or down by
+        // a counter hash) -- a change of the size of one fp32 rounding.  The loss has kinks (value clipping, the ratio clip, max(unclipped, clipped)), so two
+        // correct fp32 trajectories a rounding apart separate visibly once the first samples reach a kink; the twin's distance from the fixture proper, per step,
+        // is the yardstick the device's distance is read against (tests/test_gpu_config4_ref.py).  Thread count is NOT such a yardstick: 1 thread against 8
+        // moved the 40 steps' losses by 9e-8 (LibTorch's products do not change their summation order with it).
+        torch::NoGradGuard ng;
+        uint64_t e = 0;
+        for (auto& p : params) {
+            float* d = p.data_ptr<float>();
+            for (int64_t i = 0; i < p.numel(); i++, e++) d[i] = std::nextafter(d[i], (hl::mix64((0x5A0Aull << 32) + e) & 1u) ? INFINITY : -INFINITY);
+        }
+    }
+    if (!paramsPath.empty()) {
+        GoldWriter pw;
+        pw.add("params", params0);
+        pw.save(paramsPath);
+    }
+
+    // ---- the batch: every input a counter hash (time-major [T, N, ...] like the reference's buffers, flat index i = t * N + n) ----
+    std::vector<float> obs(static_cast<size_t>(B * O)), nobs(static_cast<size_t>(N * O)), rew(static_cast<size_t>(B)), don(static_cast<size_t>(B));
+    std::vector<int64_t> act(static_cast<size_t>(B * H));
+    std::vector<uint8_t> msk(static_cast<size_t>(B * A));
+    std::vector<int32_t> ndone(static_cast<size_t>(N));
+    for (int64_t i = 0; i < B * O; i++) obs[i] = c4::obsOf(c4::SEED_OBS, static_cast<uint64_t>(i));
+    for (int64_t i = 0; i < N * O; i++) nobs[i] = c4::obsOf(c4::SEED_NOBS, static_cast<uint64_t>(i));
+    for (int64_t i = 0; i < B; i++) {
+        rew[i] = hl::unit24(hl::mix64(c4::SEED_REW + static_cast<uint64_t>(i))) * 2.0f - 1.0f;
+        don[i] = (hl::mix64(c4::SEED_DONE + static_cast<uint64_t>(i)) % 100u) == 0u ? 1.0f : 0.0f;
+        int64_t off = 0;
+        for (int64_t h = 0; h < H; h++) {
+            const uint64_t w = static_cast<uint64_t>(heads[h]);
+            for (uint64_t a = 0; a < w; a++) msk[i * A + off + a] = (hl::mix64(c4::SEED_MASK + static_cast<uint64_t>(i * A + off) + a) % 100u) >= 35u ? 1 : 0;
+            msk[i * A + off + static_cast<int64_t>(hl::mix64(c4::SEED_KEEP + static_cast<uint64_t>(i * H + h)) % w)] = 1;     // >= 1 valid action per head
+            uint64_t a = hl::mix64(c4::SEED_START + static_cast<uint64_t>(i * H + h)) % w;                                      // the first valid action from a hashed start
+            while (!msk[i * A + off + static_cast<int64_t>(a)]) a = (a + 1) % w;
+            act[i * H + h] = static_cast<int64_t>(a);
+            off += heads[h];
+        }
+    }
+    for (int64_t n = 0; n < N; n++) ndone[n] = (hl::mix64(c4::SEED_NDONE + static_cast<uint64_t>(n)) % 100u) == 0u ? 1 : 0;
+    torch::Tensor b_obs = torch::from_blob(obs.data(), { B, O }, torch::kFloat32);
+    torch::Tensor b_masks = torch::from_blob(msk.data(), { B, A }, torch::kUInt8).to(torch::kBool);
+    torch::Tensor b_actions = torch::from_blob(act.data(), { B, H }, torch::kInt64);
+    torch::Tensor next_obs = torch::from_blob(nobs.data(), { N, O }, torch::kFloat32);
+    torch::Tensor next_done = torch::from_blob(ndone.data(), { N }, torch::kInt32);
+    g.addI64("crc_obs", { hl::crcOf(b_obs) }, { 1 });
+    g.addI64("crc_masks", { hl::crcOf(b_masks.to(torch::kUInt8)) }, { 1 });
+    g.addI64("crc_actions", { hl::crcOf(b_actions.to(torch::kInt32)) }, { 1 });
+    g.addI64("crc_rewards_dones", { hl::crcOf(torch::from_blob(rew.data(), { B }, torch::kFloat32)), hl::crcOf(torch::from_blob(don.data(), { B }, torch::kFloat32)) }, { 2 });
+
+    // ---- the agent's own log-probs / entropies / values on the batch (the rollout's NoGrad call, PPO_MultiDiscrete.cpp:559 -> Agent.cpp:137-170) ----
+    AgentOutput roll;
+    {
+        torch::NoGradGuard ng;
+        roll = agent.getActionAndValueMasked(b_obs, b_masks, b_actions.t());
+        if (!torch::equal(roll.action, b_actions)) throw std::runtime_error("config4: teacher-forced actions did not come back");
+    }
+    algo.m_rewards = torch::from_blob(rew.data(), { T, N }, torch::kFloat32).clone();
+    algo.m_dones = torch::from_blob(don.data(), { T, N }, torch::kFloat32).clone();
+    algo.m_values = roll.value.reshape({ T, N }).clone();
+    algo.m_logprobs = roll.logprob.reshape({ T, N }).clone();
+    auto gae = algo.calcAdvantage(next_obs, next_done);
+    torch::Tensor returns = gae[0], advantages = gae[1];
+    torch::Tensor next_value;
+    {
+        torch::NoGradGuard ng;
+        next_value = agent.getValue(next_obs).reshape(-1);
+    }
+    const int64_t stride = full ? 1 : 4099;
+    auto sample = [&](const torch::Tensor& t, int64_t st) { return t.detach().reshape(-1).index({ torch::indexing::Slice(0, torch::indexing::None, st) }).clone(); };
+    auto sums = [&](const torch::Tensor& t) { torch::Tensor d = t.detach().to(torch::kFloat64); return std::vector<double>{ d.sum().item<double>(), (d * d).sum().item<double>() }; };
+    g.addI64("sample_stride", { stride, 61 }, { 2 });
+    for (auto& kv : std::vector<std::pair<std::string, torch::Tensor>>{ { "logprobs", roll.logprob }, { "entropy", roll.entropy }, { "values", roll.value }, { "advantages", advantages },
+                                                                        { "returns", returns }, { "next_value", next_value } }) {
+        g.add("sample_" + kv.first, sample(kv.second, kv.first == "next_value" ? 1 : stride));
+        g.addF64("sums_" + kv.first, sums(kv.second), { 2 });
+    }
+
+    // ---- the update: injected permutations, the certified minibatch expressions, clip_grad_norm_, AdamW (PPO_MultiDiscrete.cpp:593-668) ----
+    torch::Tensor b_logprobs = algo.m_logprobs.reshape(-1), b_advantages = advantages.reshape(-1), b_returns = returns.reshape(-1), b_values = algo.m_values.reshape(-1);
+    std::vector<float>().swap(algo.m_clipfracs);
+    Config4Run run;
+    run.crcParamsBefore = hl::crcOf(params0);
+    if (other && other->crcParamsBefore != run.crcParamsBefore) throw std::runtime_error("config4: the two runs did not start from the same parameters");
+    std::vector<double>& scal = run.scal;
+    auto tensorNorms = [&](bool grads) { std::vector<double> v; for (const auto& p : params) v.push_back((grads ? p.grad() : p).detach().to(torch::kFloat64).norm().item<double>()); return v; };
+    int64_t k = 0;
+    const int64_t steps = algo.m_update_epochs * ((B + MB - 1) / MB);
+    for (int64_t epoch = 0; epoch < algo.m_update_epochs; epoch++) {
+        std::vector<std::pair<uint64_t, int64_t>> keys(static_cast<size_t>(B));
+        for (int64_t i = 0; i < B; i++) keys[i] = { hl::mix64(c4::SEED_PERM + static_cast<uint64_t>(epoch * B + i)), i };
+        std::sort(keys.begin(), keys.end());
+        std::vector<int64_t> pv(static_cast<size_t>(B));
+        for (int64_t i = 0; i < B; i++) pv[i] = keys[i].second;
+        torch::Tensor b_inds = torch::from_blob(pv.data(), { B }, torch::kInt64).clone();
+        for (int64_t start = 0; start < B; start += MB) {
+            torch::Tensor mb = b_inds.index({ torch::indexing::Slice(start, start + MB) });
+            MinibatchOut r = minibatchLossBackward<PPO_MultiDiscrete, true>(algo, mb, b_obs, b_masks, b_actions, b_logprobs, b_advantages, b_returns, b_values);
+            if (k == 0 || k == steps - 1) {
+                const std::string K = "k" + std::to_string(k) + "/";
+                g.addF64(K + "grad_norms", tensorNorms(true), { 20 });
+                g.add(K + "sample_grads", sample(flatParams(params, true), 61));
+                if (k == steps - 1) run.lastGradSample = sample(flatParams(params, true), 61);
+                g.add(K + "sample_newlogprob", sample(r.o.logprob, full ? 1 : 509));
+                g.add(K + "sample_newvalue", sample(r.o.value, full ? 1 : 509));
+                g.add(K + "sample_entropy", sample(r.o.entropy, full ? 1 : 509));
+            }
+            double total_norm = torch::nn::utils::clip_grad_norm_(params, algo.m_max_grad_norm);
+            algo.m_optimizer->step();
+            if (k == 0) g.add("k0/sample_params_after", sample(flatParams(params), 61));
+            scal.insert(scal.end(), { r.pg_loss.item<double>(), r.v_loss.item<double>(), r.entropy_loss.item<double>(), r.approx_kl.item<double>(),
+                                      static_cast<double>(algo.m_clipfracs.back()), r.loss.item<double>(), total_norm });
+            std::cerr << "[ref_harness] config4 " << N << "x" << T << " step " << k << ": loss " << r.loss.item<double>() << " pg " << r.pg_loss.item<double>() << " v " << r.v_loss.item<double>()
+                      << " kl " << r.approx_kl.item<double>() << " norm " << total_norm << "\n";
+            k++;
+        }
+    }
+    g.addF64("step_scalars", scal, { k, 7 });
+    torch::Tensor paramsAfter = flatParams(params);
+    g.add("sample_params_after", sample(paramsAfter, 61));
+    g.addF64("sums_params_after", sums(paramsAfter), { 2 });
+    g.addF64("norms_params_after", tensorNorms(false), { 20 });
+    g.addF64("max_abs_param_change", { (paramsAfter - params0).abs().max().item<double>() }, { 1 });
+    g.addF64("lr", { static_cast<torch::optim::AdamWOptions&>(algo.m_optimizer->param_groups()[0].options()).lr() }, { 1 });
+    run.paramsAfterSample = sample(paramsAfter, 61);
+    if (other) {
+        // the same scenario run by the same unmodified reference from parameters one ulp away (ulpTwin above)
+        g.addF64("ulp_twin/step_scalars", other->scal, { static_cast<int64_t>(other->scal.size() / 7), 7 });
+        g.add("ulp_twin/sample_params_after", other->paramsAfterSample);
+        g.add("ulp_twin/sample_last_grads", other->lastGradSample);
+    }
+    g.addI64("torch_threads", { at::get_num_threads() }, { 1 });
+    if (!outPath.empty()) g.save(outPath);
+    return run;
 }
 
 // (10) Learning curves: the reference's own acceptance test is "run ./PPO and watch ep_len_mean" (README.md:169-178).  The UNMODIFIED train()
@@ -1117,6 +1311,21 @@ int main(int argc, char** argv) {
             }
             return 0;
         }
+        if (mode == "config4" && argc > 2) {
+            char buf[4096];
+            std::string out = argv[2];
+            if (out[0] != '/') out = std::string(getcwd(buf, sizeof buf)) + "/" + out;
+            // optional: LibTorch intra-op threads.  MKL / ATen pick their summation order by thread count, so a second run with another count is the REFERENCE'S
+            // OWN fp32 noise over the 40 steps -- the yardstick for how far two correct fp32 trajectories drift apart (tools/c4_ref_self_distance.py)
+            // a size the scalar oracle can follow, with every per-sample tensor in full (64 envs x 16 steps, 4 minibatches of 256, 2 epochs) ...
+            Config4Run small1 = goldConfig4(64, 16, 4, 2, true, "", "", true);
+            goldConfig4(64, 16, 4, 2, true, out + "/config4_params.pgld", out + "/config4_small_64x16.pgld", false, &small1);
+            // ... and configs[4]'s per-GPU share: 16 384 envs / 8 GPUs = 2048 envs x 128 steps, 4 minibatches of 65 536 rows, the recommended 10 epochs;
+            // first the twin one ulp away (kept as "ulp_twin/*": the reference's own sensitivity), then the fixture proper
+            Config4Run share1 = goldConfig4(2048, 128, 4, 10, false, "", "", true);
+            goldConfig4(2048, 128, 4, 10, false, "", out + "/config4_share_2048x128.pgld", false, &share1);
+            return 0;
+        }
         if (mode == "curves" && argc > 6) {
             // CartPoleRecommendedSettings.toml's hyper-parameters (RunCfg's defaults) with action_size = 2, as BASELINE.json configs[0] runs them
             char buf[4096];
@@ -1127,7 +1336,7 @@ int main(int argc, char** argv) {
             return curvesReference<PPO_Discrete>(c, out);
         }
         std::cerr << "usage: ref_harness golden <outdir> | hostgold <outdir> | ptgold <outdir> | ptload <agent.pt> <optimizer.pt> <obs> <act> <out.pgld> | "
-                     "bench <num_envs> <num_steps> <updates> [threads] | curves <out.json> <num_envs> <num_steps> <total_timesteps> <seed> | headline <outdir>\n";
+                     "bench <num_envs> <num_steps> <updates> [threads] | curves <out.json> <num_envs> <num_steps> <total_timesteps> <seed> | headline <outdir> | config4 <outdir>\n";
         return 2;
     } catch (const std::exception& ex) {
         std::cerr << "[ref_harness] error: " << ex.what() << std::endl;

@@ -169,6 +169,13 @@ struct ppo_ctx {
     bool use_mfma = true;
     bool update_single_wave = false;   // PPO_KERNEL_UPDATE_ONE_WAVE
     bool rollout_vector = false;       // PPO_KERNEL_ROLLOUT_VECTOR
+    // fp16 range of the matrix-core kernels (OptGuard, ppo_internal.hpp): running maxima of |parameter| by class, on the device and mirrored into pinned
+    // host memory that the dispatch reads WITHOUT synchronising; wrange_dirty = the host wrote parameters since they were last computed from scratch
+    uint32_t* wr_dev = nullptr;
+    uint32_t* wr_host = nullptr;       // hipHostMalloc'ed, mapped: wr_host_dev is the device's address of the same words
+    uint32_t* wr_host_dev = nullptr;
+    bool wrange_dirty = true;
+    int64_t vector_fallback_launches = 0;   // launches that took a vector kernel because a weight did not fit fp16
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
     GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
     uint8_t* cur_mask = nullptr;     // generic path: action mask of the observation in NEXT_OBS, [N, A]
@@ -384,6 +391,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (c->gen) { delete c->gen; c->gen = nullptr; }
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->adam_coefs_h) (void)hipHostFree(c->adam_coefs_h);
+    if (c->wr_host) (void)hipHostFree(c->wr_host);
     if (c->snap) (void)hipHostFree(c->snap);
     for (hipEvent_t e : c->snap_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->coef_copied) if (e) (void)hipEventDestroy(e);
@@ -497,6 +505,10 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc_buf<int32_t>(c, PPO_BUF_FIN_LEN, TN));
     CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
     CK(dalloc(c, &c->error_flag, 1));
+    CK(dalloc(c, &c->wr_dev, 4));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&c->wr_host), 4 * sizeof(uint32_t), hipHostMallocMapped));
+    CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->wr_host_dev), c->wr_host, 0));
+    for (int i = 0; i < 4; i++) c->wr_host[i] = 0u;
     c->use_mfma = A <= 4;   // the matrix-core update kernel folds heads of up to 4 logits; wider policies (2 x 64 nets) run the vector kernel
     // ppo_config.kernel_flags (include/ppo_hip.h): the only switch between kernels; nothing is read from the environment
     if (cfg->kernel_flags & PPO_KERNEL_UPDATE_VECTOR) c->use_mfma = false;
@@ -666,6 +678,7 @@ extern "C" ppo_status ppo_memcpy_h2d(ppo_ctx* c, void* dst_dev, const void* src_
     HIPCHK(c, hipMemcpyAsync(dst_dev, src_h, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->gen) c->gen->planes_dirty = true;   // the copy may have landed in the parameters: re-split the weights before their next use
+    c->wrange_dirty = true;                    // ... and their fp16-range maxima are recomputed before the next matrix-core launch
     return PPO_OK;
 }
 extern "C" ppo_status ppo_memcpy_d2h(ppo_ctx* c, void* dst_h, const void* src_dev, size_t bytes) {
@@ -973,6 +986,38 @@ static ppo_status consume_finished_episodes(ppo_ctx* c) {
     return PPO_OK;
 }
 
+// The matrix-core kernels of the reference's two shapes carry some operands as fp16 (kernels_rollout.hip: 2^8 W3; kernels_update_mfma.hip: c W2 and the
+// products through its columns); the reference has no such limits.  A drop-in user never sees them: the optimizer kernels keep the running maximum of
+// |parameter| per class (OptGuard), the host reads the pinned mirror -- no synchronisation; it lags the device by the launches in flight, during which
+// AdamW moves a weight by about lr per step, hence thresholds at HALF the kernels' limits -- and a launch whose weights are out of range takes the vector
+// kernel (plain fp32, same function).  After the host wrote parameters the maxima are recomputed from scratch (one tiny launch + a synchronisation).
+constexpr float WR_LIMIT_W3 = 128.0f;    // rollout16_kernel: |W3| < 255
+constexpr float WR_LIMIT_W2 = 4.0f;      // update kernels: a column of c W2 with absolute sum ~2^10 overflows the fp16 terms of dz1: 64 x 4 x 2.885 = 739
+constexpr float WR_LIMIT_REST = 8192.0f; // c W1, c b1, c b2: < 65 504 / 2.885
+static ppo_status refresh_weight_range(ppo_ctx* c) {
+    if (!c->wrange_dirty || c->gen) return PPO_OK;
+    HIPCHK(c, launch_weight_range(B_<float>(c, PPO_BUF_PARAMS), c->L, c->wr_dev, c->wr_host_dev, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->wrange_dirty = false;
+    return PPO_OK;
+}
+static inline float wr_read(const ppo_ctx* c, int cls) {
+    const uint32_t bits = __atomic_load_n(c->wr_host + cls, __ATOMIC_RELAXED);
+    float v;
+    std::memcpy(&v, &bits, 4);
+    return v;   // NaN (a diverged run) compares false below: not-in-range, see the callers
+}
+static inline bool weights_fit_rollout16(const ppo_ctx* c) { return wr_read(c, PPO_WR_W3) < WR_LIMIT_W3; }
+static inline bool weights_fit_update_mfma(const ppo_ctx* c) {
+    return wr_read(c, PPO_WR_W3) < WR_LIMIT_REST && wr_read(c, PPO_WR_W2) < WR_LIMIT_W2 && wr_read(c, PPO_WR_REST) < WR_LIMIT_REST;
+}
+static inline OptGuard opt_guard(const ppo_ctx* c) {
+    OptGuard g;
+    if (!c->gen) { g.wr_dev = c->wr_dev; g.wr_host = c->wr_host_dev; }
+    g.error_flag = c->error_flag;
+    return g;
+}
+
 extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     NEED(c, c != nullptr, "null ctx");
     DeviceGuard dev_guard(c);
@@ -995,7 +1040,10 @@ extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     a.ep_rew = B_<float>(c, PPO_BUF_EP_REW);
     a.reset_count = B_<int32_t>(c, PPO_BUF_RESET_COUNT);
     a.reset_table = c->reset_table; a.reset_cap = c->reset_cap; a.error_flag = c->error_flag;
+    s = refresh_weight_range(c);
+    if (s != PPO_OK) return s;
     a.vector_kernel = c->rollout_vector ? 1 : 0;
+    if (!a.vector_kernel && !weights_fit_rollout16(c)) { a.vector_kernel = 1; c->vector_fallback_launches += 1; }
     a.obs = B_<float>(c, PPO_BUF_OBS);
     a.actions = B_<int32_t>(c, PPO_BUF_ACTIONS);
     a.logprobs = B_<float>(c, PPO_BUF_LOGPROBS);
@@ -1254,7 +1302,7 @@ static ppo_status pack_records(ppo_ctx* c) {
     HIPCHK(c, launch_pack_records(c->L, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS),
                                   c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
                                   B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->rec_critic,
-                                  c->rec_actor, c->ev_sums, c->stream));
+                                  c->rec_actor, c->ev_sums, c->update_single_wave ? nullptr : c->error_flag, c->stream));
     return PPO_OK;
 }
 
@@ -1285,12 +1333,18 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     a.stamps = c->stamping ? c->stamps : nullptr;
     a.error_flag = c->error_flag;
     a.single_wave = c->update_single_wave ? 1 : 0;
-    if (c->use_mfma) update_blocks_mfma((int)M, a.n_blocks);
+    bool mfma_now = c->use_mfma;
+    if (mfma_now) {   // fp16 range of the matrix-core kernels' operands: see refresh_weight_range
+        const ppo_status rs = refresh_weight_range(c);
+        if (rs != PPO_OK) return rs;
+        if (!weights_fit_update_mfma(c)) { mfma_now = false; c->vector_fallback_launches += 1; }
+    }
+    if (mfma_now) update_blocks_mfma((int)M, a.n_blocks);
     else a.n_blocks[0] = a.n_blocks[1] = update_blocks_per_net((int)M);
     {
         c->prof_last_sampled = c->prof_every <= 1 || (c->prof_count++ % c->prof_every) == c->prof_every / 2;
         ProfScope ps(c, PROF_FWD_BWD, c->prof_last_sampled);
-        if (c->use_mfma) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
+        if (mfma_now) HIPCHK(c, launch_minibatch_fwd_bwd_mfma(a, c->stream));
         else HIPCHK(c, launch_minibatch_fwd_bwd(a, c->stream));
     }
     c->last_n_blocks[0] = a.n_blocks[0]; c->last_n_blocks[1] = a.n_blocks[1];
@@ -1311,7 +1365,7 @@ static hipError_t clip_adamw_any(ppo_ctx* c, int slot, double global_M, int worl
     }
     return launch_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
                              c->L, c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, world, do_step,
-                             c->step_stats + slot, clipfrac_accum, c->norm2, c->stream);
+                             c->step_stats + slot, clipfrac_accum, c->norm2, c->stream, opt_guard(c));
 }
 
 extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* idx, int64_t M) {
@@ -1453,7 +1507,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
                                                             B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
                                                             c->cfg.max_grad_norm, c->adam_coefs + k, (double)M * c->world, c->hp, c->step_stats + k,
                                                             c->clipfrac_accum, c->fused_partial, x.peer, c->rank, c->world, x.slot_bytes, x.seq, x.timeout_flag,
-                                                            c->stream));
+                                                            c->stream, opt_guard(c)));
                 c->last_stat_slot = k;
                 continue;
             }
@@ -1463,7 +1517,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
                 ProfScope ps(c, PROF_OPT);
                 HIPCHK(c, launch_reduce_clip_adamw(c->slab, c->stat_slab, c->last_n_blocks, c->L, B_<float>(c, PPO_BUF_GRADS), c->loss_sums, B_<float>(c, PPO_BUF_PARAMS),
                                                    B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ), c->cfg.max_grad_norm, c->adam_coefs + k, (double)M,
-                                                   c->hp, c->step_stats + k, c->clipfrac_accum, c->fused_partial, c->stream));
+                                                   c->hp, c->step_stats + k, c->clipfrac_accum, c->fused_partial, c->stream, opt_guard(c)));
                 c->last_stat_slot = k;
                 continue;
             }
@@ -1542,7 +1596,12 @@ extern "C" ppo_status ppo_stats_snapshot_read(ppo_ctx* c, ppo_stats* out) {
     if (h.error_flag & PPO_ERRFLAG_ROLLOUT_RANGE)
         return fail(c, PPO_ERR_STATE, "rollout: an output-layer weight of the actor is >= 255 in magnitude and does not fit the fp16 operand of the matrix-core rollout "
                                       "(its logits are invalid): create the context with PPO_KERNEL_ROLLOUT_VECTOR in ppo_config.kernel_flags");
-    if (h.error_flag & PPO_ERRFLAG_UPDATE_PROTOCOL) return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out (gradients of that step are incomplete)");
+    if (h.error_flag & PPO_ERRFLAG_UPDATE_PROTOCOL)
+        return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out; that optimizer step and every later one were "
+                                      "NOT applied (parameters and moments hold their last good values)");
+    if (h.error_flag & PPO_ERRFLAG_UPDATE_RANGE)
+        return fail(c, PPO_ERR_STATE, "update kernel: an observation of magnitude >= 65504 does not fit the fp16 operand of the matrix-core update kernel; that optimizer "
+                                      "step and every later one were NOT applied: create the context with PPO_KERNEL_UPDATE_VECTOR in ppo_config.kernel_flags");
     if (h.xchg_flag != 0)
         return fail(c, PPO_ERR_COMM, "direct exchange: an all-reduce gave up waiting for a peer after %.1f s; its sums were incomplete, the replicas have "
                                      "diverged and the communicator is dead (every later all-reduce returns at once)", c->xchg ? c->xchg->wait_seconds : 0.0);

@@ -537,17 +537,52 @@ __global__ __launch_bounds__(NORM_THREADS) void grad_norm_kernel(const float* __
 // K9 (clip coefficient) + K10 (AdamW), element-parallel.  GRADS is left holding the UNCLIPPED gradient (the reference scales
 // .grad in place, clip_grad.h:79-81, but nothing reads it before zero_grad); the clip coefficient is applied on the fly.
 constexpr int ADAM_THREADS = 256;   // four waves: opt_total_norm spreads the twelve tensors' partials over waves 0..3
+// OptGuard (ppo_internal.hpp): class of parameter p, the running maximum of its class, the mirror into host memory
+__device__ __forceinline__ int opt_range_class(const NetLayout& L, int p) {
+    const bool w3 = (p >= L.w3[0] && p < L.b3[0]) || (p >= L.w3[1] && p < L.b3[1]);
+    const bool w2 = (p >= L.w2[0] && p < L.b2[0]) || (p >= L.w2[1] && p < L.b2[1]);
+    return w3 ? PPO_WR_W3 : (w2 ? PPO_WR_W2 : PPO_WR_REST);
+}
+__device__ __forceinline__ void opt_track_range(const NetLayout& L, const OptGuard& g, int p, float value, uint32_t seen) {
+    // `seen` = the class maximum as it stood when the kernel started (one load, requested with the element): in steady state no weight passes it and no
+    // atomic is issued.  |x| as a bit pattern orders like the float (NaN sorts above every number, which is the reading we want for it)
+    const uint32_t bits = __builtin_bit_cast(uint32_t, value) & 0x7fffffffu;
+    if (bits > seen) atomicMax(g.wr_dev + opt_range_class(L, p), bits);
+}
+__device__ __forceinline__ void opt_mirror_range(const OptGuard& g) {   // one thread: what the device word holds now (this launch's atomics may still be under way)
+    if (!g.wr_dev || !g.wr_host) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const uint32_t v = __hip_atomic_load(g.wr_dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.wr_host + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__device__ __forceinline__ bool opt_step_allowed(const OptGuard& g) {
+    return !g.error_flag || (*g.error_flag & (PPO_ERRFLAG_UPDATE_PROTOCOL | PPO_ERRFLAG_UPDATE_RANGE)) == 0;
+}
+__global__ void weight_range_kernel(const float* __restrict__ params, NetLayout L, uint32_t* wr_dev, uint32_t* wr_host) {
+    __shared__ uint32_t m[3];
+    if (threadIdx.x < 3) m[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int p = threadIdx.x; p < L.P; p += blockDim.x) atomicMax(&m[opt_range_class(L, p)], __builtin_bit_cast(uint32_t, params[p]) & 0x7fffffffu);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        wr_dev[threadIdx.x] = m[threadIdx.x];
+        __hip_atomic_store(wr_host + threadIdx.x, m[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restrict__ params, const float* __restrict__ grads, float* __restrict__ exp_avg,
                                                                   float* __restrict__ exp_avg_sq, NetLayout L, float max_norm,
                                                                   const double* __restrict__ norm2, const AdamCoef* __restrict__ coef_p,
                                                                   const double* __restrict__ loss_sums, double global_M, LossParams hp,
-                                                                  int world, int do_step, StepStats* stats_out, double* clipfrac_accum) {
+                                                                  int world, int do_step, StepStats* stats_out, double* clipfrac_accum, OptGuard guard) {
     const int tid = threadIdx.x;
     // this thread's element, the norms and the statistics scalars are all requested before anything is consumed
     const int pu = blockIdx.x * ADAM_THREADS + tid;
-    const bool upd = do_step && pu < L.P;
+    const bool upd = do_step && pu < L.P && opt_step_allowed(guard);
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
-    if (upd) { u_g = grads[pu]; u_p = params[pu]; u_m = exp_avg[pu]; u_v = exp_avg_sq[pu]; }
+    uint32_t wr_seen = 0u;
+    if (upd) { u_g = grads[pu]; u_p = params[pu]; u_m = exp_avg[pu]; u_v = exp_avg_sq[pu]; if (guard.wr_dev) wr_seen = guard.wr_dev[opt_range_class(L, pu)]; }
     double n2[12];
 #pragma unroll
     for (int t = 0; t < 12; t++) n2[t] = t < L.n_tensors ? norm2[t] : 0.0;
@@ -583,10 +618,13 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
         const float mi = __builtin_fmaf(g, omb1, u_m * b1);          // exp_avg.mul_(b1).add_(g, 1-b1)   (ATen fmadd)
         const float vi = __builtin_fmaf(omb2 * g, g, u_v * b2);      // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
         const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
-        params[pu] = pi + (k.neg_step * mi) / denom;                 // addcdiv_(exp_avg, denom, -step_size)
+        const float pn = pi + (k.neg_step * mi) / denom;             // addcdiv_(exp_avg, denom, -step_size)
+        params[pu] = pn;
         exp_avg[pu] = mi;
         exp_avg_sq[pu] = vi;
+        if (guard.wr_dev) opt_track_range(L, guard, pu, pn, wr_seen);
     }
+    if (stat_thread && do_step) opt_mirror_range(guard);
     if (stat_thread) {
         // scalars as the reference forms them (PPO_Discrete.cpp:599,619,628,631,349,352), means over the global minibatch
         const float pg = (float)(ls[0] / global_M);
@@ -627,6 +665,7 @@ struct FusedOptArgs {
     // XCHG: the one-shot direct exchange of exchange_allreduce_kernel (below), folded into the reduction: a sharded step is then the same two
     // launches as a single-rank one -- reduce + exchange + sums of squares, then norm + clip + AdamW
     void* peers[8]; int rank, n_ranks; size_t slot_bytes; unsigned long long seq; int32_t* timeout_flag;
+    OptGuard guard;
 };
 // ---- the exchange buffer of a rank (fine-grained device memory, mapped by every peer; ExchangeComm in api.hip) ----
 //   payload  [2 parities][8 source ranks][slot_bytes]     rank s WRITES its share of call k into slot [k & 1][s] of EVERY rank's buffer
@@ -818,9 +857,10 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
     const NetLayout& L = a.L;
     const int tid = threadIdx.x;
     const int p = blockIdx.x * ADAM_THREADS + tid;
-    const bool own = p < L.P;
+    const bool own = p < L.P && opt_step_allowed(a.guard);
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
-    if (own) { u_g = a.grads[p]; u_p = a.p_src[p]; u_m = a.m_src[p]; u_v = a.v_src[p]; }
+    uint32_t wr_seen = 0u;
+    if (own) { u_g = a.grads[p]; u_p = a.p_src[p]; u_m = a.m_src[p]; u_v = a.v_src[p]; if (a.guard.wr_dev) wr_seen = a.guard.wr_dev[opt_range_class(L, p)]; }
     const AdamCoef k = *a.coef;
     double ls[5] = { 0, 0, 0, 0, 0 }, cf0 = 0.0, cf1 = 0.0;
     const bool stat_thread = tid == 0 && blockIdx.x == 0;
@@ -835,7 +875,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
         a.params[p] = u_p;
         a.exp_avg[p] = u_m;
         a.exp_avg_sq[p] = u_v;
+        if (a.guard.wr_dev) opt_track_range(L, a.guard, p, u_p, wr_seen);
     }
+    if (stat_thread) opt_mirror_range(a.guard);
     if (stat_thread) opt_write_stats(ls, cf0, cf1, a.global_M, a.hp, total, a.stats_out, a.clipfrac_accum);
 }
 
@@ -1104,11 +1146,15 @@ hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const
 
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
-                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s) {
+                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s, OptGuard guard) {
     hipLaunchKernelGGL(grad_norm_kernel, dim3(L.n_tensors), dim3(NORM_THREADS), 0, s, grads, L, norm2_scratch);
     const int blocks = do_step ? (L.P + ADAM_THREADS - 1) / ADAM_THREADS : 1;
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, norm2_scratch,
-                       coef, loss_sums, global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum);
+                       coef, loss_sums, global_M, hp, world, do_step ? 1 : 0, stats_out, clipfrac_accum, guard);
+    return hipGetLastError();
+}
+hipError_t launch_weight_range(const float* params, const NetLayout& L, uint32_t* wr_dev, uint32_t* wr_host, hipStream_t s) {
+    hipLaunchKernelGGL(weight_range_kernel, dim3(1), dim3(1024), 0, s, params, L, wr_dev, wr_host);
     return hipGetLastError();
 }
 
@@ -1116,8 +1162,9 @@ int fused_opt_blocks(const NetLayout& L) { return (L.P + 63) / 64 + 1; }
 hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
-                                    double* partial, hipStream_t s) {
+                                    double* partial, hipStream_t s, OptGuard guard) {
     FusedOptArgs a{};
+    a.guard = guard;
     a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;
     a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M;
     a.p_src = params; a.m_src = exp_avg; a.v_src = exp_avg_sq;
@@ -1132,9 +1179,10 @@ hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* st
                                              double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
                                              double global_M, const LossParams& hp, StepStats* stats_out, double* clipfrac_accum, double* partial,
                                              void* const* peers, int rank, int n_ranks, size_t slot_bytes, uint64_t seq, int32_t* timeout_flag,
-                                             hipStream_t s) {
+                                             hipStream_t s, OptGuard guard) {
     if (n_ranks < 1 || n_ranks > 8 || (size_t)(L.P + 8) * sizeof(float) > slot_bytes) return hipErrorInvalidValue;
     FusedOptArgs a{};
+    a.guard = guard;
     a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;
     a.params = params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.max_norm = max_grad_norm; a.coef = coef; a.global_M = global_M;
     a.p_src = params; a.m_src = exp_avg; a.v_src = exp_avg_sq;

@@ -957,11 +957,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void fwd_bwd_mfma_kernel(UpdateArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // 1-D grid: the first n_blocks[0] workgroups run the critic, the rest the actor
     const int b = blockIdx.x;
-#ifdef MF_AB_NO_DW1M
-    constexpr bool DW1M = false;
-#else
     constexpr bool DW1M = EXACT;   // the reference's two shapes: 234 / 237 vector registers leave room for 12 more; the generic variants (245 - 247) do not
-#endif
     if (b < a.n_blocks[0]) mf_body<0, DIST, OBS, 1, true, STAMP, DW1M>(a, smem, b, a.n_blocks[0]);
     else mf_body<1, DIST, OBS, AMAX, EXACT, STAMP, DW1M>(a, smem, b - a.n_blocks[0], a.n_blocks[1]);
 }
@@ -1029,9 +1025,6 @@ __host__ __device__ constexpr int mg_slot(int fw) { return fw < MG_GW ? 2 * fw :
 // wave-uniform wait for a workgroup-shared LDS counter to reach `want`; false when the bound runs out (protocol error)
 typedef __attribute__((address_space(3))) volatile uint32_t lds_flag_t;
 __device__ __forceinline__ bool mg_wait_ge(const lds_flag_t* flag, uint32_t want) {
-#ifdef MG_DIAG_NOWAIT
-    return true;
-#endif
     for (int spin = 0; spin < (1 << 21); spin++) {
         const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)*flag);
         if (v >= want) { asm volatile("" ::: "memory"); return true; }
@@ -1149,11 +1142,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
     const int base = L.net_off[NET];
     double* dred = reinterpret_cast<double*>(smem + m.dred);
 
-#ifdef MG_DIAG_NO_F
-    if (false) {
-#else
     if (wave < MG_FW) {
-#endif
         // =================================================== F: forward, loss, d(activation) ===================================================
         float* wbase = smem + m.wave0 + mg_slot(wave) * m.wave_stride;
         uint16_t* ra16 = reinterpret_cast<uint16_t*>(wbase + m.ra);
@@ -1441,11 +1430,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
                     if constexpr (WR == 1) acc = mfma_f16(w3a[t][0], u32x4{ d1[0], d2[0], d1[0], 0u }, zero16);   // [w1 w1 w2] . [d1 d2 d1]
                     else acc = mfma_x2(w3a[t][0], w3a[t][WR == 1 ? 0 : 1], u32x4{ d1[0], d1[1], 0u, 0u }, u32x4{ d2[0], d2[1], 0u, 0u }, zero16);
 #pragma unroll
-#ifdef MG_DIAG_CHEAP_DZ2   // timing only (results wrong): 64 vector instructions less per tile
-                    for (int r = 0; r < 16; r++) dz2[16 * t + r] = acc[r];
-#else
                     for (int r = 0; r < 16; r++) dz2[16 * t + r] = acc[r] * __builtin_fmaf(-h2[16 * t + r], h2[16 * t + r], 1.0f);
-#endif
                 }
             }
             uint32_t zp[2][16];
@@ -1537,11 +1522,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         }
 #endif
         __syncthreads();   // gradient images parked (each G wave in the regions of its own two F waves: no barrier in front of that)
-#ifdef MG_DIAG_NO_G
-    } else if (false) {
-#else
     } else {
-#endif
         // =================================================== G: the products that contract over samples ===================================================
         const int g = wave - MG_FW;
         f32x16 gW2[2][2];
@@ -1725,27 +1706,17 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
             if (fw != g) MG_TR_G(23);
         };
         __builtin_amdgcn_s_setprio(2);
-#ifdef MG_DIAG_G_IDLE
-        for (int i = 0; i < 0; i++) {
-#else
         for (int i = 0; i < nt_a; i++) {   // nt_a >= nt_b (wave a's first tile comes first); nt_a - nt_b is 0 or 1
-#endif
             const int nj = i < nt_b ? 2 : 1;
 #ifdef MG_TRACE
             tr_round = i == 2;
 #endif
-#ifndef MG_DIAG_NO_E0
 #pragma nounroll
             for (int j = 0; j < nj; j++) serve_e0(j ? fw_b : g, 3u * i + 1u);
-#endif
-#ifndef MG_DIAG_NO_E1
 #pragma nounroll
             for (int j = 0; j < nj; j++) serve_e1(j ? fw_b : g, 3u * i + 2u);
-#endif
-#ifndef MG_DIAG_NO_E2
 #pragma nounroll
             for (int j = 0; j < nj; j++) serve_e2(j ? fw_b : g, 3u * i + 3u);
-#endif
         }
 #undef MG_REGION_PTRS
         __builtin_amdgcn_s_setprio(0);
@@ -1861,9 +1832,10 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
                                                            const uint8_t* __restrict__ masks, int A, const float* __restrict__ logprobs,
                                                            const float* __restrict__ advantages, const float* __restrict__ returns,
                                                            const float* __restrict__ values, int64_t B, float4* __restrict__ rec_critic,
-                                                           float4* __restrict__ rec_actor, double* __restrict__ ev_out) {
+                                                           float4* __restrict__ rec_actor, double* __restrict__ ev_out, int32_t* error_flag) {
     __shared__ double red[4][4];
     double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
+    float x_absmax = 0.0f;   // the wave-specialised update kernel cuts the observation into fp16 terms: its range is checked here, once per update, not assumed
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
         float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if constexpr (OBS == 4) x = *reinterpret_cast<const float4*>(obs + i * 4);
@@ -1871,6 +1843,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
         uint32_t ab = 0u, mb = 0xffffffffu;
         for (int h = 0; h < n_heads; h++) ab |= ((uint32_t)actions[i * n_heads + h] & 0xffu) << (8 * h);
         if (masks) { mb = 0u; for (int k = 0; k < A; k++) mb |= (masks[i * A + k] ? 1u : 0u) << k; }
+        x_absmax = fmaxf(fmaxf(x_absmax, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
         const float R = returns[i], V = values[i];
         rec_critic[2 * i] = x;
         rec_critic[2 * i + 1] = make_float4(R, V, 0.0f, 0.0f);
@@ -1879,6 +1852,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
         const double y = R, d = (double)(R - V);
         sy += y; sy2 += y * y; sd += d; sd2 += d * d;
     }
+    if (!(x_absmax < 65504.0f) && error_flag) atomicOr(error_flag, PPO_ERRFLAG_UPDATE_RANGE);   // beyond fp16 (or NaN): the optimizer kernels skip their steps
     sy = wave_sum_d_dpp(sy); sy2 = wave_sum_d_dpp(sy2); sd = wave_sum_d_dpp(sd); sd2 = wave_sum_d_dpp(sd2);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = sy; red[w][1] = sy2; red[w][2] = sd; red[w][3] = sd2; }
@@ -2092,15 +2066,15 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
 // rec_critic / rec_actor: [B][8] floats each; ev_sums: [PPO_EV_BLOCKS][4] partial sums of the explained variance
 hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
                                const float* advantages, const float* returns, const float* values, int64_t B, float* rec_critic, float* rec_actor,
-                               double* ev_sums, hipStream_t s) {
+                               double* ev_sums, int32_t* error_flag, hipStream_t s) {
     if (L.act > 4 || L.n_heads > 4) return hipErrorNotSupported;
     const dim3 grid(PPO_EV_BLOCKS), block(256);
     if (L.obs == 4)
         hipLaunchKernelGGL((pack_records_kernel<4>), grid, block, 0, s, obs, actions, L.n_heads, masks, L.act, logprobs, advantages, returns, values, B,
-                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums);
+                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums, error_flag);
     else if (L.obs == 2)
         hipLaunchKernelGGL((pack_records_kernel<2>), grid, block, 0, s, obs, actions, L.n_heads, masks, L.act, logprobs, advantages, returns, values, B,
-                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums);
+                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums, error_flag);
     else
         return hipErrorNotSupported;
     return hipGetLastError();

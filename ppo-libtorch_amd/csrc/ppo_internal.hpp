@@ -576,6 +576,7 @@ struct UpdateArgs {
     int single_wave;         // 1: the one-wave-per-tile matrix-core kernel even for the reference's two shapes (A/B; ppo_config.kernel_flags)
 };
 constexpr int32_t PPO_ERRFLAG_UPDATE_PROTOCOL = 2;
+constexpr int32_t PPO_ERRFLAG_UPDATE_RANGE = 8;    // a matrix-core update kernel met an observation that does not fit its fp16 operand (|obs| >= 65 504)
 constexpr int32_t PPO_ERRFLAG_ROLLOUT_RANGE = 4;   // rollout16_kernel: |W3| does not fit the fp16 operand (pre-scaled by 2^8)
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
@@ -585,13 +586,29 @@ void update_blocks_mfma(int M, int n_blocks[2]);
 hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
 hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
                                const float* advantages, const float* returns, const float* values, int64_t B, float* rec_critic, float* rec_actor,
-                               double* ev_sums, hipStream_t s);
+                               double* ev_sums, int32_t* error_flag, hipStream_t s);
+// What an optimizer kernel of the 2 x 64 layout keeps an eye on beside its step (every pointer may be null):
+//   * the running maxima of |parameter| by fp16-range class -- [PPO_WR_W3] both nets' output layers (rollout16_kernel carries 2^8 W3 as fp16: |W3| < 255),
+//     [PPO_WR_W2] both nets' hidden-to-hidden weights (the matrix-core update kernels carry c W2 and products through its columns as fp16 terms),
+//     [PPO_WR_REST] everything else (c W1, c b1, ... < 65 504) -- as float bit patterns, monotone until ppo_ctx's weight_range() recomputes them:
+//     wr_dev on the device (atomicMax), mirrored by one thread into wr_host (pinned host memory the HOST reads without synchronising, a step or two
+//     late) so that ppo_rollout / the update dispatch can take the vector kernels for a launch whose weights do not fit fp16 instead of failing;
+//   * the context's error word: while PPO_ERRFLAG_UPDATE_PROTOCOL / PPO_ERRFLAG_UPDATE_RANGE is set the gradient of this step is garbage, and the
+//     step is NOT applied -- parameters and moments stay at their last good values (the error is sticky and reported by ppo_read_stats).
+struct OptGuard {
+    uint32_t* wr_dev = nullptr;
+    uint32_t* wr_host = nullptr;
+    const int32_t* error_flag = nullptr;
+};
+constexpr int PPO_WR_W3 = 0, PPO_WR_W2 = 1, PPO_WR_REST = 2;
 // grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
 hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                double* sums_out, hipStream_t s);
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
-                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s);
+                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s, OptGuard guard = OptGuard());
+// recomputes the three maxima of OptGuard from the parameters (after the host wrote them): wr_dev and wr_host both
+hipError_t launch_weight_range(const float* params, const NetLayout& L, uint32_t* wr_dev, uint32_t* wr_host, hipStream_t s);
 // batched critic on the matrix cores (obs in {2, 4}); same contract as launch_values
 hipError_t launch_values_mfma(const float* params, const NetLayout& L, const float* obs0, int64_t n0, float* out0, const float* obs1, int64_t n1,
                               float* out1, hipStream_t s);
@@ -600,12 +617,12 @@ int fused_opt_blocks(const NetLayout& L);
 hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
-                                    double* partial, hipStream_t s);
+                                    double* partial, hipStream_t s, OptGuard guard = OptGuard());
 hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                              double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
                                              double global_M, const LossParams& hp, StepStats* stats_out, double* clipfrac_accum, double* partial,
                                              void* const* peers, int rank, int n_ranks, size_t slot_bytes, uint64_t seq, int32_t* timeout_flag,
-                                             hipStream_t s);
+                                             hipStream_t s, OptGuard guard = OptGuard());
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
 struct EpisodeRing {
     float rew[100];

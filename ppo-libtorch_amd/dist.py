@@ -86,6 +86,12 @@ def bootstrap_comm(ctx, dist, rank, world, make_unique_id, transport="rccl"):
                           gathered in rank order, every rank maps its peers' buffers.  No RCCL at all."""
     if world == 1:
         return
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+        # a caller that ran its own torch.distributed rendezvous: `ctx` exists, so HIP is already initialised and setting the variable now may come too late
+        import warnings
+        warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY was not set before the context was created: on hosts that only support dmabuf IPC, hipIpcGetMemHandle / "
+                      "ncclCommInitRank fail with 'invalid argument'.  Export HSA_ENABLE_IPC_MODE_LEGACY=0 in the ranks' environment (INTEGRATION.md).")
+    enable_dmabuf_ipc()
     if transport == "exchange":
         handles = gather_bytes(dist, ctx.comm_exchange_handle())
         ctx.comm_init_exchange(handles, rank, world)
@@ -132,6 +138,8 @@ def start_exchange_checked(make_ctx, warm, dist, rank, world, log=None):
     import hashlib
     import sys
     log = log or sys.stderr.write
+    if world > 1:
+        enable_dmabuf_ipc()   # before make_ctx()'s first HIP call (a no-op when the launcher exported it, as bench.py does)
     c, err, handle = None, None, None
     try:
         c = make_ctx()

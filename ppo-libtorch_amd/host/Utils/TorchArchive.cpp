@@ -307,8 +307,9 @@ struct Archive {
         }
         if (offset < 0 || numel > storage_numel) fail(file, name + ": more elements than its storage record holds");
         // a stride no honest view needs (every index x stride product then stays far inside int64: the element loop cannot overflow before its bound check)
-        for (int64_t st : strides)
-            if (st < -storage_numel || st > storage_numel) fail(file, name + ": stride outside its storage");
+        // PyTorch never dereferences the stride of a size-1 (or size-0) dimension and records 1-strides for empty tensors: only dimensions that step are bound
+        for (size_t d = 0; numel > 0 && d < strides.size(); d++)
+            if (t.sizes[d] > 1 && (strides[d] < -storage_numel || strides[d] > storage_numel)) fail(file, name + ": stride outside its storage");
         if (offset > storage_numel) fail(file, name + ": offset outside its storage");
         t.values.resize((size_t)numel);
         std::vector<int64_t> idx(t.sizes.size(), 0);

@@ -709,26 +709,54 @@ def test_vector_rollout_flag_is_bit_exact_with_policy_act(P, N):
     b.close()
 
 
-def test_matrix_core_rollout_reports_weights_beyond_fp16(P):
-    """The matrix-core rollout's output-layer operand is pre-scaled by 2^8 and cut into fp16 terms: |W3| >= 255 does not fit.  The reference has no such
-    limit, so the kernel checks: such a weight raises the context's error word and the next statistics read fails (PPO_ERR_STATE) instead of sampling
-    from inf / NaN logits; with PPO_KERNEL_ROLLOUT_VECTOR the same weights run."""
-    cfg = dict(num_envs=64, num_steps=8, num_minibatches=1, update_epochs=1, seed=5)
-    for flags, ok in ((0, False), (P.KERNEL_ROLLOUT_VECTOR, True)):
-        ctx = P.Context(P.make_config(kernel_flags=flags, **cfg))
-        ctx.init_orthogonal(3)
-        params = ctx.get_params()
-        params[-130] = 300.0          # one actor output-layer weight (the last 130 floats: actorOutputLayer.weight [2, 64] + bias [2])
-        ctx.set_params(params)
-        ctx.env_reset()
-        ctx.rollout()
-        if ok:
-            assert np.isfinite(ctx.read("LOGPROBS", (8, 64))).all()
-            ctx.stats()
-        else:
-            with pytest.raises(P.binding.PPOError, match="PPO_KERNEL_ROLLOUT_VECTOR"):
-                ctx.stats()
-        ctx.close()
+def test_weights_beyond_fp16_take_the_vector_kernels_for_that_launch(P):
+    """The matrix-core kernels carry some operands as fp16 (rollout16_kernel: 2^8 W3, |W3| < 255; the update kernels: c W2 and the products through its
+    columns).  The reference has no such limits, and a drop-in user must not meet them: the optimizer kernels keep the running maximum of |parameter| per class,
+    the host reads its pinned mirror, and a launch whose weights do not fit takes the vector kernel (plain fp32) -- with DEFAULT flags.  Here: an actor
+    output-layer weight of 300, and a hidden-to-hidden weight of 6, each set through ppo_params_set_h: the rollout equals the PPO_KERNEL_ROLLOUT_VECTOR context's
+    bit for bit (it IS that kernel), the update equals the PPO_KERNEL_UPDATE_VECTOR context's, training goes on and the statistics read reports nothing."""
+    cfg = dict(num_envs=64, num_steps=16, num_minibatches=2, update_epochs=2, seed=5, total_timesteps=64 * 16 * 4)
+    # actorOutputLayer.weight[0][0] against the context whose ROLLOUT is always the vector kernel; criticMiddleLayer.weight[0][7] against the one whose UPDATE is
+    for where, value, twin_flags in ((-130, 300.0, P.KERNEL_ROLLOUT_VECTOR), (4 * 64 + 64 + 7, 6.0, P.KERNEL_UPDATE_VECTOR)):
+        ctxs = [P.Context(P.make_config(kernel_flags=f, **cfg)) for f in (0, twin_flags)]
+        ctxs[0].init_orthogonal(3)
+        params = ctxs[0].get_params()
+        params[where] = value
+        outs = []
+        for ctx in ctxs:
+            ctx.set_params(params)
+            ctx.env_reset()
+            for _ in range(2):
+                ctx.train_iteration()
+            st = ctx.stats()                      # raises PPO_ERR_STATE if any kernel flagged a range error
+            assert np.isfinite(st["loss"]) and st["optimizer_steps"] == 8
+            outs.append((ctx.read("LOGPROBS"), ctx.read("ACTIONS"), ctx.read("VALUES"), ctx.get_params()))
+            ctx.close()
+        assert np.isfinite(outs[0][0]).all() and np.isfinite(outs[0][3]).all()
+        # the default context took the vector kernel wherever its twin does: rollout buffers and parameters after two iterations, bit for bit
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+        assert np.array_equal(outs[0][3].view(np.uint32), outs[1][3].view(np.uint32))
+        assert abs(outs[0][3][where] - value) < 0.1
+
+
+def test_observation_beyond_fp16_is_reported_and_the_step_is_not_applied(P):
+    """The wave-specialised update kernel cuts the observation into fp16 terms: |obs| >= 65504 written through the C-ABI's OBS buffer does not fit.  The record
+    packing checks it (PPO_ERRFLAG_UPDATE_RANGE); the optimizer kernels then do NOT apply the step (parameters and moments keep their last good values) and the
+    next statistics read fails with PPO_ERR_STATE naming PPO_KERNEL_UPDATE_VECTOR -- no silent NaN in the parameters."""
+    ctx = P.Context(P.make_config(num_envs=32, num_steps=8, num_minibatches=1, update_epochs=1, seed=2))
+    ctx.init_orthogonal(1)
+    ctx.env_reset()
+    ctx.rollout()
+    ctx.calc_advantage()
+    obs = ctx.read("OBS", (8, 32, 4))
+    obs[3, 5, 1] = 1.0e5
+    ctx.write("OBS", obs)
+    before = ctx.get_params()
+    ctx.update()
+    assert np.array_equal(ctx.get_params().view(np.uint32), before.view(np.uint32))
+    with pytest.raises(P.binding.PPOError, match="PPO_KERNEL_UPDATE_VECTOR"):
+        ctx.stats()
+    ctx.close()
 
 
 @pytest.mark.parametrize("T,limit", [(1, 500), (2, 1), (5, 1), (7, 2), (64, 3), (33, 500)])

@@ -312,3 +312,90 @@ def test_oracle_at_headline_size_against_the_compiled_reference(name):
     lp, _, v = O.evaluate(net, g["params_before"], obs.reshape(B, obs_dim)[rows], actions.reshape(B)[rows], mask)
     np.testing.assert_allclose(lp, g["sample_logprobs"], rtol=0, atol=3e-6)
     np.testing.assert_allclose(v, g["sample_values"], rtol=0, atol=3e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]'s OWN SHAPE (obs 376, heads [3, 3, 3, 2], 4 x 256) against the compiled reference: oracle/ref_harness.cpp `config4` swaps
+# 376 -> 256 x 4 -> {11 | 1} Sequentials into the unmodified Agent's public m_Actor / m_Critic (Agent.h:44-50) and re-drives PPO_MultiDiscrete's update
+# on a hash-made batch (tests/c4_batch.py regenerates it; the fixture's CRCs hold that file to what the reference saw).  This pins the oracle's
+# GENERIC mode (mlp_forward1 / mlp_backward1 at any width, depth and head list), which tests/test_gpu_generic.py uses as the yardstick for other shapes.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _c4_load(name):
+    import c4_batch as C4
+    g = O.read_pgld(os.path.join(G, name + ".pgld"))
+    m = C4.load_meta(g)
+    params = O.read_pgld(os.path.join(G, "config4_params.pgld"))["params"]
+    assert C4.crc(params) == int(g["crc_params_before"][0])
+    net = O.Net.make(C4.O, list(C4.HEADS), hidden=m["hidden"], n_hidden=m["n_hidden"], dist_kind=O.DIST_MASKED)
+    assert O.param_count(net) == params.size == 590860
+    assert [tuple(s) for s in O.param_shapes(net)] == [tuple(int(v) for v in s) for s in g["param_shapes"]]     # critic first, then actor (Agent.cpp:65-66)
+    hp = O.HParams(gamma=m["gamma"], gae_lambda=m["lam"], clip_coef=m["clip"], ent_coef=m["ent"], vf_coef=m["vf"], max_grad_norm=m["mgn"],
+                   norm_adv=m["norm_adv"], clip_vloss=m["clip_vloss"])
+    return C4, g, m, params.copy(), net, hp
+
+
+def test_oracle_at_config4_shape_against_the_compiled_reference():
+    """64 envs x 16 steps, 4 minibatches of 256 rows, 2 epochs, every per-sample tensor of the reference in full: forward (3e-6), calcAdvantage bit
+    for bit, then the 8 optimizer steps -- losses 1e-5 (north_star; measured 9e-8), first and last gradient 5e-6 of its largest element (measured 7e-7),
+    per-tensor gradient norms, parameters after the first step and after the update 2e-6 (measured 1.6e-7)."""
+    C4, g, m, params, net, hp = _c4_load("config4_small_64x16")
+    T, N = m["T"], m["N"]
+    B, MB = T * N, T * N // m["nmb"]
+    assert int(g["sample_stride"][0]) == 1
+    b = C4.make_batch(T, N)
+    C4.check_crcs(g, b)
+    lp, en, v = O.evaluate(net, params, b["obs"], b["actions"], b["masks"])
+    np.testing.assert_allclose(lp, g["sample_logprobs"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(en, g["sample_entropy"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(v, g["sample_values"], rtol=0, atol=3e-6)
+    assert 0.5 < g["sample_entropy"].min() and g["sample_entropy"].max() <= 3 * np.log(3) + np.log(2) + 1e-5     # the masked distribution's TRUE entropy, summed over 4 heads
+    np.testing.assert_allclose(O.get_value(net, params, b["next_obs"]), g["sample_next_value"], rtol=0, atol=3e-6)
+    adv, ret = O.gae(b["rewards"].reshape(T, N), g["sample_values"].reshape(T, N), b["dones"].reshape(T, N), g["sample_next_value"], b["next_done"],
+                     hp.gamma, hp.gae_lambda)
+    assert np.array_equal(bits(adv).ravel(), bits(g["sample_advantages"])) and np.array_equal(bits(ret).ravel(), bits(g["sample_returns"]))
+    shapes = [tuple(int(x) for x in s) for s in g["param_shapes"]]
+    offs = np.cumsum([0] + [a * c for a, c in shapes])
+    scal = g["step_scalars"]
+    exp_avg, exp_avg_sq = np.zeros_like(params), np.zeros_like(params)
+    k = 0
+    for e in range(m["epochs"]):
+        perm = C4.permutation(e, B)
+        for s in range(m["nmb"]):
+            gr, st = O.minibatch_grads(net, hp, params, b["obs"], b["actions"].astype(np.float32), g["sample_logprobs"], g["sample_advantages"], g["sample_returns"],
+                                       g["sample_values"], perm[s * MB:(s + 1) * MB].astype(np.int64), b["masks"])
+            for i, n in enumerate(O.STAT_NAMES):
+                assert abs(st[n] - scal[k, i]) <= 1e-5 * max(1.0, abs(scal[k, i])), (k, n, st[n], scal[k, i])
+            gc, total = O.clip_grad_norm(net, gr, hp.max_grad_norm)
+            assert abs(total - scal[k, 6]) <= 2e-6 * scal[k, 6], (k, total, scal[k, 6])
+            K = "k%d/" % k
+            if K + "grad_norms" in g:
+                norms = np.array([np.linalg.norm(gr[offs[i]:offs[i + 1]].astype(np.float64)) for i in range(len(shapes))])
+                assert np.abs(norms - g[K + "grad_norms"]).max() <= 2e-6 * g[K + "grad_norms"].max(), k
+                assert np.abs(gr[::61] - g[K + "sample_grads"]).max() <= 5e-6 * np.abs(gr).max(), k
+            params, exp_avg, exp_avg_sq = O.adamw_step(params, gc, exp_avg, exp_avg_sq, float(g["lr"][0]), k + 1)
+            if k == 0:
+                assert np.abs(params[::61] - g["k0/sample_params_after"]).max() <= 2e-6
+            k += 1
+    assert k == scal.shape[0] == 8
+    assert np.abs(params[::61] - g["sample_params_after"]).max() <= 2e-6
+    assert g["max_abs_param_change"][0] > 1e-3
+
+
+def test_oracle_on_the_config4_share_fixture():
+    """The per-GPU share of configs[4] (2048 envs x 128 steps, minibatches of 65 536 rows, 40 steps): too large for the scalar oracle to follow the update, so here
+    the hash-made batch against the reference's CRCs, the oracle's forward on the fixture's strided sample of rows, and the fixture's own sanity (the update
+    the reference ran moved the policy: KL grows, value loss falls).  The device's twin of this fixture is tests/test_gpu_config4_ref.py."""
+    C4, g, m, params, net, hp = _c4_load("config4_share_2048x128")
+    T, N = m["T"], m["N"]
+    assert (T, N, m["nmb"], m["epochs"]) == (128, 2048, 4, 10)
+    b = C4.make_batch(T, N)
+    C4.check_crcs(g, b)
+    rows = np.arange(0, T * N, int(g["sample_stride"][0]))
+    lp, en, v = O.evaluate(net, params, b["obs"][rows], b["actions"][rows], b["masks"][rows])
+    np.testing.assert_allclose(lp, g["sample_logprobs"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(en, g["sample_entropy"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(v, g["sample_values"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(O.get_value(net, params, b["next_obs"]), g["sample_next_value"], rtol=0, atol=3e-6)
+    scal = g["step_scalars"]
+    assert scal.shape == (40, 7) and abs(scal[0, 3]) < 1e-8 and scal[0, 4] == 0.0           # first minibatch: ratio == 1, nothing clipped
+    assert scal[-1, 3] > 5e-3 and scal[-1, 1] < scal[0, 1] and scal[-1, 0] < -1e-2         # the policy moved, the value loss fell
