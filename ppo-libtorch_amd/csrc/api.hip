@@ -568,7 +568,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
                 CK(dalloc(c, &g.dz_bf[1][i], RB * g.ld_h));
                 CK(dalloc(c, &g.dout_bf[i], RB * 128));
             }
-            g.cs_layer_stride = (int64_t)(R / 128 + 1) * g.ld_h;
+            g.cs_layer_stride = (int64_t)(R / 64 + 2) * g.ld_h;   // one row of column sums per 64-row tile at most (kernels_generic_bwd.hip: a row range is >= one tile)
             CK(dalloc(c, &g.cs_part[0], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.cs_part[1], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.head_db_part, (size_t)GEN_LOSS_BLOCKS * (GL.act + 1)));

@@ -129,6 +129,13 @@ hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_
                              float* dones, int32_t* fin_len, float* fin_rew, float* next_obs, int32_t* next_done, uint8_t* cur_mask, const int64_t* forced,
                              hipStream_t s);
 
+// kernels_generic_bwd.hip: a layer's weight gradient and the gradient handed to the layer below in ONE launch (bf16 storage, widths padded to 128 / 256)
+bool gen_fused_backward_ok(const GenericCtx& g);
+int gen_bwd_ranges(int64_t rows, int ld_in, int* tiles_per_range);
+hipError_t gen_fused_backward_layer(int n_pad, const uint16_t* d, int64_t ldd, const uint16_t* h, int64_t ldh, const uint16_t* w, int64_t ldw, uint16_t* dz_out,
+                                    int64_t ld_out, float* slab, int64_t slab_stride, float* colsum, int64_t ld_cs, const uint16_t* zeros, int64_t rows, int n_real,
+                                    int k_real, int S, int tiles_per_range, hipStream_t s);
+
 // kernels_generic.hip
 struct ppo_ctx;
 // out[rows, out_dim(last)] = net(x[rows, obs]); acts != nullptr keeps every hidden layer's activations (for the backward pass).

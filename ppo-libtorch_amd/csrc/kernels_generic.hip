@@ -703,6 +703,45 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
         const int64_t range = ((rows + want - 1) / want + 63) / 64 * 64;
         return (int)((rows + range - 1) / range);
     };
+#ifndef GEN_AB_UNFUSED_BWD   // A/B build (tools/build_variant.sh): the two tiled products per layer of rounds 1-4
+    if (gen_fused_backward_ok(g)) {
+        // one launch per layer (kernels_generic_bwd.hip): dZ_l and h_{l-1} are read ONCE for the weight gradient AND the gradient handed down; layer 0 has
+        // nothing below it and forms its weight gradient alone.  Then the fixed-order sums of all layers' slabs and column sums in one launch.
+        const uint16_t* d = g.dout_bf[net];   // [rows + 128][128]: columns >= 32 are zero for good (L.act <= 32): row 0's columns 64 .. 71 are the kernel's 16 zero bytes
+        int64_t ldd = 128;
+        float* wslab = net == 1 ? g.wslab1 : g.wslab;
+        SlabJobs jobs{};
+        jobs.slab_stride = g.wslab_stride;
+        int64_t most = 0;
+        int S_above = 0;
+        for (int l = L.n_layers - 1; l >= 0; l--) {
+            const int K = L.in_dim[l], N = L.out_dim[net][l];
+            const bool head = l == L.n_layers - 1;
+            const uint16_t* in = l == 0 ? g.xin_bf : g.acts_bf[net][l - 1];
+            const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
+            int tpr = 1;
+            const int S = gen_bwd_ranges(rows, (int)ldi, &tpr);
+            float* lslab = wslab + (size_t)l * g.wslab_layer_stride;
+            uint16_t* nd = l > 0 ? g.dz_bf[net][l & 1] : nullptr;
+            const hipError_t e = gen_fused_backward_layer(head ? 32 : g.ld_h, d, ldd, in, ldi, l > 0 ? g.wplanes + g.wp_off[net][l] : nullptr, g.wp_kpad[l], nd, g.ld_h,
+                                                          lslab, g.wslab_stride, l > 0 ? g.cs_part[net] + (size_t)l * g.cs_layer_stride : nullptr, g.ld_h, g.dout_bf[net] + 64,
+                                                          rows, N, K, S, tpr, s);
+            if (e != hipSuccess) return e;
+            SlabJob& J = jobs.j[l];
+            J.slab = lslab; J.S = S; J.n_w = (int64_t)N * K; J.n_b = N;
+            // the bias gradient of layer l: block sums of the head gradient (loss kernel), or the column sums the launch of layer l + 1 left in block l + 1
+            J.db_part = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part[net] + (size_t)(l + 1) * g.cs_layer_stride;
+            J.db_chunks = head ? GEN_LOSS_BLOCKS : S_above;
+            J.db_stride = head ? L.act + 1 : g.ld_h;
+            J.gw = grads + L.w_off[net][l]; J.gb = grads + L.b_off[net][l];
+            most = std::max<int64_t>(most, J.n_w + N);
+            S_above = S;
+            d = nd; ldd = g.ld_h;
+        }
+        hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)L.n_layers), dim3(256), 0, s, jobs);
+        return hipGetLastError();
+    }
+#endif
     if (g.bf16) {
         // bf16 storage: x, dout are not used -- the layer inputs are g.xin_bf / g.acts_bf[net], the head gradient g.dout_bf[net] (written by the
         // loss kernel together with the head's bias-gradient block sums); the bias gradient of every other layer is summed, in f32, where its

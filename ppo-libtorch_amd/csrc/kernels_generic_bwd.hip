@@ -1,0 +1,378 @@
+// ppo-libtorch_amd/csrc/kernels_generic_bwd.hip -- the backward pass of one Linear (+ tanh) layer of a bf16-storage network (generic.hpp; BASELINE
+// configs[4]: obs 376, 4 x 256, heads [3,3,3,2]) as ONE kernel: loss.backward() through `torch::nn::Linear` / `Tanh` of Agent.cpp:25-59 generalised,
+//
+//      dW_l  = dZ_l^T h_{l-1}                       (the weight gradient: contracts over the minibatch rows)
+//      dZ_{l-1} = (dZ_l W_l) (1 - h_{l-1}^2)        (what the layer below receives; its column sums are that layer's bias gradient)
+//
+// Until round 5 these were two launches of the tiled product (kernels_gemm.hip), each reading dZ_l and h_{l-1} from HBM: 168 MB per hidden layer and net
+// at 65 536 rows, at 8 % of the matrix pipe (K = 256 is eight k steps of a 128 x 128 tile: prologue, epilogue and staging dominate).  Here a workgroup owns
+// a RANGE of rows and a 64-wide COLUMN BLOCK c of the layer's input side, and per 64-row tile has dZ_l [64 x N] and h_{l-1}[:, block c] [64 x 64] brought
+// into LDS ONCE, by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write pass), into a ring of THREE buffers: two tiles (80 KB per CU) are in flight
+// while the third is multiplied -- with one tile ahead the kernel ran at the latency of its loads (a tile every ~2 us, 75 us per launch at 65 536 rows).
+// Its eight waves have two jobs, one wave of each kind per SIMD:
+//
+//   waves 0-3 (P1)  D[kcol][row] = sum_n W[n][kcol] dZ[row][n]: W_l[:, block c] stays in registers for the whole launch as the A operand (64 registers at
+//                   N = 256), the dZ rows are the B operand (16-byte LDS reads): the result has lane = row, registers = 4-groups of consecutive columns, so
+//                   the tanh' epilogue reads h and writes the bf16 result as 8-byte pieces; per-lane column sums accumulate over the tiles and meet once at the end
+//   waves 4-7 (P2)  D[n][kcol] += sum_row dZ[row][n] h[row][kcol]: both operands by transposing LDS reads (ds_read_b64_tr_b16); the accumulators of the
+//                   workgroup's [N x 64] slice of dW (64 registers per wave at N = 256) stay in registers over all its tiles and leave as one slab per row range
+//
+// 16 + 16 MFMAs per SIMD and tile, one barrier per tile.  The four (ld / 64) column-block workgroups of a row range run on ONE XCD in consecutive dispatch
+// slots: the dZ_l tile the first one pulls from HBM the other three find in that XCD's L2 (measured: 78 MB fetched per launch for 67 MB of operands).
+// The LDS images are XOR-swizzled by row (16-byte chunk index ^ f(row)), not padded: the same dZ tile is read by rows (P1) and by columns (P2), and no single
+// pitch serves both; the DMA writes lane-linearly, so the swizzle sits on its per-lane SOURCE address and on every read (the argument is at swz_d / swz_h).
+// Layer 0 (no layer below) runs P2 on all eight waves; the head (N = logits padded to 32) is the same kernel with two k steps.
+// Arithmetic = launch_matmul_bf16's: bf16 operands, f32 accumulation, tanh' and the column sums in f32 before the result is rounded to bf16.
+// Everything is summed in a fixed order: same inputs, same bits.
+#include "generic.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BW_WAVES = 8, BW_THREADS = 64 * BW_WAVES;
+constexpr int BW_ROWS = 64;    // rows per tile
+constexpr int BW_KC = 64;      // columns of the layer's input side per workgroup
+constexpr int BW_RING = 3;     // LDS buffers of the tile ring
+
+struct BwdArgs {
+    const uint16_t* d; int64_t ldd;        // dZ_l [rows + pad][ldd] bf16 (columns >= the layer's width are zero)
+    const uint16_t* h; int64_t ldh;        // h_{l-1}, or the layer-0 input [.][ldh] bf16
+    const uint16_t* w; int64_t ldw;        // bf16 plane of W_l [n_pad][ldw], zero padded (P1 only)
+    uint16_t* dz_out; int64_t ld_out;      // dZ_{l-1} (P1 only)
+    float* slab; int64_t slab_stride;      // [S][n_real][k_real] partial weight gradients, one per row range
+    float* colsum; int64_t ld_cs;          // [S][ld_cs] column sums of dZ_{l-1} over the range's rows (P1 only)
+    const uint16_t* zeros;                 // >= 16 bytes of zeros: what the DMA fetches for rows past the minibatch
+    int64_t rows;                          // rows of the minibatch
+    int n_real, k_real;                    // the layer's real widths (out, in)
+    int S, CB, tiles_per_range;
+};
+
+__device__ __forceinline__ float bw_u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint32_t bw_pack(float x0, float x1) { const bf16x2 v = { (__bf16)x0, (__bf16)x1 }; return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint2 bw_read_tr16(const uint16_t* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ f32x16 bw_mfma(const u32x4 a, const u32x4 b, const f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// LDS images: [row][W] bf16, W = 8 CPR, no padding; the 16-byte chunk j of row r sits at chunk j ^ f(r).
+//   dZ tile (CPR = 4, 16 or 32; a row is 16, 64 or 128 dwords): f(r) = ((r & 3) << 2 | (r >> 2) & 3) & (CPR - 1), a bijection of r & 15.
+//     read by rows (ds_read_b128, lane = row, 16-lane groups hold 16 different r & 15): 16 different chunks ^ f -> 16 different bank quads.
+//     read by columns (ds_read_b64_tr_b16: a 32-lane half covers 4 consecutive rows x 32 columns = 4 chunks per row): (c0 + j) ^ f(r) sends the
+//     rows' four chunks to four DIFFERENT aligned groups of four chunks ((c0 >> 2) ^ (r & 3)): 4 x 16 dwords, all 64 banks once.
+//   h / W / result tiles (64 columns: CPR = 8, a row is 32 dwords, rows r and r + 2 share banks): bit 2 of f(r) = (r >> 1) & 1 moves rows r + 2, r + 3
+//     to the other half of their bank window: the same transposing read is conflict free; the low bits (r >> 2) & 3 spread the epilogue's 8-byte accesses
+//     (lane = row, all lanes at one logical column) over the eight chunks: 2-way instead of 8-way (measured: 35 % of the LDS cycles were conflicts without).
+template <int CPR>
+__device__ __forceinline__ int swz_d(int r) { return (((r & 3) << 2) | ((r >> 2) & 3)) & (CPR - 1); }
+__device__ __forceinline__ int swz_h(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+// A bare s_barrier with the compiler held to it: the intrinsic is "no memory" for LLVM, and the DMA's LDS writes are invisible to it, so nothing else would keep
+// the next tile's ds_reads (which see no store they could depend on) from being scheduled ABOVE the barrier, where the other waves' pieces may still be under way
+// (first version: wrong gradients now and then).  The waits in front of it are the caller's (counted vmcnt, lgkmcnt(0)).
+__device__ __forceinline__ void bw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// 64 lanes x 16 bytes -> 1 KiB at lds_wave_base (wave-uniform), lane-linear.  As inline asm, not __builtin_amdgcn_global_load_lds: hipcc (ROCm 7.2) cannot tell
+// which LDS bytes a DMA will write and puts s_waitcnt vmcnt(0) in front of EVERY later ds_read of the array (seen in this kernel's assembly: four per
+// tile), which drains the ring it is there to keep full.  An asm DMA is invisible to that bookkeeping: the only waits on the vector-memory counter in the
+// tile loop are the counted ones written there (the loop holds no compiler-visible load whose own wait the extra operations could make too short; its
+// stores are never waited for).  M0 = the destination's LDS byte address, saved and restored around the instruction (the compiler reserves M0).
+__device__ __forceinline__ void bw_glds16(const uint16_t* src, uint16_t* lds_wave_base) {
+#ifdef BW_GLDS_BUILTIN
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    return;
+#endif
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// MFMA operand fragment by TRANSPOSING reads out of an image [k rows][W columns]: lane (i = lane & 31, kg = lane >> 5) receives column x0 + i of the
+// eight rows 16 ks + 8 kg .. + 7.  Lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 (see kernels_gemm.hip: frag).
+template <int W, bool DZ>
+__device__ __forceinline__ u32x4 frag_tr(const uint16_t* img, int x0, int ks, int lane) {
+    const int r = 16 * ks + 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int col = x0 + 16 * ((lane & 31) >> 4) + 4 * (lane & 3);
+    const int chunk = col >> 3, within = col & 7;
+    const int f0 = DZ ? swz_d<W / 8>(r) : swz_h(r), f1 = DZ ? swz_d<W / 8>(r + 4) : swz_h(r + 4);
+    const uint2 lo = bw_read_tr16(img + r * W + ((chunk ^ f0) << 3) + within);
+    const uint2 hi = bw_read_tr16(img + (r + 4) * W + ((chunk ^ f1) << 3) + within);
+    const u32x4 v = { lo.x, lo.y, hi.x, hi.y };
+    return v;
+}
+
+template <int NB, bool P1>
+__global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs a) {
+    constexpr int N = 32 * NB;                 // width of dZ_l as staged (the real width zero padded)
+    constexpr int CPR = N / 8;                 // 16-byte chunks per dZ row
+    constexpr int KS1 = N / 16;                // k steps of P1
+    constexpr int DSZ = BW_ROWS * (N < 64 ? 64 : N);      // elements of one dZ buffer (>= the weight block [N][64])
+    constexpr int P2W = P1 ? 4 : 8;            // waves that run P2
+    constexpr int NBW = (NB + P2W - 1) / P2W;  // n blocks of a P2 wave (each against both 32-column halves of the block)
+    constexpr int DPW = (CPR + BW_WAVES - 1) / BW_WAVES;   // 1-KiB DMA pieces of the dZ tile per wave (the tile has CPR of them)
+    static_assert(NB == 1 || NB == 4 || NB == 8, "dZ widths of 32 (a head), 128 and 256");
+    extern __shared__ __attribute__((aligned(16))) uint16_t bw_lds[];
+    uint16_t* const sD = bw_lds;                          // [3][64][N]  (buffer 2 first holds the weight block [N][64], once)
+    uint16_t* const sH = sD + BW_RING * DSZ;              // [3][64][64]
+    uint16_t* const sO = sH + BW_RING * BW_ROWS * BW_KC;  // [2][64][64] result tile of P1
+    float* const sRed = reinterpret_cast<float*>(sO + (P1 ? 2 : 0) * BW_ROWS * BW_KC);   // [2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs; the CB column blocks of a row range take consecutive slots of ONE XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int z = (slot / a.CB) * 8 + xcd, c = slot % a.CB;
+    if (z >= a.S) return;
+    const int64_t row_begin = (int64_t)z * a.tiles_per_range * BW_ROWS;
+    int n_tiles = a.tiles_per_range;
+    {
+        const int64_t left = a.rows - row_begin;
+        const int64_t have = left <= 0 ? 0 : (left + BW_ROWS - 1) / BW_ROWS;
+        if (have < n_tiles) n_tiles = (int)have;
+    }
+    const int li = lane & 31, kg = lane >> 5;
+    const bool p1_wave = P1 && wave < 4;
+    const int cb1 = wave & 1, rb1 = (wave >> 1) & 1;   // P1: the wave's 32 columns (of the block's 64) and 32 rows (of the tile's 64)
+    const int pj = P1 ? wave - 4 : wave;               // P2: the wave's index among the P2 waves (< 0: not one)
+
+    // What a wave keeps for the whole launch lives in ONE register block `st`: a P1 wave's weight fragments (4 registers per k step) or a P2 wave's
+    // accumulators (16 per n block and column half).  The two kinds of waves never need both, but two arrays would both be live through the tile loop for the
+    // register allocator (one function, wave-uniform branches): 64 + 64 registers at N = 256, and the kernel spilled into the loop -- every scratch reload
+    // is a vector-memory operation whose s_waitcnt drains the DMA ring.
+    // The block is typed as INTEGERS (bf16 pairs are not floats: kept in float-typed registers, the weight fragments came back changed -- a pair whose upper
+    // half is zero is a denormal float, and something on the way canonicalised it); the accumulators are bit-cast to floats around their MFMAs.
+    constexpr int NST = NBW * 2 > (KS1 + 3) / 4 ? NBW * 2 : (KS1 + 3) / 4;
+    typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 st[NST];
+#pragma unroll
+    for (int i = 0; i < NST; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) st[i][r] = 0u;
+    auto wfrag = [&](int ks) -> u32x4 {
+        const u32x4 v = { st[ks >> 2][4 * (ks & 3)], st[ks >> 2][4 * (ks & 3) + 1], st[ks >> 2][4 * (ks & 3) + 2], st[ks >> 2][4 * (ks & 3) + 3] };
+        return v;
+    };
+    // ---- prologue (P1): W_l[:, block c] -> LDS [n][64] -> the P1 waves' A fragments of W^T (m = column, k = n), kept for the launch ----
+    if constexpr (P1) {
+        uint16_t* const sW = sD + 2 * DSZ;
+        for (int e = tid; e < N * 8; e += BW_THREADS) {
+            const int n = e >> 3, ch = e & 7;
+            *reinterpret_cast<u32x4*>(sW + n * BW_KC + ((ch ^ swz_h(n)) << 3)) = *reinterpret_cast<const u32x4*>(a.w + (int64_t)n * a.ldw + BW_KC * c + 8 * ch);
+        }
+        __syncthreads();
+        if (p1_wave) {
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                const u32x4 w = frag_tr<BW_KC, false>(sW, 32 * cb1, ks, lane);
+#pragma unroll
+                for (int e = 0; e < 4; e++) st[ks >> 2][4 * (ks & 3) + e] = w[e];
+            }
+        }
+        __syncthreads();   // every wave has its fragments: buffer 2 may be overwritten by the DMA of tile 2
+    }
+
+    // ---- LDS-DMA of tile t into buffer t % 3: the image is lane-linear, so lane j of piece p fetches the chunk whose SWIZZLED place is 64 p + j.
+    //      EVERY wave issues DPW + 1 instructions per tile (a wave without a piece of a narrow dZ tile fetches zeros into a spare KiB): the counted
+    //      s_waitcnt vmcnt in the loop relies on it ----
+    auto issue = [&](int t) {
+        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
+        const int b = t % BW_RING;
+        uint16_t* const dD = sD + b * DSZ;
+        uint16_t* const dH = sH + b * BW_ROWS * BW_KC;
+#pragma unroll
+        for (int i = 0; i < DPW; i++) {
+            const int p = wave + BW_WAVES * i;
+            const bool have = p < CPR;
+            const int q = 64 * p + lane, row = q / CPR, ch = (q % CPR) ^ swz_d<CPR>(row);
+            const uint16_t* src = have && r0 + row < a.rows ? a.d + (r0 + row) * a.ldd + 8 * ch : a.zeros;
+            bw_glds16(src, have ? dD + 512 * p : reinterpret_cast<uint16_t*>(sRed + 2 * BW_KC) + 512 * wave);
+        }
+        {
+            const int q = 64 * wave + lane, row = q >> 3, ch = (q & 7) ^ swz_h(row);
+            const uint16_t* src = r0 + row < a.rows ? a.h + (r0 + row) * a.ldh + BW_KC * c + 8 * ch : a.zeros;
+            bw_glds16(src, dH + 512 * wave);
+        }
+    };
+    // the result tile of tile t leaves in 16-byte row pieces (rows past the minibatch are zeros: they keep the destination's padding zero)
+    auto store_out = [&](int t) {
+        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
+        const int row = tid >> 3, ch = tid & 7;
+        *reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch) =
+            *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
+    };
+    // vector-memory operations a wave issues per iteration of the steady state: the DMA pieces of one tile, and (P1) one store of the result tile
+    constexpr int VM_PER_ITER = DPW + 1 + (P1 ? 1 : 0);
+
+    float csum[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) csum[r] = 0.0f;
+
+    if (n_tiles > 0) issue(0);
+    if (n_tiles > 1) issue(1);
+    if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
+    bw_barrier();
+    for (int t = 0; t < n_tiles; t++) {
+        const uint16_t* const tD = sD + (t % BW_RING) * DSZ;
+        const uint16_t* const tH = sH + (t % BW_RING) * BW_ROWS * BW_KC;
+        if (t + 2 < n_tiles) issue(t + 2);          // into the buffer every wave finished reading before the barrier that ended iteration t - 1
+        if constexpr (P1) { if (t > 0) store_out(t - 1); }
+        if (p1_wave) {
+            // ---- P1: D[kcol][row] = sum_n W[n][kcol] dZ[row][n]; lane = row, registers = columns ----
+            f32x16 acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc1[r] = 0.0f;
+            const int row = 32 * rb1 + li;
+            const uint16_t* drow = tD + row * N;
+            const int fd = swz_d<CPR>(row);
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                const u32x4 bfr = *reinterpret_cast<const u32x4*>(drow + (((2 * ks + kg) ^ fd) << 3));
+                acc1 = bw_mfma(wfrag(ks), bfr, acc1);
+            }
+            // epilogue: register r <-> column 32 cb1 + (r & 3) + 8 (r >> 2) + 4 kg of the block; tanh' from the staged h, result to its own image
+            const int fh = swz_h(row);
+            uint16_t* const tO = sO + (t & 1) * BW_ROWS * BW_KC;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int at = row * BW_KC + (((4 * cb1 + q) ^ fh) << 3) + 4 * kg;
+                const uint2 hv = *reinterpret_cast<const uint2*>(tH + at);
+                const float h0 = bw_u2f(hv.x << 16), h1 = bw_u2f(hv.x & 0xffff0000u), h2 = bw_u2f(hv.y << 16), h3 = bw_u2f(hv.y & 0xffff0000u);
+                const float v0 = acc1[4 * q] * (1.0f - h0 * h0), v1 = acc1[4 * q + 1] * (1.0f - h1 * h1);
+                const float v2 = acc1[4 * q + 2] * (1.0f - h2 * h2), v3 = acc1[4 * q + 3] * (1.0f - h3 * h3);
+                csum[4 * q] += v0; csum[4 * q + 1] += v1; csum[4 * q + 2] += v2; csum[4 * q + 3] += v3;
+                *reinterpret_cast<uint2*>(tO + at) = make_uint2(bw_pack(v0, v1), bw_pack(v2, v3));
+            }
+        } else if (pj >= 0 && pj * NBW < NB) {
+            // ---- P2: dW[n][kcol] += dZ^T h over the tile's 64 rows (4 k steps): the wave's n blocks against both column halves ----
+#pragma unroll
+            for (int ks = 0; ks < BW_ROWS / 16; ks++) {
+                const u32x4 bf0 = frag_tr<BW_KC, false>(tH, 0, ks, lane), bf1 = frag_tr<BW_KC, false>(tH, 32, ks, lane);
+#pragma unroll
+                for (int i = 0; i < NBW; i++) {
+                    const int nb = pj * NBW + i;
+                    if (nb < NB) {
+                        const u32x4 af = frag_tr<N, true>(tD, 32 * nb, ks, lane);
+                        st[2 * i] = __builtin_bit_cast(u32x16, bw_mfma(af, bf0, __builtin_bit_cast(f32x16, st[2 * i])));
+                        st[2 * i + 1] = __builtin_bit_cast(u32x16, bw_mfma(af, bf1, __builtin_bit_cast(f32x16, st[2 * i + 1])));
+                    }
+                }
+            }
+        }
+        // this wave's pieces of tile t + 1 have landed: everything it issued up to them is done, i.e. all but what this iteration issued (the pieces of
+        // tile t + 2 and the store of tile t - 1) -- counted, so that tile t + 2 stays in flight across the barrier (a plain __syncthreads() would drain
+        // it: the compiler's fence waits for vmcnt(0)).  The last iterations issue less: they wait for everything.
+#ifdef BW_FULL_WAIT
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (false) {
+#else
+        if (t + 2 < n_tiles) {
+#endif
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_PER_ITER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(DPW + 1) : "memory");   // the first iteration has no result tile to store yet
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        bw_barrier();
+    }
+    if constexpr (P1) { if (n_tiles > 0) store_out(n_tiles - 1); }
+
+    // ---- the workgroup's slice of the weight gradient: register r of lane (i, kg) <-> n = 32 nb + (r & 3) + 8 (r >> 2) + 4 kg, column = block's 32 half + i ----
+    float* const slab = a.slab + (int64_t)z * a.slab_stride;
+    if (!p1_wave && pj >= 0) {
+#pragma unroll
+        for (int i = 0; i < NBW; i++) {
+            const int nb = pj * NBW + i;
+            if (nb < NB) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int kcol = BW_KC * c + 32 * h + li;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (n < a.n_real && kcol < a.k_real) slab[(int64_t)n * a.k_real + kcol] = bw_u2f(st[2 * i + h][r]);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (P1) {
+        // column sums of dZ_{l-1} over the range's rows: lanes (= rows) of a half first, then the two row blocks in fixed order
+        if (p1_wave) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = csum[r];
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+                csum[r] = v;
+            }
+            if (li == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) sRed[rb1 * BW_KC + 32 * cb1 + (r & 3) + 8 * (r >> 2) + 4 * kg] = csum[r];
+            }
+        }
+        __syncthreads();
+        if (tid < BW_KC) a.colsum[(int64_t)z * a.ld_cs + BW_KC * c + tid] = sRed[tid] + sRed[BW_KC + tid];
+    }
+}
+
+template <int NB>
+constexpr size_t bwd_lds_bytes() {   // ring of dZ and h tiles, two result tiles, the column-sum hand-over, a spare KiB per wave for DMA pieces a narrow tile does not have
+    return (BW_RING * ((size_t)BW_ROWS * (32 * NB < 64 ? 64 : 32 * NB) + (size_t)BW_ROWS * BW_KC) + 2 * (size_t)BW_ROWS * BW_KC) * sizeof(uint16_t) + 2 * BW_KC * sizeof(float) +
+           (size_t)BW_WAVES * 1024;
+}
+
+template <int NB, bool P1>
+hipError_t bwd_launch(const BwdArgs& a, hipStream_t s) {
+    constexpr size_t lds = bwd_lds_bytes<NB>();
+    auto kern = bwd_layer_kernel<NB, P1>;
+    if constexpr (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> lds_ok{0};
+        const hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(kern), (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const unsigned blocks = (unsigned)((a.S + 7) / 8 * 8 * a.CB);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BW_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Row ranges of a layer's fused backward launch: S ranges of whole 64-row tiles, S x (ld_in / 64) workgroups ~ one per CU.
+int gen_bwd_ranges(int64_t rows, int ld_in, int* tiles_per_range) {
+    const int cb = ld_in / BW_KC;
+    const int64_t tiles = (rows + BW_ROWS - 1) / BW_ROWS;
+    int64_t want = 256 / cb;
+    if (want < 1) want = 1;
+    if (want > tiles) want = tiles;
+    const int64_t per = (tiles + want - 1) / want;
+    *tiles_per_range = (int)per;
+    return (int)((tiles + per - 1) / per);
+}
+
+// dZ widths the kernel is instantiated for: a head (<= 32 logits in a 128-pitch buffer) or a hidden vector padded to 128 or 256; inputs in 64-column blocks
+bool gen_fused_backward_ok(const GenericCtx& g) {
+    return g.bf16 && (g.ld_h == 128 || g.ld_h == 256) && g.L.act <= 32 && g.ld_in0 % BW_KC == 0 && g.L.n_hidden >= 1;
+}
+
+// One layer: d = dZ_l [., ldd] (width n_pad in {32, 128, 256}), h = the layer's input [., ldh] (ldh / 64 column blocks), w = the layer's bf16 weight plane
+// (null: layer 0, no layer below).  Writes S slabs [n_real][k_real] (S from gen_bwd_ranges), dZ_{l-1} and its column sums per range.
+hipError_t gen_fused_backward_layer(int n_pad, const uint16_t* d, int64_t ldd, const uint16_t* h, int64_t ldh, const uint16_t* w, int64_t ldw, uint16_t* dz_out,
+                                    int64_t ld_out, float* slab, int64_t slab_stride, float* colsum, int64_t ld_cs, const uint16_t* zeros, int64_t rows, int n_real,
+                                    int k_real, int S, int tiles_per_range, hipStream_t s) {
+    BwdArgs a{};
+    a.zeros = zeros;
+    a.d = d; a.ldd = ldd; a.h = h; a.ldh = ldh; a.w = w; a.ldw = ldw; a.dz_out = dz_out; a.ld_out = ld_out; a.slab = slab; a.slab_stride = slab_stride;
+    a.colsum = colsum; a.ld_cs = ld_cs; a.rows = rows; a.n_real = n_real; a.k_real = k_real; a.S = S; a.CB = (int)(ldh / BW_KC); a.tiles_per_range = tiles_per_range;
+    const bool p1 = w != nullptr;
+    if (n_pad == 32) return p1 ? bwd_launch<1, true>(a, s) : bwd_launch<1, false>(a, s);
+    if (n_pad == 128) return p1 ? bwd_launch<4, true>(a, s) : bwd_launch<4, false>(a, s);
+    if (n_pad == 256) return p1 ? bwd_launch<8, true>(a, s) : bwd_launch<8, false>(a, s);
+    return hipErrorNotSupported;
+}
