@@ -23,7 +23,7 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 SCENARIOS = {
     "curves_config0_8x128": (8, 128, 150 * 8 * 128, list(range(1, 11))),     # BASELINE.json configs[0] shape, 150 updates
     "curves_64x128": (64, 128, 80 * 64 * 128, list(range(1, 11))),           # 80 updates of 8192 steps
-    "curves_4096x128": (4096, 128, 30 * 4096 * 128, list(range(1, 6))),      # BASELINE.json configs[1] shape: 30 updates of 524 288 steps (~10 s each here)
+    "curves_4096x128": (4096, 128, 30 * 4096 * 128, list(range(1, 11))),      # BASELINE.json configs[1] shape: 30 updates of 524 288 steps (~10 s each here)
 }
 
 

@@ -1229,8 +1229,8 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         if (two) HIPCHK(c, join());   // the loss reads the logits and the values
         HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
         if (two) HIPCHK(c, fork());
-        HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream));
-        HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, s0));
+        HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream, two));
+        HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, s0, two));
         if (two) HIPCHK(c, join());   // the flat gradient is complete
         if (two && c->gen_next_idx) {
             // nothing reads this step's gathered rows any more: the next step's gather (42 us of HBM streaming) runs on the second stream beside the

@@ -131,10 +131,11 @@ hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_
 
 // kernels_generic_bwd.hip: a layer's weight gradient and the gradient handed to the layer below in ONE launch (bf16 storage, widths padded to 128 / 256)
 bool gen_fused_backward_ok(const GenericCtx& g);
-int gen_bwd_ranges(int64_t rows, int ld_in, int* tiles_per_range);
+int gen_bwd_col_blocks(int ld_in, bool has_below);
+int gen_bwd_ranges(int64_t rows, int col_blocks, bool half_chip, int* tiles_per_range);
 hipError_t gen_fused_backward_layer(int n_pad, const uint16_t* d, int64_t ldd, const uint16_t* h, int64_t ldh, const uint16_t* w, int64_t ldw, uint16_t* dz_out,
                                     int64_t ld_out, float* slab, int64_t slab_stride, float* colsum, int64_t ld_cs, const uint16_t* zeros, int64_t rows, int n_real,
-                                    int k_real, int S, int tiles_per_range, hipStream_t s);
+                                    int k_real, int col_blocks, int S, int tiles_per_range, hipStream_t s);
 
 // kernels_generic.hip
 struct ppo_ctx;
@@ -148,8 +149,9 @@ hipError_t gen_gather(const GenLayout& L, const float* obs, const int32_t* actio
                       const float* ret, const float* values, const int32_t* idx, int64_t M, GenericCtx& g, hipStream_t s);
 hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& g, int64_t M, double inv_global_M, double global_M,
                     const AdvStat* adv_stat, hipStream_t s);
+// beside_other_net: the other net's backward pass runs at the same time on another stream (the fused launches then size themselves for half the chip)
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
-                        hipStream_t s);
+                        hipStream_t s, bool beside_other_net = false);
 hipError_t gen_loss_sums(const GenericCtx& g, double* sums_out, float* grads_tail, hipStream_t s);
 hipError_t gen_fill(float* p, int64_t n, float v, hipStream_t s);
 hipError_t gen_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const GenLayout& L, float max_grad_norm, const AdamCoef* coef,

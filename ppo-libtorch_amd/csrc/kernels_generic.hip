@@ -687,7 +687,7 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
 // kept by gen_forward(..., acts = g.acts[net]).  `ones` = g.dz[1] + rows * hidden is NOT used: bias gradients are a gemv with the
 // ones vector kept in g.row_f[4] + 2 (see api.hip: filled once at creation).
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
-                        hipStream_t s) {
+                        hipStream_t s, bool beside_other_net) {
     const GenLayout& L = g.L;
     if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
     // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single product would have N K / tile
@@ -720,12 +720,13 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
             const uint16_t* in = l == 0 ? g.xin_bf : g.acts_bf[net][l - 1];
             const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
             int tpr = 1;
-            const int S = gen_bwd_ranges(rows, (int)ldi, &tpr);
+            const int cbk = gen_bwd_col_blocks((int)ldi, l > 0);
+            const int S = gen_bwd_ranges(rows, cbk, beside_other_net, &tpr);
             float* lslab = wslab + (size_t)l * g.wslab_layer_stride;
             uint16_t* nd = l > 0 ? g.dz_bf[net][l & 1] : nullptr;
             const hipError_t e = gen_fused_backward_layer(head ? 32 : g.ld_h, d, ldd, in, ldi, l > 0 ? g.wplanes + g.wp_off[net][l] : nullptr, g.wp_kpad[l], nd, g.ld_h,
                                                           lslab, g.wslab_stride, l > 0 ? g.cs_part[net] + (size_t)l * g.cs_layer_stride : nullptr, g.ld_h, g.dout_bf[net] + 64,
-                                                          rows, N, K, S, tpr, s);
+                                                          rows, N, K, cbk, S, tpr, s);
             if (e != hipSuccess) return e;
             SlabJob& J = jobs.j[l];
             J.slab = lslab; J.S = S; J.n_w = (int64_t)N * K; J.n_b = N;

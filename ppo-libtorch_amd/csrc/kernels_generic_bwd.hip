@@ -110,8 +110,12 @@ __device__ __forceinline__ u32x4 frag_tr(const uint16_t* img, int x0, int ks, in
     return v;
 }
 
-template <int NB, bool P1>
+// KCB = 64-column blocks of the input side a workgroup owns: 1 beside P1 (its weight block and result tile are sized for 64 columns), 2 for layer 0, whose only
+// product is the weight gradient (the dZ_0 tile is then fetched by ld / 128 workgroups instead of ld / 64).
+template <int NB, bool P1, int KCB = 1>
 __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs a) {
+    static_assert(KCB == 1 || !P1, "P1 is built for one 64-column block");
+    constexpr int HSZ = KCB * BW_ROWS * BW_KC;   // elements of one h buffer: KCB images [64][64]
     constexpr int N = 32 * NB;                 // width of dZ_l as staged (the real width zero padded)
     constexpr int CPR = N / 8;                 // 16-byte chunks per dZ row
     constexpr int KS1 = N / 16;                // k steps of P1
@@ -123,12 +127,12 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
     extern __shared__ __attribute__((aligned(16))) uint16_t bw_lds[];
     uint16_t* const sD = bw_lds;                          // [3][64][N]  (buffer 2 first holds the weight block [N][64], once)
     uint16_t* const sH = sD + BW_RING * DSZ;              // [3][64][64]
-    uint16_t* const sO = sH + BW_RING * BW_ROWS * BW_KC;  // [2][64][64] result tile of P1
+    uint16_t* const sO = sH + BW_RING * HSZ;              // [2][64][64] result tile of P1
     float* const sRed = reinterpret_cast<float*>(sO + (P1 ? 2 : 0) * BW_ROWS * BW_KC);   // [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware order: workgroup ids go round-robin over the 8 XCDs; the CB column blocks of a row range take consecutive slots of ONE XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int z = (slot / a.CB) * 8 + xcd, c = slot % a.CB;
+    const int z = (slot / a.CB) * 8 + xcd, c = slot % a.CB;   // c counts blocks of 64 KCB columns
     if (z >= a.S) return;
     const int64_t row_begin = (int64_t)z * a.tiles_per_range * BW_ROWS;
     int n_tiles = a.tiles_per_range;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
     // is a vector-memory operation whose s_waitcnt drains the DMA ring.
     // The block is typed as INTEGERS (bf16 pairs are not floats: kept in float-typed registers, the weight fragments came back changed -- a pair whose upper
     // half is zero is a denormal float, and something on the way canonicalised it); the accumulators are bit-cast to floats around their MFMAs.
-    constexpr int NST = NBW * 2 > (KS1 + 3) / 4 ? NBW * 2 : (KS1 + 3) / 4;
+    constexpr int NST = NBW * 2 * KCB > (KS1 + 3) / 4 ? NBW * 2 * KCB : (KS1 + 3) / 4;
     typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
     u32x16 st[NST];
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
         const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
         const int b = t % BW_RING;
         uint16_t* const dD = sD + b * DSZ;
-        uint16_t* const dH = sH + b * BW_ROWS * BW_KC;
+        uint16_t* const dH = sH + b * HSZ;
 #pragma unroll
         for (int i = 0; i < DPW; i++) {
             const int p = wave + BW_WAVES * i;
@@ -194,10 +198,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
             const uint16_t* src = have && r0 + row < a.rows ? a.d + (r0 + row) * a.ldd + 8 * ch : a.zeros;
             bw_glds16(src, have ? dD + 512 * p : reinterpret_cast<uint16_t*>(sRed + 2 * BW_KC) + 512 * wave);
         }
-        {
+#pragma unroll
+        for (int k = 0; k < KCB; k++) {   // image k: columns 64 (KCB c + k) ..
             const int q = 64 * wave + lane, row = q >> 3, ch = (q & 7) ^ swz_h(row);
-            const uint16_t* src = r0 + row < a.rows ? a.h + (r0 + row) * a.ldh + BW_KC * c + 8 * ch : a.zeros;
-            bw_glds16(src, dH + 512 * wave);
+            const uint16_t* src = r0 + row < a.rows ? a.h + (r0 + row) * a.ldh + BW_KC * (KCB * c + k) + 8 * ch : a.zeros;
+            bw_glds16(src, dH + k * BW_ROWS * BW_KC + 512 * wave);
         }
     };
     // the result tile of tile t leaves in 16-byte row pieces (rows past the minibatch are zeros: they keep the destination's padding zero)
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
             *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
     };
     // vector-memory operations a wave issues per iteration of the steady state: the DMA pieces of one tile, and (P1) one store of the result tile
-    constexpr int VM_PER_ITER = DPW + 1 + (P1 ? 1 : 0);
+    constexpr int VM_TILE = DPW + KCB;           // DMA instructions of one tile
+    constexpr int VM_PER_ITER = VM_TILE + (P1 ? 1 : 0);
 
     float csum[16];
 #pragma unroll
@@ -216,11 +222,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
 
     if (n_tiles > 0) issue(0);
     if (n_tiles > 1) issue(1);
-    if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DPW + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
+    if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_TILE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
     bw_barrier();
     for (int t = 0; t < n_tiles; t++) {
         const uint16_t* const tD = sD + (t % BW_RING) * DSZ;
-        const uint16_t* const tH = sH + (t % BW_RING) * BW_ROWS * BW_KC;
+        const uint16_t* const tH = sH + (t % BW_RING) * HSZ;
         if (t + 2 < n_tiles) issue(t + 2);          // into the buffer every wave finished reading before the barrier that ended iteration t - 1
         if constexpr (P1) { if (t > 0) store_out(t - 1); }
         if (p1_wave) {
@@ -250,17 +256,20 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
                 *reinterpret_cast<uint2*>(tO + at) = make_uint2(bw_pack(v0, v1), bw_pack(v2, v3));
             }
         } else if (pj >= 0 && pj * NBW < NB) {
-            // ---- P2: dW[n][kcol] += dZ^T h over the tile's 64 rows (4 k steps): the wave's n blocks against both column halves ----
+            // ---- P2: dW[n][kcol] += dZ^T h over the tile's 64 rows (4 k steps): the wave's n blocks against every 32-column half of the workgroup's columns ----
 #pragma unroll
             for (int ks = 0; ks < BW_ROWS / 16; ks++) {
-                const u32x4 bf0 = frag_tr<BW_KC, false>(tH, 0, ks, lane), bf1 = frag_tr<BW_KC, false>(tH, 32, ks, lane);
+                u32x4 bf[2 * KCB];
+#pragma unroll
+                for (int h = 0; h < 2 * KCB; h++) bf[h] = frag_tr<BW_KC, false>(tH + (h >> 1) * BW_ROWS * BW_KC, 32 * (h & 1), ks, lane);
 #pragma unroll
                 for (int i = 0; i < NBW; i++) {
                     const int nb = pj * NBW + i;
                     if (nb < NB) {
                         const u32x4 af = frag_tr<N, true>(tD, 32 * nb, ks, lane);
-                        st[2 * i] = __builtin_bit_cast(u32x16, bw_mfma(af, bf0, __builtin_bit_cast(f32x16, st[2 * i])));
-                        st[2 * i + 1] = __builtin_bit_cast(u32x16, bw_mfma(af, bf1, __builtin_bit_cast(f32x16, st[2 * i + 1])));
+#pragma unroll
+                        for (int h = 0; h < 2 * KCB; h++)
+                            st[2 * KCB * i + h] = __builtin_bit_cast(u32x16, bw_mfma(af, bf[h], __builtin_bit_cast(f32x16, st[2 * KCB * i + h])));
                     }
                 }
             }
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
         if (t + 2 < n_tiles) {
 #endif
             if (t > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_PER_ITER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(DPW + 1) : "memory");   // the first iteration has no result tile to store yet
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_TILE) : "memory");   // the first iteration has no result tile to store yet
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
@@ -291,12 +300,12 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
             const int nb = pj * NBW + i;
             if (nb < NB) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int kcol = BW_KC * c + 32 * h + li;
+                for (int h = 0; h < 2 * KCB; h++) {
+                    const int kcol = BW_KC * KCB * c + 32 * h + li;
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        if (n < a.n_real && kcol < a.k_real) slab[(int64_t)n * a.k_real + kcol] = bw_u2f(st[2 * i + h][r]);
+                        if (n < a.n_real && kcol < a.k_real) slab[(int64_t)n * a.k_real + kcol] = bw_u2f(st[2 * KCB * i + h][r]);
                     }
                 }
             }
@@ -322,16 +331,17 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
     }
 }
 
-template <int NB>
-constexpr size_t bwd_lds_bytes() {   // ring of dZ and h tiles, two result tiles, the column-sum hand-over, a spare KiB per wave for DMA pieces a narrow tile does not have
-    return (BW_RING * ((size_t)BW_ROWS * (32 * NB < 64 ? 64 : 32 * NB) + (size_t)BW_ROWS * BW_KC) + 2 * (size_t)BW_ROWS * BW_KC) * sizeof(uint16_t) + 2 * BW_KC * sizeof(float) +
-           (size_t)BW_WAVES * 1024;
+template <int NB, bool P1, int KCB>
+constexpr size_t bwd_lds_bytes() {   // ring of dZ and h tiles, (P1) two result tiles, the column-sum hand-over, a spare KiB per wave for DMA pieces a narrow tile does not have
+    return (BW_RING * ((size_t)BW_ROWS * (32 * NB < 64 ? 64 : 32 * NB) + (size_t)KCB * BW_ROWS * BW_KC) + (P1 ? 2 : 0) * (size_t)BW_ROWS * BW_KC) * sizeof(uint16_t) +
+           2 * BW_KC * sizeof(float) + (size_t)BW_WAVES * 1024;
 }
 
-template <int NB, bool P1>
+template <int NB, bool P1, int KCB>
 hipError_t bwd_launch(const BwdArgs& a, hipStream_t s) {
-    constexpr size_t lds = bwd_lds_bytes<NB>();
-    auto kern = bwd_layer_kernel<NB, P1>;
+    constexpr size_t lds = bwd_lds_bytes<NB, P1, KCB>();
+    static_assert(lds <= 160 * 1024, "one workgroup per CU must fit");
+    auto kern = bwd_layer_kernel<NB, P1, KCB>;
     if constexpr (lds > 64 * 1024) {
         static std::atomic<unsigned long long> lds_ok{0};
         const hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(kern), (int)lds);
@@ -344,11 +354,14 @@ hipError_t bwd_launch(const BwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Row ranges of a layer's fused backward launch: S ranges of whole 64-row tiles, S x (ld_in / 64) workgroups ~ one per CU.
-int gen_bwd_ranges(int64_t rows, int ld_in, int* tiles_per_range) {
-    const int cb = ld_in / BW_KC;
+// Column blocks a launch cuts the layer's input side into: 64 columns beside P1; 128 for layer 0 (no layer below) when its width allows
+int gen_bwd_col_blocks(int ld_in, bool has_below) { return (!has_below && ld_in % (2 * BW_KC) == 0) ? ld_in / (2 * BW_KC) : ld_in / BW_KC; }
+
+// Row ranges of a layer's fused backward launch: S ranges of whole 64-row tiles, S x (column blocks) workgroups ~ one per CU -- or per CU of HALF the chip when
+// the other net's launch runs beside it on a second stream (a workgroup holds a CU by its LDS): half the partial slabs, written and read again, for the same work.
+int gen_bwd_ranges(int64_t rows, int col_blocks, bool half_chip, int* tiles_per_range) {
     const int64_t tiles = (rows + BW_ROWS - 1) / BW_ROWS;
-    int64_t want = 256 / cb;
+    int64_t want = (half_chip ? 128 : 256) / col_blocks;
     if (want < 1) want = 1;
     if (want > tiles) want = tiles;
     const int64_t per = (tiles + want - 1) / want;
@@ -361,18 +374,20 @@ bool gen_fused_backward_ok(const GenericCtx& g) {
     return g.bf16 && (g.ld_h == 128 || g.ld_h == 256) && g.L.act <= 32 && g.ld_in0 % BW_KC == 0 && g.L.n_hidden >= 1;
 }
 
-// One layer: d = dZ_l [., ldd] (width n_pad in {32, 128, 256}), h = the layer's input [., ldh] (ldh / 64 column blocks), w = the layer's bf16 weight plane
-// (null: layer 0, no layer below).  Writes S slabs [n_real][k_real] (S from gen_bwd_ranges), dZ_{l-1} and its column sums per range.
+// One layer: d = dZ_l [., ldd] (width n_pad in {32, 128, 256}), h = the layer's input [., ldh], w = the layer's bf16 weight plane (null: layer 0, no layer
+// below).  col_blocks from gen_bwd_col_blocks, S / tiles_per_range from gen_bwd_ranges.  Writes S slabs [n_real][k_real], dZ_{l-1} and its column sums per range.
 hipError_t gen_fused_backward_layer(int n_pad, const uint16_t* d, int64_t ldd, const uint16_t* h, int64_t ldh, const uint16_t* w, int64_t ldw, uint16_t* dz_out,
                                     int64_t ld_out, float* slab, int64_t slab_stride, float* colsum, int64_t ld_cs, const uint16_t* zeros, int64_t rows, int n_real,
-                                    int k_real, int S, int tiles_per_range, hipStream_t s) {
+                                    int k_real, int col_blocks, int S, int tiles_per_range, hipStream_t s) {
     BwdArgs a{};
     a.zeros = zeros;
     a.d = d; a.ldd = ldd; a.h = h; a.ldh = ldh; a.w = w; a.ldw = ldw; a.dz_out = dz_out; a.ld_out = ld_out; a.slab = slab; a.slab_stride = slab_stride;
-    a.colsum = colsum; a.ld_cs = ld_cs; a.rows = rows; a.n_real = n_real; a.k_real = k_real; a.S = S; a.CB = (int)(ldh / BW_KC); a.tiles_per_range = tiles_per_range;
+    a.colsum = colsum; a.ld_cs = ld_cs; a.rows = rows; a.n_real = n_real; a.k_real = k_real; a.S = S; a.CB = col_blocks; a.tiles_per_range = tiles_per_range;
     const bool p1 = w != nullptr;
-    if (n_pad == 32) return p1 ? bwd_launch<1, true>(a, s) : bwd_launch<1, false>(a, s);
-    if (n_pad == 128) return p1 ? bwd_launch<4, true>(a, s) : bwd_launch<4, false>(a, s);
-    if (n_pad == 256) return p1 ? bwd_launch<8, true>(a, s) : bwd_launch<8, false>(a, s);
+    const bool wide = !p1 && col_blocks * 2 * BW_KC == ldh;   // 128-column blocks
+    if (!p1 && !wide && col_blocks * BW_KC != ldh) return hipErrorInvalidValue;
+    if (n_pad == 32) return p1 ? bwd_launch<1, true, 1>(a, s) : (wide ? bwd_launch<1, false, 2>(a, s) : bwd_launch<1, false, 1>(a, s));
+    if (n_pad == 128) return p1 ? bwd_launch<4, true, 1>(a, s) : (wide ? bwd_launch<4, false, 2>(a, s) : bwd_launch<4, false, 1>(a, s));
+    if (n_pad == 256) return p1 ? bwd_launch<8, true, 1>(a, s) : (wide ? bwd_launch<8, false, 2>(a, s) : bwd_launch<8, false, 1>(a, s));
     return hipErrorNotSupported;
 }
