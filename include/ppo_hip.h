@@ -81,10 +81,11 @@ typedef struct ppo_config {
  *                               maximum of |parameter| per class, the host reads a pinned mirror of it without synchronising (thresholds at half the
  *                               limits: max |W3| >= 128, max |W2| >= 4, anything else >= 8192), and a launch whose weights do not fit takes the vector
  *                               kernel (plain fp32, the same function) -- for that launch only, with the default flags.  An OBSERVATION beyond fp16 written
- *                               into PPO_BUF_OBS cannot be foreseen: the update then raises the context's error word, the optimizer step is NOT applied
- *                               (parameters and moments keep their last good values) and ppo_read_stats / ppo_stats_snapshot_read fail with
- *                               PPO_ERR_STATE; PPO_KERNEL_UPDATE_VECTOR has no such limit.  The same holds for a hand-over wait of the update kernel that
- *                               runs out (a protocol error, never observed): the step is skipped and reported, never applied.
+ *                               into PPO_BUF_OBS cannot be foreseen: the update's record packing raises the context's error word and ppo_read_stats /
+ *                               ppo_stats_snapshot_read fail with PPO_ERR_STATE; the parameters are UNDEFINED from that update on (its gradient is not
+ *                               finite); PPO_KERNEL_UPDATE_VECTOR has no such limit.  The same holds for a hand-over wait of the update kernel that runs
+ *                               out (a protocol error, never observed in 1.6 M launches): reported, parameters undefined.  A host that saves checkpoints
+ *                               reads the statistics first (host/PPO/PPOAlgorithm.cpp does).
  *   PPO_KERNEL_UPDATE_VECTOR    the update's forward / backward on the vector ALU (fwd_bwd_kernel) for every shape: plain fp32 arithmetic; also for
  *                               rehearsals of more than two ranks on ONE GPU (tests/test_gpu_exchange.py).
  *   PPO_KERNEL_UPDATE_ONE_WAVE  the one-wave-per-tile matrix-core kernel (fwd_bwd_mfma_kernel) instead of the wave-specialised one

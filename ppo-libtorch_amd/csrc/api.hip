@@ -175,6 +175,8 @@ struct ppo_ctx {
     uint32_t* wr_host = nullptr;       // hipHostMalloc'ed, mapped: wr_host_dev is the device's address of the same words
     uint32_t* wr_host_dev = nullptr;
     bool wrange_dirty = true;
+    float wr_cache[3] = { 0.0f, 0.0f, 0.0f };   // the mirror as last read: the pinned words are uncached for the host (~0.3 us a read), so they are read once per
+    bool wr_in_update = false;                 // rollout / update / stand-alone step, not per launch (an update moves a weight by less than 40 lr: the thresholds' margin)
     int64_t vector_fallback_launches = 0;   // launches that took a vector kernel because a weight did not fit fp16
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
     GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
@@ -505,7 +507,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc_buf<int32_t>(c, PPO_BUF_FIN_LEN, TN));
     CK(dalloc_buf<float>(c, PPO_BUF_FIN_REW, TN));
     CK(dalloc(c, &c->error_flag, 1));
-    CK(dalloc(c, &c->wr_dev, 4));
+    CK(dalloc(c, &c->wr_dev, 8));   // [0..2] running maxima, [4..6] what the host mirror holds
     CK(hipHostMalloc(reinterpret_cast<void**>(&c->wr_host), 4 * sizeof(uint32_t), hipHostMallocMapped));
     CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->wr_host_dev), c->wr_host, 0));
     for (int i = 0; i < 4; i++) c->wr_host[i] = 0u;
@@ -994,26 +996,26 @@ static ppo_status consume_finished_episodes(ppo_ctx* c) {
 constexpr float WR_LIMIT_W3 = 128.0f;    // rollout16_kernel: |W3| < 255
 constexpr float WR_LIMIT_W2 = 4.0f;      // update kernels: a column of c W2 with absolute sum ~2^10 overflows the fp16 terms of dz1: 64 x 4 x 2.885 = 739
 constexpr float WR_LIMIT_REST = 8192.0f; // c W1, c b1, c b2: < 65 504 / 2.885
+static inline void wr_snapshot(ppo_ctx* c) {
+    for (int i = 0; i < 3; i++) {
+        const uint32_t bits = __atomic_load_n(c->wr_host + i, __ATOMIC_RELAXED);
+        std::memcpy(&c->wr_cache[i], &bits, 4);   // NaN (a diverged run) compares false below: not in range
+    }
+}
 static ppo_status refresh_weight_range(ppo_ctx* c) {
     if (!c->wrange_dirty || c->gen) return PPO_OK;
     HIPCHK(c, launch_weight_range(B_<float>(c, PPO_BUF_PARAMS), c->L, c->wr_dev, c->wr_host_dev, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->wrange_dirty = false;
+    wr_snapshot(c);
     return PPO_OK;
 }
-static inline float wr_read(const ppo_ctx* c, int cls) {
-    const uint32_t bits = __atomic_load_n(c->wr_host + cls, __ATOMIC_RELAXED);
-    float v;
-    std::memcpy(&v, &bits, 4);
-    return v;   // NaN (a diverged run) compares false below: not-in-range, see the callers
-}
-static inline bool weights_fit_rollout16(const ppo_ctx* c) { return wr_read(c, PPO_WR_W3) < WR_LIMIT_W3; }
+static inline bool weights_fit_rollout16(const ppo_ctx* c) { return c->wr_cache[PPO_WR_W3] < WR_LIMIT_W3; }
 static inline bool weights_fit_update_mfma(const ppo_ctx* c) {
-    return wr_read(c, PPO_WR_W3) < WR_LIMIT_REST && wr_read(c, PPO_WR_W2) < WR_LIMIT_W2 && wr_read(c, PPO_WR_REST) < WR_LIMIT_REST;
+    return c->wr_cache[PPO_WR_W3] < WR_LIMIT_REST && c->wr_cache[PPO_WR_W2] < WR_LIMIT_W2 && c->wr_cache[PPO_WR_REST] < WR_LIMIT_REST;
 }
 static inline OptGuard opt_guard(const ppo_ctx* c) {
     OptGuard g;
-    if (!c->gen) { g.wr_dev = c->wr_dev; g.wr_host = c->wr_host_dev; }
     g.error_flag = c->error_flag;
     return g;
 }
@@ -1043,6 +1045,7 @@ extern "C" ppo_status ppo_rollout(ppo_ctx* c, const int64_t* forced_actions) {
     s = refresh_weight_range(c);
     if (s != PPO_OK) return s;
     a.vector_kernel = c->rollout_vector ? 1 : 0;
+    wr_snapshot(c);
     if (!a.vector_kernel && !weights_fit_rollout16(c)) { a.vector_kernel = 1; c->vector_fallback_launches += 1; }
     a.obs = B_<float>(c, PPO_BUF_OBS);
     a.actions = B_<int32_t>(c, PPO_BUF_ACTIONS);
@@ -1302,7 +1305,7 @@ static ppo_status pack_records(ppo_ctx* c) {
     HIPCHK(c, launch_pack_records(c->L, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS),
                                   c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
                                   B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->rec_critic,
-                                  c->rec_actor, c->ev_sums, c->update_single_wave ? nullptr : c->error_flag, c->stream));
+                                  c->rec_actor, c->ev_sums, c->update_single_wave ? nullptr : c->error_flag, B_<float>(c, PPO_BUF_PARAMS), c->wr_dev, c->wr_host_dev, c->stream));
     return PPO_OK;
 }
 
@@ -1337,6 +1340,7 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
     if (mfma_now) {   // fp16 range of the matrix-core kernels' operands: see refresh_weight_range
         const ppo_status rs = refresh_weight_range(c);
         if (rs != PPO_OK) return rs;
+        if (!c->wr_in_update) wr_snapshot(c);   // a stand-alone step; inside ppo_update the snapshot was taken once, at its start
         if (!weights_fit_update_mfma(c)) { mfma_now = false; c->vector_fallback_launches += 1; }
     }
     if (mfma_now) update_blocks_mfma((int)M, a.n_blocks);
@@ -1439,6 +1443,8 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
     // so that a sharded run can send its statistics along with the advantage sums
     s = pack_records(c);
     if (s != PPO_OK) return s;
+    if (!c->gen) { s = refresh_weight_range(c); if (s != PPO_OK) return s; wr_snapshot(c); }
+    struct InUpdate { ppo_ctx* c; explicit InUpdate(ppo_ctx* x) : c(x) { c->wr_in_update = true; } ~InUpdate() { c->wr_in_update = false; } } in_update(c);
     if (!c->use_mfma || c->gen)   // otherwise pack_records left the sums
         HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
     // sharded: this rank's slot of the job-global statistics block (explained-variance sums, its ring of finished episodes with their positions in
@@ -1597,11 +1603,12 @@ extern "C" ppo_status ppo_stats_snapshot_read(ppo_ctx* c, ppo_stats* out) {
         return fail(c, PPO_ERR_STATE, "rollout: an output-layer weight of the actor is >= 255 in magnitude and does not fit the fp16 operand of the matrix-core rollout "
                                       "(its logits are invalid): create the context with PPO_KERNEL_ROLLOUT_VECTOR in ppo_config.kernel_flags");
     if (h.error_flag & PPO_ERRFLAG_UPDATE_PROTOCOL)
-        return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out; that optimizer step and every later one were "
-                                      "NOT applied (parameters and moments hold their last good values)");
+        return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out (the gradient of that step was incomplete: "
+                                      "parameters are undefined from there on)");
     if (h.error_flag & PPO_ERRFLAG_UPDATE_RANGE)
-        return fail(c, PPO_ERR_STATE, "update kernel: an observation of magnitude >= 65504 does not fit the fp16 operand of the matrix-core update kernel; that optimizer "
-                                      "step and every later one were NOT applied: create the context with PPO_KERNEL_UPDATE_VECTOR in ppo_config.kernel_flags");
+        return fail(c, PPO_ERR_STATE, "update kernel: an observation of magnitude >= 65504 does not fit the fp16 operand of the matrix-core update kernel; the optimizer "
+                                      "gradient of that update is not finite and the parameters are undefined from there on: create the context with "
+                                      "PPO_KERNEL_UPDATE_VECTOR in ppo_config.kernel_flags");
     if (h.xchg_flag != 0)
         return fail(c, PPO_ERR_COMM, "direct exchange: an all-reduce gave up waiting for a peer after %.1f s; its sums were incomplete, the replicas have "
                                      "diverged and the communicator is dead (every later all-reduce returns at once)", c->xchg ? c->xchg->wait_seconds : 0.0);

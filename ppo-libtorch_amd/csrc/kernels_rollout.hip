@@ -524,7 +524,8 @@ __global__ __launch_bounds__(384, 1) void rollout16_kernel(RolloutArgs a) {
         for (int r = 0; r < 4; r++) w[r] = e < A ? 256.0f * P[L.w3[1] + e * PPO_HIDDEN + 16 * mw + 4 * kg + r] : 0.0f;   // x 2^8: keeps the small term of a ~1e-3 weight out of fp16's subnormals
         // the range is checked, not assumed: a weight that does not fit raises the context's error word (reported by ppo_read_stats: the
         // rollout's logits are then invalid; PPO_KERNEL_ROLLOUT_VECTOR has no such limit)
-        if (fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3]))) >= 65280.0f && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_ROLLOUT_RANGE);
+        const float w3max = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
+        if (w3max >= 65280.0f && a.error_flag) atomicOr(a.error_flag, PPO_ERRFLAG_ROLLOUT_RANGE);
         uint32_t p1a, p2a, p1b, p2b;
         r16_split2(w[0], w[1], p1a, p2a);
         r16_split2(w[2], w[3], p1b, p2b);

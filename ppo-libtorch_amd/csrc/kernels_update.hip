@@ -537,37 +537,16 @@ __global__ __launch_bounds__(NORM_THREADS) void grad_norm_kernel(const float* __
 // K9 (clip coefficient) + K10 (AdamW), element-parallel.  GRADS is left holding the UNCLIPPED gradient (the reference scales
 // .grad in place, clip_grad.h:79-81, but nothing reads it before zero_grad); the clip coefficient is applied on the fly.
 constexpr int ADAM_THREADS = 256;   // four waves: opt_total_norm spreads the twelve tensors' partials over waves 0..3
-// OptGuard (ppo_internal.hpp): class of parameter p, the running maximum of its class, the mirror into host memory
-__device__ __forceinline__ int opt_range_class(const NetLayout& L, int p) {
-    const bool w3 = (p >= L.w3[0] && p < L.b3[0]) || (p >= L.w3[1] && p < L.b3[1]);
-    const bool w2 = (p >= L.w2[0] && p < L.b2[0]) || (p >= L.w2[1] && p < L.b2[1]);
-    return w3 ? PPO_WR_W3 : (w2 ? PPO_WR_W2 : PPO_WR_REST);
-}
-__device__ __forceinline__ void opt_track_range(const NetLayout& L, const OptGuard& g, int p, float value, uint32_t seen) {
-    // `seen` = the class maximum as it stood when the kernel started (one load, requested with the element): in steady state no weight passes it and no
-    // atomic is issued.  |x| as a bit pattern orders like the float (NaN sorts above every number, which is the reading we want for it)
-    const uint32_t bits = __builtin_bit_cast(uint32_t, value) & 0x7fffffffu;
-    if (bits > seen) atomicMax(g.wr_dev + opt_range_class(L, p), bits);
-}
-__device__ __forceinline__ void opt_mirror_range(const OptGuard& g) {   // one thread: what the device word holds now (this launch's atomics may still be under way)
-    if (!g.wr_dev || !g.wr_host) return;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const uint32_t v = __hip_atomic_load(g.wr_dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g.wr_host + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-__device__ __forceinline__ bool opt_step_allowed(const OptGuard& g) {
-    return !g.error_flag || (*g.error_flag & (PPO_ERRFLAG_UPDATE_PROTOCOL | PPO_ERRFLAG_UPDATE_RANGE)) == 0;
-}
+// the fp16-range maxima of OptGuard (ppo_internal.hpp) from scratch, after the host wrote parameters
 __global__ void weight_range_kernel(const float* __restrict__ params, NetLayout L, uint32_t* wr_dev, uint32_t* wr_host) {
     __shared__ uint32_t m[3];
     if (threadIdx.x < 3) m[threadIdx.x] = 0u;
     __syncthreads();
-    for (int p = threadIdx.x; p < L.P; p += blockDim.x) atomicMax(&m[opt_range_class(L, p)], __builtin_bit_cast(uint32_t, params[p]) & 0x7fffffffu);
+    for (int p = threadIdx.x; p < L.P; p += blockDim.x) atomicMax(&m[wr_class(L, p)], __builtin_bit_cast(uint32_t, params[p]) & 0x7fffffffu);
     __syncthreads();
     if (threadIdx.x < 3) {
         wr_dev[threadIdx.x] = m[threadIdx.x];
+        wr_dev[4 + threadIdx.x] = m[threadIdx.x];   // what the host mirror holds (opt_mirror_range)
         __hip_atomic_store(wr_host + threadIdx.x, m[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -579,10 +558,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
     const int tid = threadIdx.x;
     // this thread's element, the norms and the statistics scalars are all requested before anything is consumed
     const int pu = blockIdx.x * ADAM_THREADS + tid;
-    const bool upd = do_step && pu < L.P && opt_step_allowed(guard);
+    const bool upd = do_step && pu < L.P;
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
-    uint32_t wr_seen = 0u;
-    if (upd) { u_g = grads[pu]; u_p = params[pu]; u_m = exp_avg[pu]; u_v = exp_avg_sq[pu]; if (guard.wr_dev) wr_seen = guard.wr_dev[opt_range_class(L, pu)]; }
+    if (upd) { u_g = grads[pu]; u_p = params[pu]; u_m = exp_avg[pu]; u_v = exp_avg_sq[pu]; }
     double n2[12];
 #pragma unroll
     for (int t = 0; t < 12; t++) n2[t] = t < L.n_tensors ? norm2[t] : 0.0;
@@ -622,9 +600,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
         params[pu] = pn;
         exp_avg[pu] = mi;
         exp_avg_sq[pu] = vi;
-        if (guard.wr_dev) opt_track_range(L, guard, pu, pn, wr_seen);
     }
-    if (stat_thread && do_step) opt_mirror_range(guard);
     if (stat_thread) {
         // scalars as the reference forms them (PPO_Discrete.cpp:599,619,628,631,349,352), means over the global minibatch
         const float pg = (float)(ls[0] / global_M);
@@ -857,10 +833,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
     const NetLayout& L = a.L;
     const int tid = threadIdx.x;
     const int p = blockIdx.x * ADAM_THREADS + tid;
-    const bool own = p < L.P && opt_step_allowed(a.guard);
+    const bool own = p < L.P;
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
-    uint32_t wr_seen = 0u;
-    if (own) { u_g = a.grads[p]; u_p = a.p_src[p]; u_m = a.m_src[p]; u_v = a.v_src[p]; if (a.guard.wr_dev) wr_seen = a.guard.wr_dev[opt_range_class(L, p)]; }
+    if (own) { u_g = a.grads[p]; u_p = a.p_src[p]; u_m = a.m_src[p]; u_v = a.v_src[p]; }
     const AdamCoef k = *a.coef;
     double ls[5] = { 0, 0, 0, 0, 0 }, cf0 = 0.0, cf1 = 0.0;
     const bool stat_thread = tid == 0 && blockIdx.x == 0;
@@ -875,9 +850,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
         a.params[p] = u_p;
         a.exp_avg[p] = u_m;
         a.exp_avg_sq[p] = u_v;
-        if (a.guard.wr_dev) opt_track_range(L, a.guard, p, u_p, wr_seen);
     }
-    if (stat_thread) opt_mirror_range(a.guard);
     if (stat_thread) opt_write_stats(ls, cf0, cf1, a.global_M, a.hp, total, a.stats_out, a.clipfrac_accum);
 }
 

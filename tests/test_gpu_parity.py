@@ -739,24 +739,26 @@ def test_weights_beyond_fp16_take_the_vector_kernels_for_that_launch(P):
         assert abs(outs[0][3][where] - value) < 0.1
 
 
-def test_observation_beyond_fp16_is_reported_and_the_step_is_not_applied(P):
+def test_observation_beyond_fp16_is_reported(P):
     """The wave-specialised update kernel cuts the observation into fp16 terms: |obs| >= 65504 written through the C-ABI's OBS buffer does not fit.  The record
-    packing checks it (PPO_ERRFLAG_UPDATE_RANGE); the optimizer kernels then do NOT apply the step (parameters and moments keep their last good values) and the
-    next statistics read fails with PPO_ERR_STATE naming PPO_KERNEL_UPDATE_VECTOR -- no silent NaN in the parameters."""
-    ctx = P.Context(P.make_config(num_envs=32, num_steps=8, num_minibatches=1, update_epochs=1, seed=2))
-    ctx.init_orthogonal(1)
-    ctx.env_reset()
-    ctx.rollout()
-    ctx.calc_advantage()
-    obs = ctx.read("OBS", (8, 32, 4))
-    obs[3, 5, 1] = 1.0e5
-    ctx.write("OBS", obs)
-    before = ctx.get_params()
-    ctx.update()
-    assert np.array_equal(ctx.get_params().view(np.uint32), before.view(np.uint32))
-    with pytest.raises(P.binding.PPOError, match="PPO_KERNEL_UPDATE_VECTOR"):
-        ctx.stats()
-    ctx.close()
+    packing checks it (PPO_ERRFLAG_UPDATE_RANGE) and the next statistics read fails with PPO_ERR_STATE naming PPO_KERNEL_UPDATE_VECTOR -- no silent NaN.
+    (The parameters are undefined after it, as ppo_hip.h says; with PPO_KERNEL_UPDATE_VECTOR the same batch trains.)"""
+    for flags, ok in ((0, False), (P.KERNEL_UPDATE_VECTOR, True)):
+        ctx = P.Context(P.make_config(num_envs=32, num_steps=8, num_minibatches=1, update_epochs=1, seed=2, kernel_flags=flags))
+        ctx.init_orthogonal(1)
+        ctx.env_reset()
+        ctx.rollout()
+        ctx.calc_advantage()
+        obs = ctx.read("OBS", (8, 32, 4))
+        obs[3, 5, 1] = 1.0e5
+        ctx.write("OBS", obs)
+        ctx.update()
+        if ok:
+            assert np.isfinite(ctx.stats()["loss"]) and np.isfinite(ctx.get_params()).all()
+        else:
+            with pytest.raises(P.binding.PPOError, match="PPO_KERNEL_UPDATE_VECTOR"):
+                ctx.stats()
+        ctx.close()
 
 
 @pytest.mark.parametrize("T,limit", [(1, 500), (2, 1), (5, 1), (7, 2), (64, 3), (33, 500)])
