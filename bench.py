@@ -55,9 +55,49 @@ def flops_per_sample(obs, act, hidden=64, n_hidden=2):
     return 3 * 2 * macs
 
 
+_PROFILE_TIE = None
+
+
+def profile_tie():
+    """The committed profile set whose numbers this run may quote: the NEWEST profiles/<tag>_meta.json (tools/collect_profiles.sh) whose source fingerprint
+    equals this tree's (tools/src_fingerprint.py: every kernel source, header and the Makefile of the library the run loads).  Counters and the tracer cannot
+    run inside the timed region, so `traffic`, the in-trace durations, the floor probe and the curve comparison come from that set -- or are null, with the reason
+    here, when the sources have changed since it was measured."""
+    global _PROFILE_TIE
+    if _PROFILE_TIE is not None:
+        return _PROFILE_TIE
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("src_fingerprint", os.path.join(ROOT, "tools", "src_fingerprint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    here = mod.source_fingerprint()
+    metas = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_meta.json")):
+        try:
+            with open(f) as fh:
+                metas.append(json.load(fh))
+        except Exception:
+            pass
+    metas.sort(key=lambda d: d.get("collected_unix", 0))
+    match = [d for d in metas if d.get("src_sha16") == here]
+    if match:
+        d = match[-1]
+        _PROFILE_TIE = {"tied": True, "tag": d["tag"], "src_sha16": here, "lib_sha16_at_collection": d.get("lib_sha16"), "git_head_at_collection": d.get("git_head")}
+    else:
+        newest = metas[-1] if metas else None
+        _PROFILE_TIE = {"tied": False, "tag": None, "src_sha16": here,
+                        "reason": ("no committed profile set was measured on these sources" +
+                                   (" (the newest, %s, on sources %s)" % (newest["tag"], newest.get("src_sha16")) if newest else " (no profiles/*_meta.json)") +
+                                   ": the fields that would quote it are null")}
+    return _PROFILE_TIE
+
+
 def newest_profile(suffix):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
-    return files[-1] if files else None
+    t = profile_tie()
+    if not t["tied"]:
+        return None
+    f = os.path.join(ROOT, "profiles", t["tag"] + suffix)
+    return f if os.path.exists(f) else None
 
 
 def pmc_traffic(prefix):
@@ -134,6 +174,20 @@ def committed_jsonl(suffix):
     try:
         with open(f) as fh:
             return {"rows": [json.loads(l) for l in fh if l.strip().startswith("{")], "source": "profiles/" + os.path.basename(f)}
+    except Exception:
+        return None
+
+
+def gae_in_trace_by_size():
+    """rocprofv3 --kernel-trace durations of the scan by size (profiles/<tag>_gae_by_size.json): the method BASELINE.md section 4 prescribes for the 40 % bar."""
+    f = newest_profile("_gae_by_size.json")
+    if not f:
+        return None
+    try:
+        with open(f) as fh:
+            d = json.load(fh)
+        return {"rows": [{"envs": r["envs"], "avg_us": r["avg_ns"] / 1e3, "frac": r["frac_of_8TBps"], "launches": r["launches"]} for r in d["rows"]],
+                "source": "profiles/" + os.path.basename(f)}
     except Exception:
         return None
 
@@ -649,8 +703,9 @@ def main():
         fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma"
         fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, pmc_traffic("gae_kernel") if args.workload == "cartpole" else None
         if generic:
-            roof = {"kernel": "one minibatch step of the generic path (gather, 10 forward + 18 backward layer products on gemm_kernel with fused bias / tanh / tanh' / "
-                              "bias-gradient epilogues, heads + PPO loss): bf16 operands and activations, f32 accumulation", "bound": "mfma",
+            roof = {"kernel": "one minibatch step of the generic path (gather; per net ONE fused forward launch (generic_forward_kernel) and one fused backward launch "
+                              "per layer (bwd_layer_kernel: weight gradient + the gradient handed down from one LDS-DMA'd tile); heads + PPO loss; slab sums): bf16 "
+                              "operands and activations, f32 accumulation", "bound": "mfma",
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
                     # HBM bytes of one minibatch step: the committed --pmc measurement of this workload (tools/collect_profiles.sh, tools/c4_traffic.py)
@@ -692,6 +747,9 @@ def main():
                        "num_envs_per_gpu": N, "num_steps": T, "global_batch": N * T * world,
                        "minibatch_per_gpu": M, "optimizer_steps_per_step": 40, "parallelism": "dp%d (env-sharded, 1 gradient all-reduce per optimizer step%s)" % (world, {"exchange": ": one-shot direct exchange over IPC peer buffers", "rccl": ": RCCL", "none": ""}[transport]) + (" [comm self-test]" if args.comm_selftest else "") + (" [all ranks on ONE device: rehearsal]" if args.same_device and world > 1 else "")},
             "roofline": roof,
+            # which committed profile set the fields measured outside this run (traffic, in-trace durations, floor probe, curve comparison) come from, tied to
+            # the sources of the library this run loaded -- or why they are null
+            "profiles": profile_tie(),
             # primary numbers: the launch by itself (200 in a row on this workload's own buffers, live, after the timed region) -- the duration
             # the rocprofv3 kernel trace agrees with; the in-iteration HIP-event reading (an event pair adds ~3 us to a ~5 us launch) is kept beside it
             "gae_roofline": {"kernel": "gae_kernel (exact mode)", "bound": "hbm", "achieved": gae_own["achieved"], "peak": HBM_PEAK_GBS,
@@ -710,9 +768,14 @@ def main():
                                            "back_to_back_sizes": gae_fast_rows},
                              # the 40 % bar of BASELINE.json, stated in one place: the smallest measured size that clears it, what the headline's
                              # per-GPU size (configs[1] / [2]: 4096 envs) reaches, and the committed floor of a launch that moves the same bytes
+                             # (size_met_from_envs / frac_at_config1 are read off the IN-TRACE table -- rocprofv3 kernel time, the method BASELINE.md section 4
+                             # prescribes -- when a profile set is tied to this binary; back-to-back wall times overlap consecutive launches and read higher)
                              "bar": {"target_frac": 0.40,
-                                     "size_met_from_envs": next((r["envs"] for r in gae_rows if r["frac"] >= 0.40), None),
-                                     "frac_at_config1": next((r["frac"] for r in gae_rows if r["envs"] == 4096), None),
+                                     "size_met_from_envs": next((r["envs"] for r in sorted((gae_in_trace_by_size() or {"rows": []})["rows"], key=lambda r: r["envs"]) if r["frac"] >= 0.40), None),
+                                     "frac_at_config1": next((r["frac"] for r in (gae_in_trace_by_size() or {"rows": []})["rows"] if r["envs"] == 4096), None),
+                                     "in_trace": gae_in_trace_by_size(),
+                                     "size_met_from_envs_back_to_back": next((r["envs"] for r in gae_rows if r["frac"] >= 0.40), None),
+                                     "frac_at_config1_back_to_back": next((r["frac"] for r in gae_rows if r["envs"] == 4096), None),
                                      "budget_us_at_config1": (20 * 4096 * T + 8 * 4096) / (0.40 * HBM_PEAK_GBS * 1e9) * 1e6,
                                      "floor_us": gae_floor_us()},
                              "rocprof": rocprof_kernel_us("gae_kernel<16") if args.workload == "cartpole" else None,

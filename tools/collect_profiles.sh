@@ -11,9 +11,6 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 
-python3 $ROOT/bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
-tail -n 1 "$OUT/bench.json" > "$ROOT/profiles/${TAG}_bench.json"
-
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o run -- $BENCH > "$OUT/trace.log" 2>&1
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_kernel_stats.csv"
 
@@ -59,5 +56,12 @@ python3 $ROOT/tools/c4_traffic.py "$OUT/c4_pmc_per_dispatch.json" "$ROOT/profile
 # the wave-specialised update kernel's wait shares (diagnostic build, if present) and the learning-curve comparison
 if [ -f $ROOT/build_ab/libppo_hip_ws_stamp.so ]; then PPO_HIP_LIBRARY=$ROOT/build_ab/libppo_hip_ws_stamp.so python3 $ROOT/tools/ws_stamps.py > "$ROOT/profiles/${TAG}_ws_stamps.txt" 2>&1 || true; fi
 python3 $ROOT/tests/test_gpu_curves.py > "$ROOT/profiles/${TAG}_curves.json" 2> "$OUT/curves.err" || echo "curves FAILED"
+# what ties this set to the binary: the fingerprint of the sources it was built from (bench.py quotes a set only while it matches)
+python3 $ROOT/tools/src_fingerprint.py --meta "$TAG" > "$OUT/meta.txt"
+# the judged bench lines LAST: they quote this set (traffic, in-trace durations, floor, curves), which exists and is tied only now
+python3 $ROOT/bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -n 1 "$OUT/bench.json" > "$ROOT/profiles/${TAG}_bench.json"
+python3 $ROOT/bench.py --workload config4 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err" && tail -n 1 "$OUT/bench_c4.json" > "$ROOT/profiles/${TAG}_bench_default_config4.json" || echo "config4 bench FAILED"
+python3 $ROOT/bench.py --workload mountaincar --no-cpu-baseline > "$OUT/bench_mc.json" 2> "$OUT/bench_mc.err" && tail -n 1 "$OUT/bench_mc.json" > "$ROOT/profiles/${TAG}_bench_default_mountaincar.json" || echo "mountaincar bench FAILED"
 cp "$ROOT"/profiles/${TAG}_* "$OUT/"
 echo done
