@@ -279,6 +279,153 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The exact scan PIPELINED IN TIME (round 5).  gae_kernel above runs three phases behind two barriers -- every load, then the walk, then every store -- so the
+// memory side sees 6.3 MB of reads, then 0.5 us of nothing, then 4.2 MB of writes, and at BASELINE's sizes the launch is one round trip of each after the
+// other (4.95 us in trace at 4096 envs against 3.36 for a plain stream of the same bytes).  Here the 128-row tile is cut into four groups of 32 rows, latest
+// time first -- the order the recurrence needs them in:
+//   waves 0-3 (movers)  issue ALL their loads up front, group 3 first; as a group's loads return (they return in issue order) form delta_t, c_t for it, park
+//                       them in LDS and count the group ready; later, when the walker has counted the group walked, stream its A_t and R_t = A_t + v_t out;
+//   wave 4 (walker)     one env per lane as before; starts on group 3 as soon as that group is ready, while groups 2 .. 0 are still in flight, and hands every
+//                       finished group back at once -- so the stores of group 3 leave while group 2 is walked and groups 1, 0 arrive.
+// No barrier anywhere: LDS event counters (one wave's LDS operations execute in issue order: a count behind data writes needs no wait), polled with
+// s_sleep.  Every wait is on a wave of the same workgroup that never waits on anything but memory or an earlier group, so the waits cannot cycle; they are
+// bounded anyway.  Arithmetic, association order and the -ffp-contract=off build are gae_kernel's: the results are the same bits (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int GP_THREADS = GAE_THREADS + 64;                 // four mover waves + the walker
+#ifndef GAE_PIPE_MAX_BLOCKS
+#define GAE_PIPE_MAX_BLOCKS 256                               /* strips up to which the pipelined kernel is launched: one workgroup per CU (12 288 envs x 32 columns = 384: 9.0 - 9.3 us against 7.2) */
+#endif
+typedef __attribute__((address_space(3))) volatile uint32_t gp_flag_t;
+__device__ __forceinline__ void gp_wait_ge(gp_flag_t* flag, uint32_t want) {
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*flag) >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+template <int EPB, int MODE, int GP_GROUPS>
+__global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __restrict__ rewards, const float* __restrict__ values, const float* __restrict__ dones,
+                                                              const float* __restrict__ next_value, const int32_t* __restrict__ next_done, int T, int N, float gamma,
+                                                              float gae_lambda, float* __restrict__ adv, float* __restrict__ ret) {
+    static_assert(EPB == 16 || EPB == 32, "strips of 16 or 32 columns");
+    constexpr int GP_GROWS = GAE_TC / GP_GROUPS;       // rows of a group: 32 (four groups) or 64 (two)
+    constexpr int C4 = EPB / 4;                        // float4 columns per row
+    constexpr int NG = GAE_TC * C4 / GAE_THREADS;      // float4 slots of a mover thread: 2 (16 columns) or 4 (32); slot j = rows tid / C4 + (256 / C4) j: a wave's
+                                                       // slot j lies inside ONE group (16 or 8 consecutive rows)
+    constexpr int MOVERS_PER_GROUP = GAE_THREADS / 64 * NG / GP_GROUPS;   // (wave, slot) pairs that fill a group: what its ready count reaches per tile
+    __shared__ __attribute__((aligned(16))) float sA[GAE_TC * EPB];
+    __shared__ __attribute__((aligned(16))) float sC[GAE_TC * EPB];
+    __shared__ __attribute__((aligned(16))) float sV[GAE_TC * EPB];
+    __shared__ uint32_t s_ready[GP_GROUPS], s_done[GP_GROUPS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = strip_of_block<EPB>((int)blockIdx.x, (int)gridDim.x) * EPB;
+    const float gl = gamma * gae_lambda;   // the C++ float product of PPO_Discrete.cpp:301
+    if (tid < GP_GROUPS) { s_ready[tid] = 0u; s_done[tid] = 0u; }
+    __syncthreads();   // the only barrier: the counters exist
+    gp_flag_t* const f_ready = (gp_flag_t*)s_ready;
+    gp_flag_t* const f_done = (gp_flag_t*)s_done;
+    const int n_tiles = T / GAE_TC;
+
+    if (wave == GAE_THREADS / 64) {
+        // ======================================================= the walker =======================================================
+        const bool walker = lane < EPB && n0 + lane < N;
+        float last = 0.0f;
+        if (MODE == 1 && walker) last = next_value[n0 + lane];   // next_return = next_value at t = T-1 (:318)
+        for (int tile = 0; tile < n_tiles; tile++) {
+#pragma unroll
+            for (int gi = 0; gi < GP_GROUPS; gi++) {
+                const int g = GP_GROUPS - 1 - gi;
+                gp_wait_ge(f_ready + g, (uint32_t)(MOVERS_PER_GROUP * (tile + 1)));
+                if (walker) {
+                    // the group's rows, top row first, 16 at a time: chunk k + 1's reads are in flight while chunk k's chain runs
+                    constexpr int NCHUNK = GP_GROWS / GAE_WALK;
+                    float d[2][GAE_WALK], cc[2][GAE_WALK];
+                    const int top = (g + 1) * GP_GROWS;
+#pragma unroll
+                    for (int i = 0; i < GAE_WALK; i++) { d[0][i] = sA[(top - 1 - i) * EPB + lane]; cc[0][i] = sC[(top - 1 - i) * EPB + lane]; }
+#pragma unroll
+                    for (int k = 0; k < NCHUNK; k++) {
+                        const int cur = k & 1, nxt = cur ^ 1, r = top - k * GAE_WALK;
+                        if (k + 1 < NCHUNK) {
+#pragma unroll
+                            for (int i = 0; i < GAE_WALK; i++) { d[nxt][i] = sA[(r - GAE_WALK - 1 - i) * EPB + lane]; cc[nxt][i] = sC[(r - GAE_WALK - 1 - i) * EPB + lane]; }
+                        }
+#pragma unroll
+                        for (int i = 0; i < GAE_WALK; i++) { last = d[cur][i] + cc[cur][i] * last; d[cur][i] = last; }
+#pragma unroll
+                        for (int i = 0; i < GAE_WALK; i++) sA[(r - 1 - i) * EPB + lane] = d[cur][i];
+                    }
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) f_done[g] = (uint32_t)(tile + 1);   // behind the writes of A in this wave's LDS queue
+            }
+        }
+        return;
+    }
+
+    // ========================================================= the movers =========================================================
+    // the thread's slots, latest rows first: the jj-th one is rows r0 + (256 / C4) (NG - 1 - jj)
+    const int r0 = tid / C4, c = (tid % C4) * 4;
+    auto row_of = [&](int jj) { return r0 + (GAE_THREADS / C4) * (NG - 1 - jj); };
+    for (int tile = 0; tile < n_tiles; tile++) {
+        const int t_lo = T - (tile + 1) * GAE_TC;
+        float4 rw[NG], vv[NG], nvv[NG];
+        uint4 dd[NG];
+        // every load of the tile before the first use, latest group first; the row above the last one (t + 1 == T) reads next_value / next_done: address
+        // selects, not branches (a load inside a branch makes the compiler wait for every outstanding load at the join)
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const int r = row_of(j), t = t_lo + r;
+            const size_t gidx = (size_t)t * N + n0 + c;
+            const bool lastrow = t + 1 >= T;
+            rw[j] = *reinterpret_cast<const float4*>(rewards + gidx);
+            vv[j] = *reinterpret_cast<const float4*>(values + gidx);
+            nvv[j] = *reinterpret_cast<const float4*>(lastrow ? next_value + n0 + c : values + gidx + N);
+            dd[j] = *reinterpret_cast<const uint4*>(lastrow ? reinterpret_cast<const void*>(next_done + n0 + c) : reinterpret_cast<const void*>(dones + gidx + N));
+        }
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const int r = row_of(j), g = r / GP_GROWS, t = t_lo + r;
+            const bool lastrow = t + 1 >= T;
+            // dones are 0 / 1 floats, next_done 0 / 1 integers: either way 1 - d is exact
+            const float d0 = lastrow ? (float)(int)dd[j].x : __builtin_bit_cast(float, dd[j].x), d1 = lastrow ? (float)(int)dd[j].y : __builtin_bit_cast(float, dd[j].y);
+            const float d2 = lastrow ? (float)(int)dd[j].z : __builtin_bit_cast(float, dd[j].z), d3 = lastrow ? (float)(int)dd[j].w : __builtin_bit_cast(float, dd[j].w);
+            const float4 nnt = make_float4(1.0f - d0, 1.0f - d1, 1.0f - d2, 1.0f - d3);
+            const float4 nv = nvv[j], v = vv[j];
+            float4 a4, c4;
+            if (MODE == 0) {
+                a4 = make_float4((rw[j].x + (gamma * nv.x) * nnt.x) - v.x, (rw[j].y + (gamma * nv.y) * nnt.y) - v.y,   // :300
+                                 (rw[j].z + (gamma * nv.z) * nnt.z) - v.z, (rw[j].w + (gamma * nv.w) * nnt.w) - v.w);
+                c4 = make_float4(gl * nnt.x, gl * nnt.y, gl * nnt.z, gl * nnt.w);                                     // :301
+            } else {
+                a4 = rw[j];
+                c4 = make_float4(gamma * nnt.x, gamma * nnt.y, gamma * nnt.z, gamma * nnt.w);                         // :324
+            }
+            if (tile > 0) gp_wait_ge(f_done + g, (uint32_t)tile);   // (own slot: this thread stored the previous tile's values of it already; the walker is done with the row)
+            *reinterpret_cast<float4*>(&sA[r * EPB + c]) = a4;
+            *reinterpret_cast<float4*>(&sC[r * EPB + c]) = c4;
+            *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
+            asm volatile("" ::: "memory");
+            if (lane == 0) atomicAdd(&s_ready[g], 1u);   // behind this wave's writes in its LDS queue
+        }
+        // ---- the groups come back walked, latest first: stream A_t and R_t out ----
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const int r = row_of(j), g = r / GP_GROWS;
+            gp_wait_ge(f_done + g, (uint32_t)(tile + 1));
+            const float4 a4 = *reinterpret_cast<const float4*>(&sA[r * EPB + c]);
+            const float4 v4 = vv[j];
+            float4 o_adv, o_ret;
+            if (MODE == 0) { o_adv = a4; o_ret = make_float4(a4.x + v4.x, a4.y + v4.y, a4.z + v4.z, a4.w + v4.w); }   // :305
+            else { o_ret = a4; o_adv = make_float4(a4.x - v4.x, a4.y - v4.y, a4.z - v4.z, a4.w - v4.w); }              // :327
+            const size_t gidx = (size_t)(t_lo + r) * N + n0 + c;
+            *reinterpret_cast<float4*>(adv + gidx) = o_adv;
+            *reinterpret_cast<float4*>(ret + gidx) = o_ret;
+        }
+    }
+}
+
 template <int MODE, bool FAST = false>
 hipError_t launch_scan(const float* rewards, const float* values, const float* dones, const float* next_value,
                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
@@ -292,6 +439,27 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     // Strip width, measured on MI355X (tools/gae_sweep.py): 32 columns (48 KB of LDS, three workgroups per CU overlapping their
     // load / walk / store phases) is best from 32 768 envs up (4.5 TB/s); below ~8 192 envs 16 columns give every CU a workgroup.
     const int epb = N >= 8192 ? 32 : 16;
+#ifndef GAE_NO_TIME_PIPELINE   /* -DGAE_NO_TIME_PIPELINE: the three-phase kernel at every size (A/B) */
+    // Whole tiles, whole strips, and a grid of about one workgroup per CU: the kernel pipelined in time (same bits).  Measured in trace, builds alternated in
+    // one call, two rounds (three-phase | 16 columns x 2 groups | 16 x 4 | 32 x 2 | 32 x 4, us): 4096 envs 4.86 - 5.12 | 4.37 - 4.71 | 4.27 - 4.57 | 4.65 - 4.97 |
+    // 5.2; 8192 envs 6.2 - 7.5 | 8.1 - 8.6 | 8.1 - 8.4 | 5.9 - 6.0 | 5.66 - 5.74; 16 384 envs 9.1 | 15.4 | 15.4 | 10.0 | 9.9; 32 768 envs 18.5 | 30 | 30 | 20.7 |
+    // 20.4 -- with two and more workgroups per CU the three-phase kernel's workgroups overlap their phases among themselves and the hand-overs only cost.
+#ifdef GP_FORCE   /* exploration builds: -DGP_FORCE=<epb * 10 + groups>, e.g. 164 */
+    const int gp_epb = GP_FORCE / 10, gp_groups = GP_FORCE % 10;
+#else
+    const int gp_epb = N < 8192 ? 16 : 32, gp_groups = 4;
+#endif
+    if (!FAST && vec_ok && T % GAE_TC == 0 && N % gp_epb == 0 && N / gp_epb <= (int64_t)GAE_PIPE_MAX_BLOCKS) {
+        const dim3 grid((unsigned)(N / gp_epb)), block(GP_THREADS);
+#define PPO_GP_LAUNCH(E, G) hipLaunchKernelGGL((gae_pipe_kernel<E, MODE, G>), grid, block, 0, s, rewards, values, dones, next_value, next_done, (int)T, (int)N, gamma, gae_lambda, adv, ret)
+        if (gp_epb == 32 && gp_groups == 4) PPO_GP_LAUNCH(32, 4);
+        else if (gp_epb == 32) PPO_GP_LAUNCH(32, 2);
+        else if (gp_groups == 4) PPO_GP_LAUNCH(16, 4);
+        else PPO_GP_LAUNCH(16, 2);
+#undef PPO_GP_LAUNCH
+        return hipGetLastError();
+    }
+#endif
 #define PPO_GAE_LAUNCH(EPB)                                                                                                   \
     do {                                                                                                                      \
         const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \

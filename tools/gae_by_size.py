@@ -13,9 +13,10 @@ T = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 groups = {}
 for r in csv.DictReader(open(trace)):
     name = r["Kernel_Name"]
-    if "gae_kernel" not in name:
+    tag = "gae_pipe_kernel" if "gae_pipe_kernel" in name else ("gae_kernel" if "gae_kernel" in name else None)   # the scan pipelined in time / its three-phase form
+    if tag is None:
         continue
-    short = name[name.index("gae_kernel"):].split("(")[0]
+    short = name[name.index(tag):].split("(")[0]
     epb = int(short.split("<")[1].split(",")[0])
     envs = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) * epb   # one workgroup per strip of epb env columns
     groups.setdefault((short, envs), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

@@ -18,9 +18,10 @@ for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f, newline="")):
             name = row["Kernel_Name"]
-            if "gae_kernel" not in name:
+            tag = "gae_pipe_kernel" if "gae_pipe_kernel" in name else ("gae_kernel" if "gae_kernel" in name else None)
+            if tag is None:
                 continue
-            short = name[name.index("gae_kernel"):].split("(")[0]
+            short = name[name.index(tag):].split("(")[0]
             epb = int(short.split("<")[1].split(",")[0])
             envs = int(row["Grid_Size"]) // int(row["Workgroup_Size"]) * epb
             s = acc.setdefault((short, envs), {}).setdefault(row["Counter_Name"], [0.0, 0])
