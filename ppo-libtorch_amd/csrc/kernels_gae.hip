@@ -293,6 +293,9 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
 // bounded anyway.  Arithmetic, association order and the -ffp-contract=off build are gae_kernel's: the results are the same bits (tests/test_gpu_parity.py).
 // ---------------------------------------------------------------------------------------------------------------------------------------
 constexpr int GP_THREADS = GAE_THREADS + 64;                 // four mover waves + the walker
+#ifndef GAE_PIPE_MIN_ENVS
+#define GAE_PIPE_MIN_ENVS 4096
+#endif
 #ifndef GAE_PIPE_MAX_BLOCKS
 #define GAE_PIPE_MAX_BLOCKS 256                               /* strips up to which the pipelined kernel is launched: one workgroup per CU (12 288 envs x 32 columns = 384: 9.0 - 9.3 us against 7.2) */
 #endif
@@ -447,9 +450,12 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
 #ifdef GP_FORCE   /* exploration builds: -DGP_FORCE=<epb * 10 + groups>, e.g. 164 */
     const int gp_epb = GP_FORCE / 10, gp_groups = GP_FORCE % 10;
 #else
-    const int gp_epb = N < 8192 ? 16 : 32, gp_groups = 4;
+    const int gp_epb = 32, gp_groups = 4;
 #endif
-    if (!FAST && vec_ok && T % GAE_TC == 0 && N % gp_epb == 0 && N / gp_epb <= (int64_t)GAE_PIPE_MAX_BLOCKS) {
+    // ... and only above 4096 envs: at 4096 (16-column strips) the pipelined kernel is ahead in a trace of the scan alone (4.3 - 4.8 us against 4.9 - 5.1) but
+    // not inside the training iteration (5.34 against 5.27 us in trace) and slower back to back (6.6 against 5.1 us: five waves per workgroup leave the next
+    // launch's workgroups less room to start under the tail of this one).  8192 envs = BASELINE configs[3]'s size: 5.7 us, 0.46 of 8 TB/s in trace.
+    if (!FAST && vec_ok && T % GAE_TC == 0 && N % gp_epb == 0 && N / gp_epb <= (int64_t)GAE_PIPE_MAX_BLOCKS && N > GAE_PIPE_MIN_ENVS) {
         const dim3 grid((unsigned)(N / gp_epb)), block(GP_THREADS);
 #define PPO_GP_LAUNCH(E, G) hipLaunchKernelGGL((gae_pipe_kernel<E, MODE, G>), grid, block, 0, s, rewards, values, dones, next_value, next_done, (int)T, (int)N, gamma, gae_lambda, adv, ret)
         if (gp_epb == 32 && gp_groups == 4) PPO_GP_LAUNCH(32, 4);

@@ -270,7 +270,14 @@ def test_bench_single_gpu_line_carries_the_rebased_roofline():
     assert abs(ro["achieved"] - ro["flops_per_launch"] / (ro["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * ro["achieved"]
     assert ro["frac"] < ro["frac_executed"] < 1.0 and 2.5 < ro["executed_flops_per_launch"] / ro["flops_per_launch"] < 3.6 and "limiter" in ro
     assert d["dtype"].startswith("f32 (")
-    assert len(d["train_stats"]["learning_curve_parity"]["scenarios"]) == 2
     bar = d["gae_roofline"]["bar"]
-    assert bar["target_frac"] == 0.40 and bar["frac_at_config1"] > 0.1 and bar["size_met_from_envs"] in (4096, 8192, 32768, None)
+    assert bar["target_frac"] == 0.40 and bar["frac_at_config1_back_to_back"] > 0.1 and bar["size_met_from_envs_back_to_back"] in (4096, 8192, 32768, None)
+    # what is measured outside the run (counters, the tracer, the curve comparison) is quoted only from a committed profile set whose source fingerprint is
+    # this tree's (bench.py: profile_tie); with the sources changed since, those fields are null and the line says why
+    tie = d["profiles"]
+    if tie["tied"]:
+        assert len(d["train_stats"]["learning_curve_parity"]["scenarios"]) >= 2 and ro["traffic"] > 0
+        assert bar["frac_at_config1"] > 0.1 and bar["size_met_from_envs"] in (4096, 8192, 32768, 131072, None) and bar["in_trace"]["source"].startswith("profiles/" + tie["tag"])
+    else:
+        assert "reason" in tie and d["train_stats"]["learning_curve_parity"] is None and ro["traffic"] is None and bar["frac_at_config1"] is None
     assert d["transport"] == "none" and d["comm_ranks"] == 1 and d["transport_ab"] is None
