@@ -1861,10 +1861,17 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
         // carries the three numbers to the device words and -- when they changed -- to the host mirror
         __syncthreads();
         uint32_t m[3] = { 0u, 0u, 0u };
-        for (int p = threadIdx.x; p < L.P; p += 256) {
-            const uint32_t bits = f2u(params[p]) & 0x7fffffffu;
-            const int cls = wr_class(L, p);
-            m[0] = cls == 0 && bits > m[0] ? bits : m[0]; m[1] = cls == 1 && bits > m[1] ? bits : m[1]; m[2] = cls == 2 && bits > m[2] ? bits : m[2];
+        // every load of the sweep in flight before the first use (a plain loop waited out one memory round trip per element: 36 of them, + 16 us on this kernel);
+        // the 2 x 64 layouts hold at most 2 (64 x 8 + 64 + 4096 + 64 + 32 x 64 + 32) = 13 632 parameters
+        constexpr int SW = 56;
+        uint32_t bits[SW];
+#pragma unroll
+        for (int i = 0; i < SW; i++) { const int p = threadIdx.x + 256 * i; bits[i] = f2u(params[p < L.P ? p : 0]) & 0x7fffffffu; }
+#pragma unroll
+        for (int i = 0; i < SW; i++) {
+            const int p = threadIdx.x + 256 * i;
+            const int cls = p < L.P ? wr_class(L, p) : 3;
+            m[0] = cls == 0 && bits[i] > m[0] ? bits[i] : m[0]; m[1] = cls == 1 && bits[i] > m[1] ? bits[i] : m[1]; m[2] = cls == 2 && bits[i] > m[2] ? bits[i] : m[2];
         }
         for (int i = 0; i < 3; i++) atomicMax(&wr_max[i], m[i]);
         __syncthreads();
