@@ -174,6 +174,7 @@ struct ppo_ctx {
     uint32_t* wr_dev = nullptr;
     uint32_t* wr_host = nullptr;       // hipHostMalloc'ed, mapped: wr_host_dev is the device's address of the same words
     uint32_t* wr_host_dev = nullptr;
+    hipStream_t wr_stream = nullptr;   // the once-per-update sweep runs here, beside the update's first launches (sweep_weight_range)
     bool wrange_dirty = true;
     float wr_cache[3] = { 0.0f, 0.0f, 0.0f };   // the mirror as last read: the pinned words are uncached for the host (~0.3 us a read), so they are read once per
     bool wr_in_update = false;                 // rollout / update / stand-alone step, not per launch (an update moves a weight by less than 40 lr: the thresholds' margin)
@@ -401,6 +402,7 @@ extern "C" void ppo_ctx_destroy(ppo_ctx* c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_gather) (void)hipEventDestroy(c->ev_gather);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->wr_stream) { (void)hipStreamSynchronize(c->wr_stream); (void)hipStreamDestroy(c->wr_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -510,6 +512,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->wr_dev, 8));   // [0..2] running maxima, [4..6] what the host mirror holds
     CK(hipHostMalloc(reinterpret_cast<void**>(&c->wr_host), 4 * sizeof(uint32_t), hipHostMallocMapped));
     CK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->wr_host_dev), c->wr_host, 0));
+    CK(hipStreamCreateWithFlags(&c->wr_stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) c->wr_host[i] = 0u;
     c->use_mfma = A <= 4;   // the matrix-core update kernel folds heads of up to 4 logits; wider policies (2 x 64 nets) run the vector kernel
     // ppo_config.kernel_flags (include/ppo_hip.h): the only switch between kernels; nothing is read from the environment
@@ -1010,6 +1013,15 @@ static ppo_status refresh_weight_range(ppo_ctx* c) {
     wr_snapshot(c);
     return PPO_OK;
 }
+// The maxima again, once per update (and after a stand-alone optimizer step): one tiny launch on a stream of its own with NO dependency on the update's
+// stream -- it reads whatever the parameters are when it runs (a 32-bit load each; AdamW may be writing them), which is the lag the thresholds' margin
+// already covers, and costs the update's stream nothing (as the tail of pack_records_kernel the same sweep cost 7 us per update; inside the AdamW
+// kernels, 40 times that).
+static ppo_status sweep_weight_range(ppo_ctx* c, hipStream_t s) {
+    if (c->gen || c->wrange_dirty) return PPO_OK;   // dirty: the next matrix-core launch recomputes and waits (refresh_weight_range)
+    HIPCHK(c, launch_weight_range(B_<float>(c, PPO_BUF_PARAMS), c->L, c->wr_dev, c->wr_host_dev, s));
+    return PPO_OK;
+}
 static inline bool weights_fit_rollout16(const ppo_ctx* c) { return c->wr_cache[PPO_WR_W3] < WR_LIMIT_W3; }
 static inline bool weights_fit_update_mfma(const ppo_ctx* c) {
     return c->wr_cache[PPO_WR_W3] < WR_LIMIT_REST && c->wr_cache[PPO_WR_W2] < WR_LIMIT_W2 && c->wr_cache[PPO_WR_REST] < WR_LIMIT_REST;
@@ -1305,7 +1317,7 @@ static ppo_status pack_records(ppo_ctx* c) {
     HIPCHK(c, launch_pack_records(c->L, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS),
                                   c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
                                   B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->rec_critic,
-                                  c->rec_actor, c->ev_sums, c->update_single_wave ? nullptr : c->error_flag, B_<float>(c, PPO_BUF_PARAMS), c->wr_dev, c->wr_host_dev, c->stream));
+                                  c->rec_actor, c->ev_sums, c->update_single_wave ? nullptr : c->error_flag, c->stream));
     return PPO_OK;
 }
 
@@ -1423,7 +1435,8 @@ extern "C" ppo_status ppo_optimizer_step(ppo_ctx* c) {
     DeviceGuard dev_guard(c);
     // stand-alone use: the slot's pinned coefficient must not be rewritten while a previous copy is in flight
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return optimizer_step_slot(c, c->steps_per_update, c->last_global_M, false);
+    const ppo_status s = optimizer_step_slot(c, c->steps_per_update, c->last_global_M, false);
+    return s != PPO_OK ? s : sweep_weight_range(c, c->stream);
 }
 
 extern "C" ppo_status ppo_set_learning_rate(ppo_ctx* c, double lr) {
@@ -1443,7 +1456,12 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
     // so that a sharded run can send its statistics along with the advantage sums
     s = pack_records(c);
     if (s != PPO_OK) return s;
-    if (!c->gen) { s = refresh_weight_range(c); if (s != PPO_OK) return s; wr_snapshot(c); }
+    if (!c->gen) {
+        s = refresh_weight_range(c);
+        if (s == PPO_OK) s = sweep_weight_range(c, c->wr_stream);
+        if (s != PPO_OK) return s;
+        wr_snapshot(c);
+    }
     struct InUpdate { ppo_ctx* c; explicit InUpdate(ppo_ctx* x) : c(x) { c->wr_in_update = true; } ~InUpdate() { c->wr_in_update = false; } } in_update(c);
     if (!c->use_mfma || c->gen)   // otherwise pack_records left the sums
         HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));

@@ -1832,11 +1832,8 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
                                                            const uint8_t* __restrict__ masks, int A, const float* __restrict__ logprobs,
                                                            const float* __restrict__ advantages, const float* __restrict__ returns,
                                                            const float* __restrict__ values, int64_t B, float4* __restrict__ rec_critic,
-                                                           float4* __restrict__ rec_actor, double* __restrict__ ev_out, int32_t* error_flag,
-                                                           const float* __restrict__ params, NetLayout L, uint32_t* wr_dev, uint32_t* wr_host) {
+                                                           float4* __restrict__ rec_actor, double* __restrict__ ev_out, int32_t* error_flag) {
     __shared__ double red[4][4];
-    __shared__ uint32_t wr_max[3];
-    if (threadIdx.x < 3) wr_max[threadIdx.x] = 0u;
     double sy = 0, sy2 = 0, sd = 0, sd2 = 0;
     float x_absmax = 0.0f;   // the wave-specialised update kernel cuts the observation into fp16 terms: its range is checked here, once per update, not assumed
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
@@ -1855,28 +1852,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
         const double y = R, d = (double)(R - V);
         sy += y; sy2 += y * y; sd += d; sd2 += d * d;
     }
-    if (!(x_absmax < 65504.0f) && error_flag) atomicOr(error_flag, PPO_ERRFLAG_UPDATE_RANGE);   // beyond fp16 (or NaN): the optimizer kernels skip their steps
-    if (wr_dev && blockIdx.x == gridDim.x - 1) {
-        // fp16-range maxima of the parameters (OptGuard), exact, once per update: this workgroup's threads sweep the 9 155 parameters, its first thread
-        // carries the three numbers to the device words and -- when they changed -- to the host mirror
-        __syncthreads();
-        uint32_t m[3] = { 0u, 0u, 0u };
-        // every load of the sweep in flight before the first use (a plain loop waited out one memory round trip per element: 36 of them, + 16 us on this kernel);
-        // the 2 x 64 layouts hold at most 2 (64 x 8 + 64 + 4096 + 64 + 32 x 64 + 32) = 13 632 parameters
-        constexpr int SW = 56;
-        uint32_t bits[SW];
-#pragma unroll
-        for (int i = 0; i < SW; i++) { const int p = threadIdx.x + 256 * i; bits[i] = f2u(params[p < L.P ? p : 0]) & 0x7fffffffu; }
-#pragma unroll
-        for (int i = 0; i < SW; i++) {
-            const int p = threadIdx.x + 256 * i;
-            const int cls = p < L.P ? wr_class(L, p) : 3;
-            m[0] = cls == 0 && bits[i] > m[0] ? bits[i] : m[0]; m[1] = cls == 1 && bits[i] > m[1] ? bits[i] : m[1]; m[2] = cls == 2 && bits[i] > m[2] ? bits[i] : m[2];
-        }
-        for (int i = 0; i < 3; i++) atomicMax(&wr_max[i], m[i]);
-        __syncthreads();
-        if (threadIdx.x == 0) { const uint32_t now[3] = { wr_max[0], wr_max[1], wr_max[2] }; wr_mirror(wr_dev, wr_host, now); }
-    }
+    if (!(x_absmax < 65504.0f) && error_flag) atomicOr(error_flag, PPO_ERRFLAG_UPDATE_RANGE);   // beyond fp16 (or NaN): reported by the next call that reads the flag (api.hip: PPO_ERRFLAG_UPDATE_RANGE)
     sy = wave_sum_d_dpp(sy); sy2 = wave_sum_d_dpp(sy2); sd = wave_sum_d_dpp(sd); sd2 = wave_sum_d_dpp(sd2);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = sy; red[w][1] = sy2; red[w][2] = sd; red[w][3] = sd2; }
@@ -2090,15 +2066,15 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
 // rec_critic / rec_actor: [B][8] floats each; ev_sums: [PPO_EV_BLOCKS][4] partial sums of the explained variance
 hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
                                const float* advantages, const float* returns, const float* values, int64_t B, float* rec_critic, float* rec_actor,
-                               double* ev_sums, int32_t* error_flag, const float* params, uint32_t* wr_dev, uint32_t* wr_host, hipStream_t s) {
+                               double* ev_sums, int32_t* error_flag, hipStream_t s) {
     if (L.act > 4 || L.n_heads > 4) return hipErrorNotSupported;
     const dim3 grid(PPO_EV_BLOCKS), block(256);
     if (L.obs == 4)
         hipLaunchKernelGGL((pack_records_kernel<4>), grid, block, 0, s, obs, actions, L.n_heads, masks, L.act, logprobs, advantages, returns, values, B,
-                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums, error_flag, params, L, wr_dev, wr_host);
+                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums, error_flag);
     else if (L.obs == 2)
         hipLaunchKernelGGL((pack_records_kernel<2>), grid, block, 0, s, obs, actions, L.n_heads, masks, L.act, logprobs, advantages, returns, values, B,
-                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums, error_flag, params, L, wr_dev, wr_host);
+                           reinterpret_cast<float4*>(rec_critic), reinterpret_cast<float4*>(rec_actor), ev_sums, error_flag);
     else
         return hipErrorNotSupported;
     return hipGetLastError();

@@ -586,16 +586,17 @@ void update_blocks_mfma(int M, int n_blocks[2]);
 hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s);
 hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
                                const float* advantages, const float* returns, const float* values, int64_t B, float* rec_critic, float* rec_actor,
-                               double* ev_sums, int32_t* error_flag, const float* params, uint32_t* wr_dev, uint32_t* wr_host, hipStream_t s);
+                               double* ev_sums, int32_t* error_flag, hipStream_t s);
 // fp16 ranges of the matrix-core kernels of the 2 x 64 layout:
 //   wr_dev[0..2] = the maxima of |parameter| by class -- [PPO_WR_W3] both nets' output layers (rollout16_kernel carries 2^8 W3 as fp16: |W3| < 255),
 //   [PPO_WR_W2] both nets' hidden-to-hidden weights (the matrix-core update kernels carry c W2 and products through its columns as fp16 terms),
-//   [PPO_WR_REST] everything else (c W1, c b1, ... < 65 504) -- as float bit patterns, recomputed from the parameters ONCE PER UPDATE by the last workgroup of
-//   pack_records_kernel (a kernel that is nobody's critical path; kept inside the AdamW kernel or the update kernel's prologue the same few instructions cost
-//   0.4 - 0.7 us per optimizer step, 1.5 % of the iteration) and after every host write of the parameters (launch_weight_range); wr_dev[4..6] = what the pinned
-//   host mirror holds, so that the mirror is written only when a maximum changed.  The HOST reads the mirror without synchronising, an update or two late --
+//   [PPO_WR_REST] everything else (c W1, c b1, ... < 65 504) -- as float bit patterns, recomputed from the parameters ONCE PER UPDATE by weight_range_kernel on a
+//   stream of its own (api.hip: sweep_weight_range; no dependency on the update's stream, so it costs that stream nothing -- inside the AdamW kernel or the update
+//   kernel's prologue the same few instructions cost 0.4 - 0.7 us per optimizer step, 1.5 % of the iteration, and as an extra workgroup of pack_records_kernel
+//   7 us per update: the sweep's memory round trips and the write to the host were that kernel's tail) and, synchronously, after every host write of the parameters
+//   (refresh_weight_range); wr_dev[4..6] mirrors what the pinned host words hold.  The HOST reads the mirror without synchronising, an update or two late --
 //   AdamW moves a weight by about lr per step, hence thresholds at half the kernels' limits -- and takes the vector kernels for a launch whose weights do
-//   not fit fp16 instead of failing (api.hip: refresh_weight_range).
+//   not fit fp16 instead of failing.
 // The optimizer kernels themselves carry no guard: a load of the error word cost the latency-bound AdamW kernel 0.4 us per step, and skipping a step whose
 // gradient norm is not finite would break parity (the reference applies it: a 1-row minibatch gives NaN parameters there too, tests/test_gpu_parity.py).
 // After PPO_ERRFLAG_UPDATE_PROTOCOL / _RANGE the parameters are undefined; the error is sticky and ppo_read_stats reports it (the facade checks before saving).
@@ -606,16 +607,6 @@ __device__ __forceinline__ int wr_class(const NetLayout& L, int p) {
     const bool w3 = (p >= L.w3[0] && p < L.b3[0]) || (p >= L.w3[1] && p < L.b3[1]);
     const bool w2 = (p >= L.w2[0] && p < L.b2[0]) || (p >= L.w2[1] && p < L.b2[1]);
     return w3 ? 0 : (w2 ? 1 : 2);
-}
-__device__ __forceinline__ void wr_mirror(uint32_t* wr_dev, uint32_t* wr_host, const uint32_t now[3]) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        wr_dev[i] = now[i];
-        if (now[i] != wr_dev[4 + i]) {
-            wr_dev[4 + i] = now[i];
-            __hip_atomic_store(wr_host + i, now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
 }
 constexpr int PPO_WR_W3 = 0, PPO_WR_W2 = 1, PPO_WR_REST = 2;
 // grads[p] = sum over blocks (fixed order); loss sums -> sums_out[8]
