@@ -100,6 +100,9 @@ def newest_profile(suffix):
     return f if os.path.exists(f) else None
 
 
+GAE_EXACT_4096 = "gae_kernel<16, 0, true, false>"   # the exact scan configs[1] launches (kernels_gae.hip: launch_scan; the last flag is ppo_gae_fast)
+
+
 def pmc_traffic(prefix):
     """HBM-side bytes per launch of the kernel whose name starts with `prefix`, from the newest committed rocprofv3 --pmc summary
     (profiles/*_pmc_per_dispatch.json, written by tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in separate passes, corrected
@@ -701,7 +704,7 @@ def main():
         gae_bytes = 20 * N * T + 8 * N
         generic = args.workload == "config4"
         fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma"
-        fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, (pmc_traffic("gae_pipe_kernel") or pmc_traffic("gae_kernel")) if args.workload == "cartpole" else None
+        fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, pmc_traffic(GAE_EXACT_4096) if args.workload == "cartpole" else None
         if generic:
             roof = {"kernel": "one minibatch step of the generic path (gather; per net ONE fused forward launch (generic_forward_kernel) and one fused backward launch "
                               "per layer (bwd_layer_kernel: weight gradient + the gradient handed down from one LDS-DMA'd tile); heads + PPO loss; slab sums): bf16 "
@@ -752,7 +755,7 @@ def main():
             "profiles": profile_tie(),
             # primary numbers: the launch by itself (200 in a row on this workload's own buffers, live, after the timed region) -- the duration
             # the rocprofv3 kernel trace agrees with; the in-iteration HIP-event reading (an event pair adds ~3 us to a ~5 us launch) is kept beside it
-            "gae_roofline": {"kernel": "gae_pipe_kernel (exact mode, pipelined in time; gae_kernel from 16 384 envs)", "bound": "hbm", "achieved": gae_own["achieved"], "peak": HBM_PEAK_GBS,
+            "gae_roofline": {"kernel": "gae_kernel (exact mode; 4096 < envs <= 8192 take gae_pipe_kernel, the same scan pipelined in time)", "bound": "hbm", "achieved": gae_own["achieved"], "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_own["frac"],
                              "traffic": (gae_tr or {}).get("bytes"), "traffic_detail": gae_tr, "bytes_per_launch": gae_bytes,
                              "avg_launch_ms": gae_own["avg_launch_ms"], "launches": 200,
@@ -778,7 +781,7 @@ def main():
                                      "frac_at_config1_back_to_back": next((r["frac"] for r in gae_rows if r["envs"] == 4096), None),
                                      "budget_us_at_config1": (20 * 4096 * T + 8 * 4096) / (0.40 * HBM_PEAK_GBS * 1e9) * 1e6,
                                      "floor_us": gae_floor_us()},
-                             "rocprof": (rocprof_kernel_us("gae_pipe_kernel<16") or rocprof_kernel_us("gae_kernel<16")) if args.workload == "cartpole" else None,
+                             "rocprof": rocprof_kernel_us(GAE_EXACT_4096) if args.workload == "cartpole" else None,
                              "floor_probe": committed_jsonl("_gae_floor.jsonl")},
             # HIP-event time per iteration of the phases that were bracketed (--profile 1 brackets all of them); null = not sampled in this run
             "phase_ms_per_step": dict({k: (prof[v + "_ms"] / args.steps if prof[v + "_launches"] > 0 else None) for k, v in phases.items()},
