@@ -177,6 +177,8 @@ struct ppo_ctx {
     hipStream_t wr_stream = nullptr;   // the once-per-update sweep runs here, beside the update's first launches (sweep_weight_range)
     bool wrange_dirty = true;
     float wr_cache[3] = { 0.0f, 0.0f, 0.0f };   // the mirror as last read: the pinned words are uncached for the host (~0.3 us a read), so they are read once per
+    bool gen_opt_fused_ok = false;             // generic bf16 path: the last backward pass left the sums of squares gen_opt_fused needs, and nothing touched the gradient since
+    bool gen_obs_bf_valid = false;             // generic bf16 path: GenericCtx::obs_bf holds THIS update's observations (set by the update's first step)
     bool wr_in_update = false;                 // rollout / update / stand-alone step, not per launch (an update moves a weight by less than 40 lr: the thresholds' margin)
     int64_t vector_fallback_launches = 0;   // launches that took a vector kernel because a weight did not fit fp16
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
@@ -565,6 +567,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             g.ld_h = (GL.hidden + 127) / 128 * 128;
             const size_t RB = R + 128;
             CK(dalloc(c, &g.xin_bf, RB * g.ld_in0));
+            CK(dalloc(c, &g.obs_bf, ((size_t)B + 128) * g.ld_in0));   // the rollout's observations as bf16, once per update (gen_fwd_bwd): 201 MB at 2048 x 128 x 384
             for (int net = 0; net < 2; net++)
                 for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts_bf[net][l], RB * g.ld_h));
             for (int i = 0; i < 2; i++) {
@@ -577,6 +580,13 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             CK(dalloc(c, &g.cs_part[0], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.cs_part[1], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.head_db_part, (size_t)GEN_LOSS_BLOCKS * (GL.act + 1)));
+            {   // one pair of doubles per slab-sum workgroup (64 gradient elements) of the largest layer, per layer and net
+                int64_t most = 0;
+                for (int net = 0; net < 2; net++)
+                    for (int l = 0; l < GL.n_layers; l++) most = std::max<int64_t>(most, (int64_t)GL.out_dim[net][l] * GL.in_dim[l] + GL.out_dim[net][l]);
+                g.sq_cap = (int)((most + 63) / 64);
+                CK(dalloc(c, &g.sq_part, (size_t)2 * GL.n_layers * g.sq_cap * 2));
+            }
         } else {
             for (int net = 0; net < 2; net++)
                 for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts[net][l], R * GL.hidden));
@@ -682,7 +692,7 @@ extern "C" ppo_status ppo_memcpy_h2d(ppo_ctx* c, void* dst_dev, const void* src_
     DeviceGuard dev_guard(c);
     HIPCHK(c, hipMemcpyAsync(dst_dev, src_h, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->gen) c->gen->planes_dirty = true;   // the copy may have landed in the parameters: re-split the weights before their next use
+    if (c->gen) { c->gen->planes_dirty = true; c->gen_opt_fused_ok = false; }   // the copy may have landed in the parameters (re-split the weights before their next use) or in the gradient
     c->wrange_dirty = true;                    // ... and their fp16-range maxima are recomputed before the next matrix-core launch
     return PPO_OK;
 }
@@ -1217,37 +1227,80 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
     float* grads = B_<float>(c, PPO_BUF_GRADS);
     {
         ProfScope ps(c, PROF_FWD_BWD);
-#ifdef GEN_AB_ONE_STREAM   // A/B build (tools/build_variant.sh): every kernel alone on the chip, for per-kernel durations
-        const bool two = false;
+        // Both fused passes available (bf16 storage, widths the kernels are built for): the two nets share every launch -- forward, each layer's backward, the
+        // slab sums -- on ONE stream: the second net's workgroups take the CUs the first net's leave (forward) or run beside them on the other half of the
+        // chip (backward), with no fork / join events between the streams (four per step, several us each).  Otherwise: the critic's passes on a second stream.
+#ifdef GEN_AB_TWO_STREAMS   // A/B build (tools/build_variant.sh): one net per launch, two streams (round 5's first form)
+        const bool paired = false;
 #else
-        const bool two = g.bf16 && c->stream2 != nullptr;   // the critic's passes on their own stream: a kernel of one net fills the CUs the other net's kernel is draining
+        const bool paired = g.bf16 && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
 #endif
+#ifdef GEN_AB_TWO_STREAM_BWD   // A/B build: forward paired, the backward passes one net per launch on two streams
+        const bool paired_bwd = false;
+#else
+        const bool paired_bwd = paired;
+#endif
+        const bool two = !paired && g.bf16 && c->stream2 != nullptr;   // a kernel of one net fills the CUs the other net's kernel is draining
+        const bool two_bwd = !paired_bwd && g.bf16 && c->stream2 != nullptr;
         auto gather = [&](const int32_t* rows, int64_t n, hipStream_t st) {
             return gen_gather(GL, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS),
                               B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), rows, n, g, st);
         };
-        if (two && c->gen_pre_idx == idx && c->gen_pre_M == M) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather, 0));   // gathered ahead by the step before
-        else HIPCHK(c, gather(idx, M, c->stream));
+        // the fused kernels read the minibatch's rows in place (generic.hpp: GenericCtx::obs_bf, rows_idx); the observations are rounded once per update --
+        // a stand-alone step (whose caller may have rewritten the buffers) rounds them every time
+#ifdef GEN_AB_GATHER   // A/B build (tools/build_variant.sh): the gathered copies of rounds 1-5
+        const bool in_place = false;
+#else
+        const bool in_place = g.bf16 && g.obs_bf && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
+#endif
+        g.rows_idx = nullptr;
+        if (in_place) {
+            if (!c->gen_obs_bf_valid) {
+                HIPCHK(c, launch_to_bf16_pad(B_<float>(c, PPO_BUF_OBS), c->B, GL.obs, g.obs_bf, g.ld_in0, c->stream));
+                c->gen_obs_bf_valid = c->wr_in_update;
+            }
+            g.rows_idx = idx;
+            g.rows_src = GenRowSrc{ B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS), B_<float>(c, PPO_BUF_ADVANTAGES),
+                                    B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES) };
+        } else if (two && c->gen_pre_idx == idx && c->gen_pre_M == M) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather, 0));   // gathered ahead by the step before
+        } else {
+            HIPCHK(c, gather(idx, M, c->stream));
+        }
         c->gen_pre_idx = nullptr;
         auto fork = [&]() -> hipError_t { const hipError_t e = hipEventRecord(c->ev_fork, c->stream); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream2, c->ev_fork, 0); };
         auto join = [&]() -> hipError_t { const hipError_t e = hipEventRecord(c->ev_join, c->stream2); return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->ev_join, 0); };
         hipStream_t s0 = two ? c->stream2 : c->stream;
         if (two && g.planes_dirty) { HIPCHK(c, gen_weight_planes(g, params, c->stream)); g.planes_dirty = false; }   // shared by both nets: before the fork
         if (two) HIPCHK(c, fork());
-        if (gen_fused_forward_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage: each net's forward pass is one launch that also leaves its hidden activations
-            HIPCHK(c, gen_fused_forward(g, params, 1, nullptr, g.xin_bf, g.ld_in0, M, true, g.logits, c->stream));
-            HIPCHK(c, gen_fused_forward(g, params, 0, nullptr, g.xin_bf, g.ld_in0, M, true, g.val, s0));
+        const uint16_t* x0 = in_place ? g.obs_bf : g.xin_bf;
+        if (paired) {
+            HIPCHK(c, gen_fused_forward_both(g, params, x0, g.ld_in0, M, g.logits, g.val, c->stream, g.rows_idx));
+        } else if (gen_fused_forward_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage: each net's forward pass is one launch that also leaves its hidden activations
+            HIPCHK(c, gen_fused_forward(g, params, 1, nullptr, x0, g.ld_in0, M, true, g.logits, c->stream, g.rows_idx));
+            HIPCHK(c, gen_fused_forward(g, params, 0, nullptr, x0, g.ld_in0, M, true, g.val, s0, g.rows_idx));
         } else {
             HIPCHK(c, gen_forward(g, params, 1, g.xin, M, g.acts[1], nullptr, nullptr, g.logits, c->stream));
             HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, s0));
         }
         if (two) HIPCHK(c, join());   // the loss reads the logits and the values
         HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
-        if (two) HIPCHK(c, fork());
-        HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream, two));
-        HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, s0, two));
-        if (two) HIPCHK(c, join());   // the flat gradient is complete
-        if (two && c->gen_next_idx) {
+        // backward: paired too (A/B in one call, configs[4] share: 0.621 ms per optimizer step paired, 0.644 with the backward passes on two streams, 0.683 for
+        // round 5's first form -- two streams throughout, gathered copies, four optimizer launches)
+        if (two_bwd) HIPCHK(c, fork());
+        c->gen_opt_fused_ok = false;
+        if (paired_bwd) {
+            HIPCHK(c, gen_backward_both(g, params, M, grads, c->stream));
+        } else {
+            hipStream_t sb = two_bwd ? c->stream2 : c->stream;
+            HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream, two_bwd));
+            HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, sb, two_bwd));
+        }
+#ifndef GEN_AB_NO_FUSED_OPT   // A/B build (tools/build_variant.sh): loss sums, norm, AdamW and weight planes as four launches
+        c->gen_opt_fused_ok = g.sq_valid[0] && g.sq_valid[1] && c->world == 1 && !c->force_collectives;   // nothing changes the gradient between the slab sums and the optimizer
+#endif
+        if (two_bwd) HIPCHK(c, join());   // the flat gradient is complete
+        if (two && c->gen_next_idx && !in_place) {
             // nothing reads this step's gathered rows any more: the next step's gather (42 us of HBM streaming) runs on the second stream beside the
             // loss sums, the all-reduce, the norm, AdamW and the weight planes -- small kernels, one after the other, that leave the chip idle.
             // (Requested at the START of the step instead, into a second set of buffers, it does not overlap at all: its 16 k small workgroups take
@@ -1259,7 +1312,7 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
             c->gen_pre_idx = c->gen_next_idx; c->gen_pre_M = c->gen_next_M;
         }
     }
-    {
+    if (!c->gen_opt_fused_ok) {   // (the fused optimizer launch adds the loss kernel's block sums itself)
         ProfScope ps(c, PROF_REDUCE);
         HIPCHK(c, gen_loss_sums(g, c->loss_sums, grads + GL.P, c->stream));
     }
@@ -1373,6 +1426,11 @@ static ppo_status fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slot, b
 
 // clip + AdamW (or, with do_step false, just the loss scalars and the gradient norm) on whichever parameter layout the context has
 static hipError_t clip_adamw_any(ppo_ctx* c, int slot, double global_M, int world, bool do_step, double* clipfrac_accum) {
+    if (c->gen && c->gen_opt_fused_ok) {
+        if (do_step) c->gen_opt_fused_ok = false;   // its partial sums belong to the gradient the step consumes
+        return gen_opt_fused(*c->gen, B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
+                             c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, do_step, c->step_stats + slot, clipfrac_accum, c->stream);
+    }
     if (c->gen) {
         if (do_step) c->gen->planes_dirty = true;
         return gen_clip_adamw(B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
@@ -1462,7 +1520,11 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         if (s != PPO_OK) return s;
         wr_snapshot(c);
     }
-    struct InUpdate { ppo_ctx* c; explicit InUpdate(ppo_ctx* x) : c(x) { c->wr_in_update = true; } ~InUpdate() { c->wr_in_update = false; } } in_update(c);
+    struct InUpdate {
+        ppo_ctx* c;
+        explicit InUpdate(ppo_ctx* x) : c(x) { c->wr_in_update = true; c->gen_obs_bf_valid = false; }
+        ~InUpdate() { c->wr_in_update = false; c->gen_obs_bf_valid = false; }
+    } in_update(c);
     if (!c->use_mfma || c->gen)   // otherwise pack_records left the sums
         HIPCHK(c, launch_explained_variance(B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->ev_sums, c->stream));
     // sharded: this rank's slot of the job-global statistics block (explained-variance sums, its ring of finished episodes with their positions in

@@ -48,6 +48,9 @@ inline GenLayout make_gen_layout(int obs, int hidden, int n_hidden, int n_heads,
     return L;
 }
 
+// the rollout buffers a step's index list points into (PPO_Discrete.cpp:557-562 flattened, :576-582 indexed)
+struct GenRowSrc { const int32_t* actions; const uint8_t* masks; const float* logprobs; const float* adv; const float* ret; const float* values; };
+
 // Device workspace and library handle of one generic context (owned by ppo_ctx; see api.hip).
 struct GenericCtx {
     GenLayout L{};
@@ -82,6 +85,12 @@ struct GenericCtx {
     bool bf16 = false;
     int ld_in0 = 0, ld_h = 0;      // pitches of the network input (pad128(obs)) and of a hidden vector (pad128(hidden))
     uint16_t* xin_bf = nullptr;    // [.][ld_in0] layer-0 input: the gathered (or converted) observations
+    // A minibatch step of the fused kernels reads its rows IN PLACE: the rollout's observations are rounded to bf16 once per update (obs_bf, [T N + 128][ld_in0],
+    // zero padded) and the layer-0 loads of both passes, and the loss kernel's per-row scalars, go through the step's index list (rows_idx) -- no gathered copy
+    // is written and read back (207 MB of the 1.77 GB a 65 536-row step moved, and the 50 us kernel that made it).  rows_idx == nullptr: the dense g.xin_bf / row_*.
+    uint16_t* obs_bf = nullptr;
+    mutable const int32_t* rows_idx = nullptr;
+    mutable GenRowSrc rows_src{};
     uint16_t* acts_bf[2][GEN_MAX_LAYERS] = {};   // [net][l] [.][ld_h] kept activations of a minibatch step
     uint16_t* tmp_bf[2] = {};      // [.][ld_h] ping-pong activations of a forward pass that keeps nothing (rollout step, critic batch)
     uint16_t* dz_bf[2][2] = {};    // [net][.] [.][ld_h] ping-pong d(pre-activation); one pair per net: the two backward passes run on two streams
@@ -89,6 +98,9 @@ struct GenericCtx {
     float* cs_part[2] = {};        // [net] [layer][rows_max / 128 + 1][ld_h] per-m-tile column sums of a d(pre-activation) (the next bias gradient); one block per layer,
                                    // so that a net's slab sums can run as ONE launch behind its backward pass
     int64_t cs_layer_stride = 0;   // floats between two layers' blocks
+    double* sq_part = nullptr;     // [2 n_layers][sq_cap][2] sums of squares of the gradient per slab-sum workgroup (weights, bias): fused backward -> gen_opt_fused
+    int sq_cap = 0;                // slab-sum workgroups of the largest layer
+    mutable bool sq_valid[2] = {}; // [net]: the net's last backward pass left its part of sq_part
     float* head_db_part = nullptr; // [GEN_LOSS_BLOCKS][act + 1] block sums of d(loss)/d(logits) | d(value) (the head layers' bias gradients)
     int64_t* act64 = nullptr;      // [N, n_heads] actions of the current rollout step (int64, the stand-alone API's type)
     float* step_lp = nullptr;      // [N] log-prob / entropy of the current rollout step
@@ -122,8 +134,12 @@ hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* d
 constexpr int64_t GEN_FUSED_MAX_ROWS = 1 << 20;
 bool gen_fused_ok(const GenericCtx& g);
 bool gen_fused_forward_ok(const GenericCtx& g);
+// idx (bf16 input only, may be null): row r of the pass is row idx[r] of x_bf
 hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
-                             float* out, hipStream_t s);
+                             float* out, hipStream_t s, const int32_t* idx = nullptr);
+// both nets' passes over the same rows (activations kept) in one launch
+hipError_t gen_fused_forward_both(const GenericCtx& g, const float* params, const uint16_t* x_bf, int64_t ld_x, int64_t rows, float* logits, float* val,
+                                  hipStream_t s, const int32_t* idx = nullptr);
 hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,
                              int64_t step_base, int32_t* ep_len, float* ep_rew, float* obs, uint8_t* masks, int32_t* actions, float* logprobs, float* rewards,
                              float* dones, int32_t* fin_len, float* fin_rew, float* next_obs, int32_t* next_done, uint8_t* cur_mask, const int64_t* forced,
@@ -133,9 +149,14 @@ hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_
 bool gen_fused_backward_ok(const GenericCtx& g);
 int gen_bwd_col_blocks(int ld_in, bool has_below);
 int gen_bwd_ranges(int64_t rows, int col_blocks, bool half_chip, int* tiles_per_range);
-hipError_t gen_fused_backward_layer(int n_pad, const uint16_t* d, int64_t ldd, const uint16_t* h, int64_t ldh, const uint16_t* w, int64_t ldw, uint16_t* dz_out,
-                                    int64_t ld_out, float* slab, int64_t slab_stride, float* colsum, int64_t ld_cs, const uint16_t* zeros, int64_t rows, int n_real,
-                                    int k_real, int col_blocks, int S, int tiles_per_range, hipStream_t s);
+// one net's operands of a layer's launch: d = dZ_l [., ldd], h = the layer's input [., ldh] (idx != nullptr, layer 0 only: row r is row idx[r] of h), w = the
+// layer's bf16 weight plane (null: layer 0, nothing below), dz_out = dZ_{l-1}, slab = S partial weight gradients [n_real][k_real], colsum = per-range column sums
+struct GenBwdLayer {
+    const uint16_t* d; int64_t ldd; const uint16_t* h; int64_t ldh; const int32_t* idx; const uint16_t* w; int64_t ldw; uint16_t* dz_out; int64_t ld_out;
+    float* slab; int64_t slab_stride; float* colsum; int64_t ld_cs; int n_real, k_real, S, tiles_per_range;
+};
+// `other` != nullptr: the same layer of the other net in the same launch
+hipError_t gen_fused_backward_layer(int n_pad, const GenBwdLayer& one, const GenBwdLayer* other, int64_t rows, int col_blocks, const uint16_t* zeros, hipStream_t s);
 
 // kernels_generic.hip
 struct ppo_ctx;
@@ -152,6 +173,11 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
 // beside_other_net: the other net's backward pass runs at the same time on another stream (the fused launches then size themselves for half the chip)
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
                         hipStream_t s, bool beside_other_net = false);
+// both nets' fused backward passes in the same launches on one stream (needs gen_fused_backward_ok)
+hipError_t gen_backward_both(const GenericCtx& g, const float* params, int64_t rows, float* grads, hipStream_t s);
+// the optimizer step behind gen_backward_both on a single rank, one launch: loss sums, gradient norm (from the slab sums' partials), clip + AdamW, bf16 weight planes
+hipError_t gen_opt_fused(const GenericCtx& g, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
+                         double* sums_out, double global_M, LossParams hp, bool do_step, StepStats* stats_out, double* clipfrac_accum, hipStream_t s);
 hipError_t gen_loss_sums(const GenericCtx& g, double* sums_out, float* grads_tail, hipStream_t s);
 hipError_t gen_fill(float* p, int64_t n, float v, hipStream_t s);
 hipError_t gen_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const GenLayout& L, float max_grad_norm, const AdamCoef* coef,

@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
                                                        const int32_t* __restrict__ row_act, const uint8_t* __restrict__ row_mask,
                                                        const float* __restrict__ oldlp, const float* __restrict__ advs, const float* __restrict__ rets,
                                                        const float* __restrict__ oldv, int64_t M, float invM, const AdvStat* __restrict__ adv_stat,
-                                                       double global_M, double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf, float* head_db_part) {
+                                                       double global_M, double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf, float* head_db_part,
+                                                       const int32_t* __restrict__ idx) {
+    // idx != nullptr: row_act / row_mask / oldlp / advs / rets / oldv are the rollout's own arrays and row r of the minibatch is their row idx[r] (no gathered copies)
     __shared__ double red[5][4];
     __shared__ float sdb[4][AM + 1];
     float dbs[AM + 1];
@@ -230,12 +232,13 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
     const int act = L.act, n_heads = L.n_heads;
     const bool masked = DIST == PPO_DIST_MASKED && row_mask != nullptr;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < M; r += (int64_t)gridDim.x * 256) {
+        const int64_t q = idx ? (int64_t)idx[r] : r;   // the row of the per-sample arrays
         float z[AM], p[AM];
         bool ok[AM];
 #pragma unroll
         for (int k = 0; k < AM; k++) {
             z[k] = k < act ? logits[r * act + k] : 0.0f;
-            ok[k] = !masked || (k < act && row_mask[r * act + k] != 0);
+            ok[k] = !masked || (k < act && row_mask[q * act + k] != 0);
             if (masked && !ok[k]) z[k] = -1e8f;
             p[k] = 0.0f;
         }
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
                 for (int k = 0; k < AM; k++) if (k >= off && k < off + A) { p[k] = fast_exp(z[k] - mx); se += p[k]; }
                 const float lse = fast_log(se) + mx;
                 const float rse = __builtin_amdgcn_rcpf(se);
-                const int a = row_act[r * n_heads + h];
+                const int a = row_act[q * n_heads + h];
                 float e = 0.0f, lp = 0.0f;
 #pragma unroll
                 for (int k = 0; k < AM; k++) if (k >= off && k < off + A) {
@@ -274,9 +277,9 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
                 off += A;
             }
         }
-        const float logratio = nlp - oldlp[r];
+        const float logratio = nlp - oldlp[q];
         const float ratio = fast_exp(logratio);
-        float adv = advs[r];
+        float adv = advs[q];
         if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
         const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
         const float l1 = -adv * ratio, l2 = -adv * rc;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
         for (int h = 0; h < NH; h++) {
             if (h < n_heads) {
                 const int A = L.head_dims[h];
-                const int a = row_act[r * n_heads + h];
+                const int a = row_act[q * n_heads + h];
 #pragma unroll
                 for (int k = 0; k < AM; k++) if (k >= off && k < off + A) {
                     float d = g_nlp * ((k - off == a ? 1.0f : 0.0f) - p[k]);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
         s[2] += (double)((ratio - 1.0f) - logratio);
         s[3] += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
         // value loss (:603-625)
-        const float v = val[r], R = rets[r], vold = oldv[r];
+        const float v = val[r], R = rets[q], vold = oldv[q];
         const float un = (v - R) * (v - R);
         float g_v, lossv;
         if (hp.clip_vloss) {
@@ -548,7 +551,10 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 
 // The same sums for every layer of a net in ONE launch (bf16 storage: each layer has its own slab block): blockIdx.y = layer.
 struct SlabJob { const float* slab; const float* db_part; float* gw; float* gb; int64_t n_w, n_b, db_stride; int S, db_chunks; };
-struct SlabJobs { SlabJob j[GEN_MAX_LAYERS]; int64_t slab_stride; };
+struct SlabJobs { SlabJob j[2 * GEN_MAX_LAYERS]; int64_t slab_stride; double* sq_part; int sq_stride, sq_job0; };   // blockIdx.y = job: a net's layers, or both nets'
+// sq_part != nullptr: the workgroup also leaves the sums of squares of its 64 gradient elements, weights and bias apart, as
+// sq_part[((sq_job0 + job) * sq_stride + blockIdx.x) * 2 + {0, 1}] (job slots in the parameter order: net * n_layers + layer) -- the gradient norm then needs no
+// pass of its own over the gradient (gen_opt_fused_kernel)
 __global__ __launch_bounds__(256) void slab_sum_layers_kernel(SlabJobs jobs) {
     __shared__ float red[4][64];
     const SlabJob& J = jobs.j[blockIdx.y];
@@ -574,9 +580,148 @@ __global__ __launch_bounds__(256) void slab_sum_layers_kernel(SlabJobs jobs) {
     }
     red[q][e] = acc;
     __syncthreads();
-    if (q == 0 && i < J.n_w + J.n_b) {
-        const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-        if (i < J.n_w) J.gw[i] = t; else J.gb[i - J.n_w] = t;
+    if (q == 0) {
+        float t = 0.0f;
+        if (i < J.n_w + J.n_b) {
+            t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+            if (i < J.n_w) J.gw[i] = t; else J.gb[i - J.n_w] = t;
+        }
+        if (jobs.sq_part) {
+            const double t2 = (double)t * (double)t;
+            const double sw = wave_sum_d_dpp(i < J.n_w ? t2 : 0.0), sb = wave_sum_d_dpp(i < J.n_w ? 0.0 : t2);
+            if (e == 0) {
+                double* o = jobs.sq_part + ((size_t)(jobs.sq_job0 + blockIdx.y) * jobs.sq_stride + blockIdx.x) * 2;
+                o[0] = sw; o[1] = sb;
+            }
+        }
+    }
+}
+
+// Gradient norm + clip + AdamW + the bf16 weight planes + the step's loss scalars in ONE launch behind the slab sums (single rank, both nets' fused backward):
+//   norm   every workgroup adds the slab-sum workgroups' sums of squares per tensor (wave w takes jobs w, w + 4, ...: lanes stride the job's workgroups, one DPP
+//          reduction per tensor) -- 149 KB out of L2 per workgroup at configs[4], instead of a kernel of its own over the gradient;
+//   step   the arithmetic of gen_adamw_kernel, one batch of loads per thread (grid-stride, OPT_EPT elements in flight);
+//   planes a weight's new value goes straight to its place in the bf16 plane and the fragment-order copy (weight_planes_kernel's layout; the padding is
+//          zero from the allocation and never written), so the next forward pass needs no re-split launch;
+//   stats  workgroup 0 also adds the loss kernel's block sums (loss_sums_kernel) and writes the step's scalars.
+constexpr int OPT_EPT = 10;
+struct GenOptArgs {
+    float* params; const float* grads; float* exp_avg; float* exp_avg_sq; GenLayout L; float max_norm;
+    const double* sq_part; int xb;
+    const AdamCoef* coef; const double* loss_part; int loss_blocks; double* sums_out; float* grads_tail;
+    double global_M; LossParams hp; int do_step; StepStats* stats_out; double* clipfrac_accum;
+    uint16_t* planes; uint16_t* frags; int64_t wp_off[2][GEN_MAX_LAYERS]; int wp_kpad[GEN_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) {
+    __shared__ double s_t[4 * GEN_MAX_LAYERS];
+    __shared__ double s_ls[5][4];
+    __shared__ float s_total;
+    const GenLayout& L = a.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_jobs = 2 * L.n_layers;
+    for (int j = wave; j < n_jobs; j += 4) {
+        const int net = j / L.n_layers, l = j % L.n_layers;
+        const int64_t n_el = (int64_t)L.out_dim[net][l] * L.in_dim[l] + L.out_dim[net][l];
+        const int nblk = (int)((n_el + 63) / 64);
+        const double* src = a.sq_part + (size_t)j * a.xb * 2;
+        double aw = 0.0, ab = 0.0;
+        int b = lane;
+        for (; b + 3 * 64 < nblk; b += 4 * 64) {
+            double2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const double2*>(src + (size_t)(b + 64 * u) * 2);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { aw += v[u].x; ab += v[u].y; }
+        }
+        for (; b < nblk; b += 64) { const double2 v = *reinterpret_cast<const double2*>(src + (size_t)b * 2); aw += v.x; ab += v.y; }
+        aw = wave_sum_d_dpp(aw); ab = wave_sum_d_dpp(ab);
+        if (lane == 0) {
+            const float nw = (float)sqrt(aw), nb = (float)sqrt(ab);   // per-tensor norms as floats (clip_grad.h:58-66), then the norm of the norms
+            s_t[2 * j] = (double)nw * nw; s_t[2 * j + 1] = (double)nb * nb;
+        }
+    }
+    double lsum[5] = { 0, 0, 0, 0, 0 };
+    if (blockIdx.x == 0) {   // the loss kernel's block sums (uniform branch)
+        for (int k = 0; k < 5; k++) {
+            double v = 0.0;
+            for (int b = tid; b < a.loss_blocks; b += 256) v += a.loss_part[b * 8 + k];
+            v = wave_sum_d_dpp(v);
+            if (lane == 0) s_ls[k][wave] = v;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < 2 * n_jobs; t++) tot += s_t[t];
+        s_total = (float)sqrt(tot);
+    }
+    if (blockIdx.x == 0 && tid < 8) {
+        const double t = tid < 5 ? ((s_ls[tid][0] + s_ls[tid][1]) + s_ls[tid][2]) + s_ls[tid][3] : 0.0;
+        a.sums_out[tid] = t;
+        a.grads_tail[tid] = (float)t;
+        if (tid < 5) s_ls[tid][0] = t;
+    }
+    __syncthreads();
+    const float total = s_total;
+    float c = a.max_norm / (total + 1e-6f);
+    if (c > 1.0f) c = 1.0f;
+    const AdamCoef k = *a.coef;
+    const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
+    if (a.do_step) {
+        const int stride = gridDim.x * 256;
+        for (int p0 = blockIdx.x * 256 + tid; p0 < L.P; p0 += OPT_EPT * stride) {
+            float g[OPT_EPT], pv[OPT_EPT], mv[OPT_EPT], vv[OPT_EPT];
+#pragma unroll
+            for (int u = 0; u < OPT_EPT; u++) {
+                const int p = p0 + u * stride;
+                const int ps = p < L.P ? p : p0;
+                g[u] = a.grads[ps]; pv[u] = a.params[ps]; mv[u] = a.exp_avg[ps]; vv[u] = a.exp_avg_sq[ps];
+            }
+#pragma unroll
+            for (int u = 0; u < OPT_EPT; u++) {
+                const int p = p0 + u * stride;
+                if (p >= L.P) continue;
+                const float gc = g[u] * c;
+                const float pi = pv[u] * k.decay;
+                const float mi = __builtin_fmaf(gc, omb1, mv[u] * b1);
+                const float vi = __builtin_fmaf(omb2 * gc, gc, vv[u] * b2);
+                const float denom = sqrtf(vi) / k.sqrt_bc2 + eps;
+                const float pn = pi + (k.neg_step * mi) / denom;
+                a.params[p] = pn;
+                a.exp_avg[p] = mi;
+                a.exp_avg_sq[p] = vi;
+                if (a.planes) {
+                    // which weight matrix (if any): the layout's offsets are uniform constants; bias elements and nothing else fall through
+                    int net = -1, l = 0;
+                    for (int nn = 0; nn < 2; nn++)
+                        for (int ll = 0; ll < L.n_layers; ll++)
+                            if (p >= L.w_off[nn][ll] && p < L.b_off[nn][ll]) { net = nn; l = ll; }
+                    if (net >= 0) {
+                        const int K = L.in_dim[l], e = p - L.w_off[net][l];
+                        const int n = e / K, kk = e - n * K;
+                        const int kpad = a.wp_kpad[l];
+                        const __bf16 bq = (__bf16)pn;   // round to nearest even, as weight_planes_kernel
+                        const uint16_t bits = __builtin_bit_cast(uint16_t, bq);
+                        a.planes[a.wp_off[net][l] + (int64_t)n * kpad + kk] = bits;
+                        a.frags[a.wp_off[net][l] + (((int64_t)(n >> 5) * (kpad / 16) + (kk >> 4)) * 64 + (n & 31) + 32 * ((kk >> 3) & 1)) * 8 + (kk & 7)] = bits;
+                    }
+                }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        double ls[5];
+        for (int i = 0; i < 5; i++) ls[i] = s_ls[i][0];
+        const float pg = (float)(ls[0] / a.global_M), vl = 0.5f * (float)(ls[4] / a.global_M), el = (float)(ls[1] / a.global_M);
+        StepStats o;
+        o.pg_loss = pg; o.v_loss = vl; o.entropy_loss = el;
+        o.approx_kl = (float)(ls[2] / a.global_M);
+        o.clipfrac = (float)ls[3] / (float)a.global_M;
+        o.loss = (pg - a.hp.ent_coef * el) + vl * a.hp.vf_coef;
+        o.total_norm = total;
+        o.pad = 0.0;
+        *a.stats_out = o;
+        if (a.clipfrac_accum && a.do_step) { a.clipfrac_accum[0] += o.clipfrac; a.clipfrac_accum[1] += 1.0; }
     }
 }
 
@@ -660,11 +805,15 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
                     const AdvStat* adv_stat, hipStream_t s) {
     const dim3 grid(GEN_LOSS_BLOCKS), block(256);
     if (g.bf16) {   // bf16 storage: per-row arrays in registers, bounds 4 heads x 16 logits or the ABI's maximum
-        const uint8_t* mask = hp.dist_kind == PPO_DIST_MASKED ? g.row_mask : nullptr;
+        // the per-row scalars: gathered copies, or (rows_idx set) the rollout's own arrays through the step's index list
+        const bool direct = g.rows_idx != nullptr;
+        const GenRowSrc& R = g.rows_src;
+        const uint8_t* mask = hp.dist_kind == PPO_DIST_MASKED ? (direct ? R.masks : g.row_mask) : nullptr;
 #define GEN_LOSS_REG(DIST, NH, AM)                                                                                                                     \
-        hipLaunchKernelGGL((loss_reg_kernel<DIST, NH, AM>), grid, block, 0, s, L, hp, g.logits, g.val, g.row_act, mask, g.row_f[0], g.row_f[1], g.row_f[2], \
-                           g.row_f[3], M, (float)inv_global_M, (adv_stat && hp.norm_adv) ? adv_stat : nullptr, global_M, g.loss_part, g.dout_bf[1], g.dout_bf[0], \
-                           g.head_db_part)
+        hipLaunchKernelGGL((loss_reg_kernel<DIST, NH, AM>), grid, block, 0, s, L, hp, g.logits, g.val, direct ? R.actions : g.row_act, mask,              \
+                           direct ? R.logprobs : g.row_f[0], direct ? R.adv : g.row_f[1], direct ? R.ret : g.row_f[2], direct ? R.values : g.row_f[3], M,   \
+                           (float)inv_global_M, (adv_stat && hp.norm_adv) ? adv_stat : nullptr, global_M, g.loss_part, g.dout_bf[1], g.dout_bf[0],      \
+                           g.head_db_part, g.rows_idx)
         const bool small = L.n_heads <= 4 && L.act <= 16;
         if (hp.dist_kind == PPO_DIST_MASKED) { if (small) GEN_LOSS_REG(PPO_DIST_MASKED, 4, 16); else GEN_LOSS_REG(PPO_DIST_MASKED, PPO_MAX_HEADS, PPO_MAX_ACT); }
         else { if (small) GEN_LOSS_REG(PPO_DIST_CATEGORICAL, 4, 16); else GEN_LOSS_REG(PPO_DIST_CATEGORICAL, PPO_MAX_HEADS, PPO_MAX_ACT); }
@@ -683,12 +832,67 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
     return hipGetLastError();
 }
 
+// The fused backward pass (kernels_generic_bwd.hip): one launch per layer -- dZ_l and h_{l-1} are read ONCE for the weight gradient AND the gradient handed down;
+// layer 0 has nothing below it and forms its weight gradient alone -- then the fixed-order sums of all layers' slabs and column sums in one launch.
+// net_b >= 0: the same layers of a second net ride in the same launches (each net sized for half the chip), and one launch sums both nets' slabs.
+namespace {
+hipError_t fused_backward(const GenericCtx& g, int net_a, int net_b, int64_t rows, float* grads, hipStream_t s, bool half_chip) {
+    const GenLayout& L = g.L;
+    const int nets[2] = { net_a, net_b };
+    const int n_nets = net_b >= 0 ? 2 : 1;
+    const uint16_t* d[2];
+    int64_t ldd = 128;
+    int S_above[2] = { 0, 0 };
+    for (int i = 0; i < n_nets; i++) d[i] = g.dout_bf[nets[i]];   // [rows + 128][128]: columns >= 32 are zero for good (L.act <= 32): row 0's columns 64 .. 71 are the kernel's 16 zero bytes
+    SlabJobs jobs{};
+    jobs.slab_stride = g.wslab_stride;
+    int64_t most = 0;
+    for (int l = L.n_layers - 1; l >= 0; l--) {
+        const bool head = l == L.n_layers - 1;
+        const bool in_place = l == 0 && g.rows_idx != nullptr;   // layer 0 reads the minibatch's rows of the update's bf16 observations through the index list
+        const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
+        const int cbk = gen_bwd_col_blocks((int)ldi, l > 0);
+        int tpr = 1;
+        const int S = gen_bwd_ranges(rows, cbk, half_chip || n_nets == 2, &tpr);
+        GenBwdLayer q[2];
+        for (int i = 0; i < n_nets; i++) {
+            const int net = nets[i];
+            const int K = L.in_dim[l], N = L.out_dim[net][l];
+            float* lslab = (net == 1 ? g.wslab1 : g.wslab) + (size_t)l * g.wslab_layer_stride;
+            uint16_t* nd = l > 0 ? g.dz_bf[net][l & 1] : nullptr;
+            q[i] = GenBwdLayer{ d[i], ldd, l == 0 ? (in_place ? g.obs_bf : g.xin_bf) : g.acts_bf[net][l - 1], ldi, in_place ? g.rows_idx : nullptr,
+                                l > 0 ? g.wplanes + g.wp_off[net][l] : nullptr, g.wp_kpad[l], nd, g.ld_h, lslab, g.wslab_stride,
+                                l > 0 ? g.cs_part[net] + (size_t)l * g.cs_layer_stride : nullptr, g.ld_h, N, K, S, tpr };
+            SlabJob& J = jobs.j[(n_nets == 2 ? net : 0) * L.n_layers + l];   // both nets: jobs in the parameter order (critic's layers, then the actor's)
+            J.slab = lslab; J.S = S; J.n_w = (int64_t)N * K; J.n_b = N;
+            // the bias gradient of layer l: block sums of the head gradient (loss kernel), or the column sums the launch of layer l + 1 left in block l + 1
+            J.db_part = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part[net] + (size_t)(l + 1) * g.cs_layer_stride;
+            J.db_chunks = head ? GEN_LOSS_BLOCKS : S_above[i];
+            J.db_stride = head ? L.act + 1 : g.ld_h;
+            J.gw = grads + L.w_off[net][l]; J.gb = grads + L.b_off[net][l];
+            most = std::max<int64_t>(most, J.n_w + N);
+            S_above[i] = S;
+            d[i] = nd;
+        }
+        const hipError_t e = gen_fused_backward_layer(head ? 32 : g.ld_h, q[0], n_nets == 2 ? &q[1] : nullptr, rows, cbk, g.dout_bf[nets[0]] + 64, s);
+        if (e != hipSuccess) return e;
+        ldd = g.ld_h;
+    }
+    jobs.sq_part = (most + 63) / 64 <= g.sq_cap ? g.sq_part : nullptr;
+    jobs.sq_stride = g.sq_cap; jobs.sq_job0 = n_nets == 2 ? 0 : net_a * L.n_layers;
+    for (int i = 0; i < n_nets; i++) g.sq_valid[nets[i]] = jobs.sq_part != nullptr;
+    hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)(n_nets * L.n_layers)), dim3(256), 0, s, jobs);
+    return hipGetLastError();
+}
+}  // namespace
+
 // Backward of one net: dout = d(loss)/d(output layer) [rows, out]; fills the net's slice of the flat gradient.  Needs the activations
 // kept by gen_forward(..., acts = g.acts[net]).  `ones` = g.dz[1] + rows * hidden is NOT used: bias gradients are a gemv with the
 // ones vector kept in g.row_f[4] + 2 (see api.hip: filled once at creation).
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
                         hipStream_t s, bool beside_other_net) {
     const GenLayout& L = g.L;
+    g.sq_valid[net] = false;
     if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
     // dW[N, K] = d^T[N, rows] . in[rows, K] and db[N] = d^T . 1 contract over the minibatch rows: a single product would have N K / tile
     // workgroups walking all rows, so the rows are cut into ranges -- every range its own partial slab, enough of them for one or two workgroups
@@ -704,44 +908,7 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
         return (int)((rows + range - 1) / range);
     };
 #ifndef GEN_AB_UNFUSED_BWD   // A/B build (tools/build_variant.sh): the two tiled products per layer of rounds 1-4
-    if (gen_fused_backward_ok(g)) {
-        // one launch per layer (kernels_generic_bwd.hip): dZ_l and h_{l-1} are read ONCE for the weight gradient AND the gradient handed down; layer 0 has
-        // nothing below it and forms its weight gradient alone.  Then the fixed-order sums of all layers' slabs and column sums in one launch.
-        const uint16_t* d = g.dout_bf[net];   // [rows + 128][128]: columns >= 32 are zero for good (L.act <= 32): row 0's columns 64 .. 71 are the kernel's 16 zero bytes
-        int64_t ldd = 128;
-        float* wslab = net == 1 ? g.wslab1 : g.wslab;
-        SlabJobs jobs{};
-        jobs.slab_stride = g.wslab_stride;
-        int64_t most = 0;
-        int S_above = 0;
-        for (int l = L.n_layers - 1; l >= 0; l--) {
-            const int K = L.in_dim[l], N = L.out_dim[net][l];
-            const bool head = l == L.n_layers - 1;
-            const uint16_t* in = l == 0 ? g.xin_bf : g.acts_bf[net][l - 1];
-            const int64_t ldi = l == 0 ? g.ld_in0 : g.ld_h;
-            int tpr = 1;
-            const int cbk = gen_bwd_col_blocks((int)ldi, l > 0);
-            const int S = gen_bwd_ranges(rows, cbk, beside_other_net, &tpr);
-            float* lslab = wslab + (size_t)l * g.wslab_layer_stride;
-            uint16_t* nd = l > 0 ? g.dz_bf[net][l & 1] : nullptr;
-            const hipError_t e = gen_fused_backward_layer(head ? 32 : g.ld_h, d, ldd, in, ldi, l > 0 ? g.wplanes + g.wp_off[net][l] : nullptr, g.wp_kpad[l], nd, g.ld_h,
-                                                          lslab, g.wslab_stride, l > 0 ? g.cs_part[net] + (size_t)l * g.cs_layer_stride : nullptr, g.ld_h, g.dout_bf[net] + 64,
-                                                          rows, N, K, cbk, S, tpr, s);
-            if (e != hipSuccess) return e;
-            SlabJob& J = jobs.j[l];
-            J.slab = lslab; J.S = S; J.n_w = (int64_t)N * K; J.n_b = N;
-            // the bias gradient of layer l: block sums of the head gradient (loss kernel), or the column sums the launch of layer l + 1 left in block l + 1
-            J.db_part = head ? g.head_db_part + (net == 0 ? L.act : 0) : g.cs_part[net] + (size_t)(l + 1) * g.cs_layer_stride;
-            J.db_chunks = head ? GEN_LOSS_BLOCKS : S_above;
-            J.db_stride = head ? L.act + 1 : g.ld_h;
-            J.gw = grads + L.w_off[net][l]; J.gb = grads + L.b_off[net][l];
-            most = std::max<int64_t>(most, J.n_w + N);
-            S_above = S;
-            d = nd; ldd = g.ld_h;
-        }
-        hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)L.n_layers), dim3(256), 0, s, jobs);
-        return hipGetLastError();
-    }
+    if (gen_fused_backward_ok(g)) return fused_backward(g, net, -1, rows, grads, s, beside_other_net);
 #endif
     if (g.bf16) {
         // bf16 storage: x, dout are not used -- the layer inputs are g.xin_bf / g.acts_bf[net], the head gradient g.dout_bf[net] (written by the
@@ -816,6 +983,36 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
             d = nd;
         }
     }
+    return hipGetLastError();
+}
+
+// both nets' fused backward passes in the same launches, on one stream (bf16 storage, gen_fused_backward_ok): actor and critic side by side on the chip
+hipError_t gen_backward_both(const GenericCtx& g, const float* params, int64_t rows, float* grads, hipStream_t s) {
+    if (!gen_fused_backward_ok(g)) return hipErrorNotSupported;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    return fused_backward(g, 1, 0, rows, grads, s, true);
+}
+
+// The optimizer step behind the fused backward passes of both nets (gen_backward_both, or gen_backward per net) on a single rank: ONE launch (gen_opt_fused_kernel) for the loss sums, the gradient norm out of the slab sums'
+// partials, clip + AdamW and the refreshed bf16 weight planes.  do_step false: loss scalars and the norm only.
+hipError_t gen_opt_fused(const GenericCtx& g, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
+                         double* sums_out, double global_M, LossParams hp, bool do_step, StepStats* stats_out, double* clipfrac_accum, hipStream_t s) {
+    const GenLayout& L = g.L;
+    if (!g.sq_part || g.sq_cap <= 0) return hipErrorInvalidValue;
+    GenOptArgs a{};
+    a.params = params; a.grads = grads; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.L = L; a.max_norm = max_grad_norm;
+    a.sq_part = g.sq_part; a.xb = g.sq_cap;
+    a.coef = coef; a.loss_part = g.loss_part; a.loss_blocks = GEN_LOSS_BLOCKS; a.sums_out = sums_out; a.grads_tail = grads + L.P;
+    a.global_M = global_M; a.hp = hp; a.do_step = do_step ? 1 : 0; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum;
+    const bool planes = do_step && g.gemm_prec == PPO_MM_BF16 && g.wfrags != nullptr && !g.planes_dirty;   // dirty planes are rebuilt whole by their next user
+    a.planes = planes ? g.wplanes : nullptr; a.frags = planes ? g.wfrags : nullptr;
+    for (int net = 0; net < 2; net++) for (int l = 0; l < L.n_layers; l++) a.wp_off[net][l] = g.wp_off[net][l];
+    for (int l = 0; l < L.n_layers; l++) a.wp_kpad[l] = g.wp_kpad[l];
+    const int64_t per = (int64_t)256 * OPT_EPT;
+    int64_t blocks = do_step ? (L.P + per - 1) / per : 1;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(gen_opt_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (do_step && !planes) g.planes_dirty = true;
     return hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ constexpr int BW_RING = 3;     // LDS buffers of the tile ring
 struct BwdArgs {
     const uint16_t* d; int64_t ldd;        // dZ_l [rows + pad][ldd] bf16 (columns >= the layer's width are zero)
     const uint16_t* h; int64_t ldh;        // h_{l-1}, or the layer-0 input [.][ldh] bf16
+    const int32_t* idx;                    // layer 0 only (no P1), may be null: row r of the minibatch is row idx[r] of h (the update's observations, read in place)
     const uint16_t* w; int64_t ldw;        // bf16 plane of W_l [n_pad][ldw], zero padded (P1 only)
     uint16_t* dz_out; int64_t ld_out;      // dZ_{l-1} (P1 only)
     float* slab; int64_t slab_stride;      // [S][n_real][k_real] partial weight gradients, one per row range
@@ -112,8 +113,14 @@ __device__ __forceinline__ u32x4 frag_tr(const uint16_t* img, int x0, int ks, in
 
 // KCB = 64-column blocks of the input side a workgroup owns: 1 beside P1 (its weight block and result tile are sized for 64 columns), 2 for layer 0, whose only
 // product is the weight gradient (the dZ_0 tile is then fetched by ld / 128 workgroups instead of ld / 64).
+// Two launches in one (the same layer of the two nets, each sized for half the chip): workgroups [0, split) run a[0], the rest a[1]; split is a multiple of 8,
+// so both halves keep the XCD order below.  split == gridDim.x: one net.
+struct BwdPair { BwdArgs a[2]; int split; };
 template <int NB, bool P1, int KCB = 1>
-__global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair pp) {
+    const int second = (int)blockIdx.x >= pp.split ? 1 : 0;
+    const BwdArgs& a = pp.a[second];
+    const int bid = (int)blockIdx.x - (second ? pp.split : 0);
     static_assert(KCB == 1 || !P1, "P1 is built for one 64-column block");
     constexpr int HSZ = KCB * BW_ROWS * BW_KC;   // elements of one h buffer: KCB images [64][64]
     constexpr int N = 32 * NB;                 // width of dZ_l as staged (the real width zero padded)
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
     float* const sRed = reinterpret_cast<float*>(sO + (P1 ? 2 : 0) * BW_ROWS * BW_KC);   // [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware order: workgroup ids go round-robin over the 8 XCDs; the CB column blocks of a row range take consecutive slots of ONE XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int z = (slot / a.CB) * 8 + xcd, c = slot % a.CB;   // c counts blocks of 64 KCB columns
     if (z >= a.S) return;
     const int64_t row_begin = (int64_t)z * a.tiles_per_range * BW_ROWS;
@@ -141,6 +148,14 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
         const int64_t have = left <= 0 ? 0 : (left + BW_ROWS - 1) / BW_ROWS;
         if (have < n_tiles) n_tiles = (int)have;
     }
+#ifdef BW_PHASE_SHIFT
+    // the second net's workgroups walk their range from its middle (wrapping): the two nets' workgroups, launched together and running in step, would otherwise ask
+    // for the same offsets of their (equally laid out) buffers at the same moments
+    const int t_off = second ? n_tiles / 2 : 0;
+#else
+    const int t_off = 0;
+#endif
+    auto tile_of = [&](int t) { int u = t + t_off; if (u >= n_tiles && t < n_tiles) u -= n_tiles; return u; };
     const int li = lane & 31, kg = lane >> 5;
     const bool p1_wave = P1 && wave < 4;
     const int cb1 = wave & 1, rb1 = (wave >> 1) & 1;   // P1: the wave's 32 columns (of the block's 64) and 32 rows (of the tile's 64)
@@ -185,8 +200,20 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
     // ---- LDS-DMA of tile t into buffer t % 3: the image is lane-linear, so lane j of piece p fetches the chunk whose SWIZZLED place is 64 p + j.
     //      EVERY wave issues DPW + 1 instructions per tile (a wave without a piece of a narrow dZ tile fetches zeros into a spare KiB): the counted
     //      s_waitcnt vmcnt in the loop relies on it ----
-    auto issue = [&](int t) {
-        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
+    // Gathered h rows: the source row of this lane's row of a tile comes from a.idx.  The load is inline asm like the DMA (a load the compiler can see would get
+    // its own s_waitcnt, and the compiler counts only what it sees: vmcnt(0) in front of the first use, which drains the ring); it is issued one iteration
+    // before the DMA that needs it and IN FRONT of that iteration's DMAs, so the counted wait at the end of the iteration -- all but the last VM_TILE
+    // operations -- covers it; the wait statements carry the register as an operand, which keeps the address arithmetic behind them.
+    auto load_index = [&](int t) -> int {
+        int64_t r = row_begin + (int64_t)tile_of(t) * BW_ROWS + ((64 * wave + lane) >> 3);
+        if (r >= a.rows) r = a.rows - 1;
+        int v;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(a.idx + r) : "memory");
+        return v;
+    };
+    const bool gathered = !P1 && a.idx != nullptr;
+    auto issue = [&](int t, int hsrc) {
+        const int64_t r0 = row_begin + (int64_t)tile_of(t) * BW_ROWS;
         const int b = t % BW_RING;
         uint16_t* const dD = sD + b * DSZ;
         uint16_t* const dH = sH + b * HSZ;
@@ -201,13 +228,14 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
 #pragma unroll
         for (int k = 0; k < KCB; k++) {   // image k: columns 64 (KCB c + k) ..
             const int q = 64 * wave + lane, row = q >> 3, ch = (q & 7) ^ swz_h(row);
-            const uint16_t* src = r0 + row < a.rows ? a.h + (r0 + row) * a.ldh + BW_KC * (KCB * c + k) + 8 * ch : a.zeros;
+            const int64_t hrow = gathered ? (int64_t)hsrc : r0 + row;
+            const uint16_t* src = r0 + row < a.rows ? a.h + hrow * a.ldh + BW_KC * (KCB * c + k) + 8 * ch : a.zeros;
             bw_glds16(src, dH + k * BW_ROWS * BW_KC + 512 * wave);
         }
     };
     // the result tile of tile t leaves in 16-byte row pieces (rows past the minibatch are zeros: they keep the destination's padding zero)
     auto store_out = [&](int t) {
-        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
+        const int64_t r0 = row_begin + (int64_t)tile_of(t) * BW_ROWS;
         const int row = tid >> 3, ch = tid & 7;
         *reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch) =
             *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
@@ -220,14 +248,26 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
 #pragma unroll
     for (int r = 0; r < 16; r++) csum[r] = 0.0f;
 
-    if (n_tiles > 0) issue(0);
-    if (n_tiles > 1) issue(1);
+    int hs_next = 0;   // gathered: this lane's source row in tile t + 2 at the top of iteration t
+    {
+        int h0 = 0, h1 = 0;
+        if (gathered && n_tiles > 0) {
+            h0 = load_index(0); h1 = load_index(1); hs_next = load_index(2);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(hs_next) :: "memory");
+        }
+        if (n_tiles > 0) issue(0, h0);
+        if (n_tiles > 1) issue(1, h1);
+    }
     if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_TILE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
     bw_barrier();
     for (int t = 0; t < n_tiles; t++) {
         const uint16_t* const tD = sD + (t % BW_RING) * DSZ;
         const uint16_t* const tH = sH + (t % BW_RING) * HSZ;
-        if (t + 2 < n_tiles) issue(t + 2);          // into the buffer every wave finished reading before the barrier that ended iteration t - 1
+        int hs_load = 0;
+        if (t + 2 < n_tiles) {                      // into the buffer every wave finished reading before the barrier that ended iteration t - 1
+            if (gathered) hs_load = load_index(t + 3);
+            issue(t + 2, hs_next);
+        }
         if constexpr (P1) { if (t > 0) store_out(t - 1); }
         if (p1_wave) {
             // ---- P1: D[kcol][row] = sum_n W[n][kcol] dZ[row][n]; lane = row, registers = columns ----
@@ -278,16 +318,17 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdArgs 
         // tile t + 2 and the store of tile t - 1) -- counted, so that tile t + 2 stays in flight across the barrier (a plain __syncthreads() would drain
         // it: the compiler's fence waits for vmcnt(0)).  The last iterations issue less: they wait for everything.
 #ifdef BW_FULL_WAIT
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hs_load) :: "memory");
         if (false) {
 #else
         if (t + 2 < n_tiles) {
 #endif
-            if (t > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_PER_ITER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_TILE) : "memory");   // the first iteration has no result tile to store yet
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(hs_load) : "n"(VM_PER_ITER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(hs_load) : "n"(VM_TILE) : "memory");   // the first iteration has no result tile to store yet
         } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hs_load) :: "memory");
         }
+        hs_next = hs_load;
         bw_barrier();
     }
     if constexpr (P1) { if (n_tiles > 0) store_out(n_tiles - 1); }
@@ -338,7 +379,7 @@ constexpr size_t bwd_lds_bytes() {   // ring of dZ and h tiles, (P1) two result 
 }
 
 template <int NB, bool P1, int KCB>
-hipError_t bwd_launch(const BwdArgs& a, hipStream_t s) {
+hipError_t bwd_launch(const BwdPair& pp, unsigned blocks, hipStream_t s) {
     constexpr size_t lds = bwd_lds_bytes<NB, P1, KCB>();
     static_assert(lds <= 160 * 1024, "one workgroup per CU must fit");
     auto kern = bwd_layer_kernel<NB, P1, KCB>;
@@ -347,10 +388,10 @@ hipError_t bwd_launch(const BwdArgs& a, hipStream_t s) {
         const hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(kern), (int)lds);
         if (e != hipSuccess) return e;
     }
-    const unsigned blocks = (unsigned)((a.S + 7) / 8 * 8 * a.CB);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BW_THREADS), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BW_THREADS), lds, s, pp);
     return hipGetLastError();
 }
+inline unsigned bwd_blocks(const BwdArgs& a) { return (unsigned)((a.S + 7) / 8 * 8 * a.CB); }
 
 }  // namespace
 
@@ -376,18 +417,29 @@ bool gen_fused_backward_ok(const GenericCtx& g) {
 
 // One layer: d = dZ_l [., ldd] (width n_pad in {32, 128, 256}), h = the layer's input [., ldh], w = the layer's bf16 weight plane (null: layer 0, no layer
 // below).  col_blocks from gen_bwd_col_blocks, S / tiles_per_range from gen_bwd_ranges.  Writes S slabs [n_real][k_real], dZ_{l-1} and its column sums per range.
-hipError_t gen_fused_backward_layer(int n_pad, const uint16_t* d, int64_t ldd, const uint16_t* h, int64_t ldh, const uint16_t* w, int64_t ldw, uint16_t* dz_out,
-                                    int64_t ld_out, float* slab, int64_t slab_stride, float* colsum, int64_t ld_cs, const uint16_t* zeros, int64_t rows, int n_real,
-                                    int k_real, int col_blocks, int S, int tiles_per_range, hipStream_t s) {
+// `other` != nullptr: the same layer of the other net rides in the same launch (same n_pad, column blocks and kind of layer; its own operands and ranges).
+namespace {
+BwdArgs bwd_args(const GenBwdLayer& q, int64_t rows, int col_blocks, const uint16_t* zeros) {
     BwdArgs a{};
-    a.zeros = zeros;
-    a.d = d; a.ldd = ldd; a.h = h; a.ldh = ldh; a.w = w; a.ldw = ldw; a.dz_out = dz_out; a.ld_out = ld_out; a.slab = slab; a.slab_stride = slab_stride;
-    a.colsum = colsum; a.ld_cs = ld_cs; a.rows = rows; a.n_real = n_real; a.k_real = k_real; a.S = S; a.CB = col_blocks; a.tiles_per_range = tiles_per_range;
-    const bool p1 = w != nullptr;
-    const bool wide = !p1 && col_blocks * 2 * BW_KC == ldh;   // 128-column blocks
-    if (!p1 && !wide && col_blocks * BW_KC != ldh) return hipErrorInvalidValue;
-    if (n_pad == 32) return p1 ? bwd_launch<1, true, 1>(a, s) : (wide ? bwd_launch<1, false, 2>(a, s) : bwd_launch<1, false, 1>(a, s));
-    if (n_pad == 128) return p1 ? bwd_launch<4, true, 1>(a, s) : (wide ? bwd_launch<4, false, 2>(a, s) : bwd_launch<4, false, 1>(a, s));
-    if (n_pad == 256) return p1 ? bwd_launch<8, true, 1>(a, s) : (wide ? bwd_launch<8, false, 2>(a, s) : bwd_launch<8, false, 1>(a, s));
+    a.zeros = zeros; a.idx = q.idx;
+    a.d = q.d; a.ldd = q.ldd; a.h = q.h; a.ldh = q.ldh; a.w = q.w; a.ldw = q.ldw; a.dz_out = q.dz_out; a.ld_out = q.ld_out; a.slab = q.slab; a.slab_stride = q.slab_stride;
+    a.colsum = q.colsum; a.ld_cs = q.ld_cs; a.rows = rows; a.n_real = q.n_real; a.k_real = q.k_real; a.S = q.S; a.CB = col_blocks; a.tiles_per_range = q.tiles_per_range;
+    return a;
+}
+}  // namespace
+hipError_t gen_fused_backward_layer(int n_pad, const GenBwdLayer& one, const GenBwdLayer* other, int64_t rows, int col_blocks, const uint16_t* zeros, hipStream_t s) {
+    if (one.idx && one.w) return hipErrorInvalidValue;   // gathered inputs exist for layer 0 only
+    if (other && ((other->w != nullptr) != (one.w != nullptr) || other->ldh != one.ldh)) return hipErrorInvalidValue;
+    BwdPair pp{};
+    pp.a[0] = bwd_args(one, rows, col_blocks, zeros);
+    unsigned blocks = bwd_blocks(pp.a[0]);
+    pp.split = (int)blocks;
+    if (other) { pp.a[1] = bwd_args(*other, rows, col_blocks, zeros); blocks += bwd_blocks(pp.a[1]); }
+    const bool p1 = one.w != nullptr;
+    const bool wide = !p1 && col_blocks * 2 * BW_KC == one.ldh;   // 128-column blocks
+    if (!p1 && !wide && col_blocks * BW_KC != one.ldh) return hipErrorInvalidValue;
+    if (n_pad == 32) return p1 ? bwd_launch<1, true, 1>(pp, blocks, s) : (wide ? bwd_launch<1, false, 2>(pp, blocks, s) : bwd_launch<1, false, 1>(pp, blocks, s));
+    if (n_pad == 128) return p1 ? bwd_launch<4, true, 1>(pp, blocks, s) : (wide ? bwd_launch<4, false, 2>(pp, blocks, s) : bwd_launch<4, false, 1>(pp, blocks, s));
+    if (n_pad == 256) return p1 ? bwd_launch<8, true, 1>(pp, blocks, s) : (wide ? bwd_launch<8, false, 2>(pp, blocks, s) : bwd_launch<8, false, 1>(pp, blocks, s));
     return hipErrorNotSupported;
 }

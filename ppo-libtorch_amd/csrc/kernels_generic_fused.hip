@@ -343,6 +343,7 @@ struct FusedForwardArgs {
     FusedNet f;
     const float* x_f32;             // [rows][obs] f32 (rounded to bf16 on the way into LDS), or
     const uint16_t* x_bf;           // [rows][ld_x] bf16, zero padded
+    const int32_t* idx;             // x_bf only, may be null: row r of the pass is row idx[r] of x_bf (the minibatch's rows read in place, PPO_Discrete.cpp:576-582)
     int64_t ld_x, rows;
     float* out;                     // [rows][out_dim(last)]
     uint16_t* keep[GEN_MAX_LAYERS]; // hidden activations to keep (null: none), pitch ld_keep
@@ -356,8 +357,14 @@ struct FusedForwardArgs {
 // 16-byte input pieces per thread and tile (eight threads per row): bf16 rows of up to 384 elements, f32 rows of up to 384
 template <bool BF> constexpr int fu_np() { return BF ? 6 : 12; }
 typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+// Two passes in one launch (the two nets over the same rows): workgroups [0, split) run a[0], the rest a[1] -- the second pass's workgroups take the CUs
+// the first pass's leave, with no kernel boundary and no second stream between them.  split == gridDim.x: one pass.
+struct FusedForwardPair { FusedForwardArgs a[2]; int split; };
 template <bool BF>
-__global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardArgs a) {
+__global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardPair pp) {
+    const int second = (int)blockIdx.x >= pp.split ? 1 : 0;
+    const FusedForwardArgs& a = pp.a[second];
+    const int bid = (int)blockIdx.x - (second ? pp.split : 0), nblk = second ? (int)gridDim.x - pp.split : pp.split;
     constexpr int FU_NP = fu_np<BF>();
     extern __shared__ __attribute__((aligned(16))) uint16_t fu_lds[];
     constexpr int FM = 2, RB = 32 * FM;
@@ -375,9 +382,16 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
     const int ppr = bf ? opad / 8 : (O + 3) / 4;   // pieces per row (f32: O is a multiple of 4, host-checked)
     const int prow = tid >> 3, sub = tid & 7;
     u32x4 pf[FU_NP];
-    auto fetch = [&](int64_t tile) {   // unconditional loads: a piece that does not exist re-reads the operand's first bytes and is zeroed at use
+    // gathered input: the source row of this thread's row of a tile is requested one tile before the row itself (a whole tile's layers lie between
+    // the index load and its use; tile `first`'s is the one round trip in front of the first fetch)
+    int64_t src_next = 0;
+    auto fetch_index = [&](int64_t tile) {
         const int64_t row = tile * RB + prow;
-        const bool rok = tile < n_tiles && row < a.rows;
+        src_next = (bf && a.idx && tile < n_tiles && row < a.rows) ? (int64_t)a.idx[row] : row;
+    };
+    auto fetch = [&](int64_t tile) {   // unconditional loads: a piece that does not exist re-reads the operand's first bytes and is zeroed at use
+        const bool rok = tile < n_tiles && tile * RB + prow < a.rows;
+        const int64_t row = src_next;
 #pragma unroll
         for (int p = 0; p < FU_NP; p++) {
             const int piece = sub + 8 * p;
@@ -403,23 +417,26 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
         const int zlo = bf ? opad : O, hpad = (L.hidden + 31) / 32 * 32, zhi = opad > hpad ? opad : hpad;
         for (int e = tid; e < RB * (zhi - zlo); e += FU_THREADS) tile0[(e / (zhi - zlo)) * a.f.ldA + zlo + e % (zhi - zlo)] = 0;
     };
-    int64_t tile = blockIdx.x;
+    int64_t tile = bid;
+    fetch_index(tile);
     fetch(tile);
+    fetch_index(tile + nblk);
     // both tiles start as zeros: columns no layer ever writes are read against zero weights and must hold finite numbers
     for (int e = tid; e < 2 * RB * a.f.ldA / 8; e += FU_THREADS) { const u32x4 z = { 0u, 0u, 0u, 0u }; reinterpret_cast<u32x4*>(fu_lds)[e] = z; }
     __syncthreads();
     const int N = L.out_dim[a.f.net][L.n_layers - 1];
-    for (; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < n_tiles; tile += nblk) {
         const int64_t row0 = tile * RB;
         const int n_rows = a.rows - row0 < RB ? (int)(a.rows - row0) : RB;
         unsigned int* dbg = nullptr;
 #ifdef FU_DBG_STAMPS
-        if (blockIdx.x == 0 && tile == gridDim.x) dbg = reinterpret_cast<unsigned int*>(a.out + a.rows);   // the probe allocates 64 spare outputs
+        if (bid == 0 && tile == nblk) dbg = reinterpret_cast<unsigned int*>(a.out + a.rows);   // the probe allocates 64 spare outputs
 #endif
         FU_STAMP(0);
         stage(tile);                  // tile0 is free: the previous tile's last layer ended with a barrier
         FU_STAMP(1);
-        fetch(tile + gridDim.x);
+        fetch(tile + nblk);
+        fetch_index(tile + 2 * nblk);
         FU_STAMP(2);
         __syncthreads();
         FU_STAMP(3);
@@ -456,27 +473,52 @@ bool gen_fused_forward_ok(const GenericCtx& g) {
     return (O & 3) == 0 && O / 4 <= 8 * fu_np<false>() && opad / 8 <= 8 * fu_np<true>();
 }
 
-hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
-                             float* out, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+static FusedForwardArgs fused_forward_args(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows,
+                                           bool keep, float* out, const int32_t* idx) {
     FusedForwardArgs a{};
     a.f = make_fused_net(g, params, net);
-    a.x_f32 = x_f32; a.x_bf = x_bf; a.ld_x = ld_x; a.rows = rows; a.out = out;
+    a.x_f32 = x_f32; a.x_bf = x_bf; a.idx = x_bf ? idx : nullptr; a.ld_x = ld_x; a.rows = rows; a.out = out;
     for (int l = 0; l < g.L.n_hidden; l++) a.keep[l] = keep ? g.acts_bf[net][l] : nullptr;
     a.ld_keep = g.ld_h;
-    const size_t lds = fused_lds_bytes(a.f, 64);
+    return a;
+}
+static hipError_t fused_forward_launch(const FusedForwardPair& pp, unsigned blocks, bool bf, hipStream_t s) {
+    const size_t lds = fused_lds_bytes(pp.a[0].f, 64);
     static std::atomic<unsigned long long> lds_ok[2] = {};
     {
-        const hipError_t e = x_bf ? allow_dynamic_lds(lds_ok[0], reinterpret_cast<const void*>(&generic_forward_kernel<true>))
-                                  : allow_dynamic_lds(lds_ok[1], reinterpret_cast<const void*>(&generic_forward_kernel<false>));
+        const hipError_t e = bf ? allow_dynamic_lds(lds_ok[0], reinterpret_cast<const void*>(&generic_forward_kernel<true>))
+                                : allow_dynamic_lds(lds_ok[1], reinterpret_cast<const void*>(&generic_forward_kernel<false>));
         if (e != hipSuccess) return e;
     }
-    const int64_t n_tiles = (rows + 63) / 64;
-    const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
-    if (x_bf) hipLaunchKernelGGL(generic_forward_kernel<true>, grid, dim3(FU_THREADS), lds, s, a);
-    else hipLaunchKernelGGL(generic_forward_kernel<false>, grid, dim3(FU_THREADS), lds, s, a);
+    if (bf) hipLaunchKernelGGL(generic_forward_kernel<true>, dim3(blocks), dim3(FU_THREADS), lds, s, pp);
+    else hipLaunchKernelGGL(generic_forward_kernel<false>, dim3(blocks), dim3(FU_THREADS), lds, s, pp);
     return hipGetLastError();
+}
+
+hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, const float* x_f32, const uint16_t* x_bf, int64_t ld_x, int64_t rows, bool keep,
+                             float* out, hipStream_t s, const int32_t* idx) {
+    if (rows <= 0) return hipSuccess;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    FusedForwardPair pp{};
+    pp.a[0] = fused_forward_args(g, params, net, x_f32, x_bf, ld_x, rows, keep, out, idx);
+    const int64_t n_tiles = (rows + 63) / 64;
+    const unsigned blocks = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+    pp.split = (int)blocks;
+    return fused_forward_launch(pp, blocks, x_bf != nullptr, s);
+}
+
+// Both nets over the same bf16 rows, activations kept, in ONE launch: the actor's workgroups first (the loss kernel behind it needs both outputs)
+hipError_t gen_fused_forward_both(const GenericCtx& g, const float* params, const uint16_t* x_bf, int64_t ld_x, int64_t rows, float* logits, float* val,
+                                  hipStream_t s, const int32_t* idx) {
+    if (rows <= 0) return hipSuccess;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    FusedForwardPair pp{};
+    pp.a[0] = fused_forward_args(g, params, 1, nullptr, x_bf, ld_x, rows, true, logits, idx);
+    pp.a[1] = fused_forward_args(g, params, 0, nullptr, x_bf, ld_x, rows, true, val, idx);
+    const int64_t n_tiles = (rows + 63) / 64;
+    const unsigned per = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+    pp.split = (int)per;
+    return fused_forward_launch(pp, 2 * per, true, s);
 }
 
 hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,

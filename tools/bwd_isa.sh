@@ -6,7 +6,7 @@ python3 - <<'PY'
 import re, collections
 s=open('/tmp/bwd.s').read()
 for name in ('ILi8ELb1ELi1E','ILi8ELb0ELi2E','ILi4ELb1ELi1E','ILi1ELb1ELi1E'):
-    i=s.index('_ZN12_GLOBAL__N_116bwd_layer_kernel'+name+'EEvNS_7BwdArgsE:')
+    i=s.index('_ZN12_GLOBAL__N_116bwd_layer_kernel'+name+'EEvNS_7BwdPairE:')
     lines=[l.strip() for l in s[i:s.index('.Lfunc_end', i)].splitlines()[1:] if l.strip() and not l.strip().startswith(';')]
     c=collections.Counter(l.split()[0] for l in lines)
     meta=s[s.index('.name:           _ZN12_GLOBAL__N_116bwd_layer_kernel'+name):][:700]
