@@ -403,6 +403,10 @@ int gen_bwd_col_blocks(int ld_in, bool has_below) { return (!has_below && ld_in 
 int gen_bwd_ranges(int64_t rows, int col_blocks, bool half_chip, int* tiles_per_range) {
     const int64_t tiles = (rows + BW_ROWS - 1) / BW_ROWS;
     int64_t want = (half_chip ? 128 : 256) / col_blocks;
+    // ranges go round-robin over the 8 XCDs (the kernel's block order) and a workgroup holds a CU: a count that is not a multiple of 8 gives XCD 0 one range
+    // more than the others -- with three column blocks and both nets in the launch 36 workgroups for its 32 CUs, and the four that wait for a CU double the
+    // launch's duration (configs[4] layer 0: 42 ranges -> 97 us for the pair, 40 ranges -> see NOTES)
+    if (want >= 8) want = want / 8 * 8;
     if (want < 1) want = 1;
     if (want > tiles) want = tiles;
     const int64_t per = (tiles + want - 1) / want;
