@@ -580,11 +580,11 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             CK(dalloc(c, &g.cs_part[0], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.cs_part[1], (size_t)GL.n_layers * g.cs_layer_stride));
             CK(dalloc(c, &g.head_db_part, (size_t)GEN_LOSS_BLOCKS * (GL.act + 1)));
-            {   // one pair of doubles per slab-sum workgroup (64 gradient elements) of the largest layer, per layer and net
+            {   // one pair of doubles per slab-sum workgroup (256 gradient elements: kernels_generic.hip SLAB_EPB) of the largest layer, per layer and net
                 int64_t most = 0;
                 for (int net = 0; net < 2; net++)
                     for (int l = 0; l < GL.n_layers; l++) most = std::max<int64_t>(most, (int64_t)GL.out_dim[net][l] * GL.in_dim[l] + GL.out_dim[net][l]);
-                g.sq_cap = (int)((most + 63) / 64);
+                g.sq_cap = (int)((most + 255) / 256);
                 CK(dalloc(c, &g.sq_part, (size_t)2 * GL.n_layers * g.sq_cap * 2));
             }
         } else {

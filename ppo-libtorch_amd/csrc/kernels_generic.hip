@@ -552,15 +552,17 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 // The same sums for every layer of a net in ONE launch (bf16 storage: each layer has its own slab block): blockIdx.y = layer.
 struct SlabJob { const float* slab; const float* db_part; float* gw; float* gb; int64_t n_w, n_b, db_stride; int S, db_chunks; };
 struct SlabJobs { SlabJob j[2 * GEN_MAX_LAYERS]; int64_t slab_stride; double* sq_part; int sq_stride, sq_job0; };   // blockIdx.y = job: a net's layers, or both nets'
-// sq_part != nullptr: the workgroup also leaves the sums of squares of its 64 gradient elements, weights and bias apart, as
+// sq_part != nullptr: the workgroup also leaves the sums of squares of its SLAB_EPB gradient elements, weights and bias apart, as
 // sq_part[((sq_job0 + job) * sq_stride + blockIdx.x) * 2 + {0, 1}] (job slots in the parameter order: net * n_layers + layer) -- the gradient norm then needs no
 // pass of its own over the gradient (gen_opt_fused_kernel)
-__global__ __launch_bounds__(256) void slab_sum_layers_kernel(SlabJobs jobs) {
-    __shared__ float red[4][64];
+constexpr int SLAB_EPB = 256;   // gradient elements per workgroup of slab_sum_layers_kernel (four groups of SLAB_EPB threads split the slabs)
+__global__ __launch_bounds__(4 * SLAB_EPB) void slab_sum_layers_kernel(SlabJobs jobs) {
+    __shared__ float red[4][SLAB_EPB];
+    __shared__ double sq[SLAB_EPB / 64][2];
     const SlabJob& J = jobs.j[blockIdx.y];
-    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + e;
-    if ((int64_t)blockIdx.x * 64 >= J.n_w + J.n_b) return;   // whole block past this layer's elements (uniform: no barrier is skipped by part of a block)
+    const int e = threadIdx.x % SLAB_EPB, q = threadIdx.x / SLAB_EPB;
+    const int64_t i = (int64_t)blockIdx.x * SLAB_EPB + e;
+    if ((int64_t)blockIdx.x * SLAB_EPB >= J.n_w + J.n_b) return;   // whole block past this layer's elements (uniform: no barrier is skipped by part of a block)
     float acc = 0.0f;
     if (i < J.n_w + J.n_b) {
         const bool w = i < J.n_w;
@@ -589,22 +591,27 @@ __global__ __launch_bounds__(256) void slab_sum_layers_kernel(SlabJobs jobs) {
         if (jobs.sq_part) {
             const double t2 = (double)t * (double)t;
             const double sw = wave_sum_d_dpp(i < J.n_w ? t2 : 0.0), sb = wave_sum_d_dpp(i < J.n_w ? 0.0 : t2);
-            if (e == 0) {
-                double* o = jobs.sq_part + ((size_t)(jobs.sq_job0 + blockIdx.y) * jobs.sq_stride + blockIdx.x) * 2;
-                o[0] = sw; o[1] = sb;
-            }
+            if ((e & 63) == 0) { sq[e >> 6][0] = sw; sq[e >> 6][1] = sb; }
+        }
+    }
+    if (jobs.sq_part) {
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            double v = 0.0;
+            for (int w = 0; w < SLAB_EPB / 64; w++) v += sq[w][threadIdx.x];
+            jobs.sq_part[((size_t)(jobs.sq_job0 + blockIdx.y) * jobs.sq_stride + blockIdx.x) * 2 + threadIdx.x] = v;
         }
     }
 }
 
 // Gradient norm + clip + AdamW + the bf16 weight planes + the step's loss scalars in ONE launch behind the slab sums (single rank, both nets' fused backward):
 //   norm   every workgroup adds the slab-sum workgroups' sums of squares per tensor (wave w takes jobs w, w + 4, ...: lanes stride the job's workgroups, one DPP
-//          reduction per tensor) -- 149 KB out of L2 per workgroup at configs[4], instead of a kernel of its own over the gradient;
+//          reduction per tensor) -- 37 KB out of L2 per workgroup at configs[4], instead of a kernel of its own over the gradient;
 //   step   the arithmetic of gen_adamw_kernel, one batch of loads per thread (grid-stride, OPT_EPT elements in flight);
 //   planes a weight's new value goes straight to its place in the bf16 plane and the fragment-order copy (weight_planes_kernel's layout; the padding is
 //          zero from the allocation and never written), so the next forward pass needs no re-split launch;
 //   stats  workgroup 0 also adds the loss kernel's block sums (loss_sums_kernel) and writes the step's scalars.
-constexpr int OPT_EPT = 10;
+constexpr int OPT_EPT = 2;
 struct GenOptArgs {
     float* params; const float* grads; float* exp_avg; float* exp_avg_sq; GenLayout L; float max_norm;
     const double* sq_part; int xb;
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) 
     for (int j = wave; j < n_jobs; j += 4) {
         const int net = j / L.n_layers, l = j % L.n_layers;
         const int64_t n_el = (int64_t)L.out_dim[net][l] * L.in_dim[l] + L.out_dim[net][l];
-        const int nblk = (int)((n_el + 63) / 64);
+        const int nblk = (int)((n_el + SLAB_EPB - 1) / SLAB_EPB);
         const double* src = a.sq_part + (size_t)j * a.xb * 2;
         double aw = 0.0, ab = 0.0;
         int b = lane;
@@ -641,11 +648,18 @@ __global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) 
         }
     }
     double lsum[5] = { 0, 0, 0, 0, 0 };
-    if (blockIdx.x == 0) {   // the loss kernel's block sums (uniform branch)
+    if (blockIdx.x == 0) {   // the loss kernel's block sums (uniform branch): the five columns requested together
+        double v5[5] = { 0, 0, 0, 0, 0 };
+        for (int b = tid; b < a.loss_blocks; b += 256) {
+            double t[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) t[k] = a.loss_part[b * 8 + k];
+#pragma unroll
+            for (int k = 0; k < 5; k++) v5[k] += t[k];
+        }
+#pragma unroll
         for (int k = 0; k < 5; k++) {
-            double v = 0.0;
-            for (int b = tid; b < a.loss_blocks; b += 256) v += a.loss_part[b * 8 + k];
-            v = wave_sum_d_dpp(v);
+            const double v = wave_sum_d_dpp(v5[k]);
             if (lane == 0) s_ls[k][wave] = v;
         }
     }
@@ -878,10 +892,10 @@ hipError_t fused_backward(const GenericCtx& g, int net_a, int net_b, int64_t row
         if (e != hipSuccess) return e;
         ldd = g.ld_h;
     }
-    jobs.sq_part = (most + 63) / 64 <= g.sq_cap ? g.sq_part : nullptr;
+    jobs.sq_part = (most + SLAB_EPB - 1) / SLAB_EPB <= g.sq_cap ? g.sq_part : nullptr;
     jobs.sq_stride = g.sq_cap; jobs.sq_job0 = n_nets == 2 ? 0 : net_a * L.n_layers;
     for (int i = 0; i < n_nets; i++) g.sq_valid[nets[i]] = jobs.sq_part != nullptr;
-    hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)(n_nets * L.n_layers)), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + SLAB_EPB - 1) / SLAB_EPB), (unsigned)(n_nets * L.n_layers)), dim3(4 * SLAB_EPB), 0, s, jobs);
     return hipGetLastError();
 }
 }  // namespace
@@ -957,7 +971,7 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
                 d = nd; ldd = g.ld_h;
             }
         }
-        hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + 63) / 64), (unsigned)L.n_layers), dim3(256), 0, s, jobs);
+        hipLaunchKernelGGL(slab_sum_layers_kernel, dim3((unsigned)((most + SLAB_EPB - 1) / SLAB_EPB), (unsigned)L.n_layers), dim3(4 * SLAB_EPB), 0, s, jobs);
         return hipGetLastError();
     }
     const float* d = dout;
@@ -1010,7 +1024,7 @@ hipError_t gen_opt_fused(const GenericCtx& g, float* params, float* grads, float
     for (int l = 0; l < L.n_layers; l++) a.wp_kpad[l] = g.wp_kpad[l];
     const int64_t per = (int64_t)256 * OPT_EPT;
     int64_t blocks = do_step ? (L.P + per - 1) / per : 1;
-    if (blocks > 256) blocks = 256;
+    if (blocks > 2048) blocks = 2048;   // every workgroup re-adds the partial sums of squares: a few per CU, not thousands
     hipLaunchKernelGGL(gen_opt_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     if (do_step && !planes) g.planes_dirty = true;
     return hipGetLastError();

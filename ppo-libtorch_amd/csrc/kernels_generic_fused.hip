@@ -186,10 +186,24 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0,
         __syncthreads();
         FU_STAMP(9 + 2 * l);
         if (!last && keep && keep[l]) {   // the activation tile leaves for the backward pass in 16-byte row pieces
-            const int p8 = (N + 7) / 8;
-            for (int e = tid; e < 32 * FM * p8; e += FU_THREADS) {
-                const int row = e / p8, c8 = e % p8;
-                if (row < n_rows) *reinterpret_cast<u32x4*>(keep[l] + (row0 + row) * ld_keep + 8 * c8) = *reinterpret_cast<const u32x4*>(dst + row * f.ldA + 8 * c8);
+            // four pieces per thread with their LDS reads in flight together (one after the other -- read, wait, store -- the copy of a 256-wide
+            // tile held every wave ~1 500 cycles in front of the next layer: FU_DBG_STAMPS); the piece -> (row, column) split without a division when
+            // the row holds a power of two of pieces
+            const int p8 = (N + 7) / 8, total = 32 * FM * p8;
+            const bool pow2 = (p8 & (p8 - 1)) == 0;
+            const int sh = __builtin_ctz((unsigned)p8);
+            for (int e0 = tid; e0 < total; e0 += 4 * FU_THREADS) {
+                u32x4 v[4];
+                int row[4], c8[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = e0 + j * FU_THREADS, ee = e < total ? e : 0;
+                    row[j] = pow2 ? ee >> sh : ee / p8; c8[j] = pow2 ? ee & (p8 - 1) : ee % p8;
+                    v[j] = *reinterpret_cast<const u32x4*>(dst + row[j] * f.ldA + 8 * c8[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (e0 + j * FU_THREADS < total && row[j] < n_rows) *reinterpret_cast<u32x4*>(keep[l] + (row0 + row[j]) * ld_keep + 8 * c8[j]) = v[j];
             }
         }
         uint16_t* t = src; src = dst; dst = t;
