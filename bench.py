@@ -208,7 +208,7 @@ def gae_floor_us():
                 # (chain-free strip) plus the walk, which can start only when its first rows are there and must end before its last rows leave
                 out.update({"chain_only_us": row.get("chain_us"), "chain_minus_empty_us": row.get("chain_minus_empty_us"),
                             "strip_plus_chain_us": row.get("column_plus_chain_us"),
-                            "verdict": "the 40 % bar at 4096 envs (3.28 us per launch) is below the chain-free strip + the unhidable chain on this part; it is met from 8192 envs"
+                            "verdict": "probes, not a bound: the bar at 4096 envs allows 3.28 us per launch, an empty launch and a plain stream of the same bytes leave it 0.9 and 0.2 us; the scan pipelined in time (gae_pipe_kernel: load, walk and store overlapped) was built and runs 4.3 - 4.8 us there, no faster than the three-phase kernel; the bar is met from 8192 envs (in trace)"
                                        if (row.get("column_plus_chain_us") or 0) > 3.29 else None})
             return out
     return None
