@@ -77,8 +77,8 @@ typedef struct ppo_config {
  *                               sits within ~1e-6 of a bin edge can differ (measured: <= 2 of 8 192).  Use this flag for golden / bit-exact replays.
  *   fp16 ranges                 The matrix-core kernels carry some operands as fp16 terms: rollout16_kernel 2^8 W3 (|W3| < 255), the update kernels c W2 and
  *                               the products through its columns (sum |W2[:, k]| < ~350), c W1 / c b1 / c b2 (< 22 700) and the observation (< 65 504).  The
- *                               reference has none of these limits and a caller never meets the weight limits: the optimizer kernels keep the running
- *                               maximum of |parameter| per class, the host reads a pinned mirror of it without synchronising (thresholds at half the
+ *                               reference has none of these limits and a caller never meets the weight limits: the maxima of |parameter| per class are taken
+ *                               once per update (and after every host write of the parameters), the host reads a pinned mirror of them without synchronising (thresholds at half the
  *                               limits: max |W3| >= 128, max |W2| >= 4, anything else >= 8192), and a launch whose weights do not fit takes the vector
  *                               kernel (plain fp32, the same function) -- for that launch only, with the default flags.  An OBSERVATION beyond fp16 written
  *                               into PPO_BUF_OBS cannot be foreseen: the update's record packing raises the context's error word and ppo_read_stats /
@@ -92,8 +92,14 @@ typedef struct ppo_config {
  *                               (fwd_bwd_mfma_ws_kernel) for the reference's two shapes: the A/B partner of the default.
  *   PPO_KERNEL_COMM_SELFTEST    ppo_comm_init(..., rank 0, nranks 1) really creates a ONE-rank RCCL communicator and every collective of the multi-rank
  *                               path is really issued (sums over one rank = identity): the only way to drive the RCCL calls -- library lookup,
- *                               datatype / op enums, stream ordering, the three-kernel optimizer path -- on a box with a single GPU. */
-enum { PPO_KERNEL_ROLLOUT_VECTOR = 1, PPO_KERNEL_UPDATE_VECTOR = 2, PPO_KERNEL_UPDATE_ONE_WAVE = 4, PPO_KERNEL_COMM_SELFTEST = 8 };
+ *                               datatype / op enums, stream ordering, the three-kernel optimizer path -- on a box with a single GPU.
+ *   PPO_KERNEL_GENERIC_CLASSIC  generic networks with bf16 storage (PPO_ENV_SYNTHETIC, e.g. BASELINE configs[4]): a minibatch step in its first form -- the
+ *                               minibatch gathered into dense copies, one net per launch with the critic's passes on a second stream, loss sums / gradient
+ *                               norm / AdamW / weight planes as four launches -- instead of rows read in place through the index list, both nets in every
+ *                               launch on one stream and one optimizer launch.  Same kernels for the products, same partial-sum partitions: the two forms
+ *                               agree to the last bits of a float (only the order in which the gradient norm's partial sums are added differs).  For A/B
+ *                               runs and tests. */
+enum { PPO_KERNEL_ROLLOUT_VECTOR = 1, PPO_KERNEL_UPDATE_VECTOR = 2, PPO_KERNEL_UPDATE_ONE_WAVE = 4, PPO_KERNEL_COMM_SELFTEST = 8, PPO_KERNEL_GENERIC_CLASSIC = 16 };
 
 /* Scalars the reference prints per update (PPO_Discrete.cpp:700-774) plus per-step diagnostics. */
 typedef struct ppo_stats {

@@ -424,7 +424,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     if (cfg->dist_kind != PPO_DIST_CATEGORICAL && cfg->dist_kind != PPO_DIST_MASKED) return fail(nullptr, PPO_ERR_INVALID, "unknown dist_kind %d", cfg->dist_kind);
     if (cfg->compute_dtype != PPO_DTYPE_F32 && cfg->compute_dtype != PPO_DTYPE_BF16) return fail(nullptr, PPO_ERR_INVALID, "unknown compute_dtype %d", cfg->compute_dtype);
-    if (cfg->kernel_flags & ~(PPO_KERNEL_ROLLOUT_VECTOR | PPO_KERNEL_UPDATE_VECTOR | PPO_KERNEL_UPDATE_ONE_WAVE | PPO_KERNEL_COMM_SELFTEST)) return fail(nullptr, PPO_ERR_INVALID, "unknown bits in kernel_flags 0x%x", cfg->kernel_flags);
+    if (cfg->kernel_flags & ~(PPO_KERNEL_ROLLOUT_VECTOR | PPO_KERNEL_UPDATE_VECTOR | PPO_KERNEL_UPDATE_ONE_WAVE | PPO_KERNEL_COMM_SELFTEST | PPO_KERNEL_GENERIC_CLASSIC)) return fail(nullptr, PPO_ERR_INVALID, "unknown bits in kernel_flags 0x%x", cfg->kernel_flags);
     if (cfg->compute_dtype == PPO_DTYPE_BF16 && !generic)
         return fail(nullptr, PPO_ERR_UNSUPPORTED, "compute_dtype = PPO_DTYPE_BF16 applies to networks whose layers are GEMMs (env_kind = PPO_ENV_SYNTHETIC); the reference's "
                     "2 x 64 networks always compute in f32");
@@ -1230,16 +1230,9 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         // Both fused passes available (bf16 storage, widths the kernels are built for): the two nets share every launch -- forward, each layer's backward, the
         // slab sums -- on ONE stream: the second net's workgroups take the CUs the first net's leave (forward) or run beside them on the other half of the
         // chip (backward), with no fork / join events between the streams (four per step, several us each).  Otherwise: the critic's passes on a second stream.
-#ifdef GEN_AB_TWO_STREAMS   // A/B build (tools/build_variant.sh): one net per launch, two streams (round 5's first form)
-        const bool paired = false;
-#else
-        const bool paired = g.bf16 && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
-#endif
-#ifdef GEN_AB_TWO_STREAM_BWD   // A/B build: forward paired, the backward passes one net per launch on two streams
-        const bool paired_bwd = false;
-#else
+        const bool classic = (c->cfg.kernel_flags & PPO_KERNEL_GENERIC_CLASSIC) != 0;   // the step's first form (ppo_hip.h): A/B runs and tests
+        const bool paired = !classic && g.bf16 && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
         const bool paired_bwd = paired;
-#endif
         const bool two = !paired && g.bf16 && c->stream2 != nullptr;   // a kernel of one net fills the CUs the other net's kernel is draining
         const bool two_bwd = !paired_bwd && g.bf16 && c->stream2 != nullptr;
         auto gather = [&](const int32_t* rows, int64_t n, hipStream_t st) {
@@ -1248,11 +1241,7 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         };
         // the fused kernels read the minibatch's rows in place (generic.hpp: GenericCtx::obs_bf, rows_idx); the observations are rounded once per update --
         // a stand-alone step (whose caller may have rewritten the buffers) rounds them every time
-#ifdef GEN_AB_GATHER   // A/B build (tools/build_variant.sh): the gathered copies of rounds 1-5
-        const bool in_place = false;
-#else
-        const bool in_place = g.bf16 && g.obs_bf && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
-#endif
+        const bool in_place = !classic && g.bf16 && g.obs_bf && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
         g.rows_idx = nullptr;
         if (in_place) {
             if (!c->gen_obs_bf_valid) {
@@ -1296,9 +1285,7 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
             HIPCHK(c, gen_backward(g, params, 1, g.xin, M, g.dlogits, grads, c->stream, two_bwd));
             HIPCHK(c, gen_backward(g, params, 0, g.xin, M, g.dval, grads, sb, two_bwd));
         }
-#ifndef GEN_AB_NO_FUSED_OPT   // A/B build (tools/build_variant.sh): loss sums, norm, AdamW and weight planes as four launches
-        c->gen_opt_fused_ok = g.sq_valid[0] && g.sq_valid[1] && c->world == 1 && !c->force_collectives;   // nothing changes the gradient between the slab sums and the optimizer
-#endif
+        c->gen_opt_fused_ok = !classic && g.sq_valid[0] && g.sq_valid[1] && c->world == 1 && !c->force_collectives;   // nothing changes the gradient between the slab sums and the optimizer
         if (two_bwd) HIPCHK(c, join());   // the flat gradient is complete
         if (two && c->gen_next_idx && !in_place) {
             // nothing reads this step's gathered rows any more: the next step's gather (42 us of HBM streaming) runs on the second stream beside the

@@ -233,6 +233,12 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
     const bool masked = DIST == PPO_DIST_MASKED && row_mask != nullptr;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < M; r += (int64_t)gridDim.x * 256) {
         const int64_t q = idx ? (int64_t)idx[r] : r;   // the row of the per-sample arrays
+        // everything the row needs is requested here, behind the index: one more memory round trip for the thread, not one per head (a thread is a row and a CU
+        // holds four waves of this kernel: nothing else hides a load that is issued where it is used)
+        int acts[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) acts[h] = h < n_heads ? row_act[q * n_heads + h] : 0;
+        const float in_oldlp = oldlp[q], in_adv = advs[q], in_ret = rets[q], in_oldv = oldv[q], in_val = val[r];
         float z[AM], p[AM];
         bool ok[AM];
 #pragma unroll
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
                 for (int k = 0; k < AM; k++) if (k >= off && k < off + A) { p[k] = fast_exp(z[k] - mx); se += p[k]; }
                 const float lse = fast_log(se) + mx;
                 const float rse = __builtin_amdgcn_rcpf(se);
-                const int a = row_act[q * n_heads + h];
+                const int a = acts[h];
                 float e = 0.0f, lp = 0.0f;
 #pragma unroll
                 for (int k = 0; k < AM; k++) if (k >= off && k < off + A) {
@@ -277,9 +283,9 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
                 off += A;
             }
         }
-        const float logratio = nlp - oldlp[q];
+        const float logratio = nlp - in_oldlp;
         const float ratio = fast_exp(logratio);
-        float adv = advs[q];
+        float adv = in_adv;
         if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
         const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
         const float l1 = -adv * ratio, l2 = -adv * rc;
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
         for (int h = 0; h < NH; h++) {
             if (h < n_heads) {
                 const int A = L.head_dims[h];
-                const int a = row_act[q * n_heads + h];
+                const int a = acts[h];
 #pragma unroll
                 for (int k = 0; k < AM; k++) if (k >= off && k < off + A) {
                     float d = g_nlp * ((k - off == a ? 1.0f : 0.0f) - p[k]);
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
         s[2] += (double)((ratio - 1.0f) - logratio);
         s[3] += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
         // value loss (:603-625)
-        const float v = val[r], R = rets[q], vold = oldv[q];
+        const float v = in_val, R = in_ret, vold = in_oldv;
         const float un = (v - R) * (v - R);
         float g_v, lossv;
         if (hp.clip_vloss) {

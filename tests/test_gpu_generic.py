@@ -29,9 +29,10 @@ def P():
 # tanh (hardware exp2 against tanhf), which now and then tips a value across a bf16 rounding boundary (one part in 256 of that activation).
 # Measured at configs[4]'s shape (tools/bf16_dev_report.py): log-prob 6e-4 max / 4e-6 mean, value 2e-3 max / 2e-5 mean, losses 2e-6, gradient 2e-4
 # of its largest element -- against 0.38 / 1e-2 / 1e-2 between the bf16 and the f32 arithmetic themselves.
-# PARITY UNPINNED for every shape of _check_shape: the reference hard-wires 2 x 64 networks (Agent.cpp:25-59), so nothing the reference holds can pin a
-# 4 x 256 network or bf16 arithmetic; the yardstick is the oracle's own generic / bf16 mode (ORC_DTYPE_BF16), whose f32 2 x 64 case IS pinned.
-# What the reference CAN pin is this file's code at the reference's own shape: the tests at the end of the file.
+# What pins what: the yardstick of _check_shape is the oracle's generic / bf16 mode (ORC_DTYPE_BF16).  The oracle's f32 arithmetic is held to the compiled reference at the
+# reference's own 2 x 64 shape AND at configs[4]'s shape (obs 376, 4 x 256, heads [3, 3, 3, 2]: tests/test_oracle_vs_golden.py against tests/golden/config4_*.pgld), and the
+# build's f32 generic path is held to the same fixtures directly (tests/test_gpu_config4_ref.py; the tests at the end of this file for 2 x 64).  bf16 arithmetic has no
+# counterpart in the reference: its bars are distances (measured, x 3), not parity.
 # bf16 bars = ~3x the measured values above (log-prob 6e-4 -> 2e-3, value 2e-3 -> 4e-3 (2x), losses 2e-6 -> 6e-6, gradient 2e-4 -> 6e-4 of max).
 TOL = {0: dict(fwd=5e-6, fwd_v=5e-6, agree=0.995, loss=1e-5, grad=1e-4, same=1e-6), 1: dict(fwd=2e-3, fwd_v=4e-3, agree=0.98, loss=6e-6, grad=6e-4, same=1e-6)}
 
@@ -413,3 +414,34 @@ def test_generic_forward_kernels_on_the_reference_multihead_agent(P):
             print("bf16 against the reference's multi-head agent: log-prob %.1e, entropy %.1e, value %.1e (max abs)" %
                   (np.abs(lp - g["logprob"]).max(), np.abs(en - g["entropy"]).max(), np.abs(v - g["value"].ravel()).max()))
         ctx.close()
+
+
+def test_generic_bf16_step_forms_agree(P):
+    """The bf16-storage minibatch step exists in three forms that must compute the same update: the default (rows read in place through the permutation, both
+    nets in every launch on one stream, ONE optimizer launch that takes the gradient norm from the slab sums' partial sums of squares and refreshes the bf16
+    weight planes itself), PPO_KERNEL_GENERIC_CLASSIC (gathered copies, one net per launch on two streams, loss sums / norm / AdamW / planes as four launches)
+    and the multi-rank form driven on one GPU by PPO_KERNEL_COMM_SELFTEST (paired launches, the loss sums riding the gradient's all-reduce, norm kernel).
+    Same product kernels and the same partition of every partial sum: after a whole iteration (eight optimizer steps) at a shape the fused kernels take (hidden 256, obs padded
+    to 128-column blocks) the parameters agree to float rounding -- the one thing that differs is the ORDER in which the norm's partial sums are added."""
+    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=376, head_dims=(3, 3, 3, 2), hidden=256, n_hidden=4, num_envs=64, num_steps=32,
+              num_minibatches=4, update_epochs=2, max_episode_steps=50, seed=21, total_timesteps=64 * 32 * 4, learning_rate=3e-4, ent_coef=0.01,
+              compute_dtype=P.DTYPE_BF16)
+    got = {}
+    for name, flags, comm in (("default", 0, False), ("classic", P.KERNEL_GENERIC_CLASSIC, False), ("multi-rank path", P.KERNEL_COMM_SELFTEST, True)):
+        ctx = P.Context(P.make_config(kernel_flags=flags, **kw))
+        if comm:
+            ctx.comm_init(P.comm_unique_id(), 0, 1)
+        ctx.init_orthogonal(5)
+        ctx.env_reset()
+        ctx.train_iteration()   # ONE iteration: the rollout is the same kernel on the same parameters in all three; a second one would sample from parameters a rounding apart
+        st = ctx.stats()
+        got[name] = (ctx.get_params(), st["loss"], st["approx_kl"], ctx.read("LOGPROBS"))
+        assert np.isfinite(got[name][0]).all() and st["optimizer_steps"] == 8, name
+        ctx.close()
+    p0 = got["default"][0]
+    scale = np.abs(p0).max()
+    for name in ("classic", "multi-rank path"):
+        p1 = got[name][0]
+        assert np.abs(p1 - p0).max() <= 2e-6 * scale, (name, np.abs(p1 - p0).max(), scale)
+        assert abs(got[name][1] - got["default"][1]) <= 1e-5 * max(1.0, abs(got["default"][1])), name
+        assert np.array_equal(bits(got[name][3]), bits(got["default"][3])), name   # the rollout's log-probs: the same launch
