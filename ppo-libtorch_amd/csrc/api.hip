@@ -567,6 +567,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
             g.ld_h = (GL.hidden + 127) / 128 * 128;
             const size_t RB = R + 128;
             CK(dalloc(c, &g.xin_bf, RB * g.ld_in0));
+            if (gen_rows_packable(GL)) CK(dalloc(c, &g.row_rec, (size_t)B * 8));
             CK(dalloc(c, &g.obs_bf, ((size_t)B + 128) * g.ld_in0));   // the rollout's observations as bf16, once per update (gen_fwd_bwd): 201 MB at 2048 x 128 x 384
             for (int net = 0; net < 2; net++)
                 for (int l = 0; l < GL.n_hidden; l++) CK(dalloc(c, &g.acts_bf[net][l], RB * g.ld_h));
@@ -1243,14 +1244,17 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         // a stand-alone step (whose caller may have rewritten the buffers) rounds them every time
         const bool in_place = !classic && g.bf16 && g.obs_bf && gen_fused_forward_ok(g) && gen_fused_backward_ok(g) && M <= GEN_FUSED_MAX_ROWS;
         g.rows_idx = nullptr;
+        g.rows_rec = nullptr;
         if (in_place) {
+            g.rows_src = GenRowSrc{ B_<int32_t>(c, PPO_BUF_ACTIONS), c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
+                                    B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES) };
             if (!c->gen_obs_bf_valid) {
                 HIPCHK(c, launch_to_bf16_pad(B_<float>(c, PPO_BUF_OBS), c->B, GL.obs, g.obs_bf, g.ld_in0, c->stream));
+                if (g.row_rec) HIPCHK(c, gen_pack_rows(GL, g.rows_src, c->B, g.row_rec, c->stream));
                 c->gen_obs_bf_valid = c->wr_in_update;
             }
             g.rows_idx = idx;
-            g.rows_src = GenRowSrc{ B_<int32_t>(c, PPO_BUF_ACTIONS), B_<uint8_t>(c, PPO_BUF_MASKS), B_<float>(c, PPO_BUF_LOGPROBS), B_<float>(c, PPO_BUF_ADVANTAGES),
-                                    B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES) };
+            g.rows_rec = reinterpret_cast<const float4*>(g.row_rec);
         } else if (two && c->gen_pre_idx == idx && c->gen_pre_M == M) {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gather, 0));   // gathered ahead by the step before
         } else {

@@ -91,6 +91,8 @@ struct GenericCtx {
     uint16_t* obs_bf = nullptr;
     mutable const int32_t* rows_idx = nullptr;
     mutable GenRowSrc rows_src{};
+    float* row_rec = nullptr;                       // [T N][8] one 32-byte record of per-row scalars per sample (gen_pack_rows, once per update; gen_rows_packable shapes)
+    mutable const float4* rows_rec = nullptr;       // = row_rec for a step whose records are valid, else null: the loss kernel then indexes rows_src's arrays
     uint16_t* acts_bf[2][GEN_MAX_LAYERS] = {};   // [net][l] [.][ld_h] kept activations of a minibatch step
     uint16_t* tmp_bf[2] = {};      // [.][ld_h] ping-pong activations of a forward pass that keeps nothing (rollout step, critic batch)
     uint16_t* dz_bf[2][2] = {};    // [net][.] [.][ld_h] ping-pong d(pre-activation); one pair per net: the two backward passes run on two streams
@@ -170,6 +172,9 @@ hipError_t gen_gather(const GenLayout& L, const float* obs, const int32_t* actio
                       const float* ret, const float* values, const int32_t* idx, int64_t M, GenericCtx& g, hipStream_t s);
 hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& g, int64_t M, double inv_global_M, double global_M,
                     const AdvStat* adv_stat, hipStream_t s);
+// the per-row scalars of all T N samples as one 32-byte record each (the loss kernel of an in-place step reads one record per row)
+bool gen_rows_packable(const GenLayout& L);
+hipError_t gen_pack_rows(const GenLayout& L, const GenRowSrc& src, int64_t B, float* rec, hipStream_t s);
 // beside_other_net: the other net's backward pass runs at the same time on another stream (the fused launches then size themselves for half the chip)
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
                         hipStream_t s, bool beside_other_net = false);

@@ -202,13 +202,28 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
 // them to scratch memory (416 B per thread; 41 us for 65 536 rows).  Here the loops over heads (NH) and logits (AM) have compile-time bounds and a
 // logit takes part in a head's pass when `off <= k < off + A` -- wave-uniform predicates.  Same operations in the same order per row as
 // categorical_head_fast + loss_kernel, so both give the same bits.
+// One 32-byte record per sample for the loss kernel of a step that reads its rows in place (once per update, with the bf16 observations):
+// { old log-prob, advantage, return, old value | actions (8 bits per head), mask bits (1 = valid; all ones without masks), 0, 0 }.  Needs <= 4 heads of <= 256 actions
+// and <= 32 logits (gen_rows_packable).
+__global__ __launch_bounds__(256) void pack_rows_kernel(GenLayout L, const int32_t* __restrict__ actions, const uint8_t* __restrict__ masks,
+                                                       const float* __restrict__ logprobs, const float* __restrict__ adv, const float* __restrict__ ret,
+                                                       const float* __restrict__ values, int64_t B, float4* __restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    uint32_t ab = 0u, mb = 0xffffffffu;
+    for (int h = 0; h < L.n_heads; h++) ab |= ((uint32_t)actions[i * L.n_heads + h] & 0xffu) << (8 * h);
+    if (masks) { mb = 0u; for (int k = 0; k < L.act; k++) mb |= (masks[i * L.act + k] ? 1u : 0u) << k; }
+    rec[2 * i] = make_float4(logprobs[i], adv[i], ret[i], values[i]);
+    rec[2 * i + 1] = make_float4(__builtin_bit_cast(float, ab), __builtin_bit_cast(float, mb), 0.0f, 0.0f);
+}
+
 template <int DIST, int NH, int AM>
 __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams hp, const float* __restrict__ logits, const float* __restrict__ val,
                                                        const int32_t* __restrict__ row_act, const uint8_t* __restrict__ row_mask,
                                                        const float* __restrict__ oldlp, const float* __restrict__ advs, const float* __restrict__ rets,
                                                        const float* __restrict__ oldv, int64_t M, float invM, const AdvStat* __restrict__ adv_stat,
                                                        double global_M, double* loss_part, uint16_t* dlogits_bf, uint16_t* dval_bf, float* head_db_part,
-                                                       const int32_t* __restrict__ idx) {
+                                                       const int32_t* __restrict__ idx, const float4* __restrict__ rec) {
     // idx != nullptr: row_act / row_mask / oldlp / advs / rets / oldv are the rollout's own arrays and row r of the minibatch is their row idx[r] (no gathered copies)
     __shared__ double red[5][4];
     __shared__ float sdb[4][AM + 1];
@@ -235,16 +250,30 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
         const int64_t q = idx ? (int64_t)idx[r] : r;   // the row of the per-sample arrays
         // everything the row needs is requested here, behind the index: one more memory round trip for the thread, not one per head (a thread is a row and a CU
         // holds four waves of this kernel: nothing else hides a load that is issued where it is used)
+        // rec != nullptr: ONE 32-byte record per sample holds all of it (pack_rows_kernel, once per update): { old log-prob, advantage, return, old value,
+        // actions (8 bits per head), mask bits } -- a single gathered load per row instead of six 4-byte ones + the action and mask bytes (each a sector of its own)
         int acts[NH];
+        float in_oldlp, in_adv, in_ret, in_oldv;
+        uint32_t mask_bits = 0xffffffffu;
+        if (rec) {
+            const float4 r0 = rec[2 * q], r1 = rec[2 * q + 1];
+            in_oldlp = r0.x; in_adv = r0.y; in_ret = r0.z; in_oldv = r0.w;
+            const uint32_t ab = __builtin_bit_cast(uint32_t, r1.x);
+            mask_bits = __builtin_bit_cast(uint32_t, r1.y);
 #pragma unroll
-        for (int h = 0; h < NH; h++) acts[h] = h < n_heads ? row_act[q * n_heads + h] : 0;
-        const float in_oldlp = oldlp[q], in_adv = advs[q], in_ret = rets[q], in_oldv = oldv[q], in_val = val[r];
+            for (int h = 0; h < NH; h++) acts[h] = h < 4 ? (int)((ab >> (8 * h)) & 0xffu) : 0;
+        } else {
+#pragma unroll
+            for (int h = 0; h < NH; h++) acts[h] = h < n_heads ? row_act[q * n_heads + h] : 0;
+            in_oldlp = oldlp[q]; in_adv = advs[q]; in_ret = rets[q]; in_oldv = oldv[q];
+        }
+        const float in_val = val[r];
         float z[AM], p[AM];
         bool ok[AM];
 #pragma unroll
         for (int k = 0; k < AM; k++) {
             z[k] = k < act ? logits[r * act + k] : 0.0f;
-            ok[k] = !masked || (k < act && row_mask[q * act + k] != 0);
+            ok[k] = !masked || (k < act && (rec ? ((mask_bits >> k) & 1u) != 0 : row_mask[q * act + k] != 0));
             if (masked && !ok[k]) z[k] = -1e8f;
             p[k] = 0.0f;
         }
@@ -821,6 +850,18 @@ __global__ void adv_finish_kernel(const AdvStat* adv_stat, double global_M, int 
 }
 }  // namespace
 
+bool gen_rows_packable(const GenLayout& L) {
+    if (L.n_heads > 4 || L.act > 32) return false;
+    for (int h = 0; h < L.n_heads; h++) if (L.head_dims[h] > 256) return false;
+    return true;
+}
+hipError_t gen_pack_rows(const GenLayout& L, const GenRowSrc& src, int64_t B, float* rec, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, L, src.actions, src.masks, src.logprobs, src.adv, src.ret, src.values, B,
+                       reinterpret_cast<float4*>(rec));
+    return hipGetLastError();
+}
+
 hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& g, int64_t M, double inv_global_M, double global_M,
                     const AdvStat* adv_stat, hipStream_t s) {
     const dim3 grid(GEN_LOSS_BLOCKS), block(256);
@@ -833,7 +874,7 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
         hipLaunchKernelGGL((loss_reg_kernel<DIST, NH, AM>), grid, block, 0, s, L, hp, g.logits, g.val, direct ? R.actions : g.row_act, mask,              \
                            direct ? R.logprobs : g.row_f[0], direct ? R.adv : g.row_f[1], direct ? R.ret : g.row_f[2], direct ? R.values : g.row_f[3], M,   \
                            (float)inv_global_M, (adv_stat && hp.norm_adv) ? adv_stat : nullptr, global_M, g.loss_part, g.dout_bf[1], g.dout_bf[0],      \
-                           g.head_db_part, g.rows_idx)
+                           g.head_db_part, g.rows_idx, direct ? g.rows_rec : nullptr)
         const bool small = L.n_heads <= 4 && L.act <= 16;
         if (hp.dist_kind == PPO_DIST_MASKED) { if (small) GEN_LOSS_REG(PPO_DIST_MASKED, 4, 16); else GEN_LOSS_REG(PPO_DIST_MASKED, PPO_MAX_HEADS, PPO_MAX_ACT); }
         else { if (small) GEN_LOSS_REG(PPO_DIST_CATEGORICAL, 4, 16); else GEN_LOSS_REG(PPO_DIST_CATEGORICAL, PPO_MAX_HEADS, PPO_MAX_ACT); }

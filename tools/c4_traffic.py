@@ -26,7 +26,7 @@ for row in csv.DictReader(open(sys.argv[2])):
         out.append(ch)
     calls["".join(out).strip()] = int(row["Calls"])
 STEPS = 280
-AMORTIZED = ("to_bf16_pad_kernel",)   # once per update, for the update's steps
+AMORTIZED = ("to_bf16_pad_kernel", "pack_rows_kernel")   # once per update, for the update's steps
 step, per_iter = {}, {}
 for k, v in pmc.items():
     if "hbm_read_bytes" not in v or k not in calls:
