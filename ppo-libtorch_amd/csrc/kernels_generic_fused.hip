@@ -75,10 +75,11 @@ __device__ __forceinline__ void load_btail(BFrags& b, const FusedNet& f, int l, 
 }
 
 template <int FM>
-__device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0, uint16_t* tile1, float* s_out, uint16_t* const* keep, int64_t ld_keep, int64_t row0,
-                                             int n_rows, BFrags& pre, unsigned int* dbg = nullptr) {
+__device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off0, uint16_t* tile0, uint16_t* tile1, float* s_out, uint16_t* const* keep, int64_t ld_keep,
+                                             int64_t row0, int n_rows, BFrags& pre, unsigned int* dbg = nullptr) {
     // `pre` holds, on entry, the fragments of (layer 0, column block = wave, k steps 0 ..) -- requested by the caller, e.g. while the input tile
-    // was still being written -- and on exit those of layer 0 again (for the next call): a layer's first fragments are always requested
+    // was still being written -- and on exit those of layer 0 of the net of the NEXT call, whose offset into the fragment array is next_off0
+    // (the same net's, or the other net's when a workgroup runs both nets on every tile; a scalar, not a reference chosen at run time: that sends the argument struct to scratch): a layer's first fragments are always requested
     // before the epilogue and the barrier of the layer above, so their trip to L2 is never waited for with nothing else to do.
     const GenLayout& L = f.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, uint16_t* tile0,
             // the wave's last pass of this layer: the next layer's first fragments are requested now -- by a wave with an epilogue to do in four
             // pieces spread over it (sixteen loads in a row from all eight waves fill the CU's load queue: ~1 200 cycles of issue stall each)
             const bool pf_next = cb + FU_WAVES >= nblk;
-            const uint16_t* nblkp = f.wfrags + f.wp_off[ln] + ((int64_t)wave * (f.wp_kpad[ln] / 16) * 64 + lane) * 8;
+            const uint16_t* nblkp = f.wfrags + (last ? next_off0 : f.wp_off[ln]) + ((int64_t)wave * (f.wp_kpad[ln] / 16) * 64 + lane) * 8;   // (layer widths are the same in both nets)
             auto next_piece = [&](int pc) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) pre.q[4 * pc + j] = *reinterpret_cast<const u32x4*>(nblkp + (int64_t)(4 * pc + j) * 512);
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_rollout_kernel(const Fu
     for (int t = 0; t < a.T; t++) {
         const int64_t step = a.step_base + t;
         const size_t tn = (size_t)t * a.N;
-        fused_layers<1>(a.f, tile0, tile1, s_out, nullptr, 0, 0, 32, pre);   // ends with a barrier: logits in s_out, tile0 free again
+        fused_layers<1>(a.f, a.f.wp_off[0], tile0, tile1, s_out, nullptr, 0, 0, 32, pre);   // ends with a barrier: logits in s_out, tile0 free again
         if (wave != 0) {
             const bool more = t + 1 < a.T;   // the observation the agent sees next: row t + 1 of the buffers, or NEXT_OBS / the current mask after the last step
             observe(step + 1, more ? a.obs + (tn + a.N) * O : a.next_obs, more ? (a.masks ? a.masks + (tn + a.N) * A : nullptr) : a.cur_mask, (t + 1) & 1, 64, FU_THREADS - 64);
@@ -373,7 +374,8 @@ template <bool BF> constexpr int fu_np() { return BF ? 6 : 12; }
 typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 // Two passes in one launch (the two nets over the same rows): workgroups [0, split) run a[0], the rest a[1] -- the second pass's workgroups take the CUs
 // the first pass's leave, with no kernel boundary and no second stream between them.  split == gridDim.x: one pass.
-struct FusedForwardPair { FusedForwardArgs a[2]; int split; };
+// dual: every workgroup runs BOTH passes on each of its tiles -- the input tile is fetched and staged from the same registers twice, read from memory once.
+struct FusedForwardPair { FusedForwardArgs a[2]; int split; int dual; };
 template <bool BF>
 __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardPair pp) {
     const int second = (int)blockIdx.x >= pp.split ? 1 : 0;
@@ -438,25 +440,32 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
     // both tiles start as zeros: columns no layer ever writes are read against zero weights and must hold finite numbers
     for (int e = tid; e < 2 * RB * a.f.ldA / 8; e += FU_THREADS) { const u32x4 z = { 0u, 0u, 0u, 0u }; reinterpret_cast<u32x4*>(fu_lds)[e] = z; }
     __syncthreads();
-    const int N = L.out_dim[a.f.net][L.n_layers - 1];
+    // dual: both passes on every tile, as an inner loop over the argument sets (ONE inlined copy of the layers; two call sites spilled 73 registers)
+    const int npass = pp.dual ? 2 : 1;
     for (; tile < n_tiles; tile += nblk) {
         const int64_t row0 = tile * RB;
         const int n_rows = a.rows - row0 < RB ? (int)(a.rows - row0) : RB;
-        unsigned int* dbg = nullptr;
+        for (int pass = 0; pass < npass; pass++) {
+            const FusedForwardArgs& x = pp.a[pp.dual ? pass : second];
+            const int64_t next_off0 = pp.a[pp.dual ? (pass ^ 1) : second].f.wp_off[0];   // whose layer 0 comes next: the other net's (same tile, or the next tile's first pass), or this net's
+            unsigned int* dbg = nullptr;
 #ifdef FU_DBG_STAMPS
-        if (bid == 0 && tile == nblk) dbg = reinterpret_cast<unsigned int*>(a.out + a.rows);   // the probe allocates 64 spare outputs
+            if (bid == 0 && tile == nblk && pass == 0) dbg = reinterpret_cast<unsigned int*>(a.out + a.rows);   // the probe allocates 64 spare outputs
 #endif
-        FU_STAMP(0);
-        stage(tile);                  // tile0 is free: the previous tile's last layer ended with a barrier
-        FU_STAMP(1);
-        fetch(tile + nblk);
-        fetch_index(tile + 2 * nblk);
-        FU_STAMP(2);
-        __syncthreads();
-        FU_STAMP(3);
-        fused_layers<FM>(a.f, tile0, tile1, s_out, a.keep, a.ld_keep, row0, n_rows, pre, dbg);
-        for (int e = tid; e < n_rows * N; e += FU_THREADS) a.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];
-        FU_STAMP(30);
+            FU_STAMP(0);
+            // tile0 is free: the previous pass's last layer ended with a barrier.  The second pass stages the tile again from the registers it was fetched into (the
+            // layers have overwritten it); only behind the last pass's staging do those registers take the next tile
+            stage(tile);
+            FU_STAMP(1);
+            if (pass == npass - 1) { fetch(tile + nblk); fetch_index(tile + 2 * nblk); }
+            FU_STAMP(2);
+            __syncthreads();
+            FU_STAMP(3);
+            fused_layers<FM>(x.f, next_off0, tile0, tile1, s_out, x.keep, x.ld_keep, row0, n_rows, pre, dbg);
+            const int N = L.out_dim[x.f.net][L.n_layers - 1];
+            for (int e = tid; e < n_rows * N; e += FU_THREADS) x.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];   // (s_out is written again four barriers from here)
+            FU_STAMP(30);
+        }
     }
 }
 
@@ -531,8 +540,13 @@ hipError_t gen_fused_forward_both(const GenericCtx& g, const float* params, cons
     pp.a[1] = fused_forward_args(g, params, 0, nullptr, x_bf, ld_x, rows, true, val, idx);
     const int64_t n_tiles = (rows + 63) / 64;
     const unsigned per = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+#ifdef FU_AB_TWO_HALVES   // A/B build: the actor's workgroups, then the critic's (each fetching its own copy of the rows)
     pp.split = (int)per;
     return fused_forward_launch(pp, 2 * per, true, s);
+#else
+    pp.split = (int)per; pp.dual = 1;   // every workgroup runs both nets on each of its tiles: the rows are fetched once
+    return fused_forward_launch(pp, per, true, s);
+#endif
 }
 
 hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,
