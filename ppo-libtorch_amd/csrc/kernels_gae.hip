@@ -441,7 +441,11 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     // Strip width: wide strips coalesce better (EPB*4-byte rows), narrow strips give more workgroups.  Keep >= ~2 per CU.
     // Strip width, measured on MI355X (tools/gae_sweep.py): 32 columns (48 KB of LDS, three workgroups per CU overlapping their
     // load / walk / store phases) is best from 32 768 envs up (4.5 TB/s); below ~8 192 envs 16 columns give every CU a workgroup.
+#ifdef GAE_EPB64_FROM   /* exploration builds: 64-column strips (96 KB of LDS: one workgroup per CU) from this many envs -- measured at 131 072 / 2^20 envs: 2.88 / 2.88 TB/s against 4.34 / 4.06 */
+    const int epb = N >= GAE_EPB64_FROM ? 64 : (N >= 8192 ? 32 : 16);
+#else
     const int epb = N >= 8192 ? 32 : 16;
+#endif
 #ifndef GAE_NO_TIME_PIPELINE   /* -DGAE_NO_TIME_PIPELINE: the three-phase kernel at every size (A/B) */
     // Whole tiles, whole strips, and a grid of about one workgroup per CU: the kernel pipelined in time (same bits).  Measured in trace, builds alternated in
     // one call, two rounds (three-phase | 16 columns x 2 groups | 16 x 4 | 32 x 2 | 32 x 4, us): 4096 envs 4.86 - 5.12 | 4.37 - 4.71 | 4.27 - 4.57 | 4.65 - 4.97 |
