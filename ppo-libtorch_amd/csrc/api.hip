@@ -1534,7 +1534,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         if (sharded) s = allreduce_sum(c, c->gstats, (size_t)PPO_GSTAT_DOUBLES + (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         else s = allreduce_sum(c, c->adv_stats, (size_t)2 * E * nmb * PPO_ADV_PARTS, true);
         if (s != PPO_OK) return s;
-        HIPCHK(c, launch_adv_norm(c->adv_stats, E * nmb, nmb, c->B, c->MB, 0, c->world, c->adv_norm, c->stream));
+        HIPCHK(c, launch_adv_norm(c->adv_stats, E * nmb, nmb, c->B, c->MB, 0, c->world, c->adv_norm, c->stream, c->clipfrac_accum));   // also: m_clipfracs reset, :564
     } else {
         s = ppo_generate_permutations(c);
         if (s != PPO_OK) return s;
@@ -1555,7 +1555,7 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->adam_coefs, h, (size_t)E * nmb * sizeof(AdamCoef), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipEventRecord(c->coef_copied[half], c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->clipfrac_accum, 0, 2 * sizeof(double), c->stream));  // m_clipfracs reset, :564
+    if (!c->cfg.norm_adv) HIPCHK(c, hipMemsetAsync(c->clipfrac_accum, 0, 2 * sizeof(double), c->stream));  // m_clipfracs reset, :564 (with norm_adv: cleared by the adv_norm launch above)
     c->gen_pre_idx = nullptr;   // nothing gathered ahead survives an update (an error return may have left a claim behind)
     int k = 0;
     for (int e = 0; e < E; e++) {

@@ -1169,8 +1169,9 @@ hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* st
 // One thread per minibatch slot: the PPO_ADV_PARTS partial sums in order, then mean and Bessel std in binary64 as the update kernels used to do in
 // every launch (32 dependent scalar loads behind the weight loads: ~2 us of the actor's prologue, 40 times per update).
 __global__ void adv_norm_kernel(const AdvStat* __restrict__ stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world,
-                                float4* __restrict__ out) {
+                                float4* __restrict__ out, double* zero2) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && zero2) { zero2[0] = 0.0; zero2[1] = 0.0; }   // the update's clip-fraction accumulator (m_clipfracs reset, PPO_Discrete.cpp:564): a memset launch less
     if (k >= n) return;
     double t1 = 0.0, t2 = 0.0;
     for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += stats[(size_t)k * PPO_ADV_PARTS + i].s1; t2 += stats[(size_t)k * PPO_ADV_PARTS + i].s2; }
@@ -1183,9 +1184,9 @@ __global__ void adv_norm_kernel(const AdvStat* __restrict__ stats, int n, int pe
     const float std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
     out[k] = make_float4(mean_f, 1.0f / (std_f + 1e-8f), std_f, 0.0f);
 }
-hipError_t launch_adv_norm(const AdvStat* stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world, float4* out, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(adv_norm_kernel, dim3((n + 63) / 64), dim3(64), 0, s, stats, n, per_epoch > 0 ? per_epoch : 1, B, MB, explicit_M, world, out);
+hipError_t launch_adv_norm(const AdvStat* stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world, float4* out, hipStream_t s, double* zero2) {
+    if (n <= 0) return zero2 ? hipMemsetAsync(zero2, 0, 2 * sizeof(double), s) : hipSuccess;
+    hipLaunchKernelGGL(adv_norm_kernel, dim3((n + 63) / 64), dim3(64), 0, s, stats, n, per_epoch > 0 ? per_epoch : 1, B, MB, explicit_M, world, out, zero2);
     return hipGetLastError();
 }
 

@@ -79,7 +79,9 @@ struct LossParams {
 
 // Per-minibatch advantage statistics (sum, sum of squares over the GLOBAL minibatch) and the scalars derived from them.
 struct AdvStat { double s1, s2; };
+#ifndef PPO_ADV_PARTS
 #define PPO_ADV_PARTS 32  // partial sums per minibatch (one workgroup each), added in order by the consumer (A/B on one box, tools/ab.sh: 32 parts 56.7 us per update launch and 161.7 M env-steps/s, 8 parts 57.9 us and 158.5 M)
+#endif
 #define PPO_EV_BLOCKS 512 // partial rows of the explained-variance sums, added in order by the host
 // Job-global statistics block of a sharded run (doubles; summed over ranks by the per-update all-reduce, every rank writes only its own slot, so the
 // "sum" is a gather): the reference prints ONE table for the job (PPO_Discrete.cpp:474-480, 647-648, 700-774), so every rank must hold the same numbers.
@@ -649,7 +651,8 @@ hipError_t launch_permutations(int32_t* perm, int64_t B, int E, int64_t seed, in
 // the two above in one pass (ppo_update with norm_adv): perm[e][j] and the advantage sums of every minibatch of the update
 // { mean, 1 / (std + 1e-8), std, 0 } of the advantages of minibatch slots [0, n) from their PPO_ADV_PARTS partial sums (PPO_Discrete.cpp:591-594); slot k is
 // minibatch k % per_epoch of an epoch (rows min(MB, B - start) x world), or explicit_M x world rows when explicit_M > 0
-hipError_t launch_adv_norm(const AdvStat* stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world, float4* out, hipStream_t s);
+// zero2 != nullptr: the launch also clears those two doubles (the update's clip-fraction accumulator)
+hipError_t launch_adv_norm(const AdvStat* stats, int n, int per_epoch, int64_t B, int64_t MB, int64_t explicit_M, int world, float4* out, hipStream_t s, double* zero2 = nullptr);
 hipError_t launch_permutations_adv_stats(const float* advantages, int32_t* perm, int64_t B, int E, int64_t MB, int64_t seed, int64_t update_index,
                                          int64_t rank_salt, AdvStat* out, hipStream_t s);
 hipError_t launch_explained_variance(const float* returns, const float* values, int64_t B, double* sums4, hipStream_t s);
