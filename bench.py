@@ -706,9 +706,9 @@ def main():
         fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma"
         fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, pmc_traffic(GAE_EXACT_4096) if args.workload == "cartpole" else None
         if generic:
-            roof = {"kernel": "one minibatch step of the generic path (gather; per net ONE fused forward launch (generic_forward_kernel) and one fused backward launch "
-                              "per layer (bwd_layer_kernel: weight gradient + the gradient handed down from one LDS-DMA'd tile); heads + PPO loss; slab sums): bf16 "
-                              "operands and activations, f32 accumulation", "bound": "mfma",
+            roof = {"kernel": "one minibatch step of the generic path, both nets in every launch: ONE fused forward launch (generic_forward_kernel, rows read in place through the "
+                              "index list), heads + PPO loss, one fused backward launch per layer (bwd_layer_kernel: weight gradient + the gradient handed down from one LDS-DMA'd "
+                              "tile), slab sums; the optimizer launch is outside the bracket: bf16 operands and activations, f32 accumulation", "bound": "mfma",
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
                     # HBM bytes of one minibatch step: the committed --pmc measurement of this workload (tools/collect_profiles.sh, tools/c4_traffic.py)
