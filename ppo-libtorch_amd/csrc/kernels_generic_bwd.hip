@@ -97,6 +97,13 @@ __device__ __forceinline__ void bw_glds16(const uint16_t* src, uint16_t* lds_wav
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
+// The same with the source as a wave-uniform base (SGPR pair) + a 32-bit byte offset per lane: no 64-bit address arithmetic on the vector ALU per instruction.
+__device__ __forceinline__ void bw_glds16_s(const uint16_t* sbase, uint32_t voff_bytes, uint16_t* lds_wave_base) {
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(dst) : "memory");
+}
+
 // MFMA operand fragment by TRANSPOSING reads out of an image [k rows][W columns]: lane (i = lane & 31, kg = lane >> 5) receives column x0 + i of the
 // eight rows 16 ks + 8 kg .. + 7.  Lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 (see kernels_gemm.hip: frag).
 template <int W, bool DZ>
@@ -108,6 +115,24 @@ __device__ __forceinline__ u32x4 frag_tr(const uint16_t* img, int x0, int ks, in
     const uint2 lo = bw_read_tr16(img + r * W + ((chunk ^ f0) << 3) + within);
     const uint2 hi = bw_read_tr16(img + (r + 4) * W + ((chunk ^ f1) << 3) + within);
     const u32x4 v = { lo.x, lo.y, hi.x, hi.y };
+    return v;
+}
+
+// The two element offsets of frag_tr's reads at k step 0 (a k step further is 16 rows further: both swizzles repeat with period 16 in the row, so the offset of k step
+// ks is this + 16 ks W -- an immediate).  Computed ONCE per launch: formed inside the tile loop, the swizzle arithmetic of the 32 transposing reads of a tile was 230
+// vector instructions per wave and tile against 16 MFMAs (counters: 15.4 M vector-ALU instructions per launch, the vector ALU 40 % busy).
+template <int W, bool DZ>
+__device__ __forceinline__ void frag_off(int x0, int lane, int& lo, int& hi) {
+    const int r = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int col = x0 + 16 * ((lane & 31) >> 4) + 4 * (lane & 3);
+    const int chunk = col >> 3, within = col & 7;
+    const int f0 = DZ ? swz_d<W / 8>(r) : swz_h(r), f1 = DZ ? swz_d<W / 8>(r + 4) : swz_h(r + 4);
+    lo = r * W + ((chunk ^ f0) << 3) + within;
+    hi = (r + 4) * W + ((chunk ^ f1) << 3) + within;
+}
+__device__ __forceinline__ u32x4 frag_at(const uint16_t* img, int lo, int hi) {
+    const uint2 a = bw_read_tr16(img + lo), b = bw_read_tr16(img + hi);
+    const u32x4 v = { a.x, a.y, b.x, b.y };
     return v;
 }
 
@@ -148,14 +173,6 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         const int64_t have = left <= 0 ? 0 : (left + BW_ROWS - 1) / BW_ROWS;
         if (have < n_tiles) n_tiles = (int)have;
     }
-#ifdef BW_PHASE_SHIFT
-    // the second net's workgroups walk their range from its middle (wrapping): the two nets' workgroups, launched together and running in step, would otherwise ask
-    // for the same offsets of their (equally laid out) buffers at the same moments
-    const int t_off = second ? n_tiles / 2 : 0;
-#else
-    const int t_off = 0;
-#endif
-    auto tile_of = [&](int t) { int u = t + t_off; if (u >= n_tiles && t < n_tiles) u -= n_tiles; return u; };
     const int li = lane & 31, kg = lane >> 5;
     const bool p1_wave = P1 && wave < 4;
     const int cb1 = wave & 1, rb1 = (wave >> 1) & 1;   // P1: the wave's 32 columns (of the block's 64) and 32 rows (of the tile's 64)
@@ -205,37 +222,58 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     // before the DMA that needs it and IN FRONT of that iteration's DMAs, so the counted wait at the end of the iteration -- all but the last VM_TILE
     // operations -- covers it; the wait statements carry the register as an operand, which keeps the address arithmetic behind them.
     auto load_index = [&](int t) -> int {
-        int64_t r = row_begin + (int64_t)tile_of(t) * BW_ROWS + ((64 * wave + lane) >> 3);
+        int64_t r = row_begin + (int64_t)t * BW_ROWS + ((64 * wave + lane) >> 3);
         if (r >= a.rows) r = a.rows - 1;
         int v;
         asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(a.idx + r) : "memory");
         return v;
     };
     const bool gathered = !P1 && a.idx != nullptr;
-    auto issue = [&](int t, int hsrc) {
-        const int64_t r0 = row_begin + (int64_t)tile_of(t) * BW_ROWS;
-        const int b = t % BW_RING;
+    // this lane's share of a tile's DMA, fixed for the launch: piece p = wave + 8 i of the dZ tile (lane j of piece p fetches the chunk whose swizzled place is 64 p + j)
+    // and one piece of each h image -- row within the tile, and the byte offset from the tile's first row
+    int d_row[DPW], h_row;
+    uint32_t d_off[DPW], h_off[KCB];
+#pragma unroll
+    for (int i = 0; i < DPW; i++) {
+        const int q = 64 * (wave + BW_WAVES * i) + lane;
+        d_row[i] = q / CPR;
+        d_off[i] = (uint32_t)(d_row[i] * (int)a.ldd + 8 * ((q % CPR) ^ swz_d<CPR>(d_row[i]))) * 2u;
+    }
+    {
+        const int q = 64 * wave + lane;
+        h_row = q >> 3;
+#pragma unroll
+        for (int k = 0; k < KCB; k++) h_off[k] = (uint32_t)(h_row * (int)a.ldh + BW_KC * (KCB * c + k) + 8 * ((q & 7) ^ swz_h(h_row))) * 2u;
+    }
+    auto issue = [&](int t, int b, int hsrc) {   // tile t into ring buffer b = t % BW_RING
+        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
         uint16_t* const dD = sD + b * DSZ;
         uint16_t* const dH = sH + b * HSZ;
+        const bool whole = r0 + BW_ROWS <= a.rows;   // wave-uniform: every row of the tile exists (all tiles but the minibatch's last)
+        const uint16_t* const dbase = a.d + r0 * a.ldd;   // wave-uniform bases: SGPR pair + the lane's 32-bit offset
+        const uint16_t* const hbase = a.h + r0 * a.ldh;
 #pragma unroll
         for (int i = 0; i < DPW; i++) {
             const int p = wave + BW_WAVES * i;
             const bool have = p < CPR;
-            const int q = 64 * p + lane, row = q / CPR, ch = (q % CPR) ^ swz_d<CPR>(row);
-            const uint16_t* src = have && r0 + row < a.rows ? a.d + (r0 + row) * a.ldd + 8 * ch : a.zeros;
-            bw_glds16(src, have ? dD + 512 * p : reinterpret_cast<uint16_t*>(sRed + 2 * BW_KC) + 512 * wave);
+            uint16_t* const dst = have ? dD + 512 * p : reinterpret_cast<uint16_t*>(sRed + 2 * BW_KC) + 512 * wave;
+            if (whole && have) bw_glds16_s(dbase, d_off[i], dst);
+            else bw_glds16(have && r0 + d_row[i] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i]) : a.zeros, dst);
         }
 #pragma unroll
         for (int k = 0; k < KCB; k++) {   // image k: columns 64 (KCB c + k) ..
-            const int q = 64 * wave + lane, row = q >> 3, ch = (q & 7) ^ swz_h(row);
-            const int64_t hrow = gathered ? (int64_t)hsrc : r0 + row;
-            const uint16_t* src = r0 + row < a.rows ? a.h + hrow * a.ldh + BW_KC * (KCB * c + k) + 8 * ch : a.zeros;
-            bw_glds16(src, dH + k * BW_ROWS * BW_KC + 512 * wave);
+            uint16_t* const dst = dH + k * BW_ROWS * BW_KC + 512 * wave;
+            if (whole && !gathered) bw_glds16_s(hbase, h_off[k], dst);
+            else {
+                const uint16_t* src = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k] - (uint32_t)(h_row * (int)a.ldh) * 2u))
+                                               : reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(hbase) + h_off[k]);
+                bw_glds16(r0 + h_row < a.rows ? src : a.zeros, dst);
+            }
         }
     };
     // the result tile of tile t leaves in 16-byte row pieces (rows past the minibatch are zeros: they keep the destination's padding zero)
     auto store_out = [&](int t) {
-        const int64_t r0 = row_begin + (int64_t)tile_of(t) * BW_ROWS;
+        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
         const int row = tid >> 3, ch = tid & 7;
         *reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch) =
             *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
@@ -255,18 +293,34 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             h0 = load_index(0); h1 = load_index(1); hs_next = load_index(2);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(hs_next) :: "memory");
         }
-        if (n_tiles > 0) issue(0, h0);
-        if (n_tiles > 1) issue(1, h1);
+        if (n_tiles > 0) issue(0, 0, h0);
+        if (n_tiles > 1) issue(1, 1, h1);
+    }
+    // lane-constant LDS offsets of everything the tile loop reads (elements; see frag_off)
+    int p1_rd[KS1], ep_at[4];          // P1: the row's 16-byte B fragments of dZ; the epilogue's 8-byte places in the h / result images
+    int a_lo[NBW], a_hi[NBW], h_lo[2 * KCB], h_hi[2 * KCB];   // P2: transposing reads of dZ (A) and h (B) at k step 0
+    {
+        const int row = 32 * rb1 + li, fd = swz_d<CPR>(row), fh = swz_h(row);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) p1_rd[ks] = row * N + (((2 * ks + kg) ^ fd) << 3);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ep_at[q] = row * BW_KC + (((4 * cb1 + q) ^ fh) << 3) + 4 * kg;
+#pragma unroll
+        for (int i = 0; i < NBW; i++) frag_off<N, true>(32 * ((pj < 0 ? 0 : pj) * NBW + i), lane, a_lo[i], a_hi[i]);
+#pragma unroll
+        for (int h = 0; h < 2 * KCB; h++) { frag_off<BW_KC, false>(32 * (h & 1), lane, h_lo[h], h_hi[h]); h_lo[h] += (h >> 1) * BW_ROWS * BW_KC; h_hi[h] += (h >> 1) * BW_ROWS * BW_KC; }
     }
     if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_TILE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
     bw_barrier();
+    int rb = 0;   // ring buffer of tile t (t % BW_RING, kept by rotation: no division in the loop)
     for (int t = 0; t < n_tiles; t++) {
-        const uint16_t* const tD = sD + (t % BW_RING) * DSZ;
-        const uint16_t* const tH = sH + (t % BW_RING) * HSZ;
+        const uint16_t* const tD = sD + rb * DSZ;
+        const uint16_t* const tH = sH + rb * HSZ;
+        const int rb2 = rb == 0 ? BW_RING - 1 : rb - 1;   // (t + 2) % 3
         int hs_load = 0;
         if (t + 2 < n_tiles) {                      // into the buffer every wave finished reading before the barrier that ended iteration t - 1
             if (gathered) hs_load = load_index(t + 3);
-            issue(t + 2, hs_next);
+            issue(t + 2, rb2, hs_next);
         }
         if constexpr (P1) { if (t > 0) store_out(t - 1); }
         if (p1_wave) {
@@ -274,26 +328,21 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             f32x16 acc1;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc1[r] = 0.0f;
-            const int row = 32 * rb1 + li;
-            const uint16_t* drow = tD + row * N;
-            const int fd = swz_d<CPR>(row);
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) {
-                const u32x4 bfr = *reinterpret_cast<const u32x4*>(drow + (((2 * ks + kg) ^ fd) << 3));
+                const u32x4 bfr = *reinterpret_cast<const u32x4*>(tD + p1_rd[ks]);
                 acc1 = bw_mfma(wfrag(ks), bfr, acc1);
             }
             // epilogue: register r <-> column 32 cb1 + (r & 3) + 8 (r >> 2) + 4 kg of the block; tanh' from the staged h, result to its own image
-            const int fh = swz_h(row);
             uint16_t* const tO = sO + (t & 1) * BW_ROWS * BW_KC;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int at = row * BW_KC + (((4 * cb1 + q) ^ fh) << 3) + 4 * kg;
-                const uint2 hv = *reinterpret_cast<const uint2*>(tH + at);
+                const uint2 hv = *reinterpret_cast<const uint2*>(tH + ep_at[q]);
                 const float h0 = bw_u2f(hv.x << 16), h1 = bw_u2f(hv.x & 0xffff0000u), h2 = bw_u2f(hv.y << 16), h3 = bw_u2f(hv.y & 0xffff0000u);
                 const float v0 = acc1[4 * q] * (1.0f - h0 * h0), v1 = acc1[4 * q + 1] * (1.0f - h1 * h1);
                 const float v2 = acc1[4 * q + 2] * (1.0f - h2 * h2), v3 = acc1[4 * q + 3] * (1.0f - h3 * h3);
                 csum[4 * q] += v0; csum[4 * q + 1] += v1; csum[4 * q + 2] += v2; csum[4 * q + 3] += v3;
-                *reinterpret_cast<uint2*>(tO + at) = make_uint2(bw_pack(v0, v1), bw_pack(v2, v3));
+                *reinterpret_cast<uint2*>(tO + ep_at[q]) = make_uint2(bw_pack(v0, v1), bw_pack(v2, v3));
             }
         } else if (pj >= 0 && pj * NBW < NB) {
             // ---- P2: dW[n][kcol] += dZ^T h over the tile's 64 rows (4 k steps): the wave's n blocks against every 32-column half of the workgroup's columns ----
@@ -301,12 +350,12 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             for (int ks = 0; ks < BW_ROWS / 16; ks++) {
                 u32x4 bf[2 * KCB];
 #pragma unroll
-                for (int h = 0; h < 2 * KCB; h++) bf[h] = frag_tr<BW_KC, false>(tH + (h >> 1) * BW_ROWS * BW_KC, 32 * (h & 1), ks, lane);
+                for (int h = 0; h < 2 * KCB; h++) bf[h] = frag_at(tH + 16 * ks * BW_KC, h_lo[h], h_hi[h]);
 #pragma unroll
                 for (int i = 0; i < NBW; i++) {
                     const int nb = pj * NBW + i;
                     if (nb < NB) {
-                        const u32x4 af = frag_tr<N, true>(tD, 32 * nb, ks, lane);
+                        const u32x4 af = frag_at(tD + 16 * ks * N, a_lo[i], a_hi[i]);
 #pragma unroll
                         for (int h = 0; h < 2 * KCB; h++)
                             st[2 * KCB * i + h] = __builtin_bit_cast(u32x16, bw_mfma(af, bf[h], __builtin_bit_cast(f32x16, st[2 * KCB * i + h])));
@@ -329,6 +378,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hs_load) :: "memory");
         }
         hs_next = hs_load;
+        rb = rb == BW_RING - 1 ? 0 : rb + 1;
         bw_barrier();
     }
     if constexpr (P1) { if (n_tiles > 0) store_out(n_tiles - 1); }
