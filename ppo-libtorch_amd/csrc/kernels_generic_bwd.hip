@@ -87,21 +87,23 @@ __device__ __forceinline__ void bw_barrier() {
 // tile), which drains the ring it is there to keep full.  An asm DMA is invisible to that bookkeeping: the only waits on the vector-memory counter in the
 // tile loop are the counted ones written there (the loop holds no compiler-visible load whose own wait the extra operations could make too short; its
 // stores are never waited for).  M0 = the destination's LDS byte address, saved and restored around the instruction (the compiler reserves M0).
-__device__ __forceinline__ void bw_glds16(const uint16_t* src, uint16_t* lds_wave_base) {
+// The destination is the LDS BYTE ADDRESS as an integer (bw_lds_addr of the array's start + offsets): handed over as a generic pointer, every instruction paid a
+// generic -> local conversion (null check, aperture base) and two v_readfirstlane on top of its address arithmetic.
+__device__ __forceinline__ uint32_t bw_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ void bw_glds16(const uint16_t* src, uint32_t dst) {
 #ifdef BW_GLDS_BUILTIN
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
     return;
 #endif
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)lds_wave_base);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);   // wave-uniform by construction (it depends on the wave's index): the compiler has to be told
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
 }
-
 // The same with the source as a wave-uniform base (SGPR pair) + a 32-bit byte offset per lane: no 64-bit address arithmetic on the vector ALU per instruction.
-__device__ __forceinline__ void bw_glds16_s(const uint16_t* sbase, uint32_t voff_bytes, uint16_t* lds_wave_base) {
-    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)lds_wave_base);
+__device__ __forceinline__ void bw_glds16_s(const uint16_t* sbase, uint32_t voff_bytes, uint32_t dst) {
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(d) : "memory");
 }
 
 // MFMA operand fragment by TRANSPOSING reads out of an image [k rows][W columns]: lane (i = lane & 31, kg = lane >> 5) receives column x0 + i of the
@@ -245,10 +247,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #pragma unroll
         for (int k = 0; k < KCB; k++) h_off[k] = (uint32_t)(h_row * (int)a.ldh + BW_KC * (KCB * c + k) + 8 * ((q & 7) ^ swz_h(h_row))) * 2u;
     }
+    const uint32_t lds0 = bw_lds_addr(bw_lds), spare0 = bw_lds_addr(sRed + 2 * BW_KC);
     auto issue = [&](int t, int b, int hsrc) {   // tile t into ring buffer b = t % BW_RING
         const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
-        uint16_t* const dD = sD + b * DSZ;
-        uint16_t* const dH = sH + b * HSZ;
+        const uint32_t dD = lds0 + (uint32_t)(b * DSZ) * 2u;                          // byte addresses in LDS (wave-uniform)
+        const uint32_t dH = lds0 + (uint32_t)(BW_RING * DSZ + b * HSZ) * 2u;
         const bool whole = r0 + BW_ROWS <= a.rows;   // wave-uniform: every row of the tile exists (all tiles but the minibatch's last)
         const uint16_t* const dbase = a.d + r0 * a.ldd;   // wave-uniform bases: SGPR pair + the lane's 32-bit offset
         const uint16_t* const hbase = a.h + r0 * a.ldh;
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         for (int i = 0; i < DPW; i++) {
             const int p = wave + BW_WAVES * i;
             const bool have = p < CPR;
-            uint16_t* const dst = have ? dD + 512 * p : reinterpret_cast<uint16_t*>(sRed + 2 * BW_KC) + 512 * wave;
+            const uint32_t dst = have ? dD + 1024u * p : spare0 + 1024u * wave;
             if (whole && have) bw_glds16_s(dbase, d_off[i], dst);
             else bw_glds16(have && r0 + d_row[i] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i]) : a.zeros, dst);
         }
 #pragma unroll
         for (int k = 0; k < KCB; k++) {   // image k: columns 64 (KCB c + k) ..
-            uint16_t* const dst = dH + k * BW_ROWS * BW_KC + 512 * wave;
+            const uint32_t dst = dH + (uint32_t)(k * BW_ROWS * BW_KC) * 2u + 1024u * wave;
             if (whole && !gathered) bw_glds16_s(hbase, h_off[k], dst);
             else {
                 const uint16_t* src = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k] - (uint32_t)(h_row * (int)a.ldh) * 2u))
