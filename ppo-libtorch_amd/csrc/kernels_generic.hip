@@ -398,6 +398,168 @@ __global__ __launch_bounds__(256) void loss_reg_kernel(GenLayout L, LossParams h
     }
 }
 
+// loss_reg_kernel for the shapes of a step that reads packed row records (rec, idx) with at most 4 heads of at most 4 logits (configs[4]: [3, 3, 3, 2]): the same
+// operations in the same order per row, but every per-head loop runs over the head's own <= 4 slots (compile-time indices, wave-uniform "slot exists" predicates)
+// instead of all AM logits under a per-element range test -- loss_reg_kernel<., 4, 16> is 5 500 instructions per row, three quarters of them predication,
+// selects and scalar-register spills, and a CU holds four waves of it: the kernel was bound by its own instruction stream (20 us).  The head gradients leave as
+// 2-byte stores at their columns; the columns between the policy's width and 32 are never written (zero since allocation), as the consumer expects.
+template <int DIST>
+__global__ __launch_bounds__(256) void loss_small_kernel(GenLayout L, LossParams hp, const float* __restrict__ logits, const float* __restrict__ val, int64_t M,
+                                                         float invM, const AdvStat* __restrict__ adv_stat, double global_M, double* loss_part, uint16_t* dlogits_bf,
+                                                         uint16_t* dval_bf, float* head_db_part, const int32_t* __restrict__ idx, const float4* __restrict__ rec) {
+    constexpr int NH = 4, W = 4;
+    __shared__ double red[5][4];
+    __shared__ float sdb[4][NH * W + 1];
+    float dbs[NH][W], dbv = 0.0f;
+#pragma unroll
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int j = 0; j < W; j++) dbs[h][j] = 0.0f;
+    double s[5] = { 0, 0, 0, 0, 0 };
+    float mean_f = 0.0f, std_f = 0.0f;
+    if (adv_stat) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += adv_stat[i].s1; t2 += adv_stat[i].s2; }
+        const double mean = t1 / global_M;
+        const double var = (t2 - t1 * mean) / (global_M - 1.0);
+        mean_f = (float)mean;
+        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+    }
+    const float inv_std = 1.0f / (std_f + 1e-8f);
+    const float clip = hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip;
+    const int act = L.act;
+    int A[NH], off[NH];   // wave-uniform: a head's width (0: no such head) and first column
+    {
+        int o = 0;
+#pragma unroll
+        for (int h = 0; h < NH; h++) { A[h] = h < L.n_heads ? L.head_dims[h] : 0; off[h] = o; o += A[h]; }
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < M; r += (int64_t)gridDim.x * 256) {
+        const int64_t q = (int64_t)idx[r];
+        const float4 r0 = rec[2 * q], r1 = rec[2 * q + 1];
+        const float in_oldlp = r0.x, in_adv = r0.y, in_ret = r0.z, in_oldv = r0.w, in_val = val[r];
+        const uint32_t ab = __builtin_bit_cast(uint32_t, r1.x), mask_bits = DIST == PPO_DIST_MASKED ? __builtin_bit_cast(uint32_t, r1.y) : 0xffffffffu;
+        float z[NH][W], p[NH][W];
+        bool ok[NH][W];
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                const bool in = j < A[h];
+                z[h][j] = in ? logits[r * act + off[h] + j] : 0.0f;
+                ok[h][j] = in && ((mask_bits >> (off[h] + j)) & 1u) != 0;
+                if (DIST == PPO_DIST_MASKED && in && !ok[h][j]) z[h][j] = -1e8f;
+                p[h][j] = 0.0f;
+            }
+        float nlp = 0.0f, ent = 0.0f, headH[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            headH[h] = 0.0f;
+            if (A[h] > 0) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < W; j++) if (j < A[h]) mx = z[h][j] > mx ? z[h][j] : mx;
+                float se = 0.0f;
+#pragma unroll
+                for (int j = 0; j < W; j++) if (j < A[h]) { p[h][j] = fast_exp(z[h][j] - mx); se += p[h][j]; }
+                const float lse = fast_log(se) + mx;
+                const float rse = __builtin_amdgcn_rcpf(se);
+                const int a = (int)((ab >> (8 * h)) & 0xffu);
+                float e = 0.0f, lp = 0.0f;
+#pragma unroll
+                for (int j = 0; j < W; j++) if (j < A[h]) {
+                    z[h][j] = z[h][j] - lse;
+                    p[h][j] = p[h][j] * rse;
+                    if (DIST == PPO_DIST_CATEGORICAL) {
+                        const float l = z[h][j] > 1.17549435e-38f ? z[h][j] : 1.17549435e-38f;
+                        e += l * p[h][j];
+                    } else {
+                        const float plp = z[h][j] * p[h][j];
+                        e += ok[h][j] ? plp : 0.0f;
+                    }
+                    if (j == a) lp = z[h][j];
+                }
+                headH[h] = -e;
+                if (h == 0) { nlp = lp; ent = headH[h]; } else { nlp += lp; ent += headH[h]; }
+            }
+        }
+        const float logratio = nlp - in_oldlp;
+        const float ratio = fast_exp(logratio);
+        float adv = in_adv;
+        if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
+        const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
+        const float l1 = -adv * ratio, l2 = -adv * rc;
+        const bool inside = (ratio >= lo && ratio <= hi_c);
+        float d_ratio;
+        if (l1 > l2) d_ratio = -adv;
+        else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+        else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half/half
+        const float g_nlp = invM * d_ratio * ratio;
+        const float g_ent = -hp.ent_coef * invM;
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int a = (int)((ab >> (8 * h)) & 0xffu);
+#pragma unroll
+            for (int j = 0; j < W; j++) if (j < A[h]) {
+                float d = g_nlp * ((j == a ? 1.0f : 0.0f) - p[h][j]);
+                if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[h][j] * (z[h][j] + headH[h]));
+                d = (DIST != PPO_DIST_MASKED || ok[h][j]) ? d : 0.0f;
+                const __bf16 b = (__bf16)d;
+                dlogits_bf[r * 128 + off[h] + j] = __builtin_bit_cast(uint16_t, b);
+                dbs[h][j] += d;
+            }
+        }
+        s[0] += (double)(l1 > l2 ? l1 : l2);
+        s[1] += (double)ent;
+        s[2] += (double)((ratio - 1.0f) - logratio);
+        s[3] += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
+        // value loss (:603-625)
+        const float v = in_val, R = in_ret, vold = in_oldv;
+        const float un = (v - R) * (v - R);
+        float g_v, lossv;
+        if (hp.clip_vloss) {
+            const float dv = v - vold;
+            const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+            const float vc = vold + dvc;
+            const float cl = (vc - R) * (vc - R);
+            lossv = un > cl ? un : cl;
+            const bool vin = (dv >= -clip && dv <= clip);
+            const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+            const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);
+            g_v = hp.vf_coef * 0.5f * invM * d;
+        } else {
+            lossv = un;
+            g_v = hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+        }
+        const __bf16 bv = (__bf16)g_v;
+        dval_bf[r * 128] = __builtin_bit_cast(uint16_t, bv);
+        dbv += g_v;
+        s[4] += (double)lossv;
+    }
+#pragma unroll
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int j = 0; j < W; j++)
+            if (j < A[h]) {
+                const float t = wave_sum(dbs[h][j]);
+                if ((threadIdx.x & 63) == 0) sdb[threadIdx.x >> 6][off[h] + j] = t;
+            }
+    {
+        const float t = wave_sum(dbv);
+        if ((threadIdx.x & 63) == 0) sdb[threadIdx.x >> 6][NH * W] = t;
+    }
+    for (int k = 0; k < 5; k++) {
+        const double t = wave_sum_d_dpp(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) loss_part[blockIdx.x * 8 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+    if ((int)threadIdx.x <= act) {   // head_db_part[block][0 .. act - 1] = d(logits) column sums, [act] = the d(value) sum
+        const int k = (int)threadIdx.x < act ? (int)threadIdx.x : NH * W;
+        head_db_part[blockIdx.x * (act + 1) + threadIdx.x] = ((sdb[0][k] + sdb[1][k]) + sdb[2][k]) + sdb[3][k];
+    }
+}
+
 __global__ __launch_bounds__(256) void loss_sums_kernel(const double* __restrict__ loss_part, int blocks, double* sums_out, float* grads_tail) {
     __shared__ double red[5][4];
     for (int k = 0; k < 5; k++) {
@@ -875,6 +1037,23 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
                            direct ? R.logprobs : g.row_f[0], direct ? R.adv : g.row_f[1], direct ? R.ret : g.row_f[2], direct ? R.values : g.row_f[3], M,   \
                            (float)inv_global_M, (adv_stat && hp.norm_adv) ? adv_stat : nullptr, global_M, g.loss_part, g.dout_bf[1], g.dout_bf[0],      \
                            g.head_db_part, g.rows_idx, direct ? g.rows_rec : nullptr)
+        {   // <= 4 heads of <= 4 logits behind packed row records: the slot-wise kernel
+            bool slots = direct && g.rows_rec != nullptr && L.n_heads <= 4;
+            for (int h = 0; h < L.n_heads; h++) slots = slots && L.head_dims[h] <= 4;
+#ifdef GEN_AB_LOSS_REG   // A/B build: the general kernel for every shape
+            slots = false;
+#endif
+            if (slots) {
+                const AdvStat* st = (adv_stat && hp.norm_adv) ? adv_stat : nullptr;
+                if (hp.dist_kind == PPO_DIST_MASKED)
+                    hipLaunchKernelGGL(loss_small_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, hp, g.logits, g.val, M, (float)inv_global_M, st, global_M, g.loss_part, g.dout_bf[1],
+                                       g.dout_bf[0], g.head_db_part, g.rows_idx, g.rows_rec);
+                else
+                    hipLaunchKernelGGL(loss_small_kernel<PPO_DIST_CATEGORICAL>, grid, block, 0, s, L, hp, g.logits, g.val, M, (float)inv_global_M, st, global_M, g.loss_part,
+                                       g.dout_bf[1], g.dout_bf[0], g.head_db_part, g.rows_idx, g.rows_rec);
+                return hipGetLastError();
+            }
+        }
         const bool small = L.n_heads <= 4 && L.act <= 16;
         if (hp.dist_kind == PPO_DIST_MASKED) { if (small) GEN_LOSS_REG(PPO_DIST_MASKED, 4, 16); else GEN_LOSS_REG(PPO_DIST_MASKED, PPO_MAX_HEADS, PPO_MAX_ACT); }
         else { if (small) GEN_LOSS_REG(PPO_DIST_CATEGORICAL, 4, 16); else GEN_LOSS_REG(PPO_DIST_CATEGORICAL, PPO_MAX_HEADS, PPO_MAX_ACT); }
