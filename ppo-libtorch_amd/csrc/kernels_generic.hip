@@ -441,12 +441,18 @@ __global__ __launch_bounds__(256) void loss_small_kernel(GenLayout L, LossParams
         const uint32_t ab = __builtin_bit_cast(uint32_t, r1.x), mask_bits = DIST == PPO_DIST_MASKED ? __builtin_bit_cast(uint32_t, r1.y) : 0xffffffffu;
         float z[NH][W], p[NH][W];
         bool ok[NH][W];
+        // all sixteen slots are requested unconditionally (a slot that does not exist re-reads the row's last logit): behind a per-slot branch the loads of a
+        // head left in a basic block of their own, each with its own wait -- one memory round trip per head for a thread nothing else covers
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int j = 0; j < W; j++) { const int k = off[h] + j; z[h][j] = logits[r * act + (k < act ? k : act - 1)]; }
 #pragma unroll
         for (int h = 0; h < NH; h++)
 #pragma unroll
             for (int j = 0; j < W; j++) {
                 const bool in = j < A[h];
-                z[h][j] = in ? logits[r * act + off[h] + j] : 0.0f;
+                z[h][j] = in ? z[h][j] : 0.0f;
                 ok[h][j] = in && ((mask_bits >> (off[h] + j)) & 1u) != 0;
                 if (DIST == PPO_DIST_MASKED && in && !ok[h][j]) z[h][j] = -1e8f;
                 p[h][j] = 0.0f;
