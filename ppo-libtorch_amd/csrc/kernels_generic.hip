@@ -566,6 +566,172 @@ __global__ __launch_bounds__(256) void loss_small_kernel(GenLayout L, LossParams
     }
 }
 
+// The slot-wise loss with FOUR LANES PER ROW -- lane (row, head) -- and 1024 threads per workgroup: a row's heads run side by side (each lane the <= 4 slots of its
+// head), the row's log-prob and entropy are added over the four lanes in head order (the order loss_reg_kernel adds them in), lane 0 of the row forms the ratio,
+// the policy gradient's scalars and the value loss, and every lane writes its own head's gradient.  A third of the instructions per lane and four times the waves:
+// with a row per thread a CU held four waves of this kernel and nothing covered a load or a transcendental (17.8 us for 65 536 rows).
+template <int DIST>
+__global__ __launch_bounds__(1024) void loss_lanes_kernel(GenLayout L, LossParams hp, const float* __restrict__ logits, const float* __restrict__ val, int64_t M,
+                                                          float invM, const AdvStat* __restrict__ adv_stat, double global_M, double* loss_part, uint16_t* dlogits_bf,
+                                                          uint16_t* dval_bf, float* head_db_part, const int32_t* __restrict__ idx, const float4* __restrict__ rec) {
+    constexpr int NH = 4, W = 4, WAVES = 16;
+    __shared__ double red[5][WAVES];
+    __shared__ float sdb[WAVES][NH * W + 1];
+    float dbs[W], dbv = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; j++) dbs[j] = 0.0f;
+    double s[5] = { 0, 0, 0, 0, 0 };
+    float mean_f = 0.0f, std_f = 0.0f;
+    if (adv_stat) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += adv_stat[i].s1; t2 += adv_stat[i].s2; }
+        const double mean = t1 / global_M;
+        const double var = (t2 - t1 * mean) / (global_M - 1.0);
+        mean_f = (float)mean;
+        std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+    }
+    const float inv_std = 1.0f / (std_f + 1e-8f);
+    const float clip = hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip;
+    const int act = L.act, n_heads = L.n_heads;
+    const int h = threadIdx.x & 3;                     // this lane's head
+    int A = 0, off = 0;
+#pragma unroll
+    for (int hh = 0; hh < NH; hh++) { const int a = hh < n_heads ? L.head_dims[hh] : 0; if (hh < h) off += a; if (hh == h) A = a; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + (threadIdx.x >> 2); r < M; r += (int64_t)gridDim.x * 256) {   // every row's four lanes take the same trips
+        const int64_t q = (int64_t)idx[r];
+        const float4 r0 = rec[2 * q], r1 = rec[2 * q + 1];
+        const uint32_t ab = __builtin_bit_cast(uint32_t, r1.x), mask_bits = DIST == PPO_DIST_MASKED ? __builtin_bit_cast(uint32_t, r1.y) : 0xffffffffu;
+        const float in_val = val[r];
+        float z[W], p[W];
+        bool ok[W];
+#pragma unroll
+        for (int j = 0; j < W; j++) { const int k = off + j; z[j] = logits[r * act + (k < act ? k : act - 1)]; }
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const bool in = j < A;
+            ok[j] = in && ((mask_bits >> (off + j)) & 1u) != 0;
+            z[j] = in ? ((DIST == PPO_DIST_MASKED && !ok[j]) ? -1e8f : z[j]) : -INFINITY;   // a slot that does not exist: exp -> 0, never the maximum
+            p[j] = 0.0f;
+        }
+        float lp = 0.0f, hH = 0.0f;
+        const int a = (int)((ab >> (8 * h)) & 0xffu);
+        if (A > 0) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < W; j++) if (j < A) mx = z[j] > mx ? z[j] : mx;
+            float se = 0.0f;
+#pragma unroll
+            for (int j = 0; j < W; j++) if (j < A) { p[j] = fast_exp(z[j] - mx); se += p[j]; }
+            const float lse = fast_log(se) + mx;
+            const float rse = __builtin_amdgcn_rcpf(se);
+            float e = 0.0f;
+#pragma unroll
+            for (int j = 0; j < W; j++) if (j < A) {
+                z[j] = z[j] - lse;
+                p[j] = p[j] * rse;
+                if (DIST == PPO_DIST_CATEGORICAL) {
+                    const float l = z[j] > 1.17549435e-38f ? z[j] : 1.17549435e-38f;
+                    e += l * p[j];
+                } else {
+                    const float plp = z[j] * p[j];
+                    e += ok[j] ? plp : 0.0f;
+                }
+                if (j == a) lp = z[j];
+            }
+            hH = -e;
+        }
+        // the row's sums in head order, on every lane of the row (the four lanes are consecutive): ((h0 + h1) + h2) + h3 over the heads that exist
+        const int base = lane & ~3;
+        float nlp = __shfl(lp, base, 64), ent = __shfl(hH, base, 64);
+#pragma unroll
+        for (int hh = 1; hh < NH; hh++) {
+            const float l2 = __shfl(lp, base + hh, 64), e2 = __shfl(hH, base + hh, 64);
+            if (hh < n_heads) { nlp += l2; ent += e2; }
+        }
+        const float logratio = nlp - r0.x;
+        const float ratio = fast_exp(logratio);
+        float adv = r0.y;
+        if (hp.norm_adv) adv = (adv - mean_f) * inv_std;
+        const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
+        const float l1 = -adv * ratio, l2 = -adv * rc;
+        const bool inside = (ratio >= lo && ratio <= hi_c);
+        float d_ratio;
+        if (l1 > l2) d_ratio = -adv;
+        else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+        else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half/half
+        const float g_nlp = invM * d_ratio * ratio;
+        const float g_ent = -hp.ent_coef * invM;
+#pragma unroll
+        for (int j = 0; j < W; j++) if (j < A) {
+            float d = g_nlp * ((j == a ? 1.0f : 0.0f) - p[j]);
+            if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[j] * (z[j] + hH));
+            d = (DIST != PPO_DIST_MASKED || ok[j]) ? d : 0.0f;
+            const __bf16 b = (__bf16)d;
+            dlogits_bf[r * 128 + off + j] = __builtin_bit_cast(uint16_t, b);
+            dbs[j] += d;
+        }
+        if (h == 0) {   // the row's scalars and the value loss (:603-625), once per row
+            s[0] += (double)(l1 > l2 ? l1 : l2);
+            s[1] += (double)ent;
+            s[2] += (double)((ratio - 1.0f) - logratio);
+            s[3] += (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
+            const float v = in_val, R = r0.z, vold = r0.w;
+            const float un = (v - R) * (v - R);
+            float g_v, lossv;
+            if (hp.clip_vloss) {
+                const float dv = v - vold;
+                const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+                const float vc = vold + dvc;
+                const float cl = (vc - R) * (vc - R);
+                lossv = un > cl ? un : cl;
+                const bool vin = (dv >= -clip && dv <= clip);
+                const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+                const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);
+                g_v = hp.vf_coef * 0.5f * invM * d;
+            } else {
+                lossv = un;
+                g_v = hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+            }
+            const __bf16 bv = (__bf16)g_v;
+            dval_bf[r * 128] = __builtin_bit_cast(uint16_t, bv);
+            dbv += g_v;
+            s[4] += (double)lossv;
+        }
+    }
+    // column sums of the head gradients: column off(hh) + j lives on the lanes of head hh
+#pragma unroll
+    for (int hh = 0; hh < NH; hh++)
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const float t = wave_sum(h == hh ? dbs[j] : 0.0f);
+            int o = 0, a = 0;
+#pragma unroll
+            for (int g = 0; g < NH; g++) { const int w = g < n_heads ? L.head_dims[g] : 0; if (g < hh) o += w; if (g == hh) a = w; }
+            if (lane == 0 && j < a) sdb[wave][o + j] = t;
+        }
+    {
+        const float t = wave_sum(dbv);
+        if (lane == 0) sdb[wave][NH * W] = t;
+    }
+    for (int k = 0; k < 5; k++) {
+        const double t = wave_sum_d_dpp(s[k]);
+        if (lane == 0) red[k][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double t = 0.0;
+        for (int w = 0; w < WAVES; w++) t += red[threadIdx.x][w];
+        loss_part[blockIdx.x * 8 + threadIdx.x] = t;
+    }
+    if ((int)threadIdx.x <= act) {   // head_db_part[block][0 .. act - 1] = d(logits) column sums, [act] = the d(value) sum
+        const int k = (int)threadIdx.x < act ? (int)threadIdx.x : NH * W;
+        float t = 0.0f;
+        for (int w = 0; w < WAVES; w++) t += sdb[w][k];
+        head_db_part[blockIdx.x * (act + 1) + threadIdx.x] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void loss_sums_kernel(const double* __restrict__ loss_part, int blocks, double* sums_out, float* grads_tail) {
     __shared__ double red[5][4];
     for (int k = 0; k < 5; k++) {
@@ -1051,6 +1217,15 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
 #endif
             if (slots) {
                 const AdvStat* st = (adv_stat && hp.norm_adv) ? adv_stat : nullptr;
+#ifndef GEN_AB_LOSS_SMALL   // A/B build: a row per thread
+                if (hp.dist_kind == PPO_DIST_MASKED)
+                    hipLaunchKernelGGL(loss_lanes_kernel<PPO_DIST_MASKED>, grid, dim3(1024), 0, s, L, hp, g.logits, g.val, M, (float)inv_global_M, st, global_M, g.loss_part, g.dout_bf[1],
+                                       g.dout_bf[0], g.head_db_part, g.rows_idx, g.rows_rec);
+                else
+                    hipLaunchKernelGGL(loss_lanes_kernel<PPO_DIST_CATEGORICAL>, grid, dim3(1024), 0, s, L, hp, g.logits, g.val, M, (float)inv_global_M, st, global_M, g.loss_part,
+                                       g.dout_bf[1], g.dout_bf[0], g.head_db_part, g.rows_idx, g.rows_rec);
+                return hipGetLastError();
+#endif
                 if (hp.dist_kind == PPO_DIST_MASKED)
                     hipLaunchKernelGGL(loss_small_kernel<PPO_DIST_MASKED>, grid, block, 0, s, L, hp, g.logits, g.val, M, (float)inv_global_M, st, global_M, g.loss_part, g.dout_bf[1],
                                        g.dout_bf[0], g.head_db_part, g.rows_idx, g.rows_rec);
