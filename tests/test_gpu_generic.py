@@ -212,16 +212,21 @@ def test_config4_runs_are_bit_reproducible(P, dtype):
     assert np.array_equal(bits(outs[0][1]), bits(outs[1][1])) and np.array_equal(outs[0][2], outs[1][2]) and outs[0][3] == outs[1][3]
 
 
-def test_generic_two_rank_shards_equal_single_context(P):
+@pytest.mark.parametrize("shape", ["f32 small", "bf16 configs[4] widths"])
+def test_generic_two_rank_shards_equal_single_context(P, shape):
     """Data parallelism on the generic path: two shards (env_offset / global_num_envs) reproduce their columns of the single-context rollout
     -- env buffers and actions bit for bit, network outputs to float noise (the library GEMM picks its kernel, and with it the order of
     the K-sum, by batch size) -- and one optimizer step over the in-process communicator (same protocol as RCCL: global advantage sums, then ONE
     all-reduce of the 1/M_global-scaled gradient) equals the single-context step on the concatenated minibatch."""
     import threading
-    N, T, heads, obs_dim = 64, 16, (3, 2), 20
+    # the second shape takes the fused bf16 kernels (rows read in place, both nets per launch) on every rank, and the multi-rank optimizer path behind them
+    bf16 = shape != "f32 small"
+    N, T = 64, 16
+    heads, obs_dim, hidden, n_hidden = ((3, 3, 3, 2), 376, 256, 4) if bf16 else ((3, 2), 20, 32, 2)
     A = sum(heads)
-    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=obs_dim, head_dims=heads, hidden=32, n_hidden=2, num_steps=T, num_minibatches=2,
-              update_epochs=1, max_episode_steps=30, seed=11, total_timesteps=4 * N * T, ent_coef=0.01, anneal_lr=False)
+    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=obs_dim, head_dims=heads, hidden=hidden, n_hidden=n_hidden, num_steps=T, num_minibatches=2,
+              update_epochs=1, max_episode_steps=30, seed=11, total_timesteps=4 * N * T, ent_coef=0.01, anneal_lr=False,
+              compute_dtype=P.DTYPE_BF16 if bf16 else P.DTYPE_F32)
     whole = P.Context(P.make_config(num_envs=N, **kw))
     whole.init_orthogonal(4)
     params = whole.get_params()
@@ -242,7 +247,7 @@ def test_generic_two_rank_shards_equal_single_context(P):
             ctx.set_params(params)
             ctx.env_reset(); ctx.rollout(); ctx.calc_advantage()
             sl = slice(off, off + n)
-            for name, shape in (("OBS", (T, N, obs_dim)), ("MASKS", (T, N, A)), ("ACTIONS", (T, N, 2)), ("LOGPROBS", (T, N)), ("REWARDS", (T, N)),
+            for name, shape in (("OBS", (T, N, obs_dim)), ("MASKS", (T, N, A)), ("ACTIONS", (T, N, len(heads))), ("LOGPROBS", (T, N)), ("REWARDS", (T, N)),
                                 ("VALUES", (T, N)), ("ADVANTAGES", (T, N))):
                 full, part = whole.read(name, shape), ctx.read(name, (T, n) + shape[2:])
                 if name in ("LOGPROBS", "VALUES", "ADVANTAGES"):
