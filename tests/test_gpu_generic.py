@@ -421,15 +421,16 @@ def test_generic_forward_kernels_on_the_reference_multihead_agent(P):
         ctx.close()
 
 
-def test_generic_bf16_step_forms_agree(P):
+@pytest.mark.parametrize("envs,steps", [(64, 32), (50, 18)])   # 512-row minibatches (whole 64-row tiles) and 225-row ones (a partial tile at the end of every pass)
+def test_generic_bf16_step_forms_agree(P, envs, steps):
     """The bf16-storage minibatch step exists in three forms that must compute the same update: the default (rows read in place through the permutation, both
     nets in every launch on one stream, ONE optimizer launch that takes the gradient norm from the slab sums' partial sums of squares and refreshes the bf16
     weight planes itself), PPO_KERNEL_GENERIC_CLASSIC (gathered copies, one net per launch on two streams, loss sums / norm / AdamW / planes as four launches)
     and the multi-rank form driven on one GPU by PPO_KERNEL_COMM_SELFTEST (paired launches, the loss sums riding the gradient's all-reduce, norm kernel).
     Same product kernels and the same partition of every partial sum: after a whole iteration (eight optimizer steps) at a shape the fused kernels take (hidden 256, obs padded
     to 128-column blocks) the parameters agree to float rounding -- the one thing that differs is the ORDER in which the norm's partial sums are added."""
-    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=376, head_dims=(3, 3, 3, 2), hidden=256, n_hidden=4, num_envs=64, num_steps=32,
-              num_minibatches=4, update_epochs=2, max_episode_steps=50, seed=21, total_timesteps=64 * 32 * 4, learning_rate=3e-4, ent_coef=0.01,
+    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=376, head_dims=(3, 3, 3, 2), hidden=256, n_hidden=4, num_envs=envs, num_steps=steps,
+              num_minibatches=4, update_epochs=2, max_episode_steps=50, seed=21, total_timesteps=envs * steps * 4, learning_rate=3e-4, ent_coef=0.01,
               compute_dtype=P.DTYPE_BF16)
     got = {}
     for name, flags, comm in (("default", 0, False), ("classic", P.KERNEL_GENERIC_CLASSIC, False), ("multi-rank path", P.KERNEL_COMM_SELFTEST, True)):
