@@ -1105,7 +1105,7 @@ extern "C" ppo_status ppo_matmul(int32_t trans_a, int32_t trans_b, int64_t M, in
 extern "C" ppo_status ppo_gae(const float* rewards, const float* values, const float* dones, const float* next_value, const int32_t* next_done,
                               int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
     if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;
-    return launch_gae(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, advantages, returns, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+    return launch_gae(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, advantages, returns, nullptr, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
 }
 extern "C" ppo_status ppo_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value, const int32_t* next_done,
                                    int64_t T, int64_t N, float gamma, float gae_lambda, float* advantages, float* returns, void* stream) {
@@ -1115,7 +1115,7 @@ extern "C" ppo_status ppo_gae_fast(const float* rewards, const float* values, co
 extern "C" ppo_status ppo_nstep_returns(const float* rewards, const float* values, const float* dones, const float* next_value,
                                         const int32_t* next_done, int64_t T, int64_t N, float gamma, float* advantages, float* returns, void* stream) {
     if (!rewards || !values || !dones || !next_value || !next_done || !advantages || !returns || T < 0 || N < 0) return PPO_ERR_INVALID;
-    return launch_nstep(rewards, values, dones, next_value, next_done, T, N, gamma, advantages, returns, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
+    return launch_nstep(rewards, values, dones, next_value, next_done, T, N, gamma, advantages, returns, nullptr, (hipStream_t)stream) == hipSuccess ? PPO_OK : PPO_ERR_HIP;
 }
 
 // K4 on the context's buffers: GAE (PPO_Discrete.cpp:283-306) or n-step returns (:309-329) by cfg.use_gae.
@@ -1124,11 +1124,11 @@ static ppo_status run_scan(ppo_ctx* c) {
     if (c->cfg.use_gae)
         HIPCHK(c, launch_gae(B_<float>(c, PPO_BUF_REWARDS), B_<float>(c, PPO_BUF_VALUES), B_<float>(c, PPO_BUF_DONES), B_<float>(c, PPO_BUF_NEXT_VALUE),
                              B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->T, c->N, c->cfg.gamma, c->cfg.gae_lambda, B_<float>(c, PPO_BUF_ADVANTAGES),
-                             B_<float>(c, PPO_BUF_RETURNS), c->stream));
+                             B_<float>(c, PPO_BUF_RETURNS), c->error_flag, c->stream));
     else
         HIPCHK(c, launch_nstep(B_<float>(c, PPO_BUF_REWARDS), B_<float>(c, PPO_BUF_VALUES), B_<float>(c, PPO_BUF_DONES), B_<float>(c, PPO_BUF_NEXT_VALUE),
                                B_<int32_t>(c, PPO_BUF_NEXT_DONE), c->T, c->N, c->cfg.gamma, B_<float>(c, PPO_BUF_ADVANTAGES),
-                               B_<float>(c, PPO_BUF_RETURNS), c->stream));
+                               B_<float>(c, PPO_BUF_RETURNS), c->error_flag, c->stream));
     return PPO_OK;
 }
 
@@ -1676,6 +1676,9 @@ extern "C" ppo_status ppo_stats_snapshot_read(ppo_ctx* c, ppo_stats* out) {
     if (h.error_flag & PPO_ERRFLAG_UPDATE_PROTOCOL)
         return fail(c, PPO_ERR_STATE, "update kernel: a bounded wait between its forward and gradient waves ran out (the gradient of that step was incomplete: "
                                       "parameters are undefined from there on)");
+    if (h.error_flag & PPO_ERRFLAG_GAE_PROTOCOL)
+        return fail(c, PPO_ERR_STATE, "advantage scan: a bounded wait between the mover waves and the walker of the time-pipelined kernel ran out (the advantages and "
+                                      "returns of that strip of envs are NaN, and so is everything trained on them)");
     if (h.error_flag & PPO_ERRFLAG_UPDATE_RANGE)
         return fail(c, PPO_ERR_STATE, "update kernel: an observation of magnitude >= 65504 does not fit the fp16 operand of the matrix-core update kernel; the optimizer "
                                       "gradient of that update is not finite and the parameters are undefined from there on: create the context with "

@@ -61,19 +61,32 @@ __device__ __forceinline__ int strip_of_block(int b, int grid) {
     return (((k >> 1) << 3) + xcd) * 2 + (k & 1);
 }
 
+#ifndef GAE_KEEPV_ALL
+#define GAE_KEEPV_ALL false   /* -DGAE_KEEPV_ALL=true: v_t in registers in the 16- / 32-column kernels of the smaller sizes too (A/B) */
+#endif
 #ifndef GAE_NO_PIPELINE
 #define GAE_NO_PIPELINE 0   /* -DGAE_NO_PIPELINE=1: the walk without software-pipelined LDS reads (A/B) */
 #endif
 // MODE 0: GAE.  MODE 1: n-step returns (PPO_Discrete.cpp:309-329: ret_t = r_t + (gamma*nnt_t)*ret_{t+1}; adv = ret - v).
-template <int EPB, int MODE, bool VEC, bool FAST = false>
+// TC: time steps per LDS tile (GAE_TC; 64 / 32 for the wide strips of HBM-resident sizes, launch_scan).  KEEPV (VEC only): v_t stays in the
+// registers of the thread that loaded it until the same thread stores R_t = A_t + v_t -- no third LDS tile (EPB = 32, TC = 128: 32 KB instead of 48).
+typedef float gae_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void gae_st4(float* p, const float4 v) {
+    if (NT) { gae_f4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<gae_f4*>(p)); }
+    else *reinterpret_cast<float4*>(p) = v;
+}
+// NT: A_t and R_t leave by non-temporal stores (HBM-resident sizes: the outputs do not evict the inputs from the memory-side cache).
+template <int EPB, int MODE, bool VEC, bool FAST = false, int TC = GAE_TC, bool KEEPV = false, bool NT = false>
 __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
                                                            const float* __restrict__ dones, const float* __restrict__ next_value,
                                                            const int32_t* __restrict__ next_done, int T, int N, float gamma,
                                                            float gae_lambda, float* __restrict__ adv, float* __restrict__ ret) {
     // sA: delta_t (MODE 0) / r_t (MODE 1) on input of the walk, A_t / ret_t on output.  sC: chain coefficient.  sV: v_t.
-    __shared__ __attribute__((aligned(16))) float sA[GAE_TC * EPB];
-    __shared__ __attribute__((aligned(16))) float sC[GAE_TC * EPB];
-    __shared__ __attribute__((aligned(16))) float sV[GAE_TC * EPB];
+    static_assert(!KEEPV || (VEC && !FAST), "v_t in registers: the vector path of the exact mode only");
+    static_assert(TC % GAE_WALK == 0 && (!VEC || (TC * (EPB / 4)) % GAE_THREADS == 0), "whole walk chunks, whole float4 slots per thread");
+    __shared__ __attribute__((aligned(16))) float sA[TC * EPB];
+    __shared__ __attribute__((aligned(16))) float sC[TC * EPB];
+    __shared__ __attribute__((aligned(16))) float sV[KEEPV ? 4 : TC * EPB];
     const int tid = threadIdx.x;
     const int n0 = strip_of_block<EPB>((int)blockIdx.x, (int)gridDim.x) * EPB;
     const float gl = gamma * gae_lambda;  // the C++ float product of PPO_Discrete.cpp:301
@@ -82,7 +95,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
     const bool walker = tid < EPB && (n0 + tid) < N;
     if (MODE == 1 && walker) carry = next_value[n0 + tid];  // next_return = next_value at t = T-1 (:318)
     // FAST: chunk maps [chunk][column] and the tile's carry per column (two copies: the one a tile reads, the one it leaves)
-    constexpr int NCH = GAE_THREADS / EPB, CH = GAE_TC / NCH;
+    constexpr int NCH = GAE_THREADS / EPB, CH = TC / NCH > 0 ? TC / NCH : 1;
     __shared__ float sCk[FAST ? NCH * EPB : 1], sDk[FAST ? NCH * EPB : 1], sCarry[FAST ? 2 * EPB : 1];
     int tile_par = 0;
     if (FAST) {
@@ -90,8 +103,10 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         __syncthreads();
     }
 
-    for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {        // tile covers rows [t_lo, t_hi)
-        const int t_lo = t_hi > GAE_TC ? t_hi - GAE_TC : 0;
+    constexpr int KV = (KEEPV && VEC) ? TC * (EPB / 4) / GAE_THREADS : 1;
+    float4 keepv[KV];                                      // KEEPV: v_t of this thread's float4 slots, from phase A to phase C
+    for (int t_hi = T; t_hi > 0; t_hi -= TC) {            // tile covers rows [t_lo, t_hi)
+        const int t_lo = t_hi > TC ? t_hi - TC : 0;
         const int rows = t_hi - t_lo;
 
         // ---- phase A: stream r_t, v_t, v_{t+1}, dones_{t+1}; delta_t and c_t are element-wise (every rounding as the
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         //      it is served by L1/L2, not HBM. ----
         if (VEC) {
             constexpr int C4 = EPB / 4;                    // float4 columns per row
-            constexpr int ITERS = GAE_TC * C4 / GAE_THREADS;
+            constexpr int ITERS = TC * C4 / GAE_THREADS;
             // every load of the tile is issued before the first use: one memory round trip per tile, not one per row group
             float4 rw[ITERS], vv[ITERS], nvv[ITERS], dd[ITERS];
 #pragma unroll
@@ -139,7 +154,8 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
                     }
                     *reinterpret_cast<float4*>(&sA[r * EPB + c]) = a4;
                     *reinterpret_cast<float4*>(&sC[r * EPB + c]) = c4;
-                    *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
+                    if (KEEPV) keepv[KEEPV ? i : 0] = v;
+                    else *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
                 }
             }
         } else {
@@ -194,17 +210,17 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
             if (k == 0) sCarry[(tile_par ^ 1) * EPB + c] = x;   // A of the tile's first row: the carry of the next (earlier) tile
             tile_par ^= 1;
             (void)r_hi; (void)r_lo;
-        } else if (walker && rows == GAE_TC && !GAE_NO_PIPELINE) {
+        } else if (walker && rows == TC && !GAE_NO_PIPELINE) {
             // full tile: the chunks' LDS reads are software-pipelined -- chunk k + 1's 32 reads are in flight while chunk k's 16-step chain runs, so
             // only the chain itself (2 dependent operations per row) and the first chunk's read latency are serial
             float last = carry;
             float d[2][GAE_WALK], cc[2][GAE_WALK];
 #pragma unroll
-            for (int i = 0; i < GAE_WALK; i++) { d[0][i] = sA[(GAE_TC - 1 - i) * EPB + tid]; cc[0][i] = sC[(GAE_TC - 1 - i) * EPB + tid]; }
+            for (int i = 0; i < GAE_WALK; i++) { d[0][i] = sA[(TC - 1 - i) * EPB + tid]; cc[0][i] = sC[(TC - 1 - i) * EPB + tid]; }
 #pragma unroll
-            for (int k = 0; k < GAE_TC / GAE_WALK; k++) {
-                const int cur = k & 1, nxt = cur ^ 1, r = GAE_TC - k * GAE_WALK;
-                if (k + 1 < GAE_TC / GAE_WALK) {
+            for (int k = 0; k < TC / GAE_WALK; k++) {
+                const int cur = k & 1, nxt = cur ^ 1, r = TC - k * GAE_WALK;
+                if (k + 1 < TC / GAE_WALK) {
 #pragma unroll
                     for (int i = 0; i < GAE_WALK; i++) { d[nxt][i] = sA[(r - GAE_WALK - 1 - i) * EPB + tid]; cc[nxt][i] = sC[(r - GAE_WALK - 1 - i) * EPB + tid]; }
                 }
@@ -249,10 +265,14 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
         // ---- phase C: stream out advantages and returns ----
         if (VEC) {
             constexpr int C4 = EPB / 4;
-            for (int e = tid; e < rows * C4; e += GAE_THREADS) {
+            constexpr int ITERS = TC * C4 / GAE_THREADS;
+#pragma unroll
+            for (int i = 0; i < ITERS; i++) {              // the same slots as phase A: slot i's v_t may still be in this thread's registers
+                const int e = tid + i * GAE_THREADS;
                 const int r = e / C4, c = (e % C4) * 4;
+                if (r >= rows) continue;
                 const float4 a4 = *reinterpret_cast<const float4*>(&sA[r * EPB + c]);
-                const float4 v4 = *reinterpret_cast<const float4*>(&sV[r * EPB + c]);
+                const float4 v4 = KEEPV ? keepv[KEEPV ? i : 0] : *reinterpret_cast<const float4*>(&sV[r * EPB + c]);
                 float4 o_adv, o_ret;
                 if (MODE == 0) {
                     o_adv = a4;
@@ -262,8 +282,8 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_kernel(const float* __restric
                     o_adv = make_float4(a4.x - v4.x, a4.y - v4.y, a4.z - v4.z, a4.w - v4.w);   // :327
                 }
                 const size_t g = (size_t)(t_lo + r) * N + n0 + c;
-                *reinterpret_cast<float4*>(adv + g) = o_adv;
-                *reinterpret_cast<float4*>(ret + g) = o_ret;
+                gae_st4<NT>(adv + g, o_adv);
+                gae_st4<NT>(ret + g, o_ret);
             }
         } else {
             for (int e = tid; e < rows * EPB; e += GAE_THREADS) {
@@ -300,17 +320,21 @@ constexpr int GP_THREADS = GAE_THREADS + 64;                 // four mover waves
 #define GAE_PIPE_MAX_BLOCKS 256                               /* strips up to which the pipelined kernel is launched: one workgroup per CU (12 288 envs x 32 columns = 384: 9.0 - 9.3 us against 7.2) */
 #endif
 typedef __attribute__((address_space(3))) volatile uint32_t gp_flag_t;
-__device__ __forceinline__ void gp_wait_ge(gp_flag_t* flag, uint32_t want) {
+// Bounded wait.  false = the count never came (cannot happen by construction, above): the caller poisons what it would have produced with NaN and raises the
+// context's error word where there is one -- never a silently wrong advantage (mg_wait_ge of the update kernel does the same).
+__device__ __forceinline__ bool gp_wait_ge(gp_flag_t* flag, uint32_t want) {
+    bool ok = false;
     for (int spin = 0; spin < (1 << 22); spin++) {
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*flag) >= want) break;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*flag) >= want) { ok = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
+    return ok;
 }
 template <int EPB, int MODE, int GP_GROUPS>
 __global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __restrict__ rewards, const float* __restrict__ values, const float* __restrict__ dones,
                                                               const float* __restrict__ next_value, const int32_t* __restrict__ next_done, int T, int N, float gamma,
-                                                              float gae_lambda, float* __restrict__ adv, float* __restrict__ ret) {
+                                                              float gae_lambda, float* __restrict__ adv, float* __restrict__ ret, int32_t* __restrict__ error_flag) {
     static_assert(EPB == 16 || EPB == 32, "strips of 16 or 32 columns");
     constexpr int GP_GROWS = GAE_TC / GP_GROUPS;       // rows of a group: 32 (four groups) or 64 (two)
     constexpr int C4 = EPB / 4;                        // float4 columns per row
@@ -319,8 +343,7 @@ __global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __res
     constexpr int MOVERS_PER_GROUP = GAE_THREADS / 64 * NG / GP_GROUPS;   // (wave, slot) pairs that fill a group: what its ready count reaches per tile
     __shared__ __attribute__((aligned(16))) float sA[GAE_TC * EPB];
     __shared__ __attribute__((aligned(16))) float sC[GAE_TC * EPB];
-    __shared__ __attribute__((aligned(16))) float sV[GAE_TC * EPB];
-    __shared__ uint32_t s_ready[GP_GROUPS], s_done[GP_GROUPS];
+    __shared__ uint32_t s_ready[GP_GROUPS], s_done[GP_GROUPS];   // (v_t stays in the mover's registers: no third tile)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n0 = strip_of_block<EPB>((int)blockIdx.x, (int)gridDim.x) * EPB;
     const float gl = gamma * gae_lambda;   // the C++ float product of PPO_Discrete.cpp:301
@@ -339,7 +362,10 @@ __global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __res
 #pragma unroll
             for (int gi = 0; gi < GP_GROUPS; gi++) {
                 const int g = GP_GROUPS - 1 - gi;
-                gp_wait_ge(f_ready + g, (uint32_t)(MOVERS_PER_GROUP * (tile + 1)));
+                if (!gp_wait_ge(f_ready + g, (uint32_t)(MOVERS_PER_GROUP * (tile + 1)))) {
+                    last = __builtin_nanf("");   // the group never landed: everything below it in this strip is NaN, and the error word says why
+                    if (lane == 0 && error_flag) atomicOr(error_flag, PPO_ERRFLAG_GAE_PROTOCOL);
+                }
                 if (walker) {
                     // the group's rows, top row first, 16 at a time: chunk k + 1's reads are in flight while chunk k's chain runs
                     constexpr int NCHUNK = GP_GROWS / GAE_WALK;
@@ -405,10 +431,12 @@ __global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __res
                 a4 = rw[j];
                 c4 = make_float4(gamma * nnt.x, gamma * nnt.y, gamma * nnt.z, gamma * nnt.w);                         // :324
             }
-            if (tile > 0) gp_wait_ge(f_done + g, (uint32_t)tile);   // (own slot: this thread stored the previous tile's values of it already; the walker is done with the row)
+            if (tile > 0 && !gp_wait_ge(f_done + g, (uint32_t)tile)) {   // (own slot: this thread stored the previous tile's values of it already; the walker is done with the row)
+                a4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                if (lane == 0 && error_flag) atomicOr(error_flag, PPO_ERRFLAG_GAE_PROTOCOL);
+            }
             *reinterpret_cast<float4*>(&sA[r * EPB + c]) = a4;
             *reinterpret_cast<float4*>(&sC[r * EPB + c]) = c4;
-            *reinterpret_cast<float4*>(&sV[r * EPB + c]) = v;
             asm volatile("" ::: "memory");
             if (lane == 0) atomicAdd(&s_ready[g], 1u);   // behind this wave's writes in its LDS queue
         }
@@ -416,8 +444,12 @@ __global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             const int r = row_of(j), g = r / GP_GROWS;
-            gp_wait_ge(f_done + g, (uint32_t)(tile + 1));
-            const float4 a4 = *reinterpret_cast<const float4*>(&sA[r * EPB + c]);
+            const bool walked = gp_wait_ge(f_done + g, (uint32_t)(tile + 1));
+            float4 a4 = *reinterpret_cast<const float4*>(&sA[r * EPB + c]);
+            if (!walked) {
+                a4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                if (lane == 0 && error_flag) atomicOr(error_flag, PPO_ERRFLAG_GAE_PROTOCOL);
+            }
             const float4 v4 = vv[j];
             float4 o_adv, o_ret;
             if (MODE == 0) { o_adv = a4; o_ret = make_float4(a4.x + v4.x, a4.y + v4.y, a4.z + v4.z, a4.w + v4.w); }   // :305
@@ -432,7 +464,7 @@ __global__ __launch_bounds__(GP_THREADS) void gae_pipe_kernel(const float* __res
 template <int MODE, bool FAST = false>
 hipError_t launch_scan(const float* rewards, const float* values, const float* dones, const float* next_value,
                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
-                       hipStream_t s) {
+                       int32_t* error_flag, hipStream_t s) {
     if (T <= 0 || N <= 0) return hipSuccess;
     if (T > INT32_MAX || N > INT32_MAX) return hipErrorInvalidValue;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -461,7 +493,7 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
     // launch's workgroups less room to start under the tail of this one).  8192 envs = BASELINE configs[3]'s size: 5.7 us, 0.46 of 8 TB/s in trace.
     if (!FAST && vec_ok && T % GAE_TC == 0 && N % gp_epb == 0 && N / gp_epb <= (int64_t)GAE_PIPE_MAX_BLOCKS && N > GAE_PIPE_MIN_ENVS) {
         const dim3 grid((unsigned)(N / gp_epb)), block(GP_THREADS);
-#define PPO_GP_LAUNCH(E, G) hipLaunchKernelGGL((gae_pipe_kernel<E, MODE, G>), grid, block, 0, s, rewards, values, dones, next_value, next_done, (int)T, (int)N, gamma, gae_lambda, adv, ret)
+#define PPO_GP_LAUNCH(E, G) hipLaunchKernelGGL((gae_pipe_kernel<E, MODE, G>), grid, block, 0, s, rewards, values, dones, next_value, next_done, (int)T, (int)N, gamma, gae_lambda, adv, ret, error_flag)
         if (gp_epb == 32 && gp_groups == 4) PPO_GP_LAUNCH(32, 4);
         else if (gp_epb == 32) PPO_GP_LAUNCH(32, 2);
         else if (gp_groups == 4) PPO_GP_LAUNCH(16, 4);
@@ -470,19 +502,43 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
         return hipGetLastError();
     }
 #endif
-#define PPO_GAE_LAUNCH(EPB)                                                                                                   \
+    // From GAE_WIDE_FROM envs (two and more workgroups per CU even with 64-column strips): strips of 64 columns x a time tile of 32 rows, v_t kept in registers.
+    // The 64-column strip reads 256-byte row pieces (two memory lines per row and array instead of one) and fills all 64 lanes of the walking wave; the SHORT
+    // time tile keeps its LDS at 16 KB so that eight workgroups share a CU and overlap each other's load / walk / store phases -- round 5's 64-column experiment
+    // kept 128 rows (96 KB, ONE workgroup per CU) and lost for that reason.  Same chain, same operation order: same bits (the carry crosses tiles in a register
+    // as before).  Measured in trace, builds alternated in one call (profiles/NOTES.md "GAE: wide strips", fraction of 8 TB/s at 16 384 / 32 768 / 65 536 /
+    // 131 072 / 2^20 envs): 32 x 128 (round 5) 0.58 / 0.57 / 0.61 / 0.53 - 0.55 / 0.51; 64 x 128 - / - / 0.50 / 0.36 / 0.37; 64 x 64 - / - / 0.69 / 0.57 - 0.59 /
+    // 0.60 - 0.63; 64 x 32 - / - / 0.75 / 0.60 / 0.62 - 0.64; 64 x 16 and 128 x 16, 128 x 32: within 0.02 of 64 x 32; 64 x 32 with non-temporal stores
+    // 0.66 / 0.68 / 0.76 / 0.75 - 0.79 / 0.63 - 0.69 (non-temporal loads as well: worse at 65 536 and 131 072, the same at 2^20).
+    // Non-temporal stores from GAE_NT_FROM envs only: below that the batch (20 B x T x N) fits the memory-side cache with room to spare and the kernels that read
+    // the advantages next (pack_records, perm_adv_stats) find them there.
+#ifndef GAE_WIDE_FROM
+#define GAE_WIDE_FROM 16384
+#endif
+#ifndef GAE_NT_FROM
+#define GAE_NT_FROM 65536
+#endif
+#ifndef GAE_WIDE_CFG   /* exploration builds: -DGAE_WIDE_CFG=<epb * 1000 + tc>, e.g. 64064, 64016, 128016, 32128 */
+#define GAE_WIDE_CFG 64032
+#endif
+#define PPO_GAE_LAUNCH(EPB, TC, KEEPV, NT)                                                                                    \
     do {                                                                                                                      \
         const dim3 grid((unsigned)((N + EPB - 1) / EPB)), block(GAE_THREADS);                                                  \
         if (vec_ok && N % EPB == 0)                                                                                           \
-            hipLaunchKernelGGL((gae_kernel<EPB, MODE, true, FAST>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
+            hipLaunchKernelGGL((gae_kernel<EPB, MODE, true, FAST, TC, KEEPV && !FAST, NT>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
                                (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
         else                                                                                                                  \
-            hipLaunchKernelGGL((gae_kernel<EPB, MODE, false, FAST>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
+            hipLaunchKernelGGL((gae_kernel<EPB, MODE, false, FAST, TC, false, false>), grid, block, 0, s, rewards, values, dones, next_value, next_done, \
                                (int)T, (int)N, gamma, gae_lambda, adv, ret);                                                  \
     } while (0)
-    if (epb == 64) PPO_GAE_LAUNCH(64);
-    else if (epb == 32) PPO_GAE_LAUNCH(32);
-    else PPO_GAE_LAUNCH(16);
+    constexpr int wide_epb = GAE_WIDE_CFG / 1000, wide_tc = GAE_WIDE_CFG % 1000;
+    if (!FAST && vec_ok && N >= GAE_WIDE_FROM && N % wide_epb == 0) {
+        if (N >= GAE_NT_FROM) PPO_GAE_LAUNCH(wide_epb, wide_tc, true, true);
+        else PPO_GAE_LAUNCH(wide_epb, wide_tc, true, false);
+    }
+    else if (epb == 64) PPO_GAE_LAUNCH(64, GAE_TC, false, false);
+    else if (epb == 32) PPO_GAE_LAUNCH(32, GAE_TC, GAE_KEEPV_ALL, false);
+    else PPO_GAE_LAUNCH(16, GAE_TC, GAE_KEEPV_ALL, false);
 #undef PPO_GAE_LAUNCH
     return hipGetLastError();
 }
@@ -491,17 +547,17 @@ hipError_t launch_scan(const float* rewards, const float* values, const float* d
 
 hipError_t launch_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
                       const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
-                      hipStream_t s) {
-    return launch_scan<0>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, s);
+                      int32_t* error_flag, hipStream_t s) {
+    return launch_scan<0>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, error_flag, s);
 }
 
 hipError_t launch_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value,
                            const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
                            hipStream_t s) {
-    return launch_scan<0, true>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, s);
+    return launch_scan<0, true>(rewards, values, dones, next_value, next_done, T, N, gamma, gae_lambda, adv, ret, nullptr, s);
 }
 
 hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
-                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s) {
-    return launch_scan<1>(rewards, values, dones, next_value, next_done, T, N, gamma, 1.0f, adv, ret, s);
+                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, int32_t* error_flag, hipStream_t s) {
+    return launch_scan<1>(rewards, values, dones, next_value, next_done, T, N, gamma, 1.0f, adv, ret, error_flag, s);
 }

@@ -541,14 +541,16 @@ hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t*
 hipError_t launch_categorical_sample(const float* probs, int64_t n, int A, int64_t seed, int64_t row_offset, int64_t step_index, int head,
                                      int64_t* out, hipStream_t s);
 
+// error_flag (may be null: the stateless entry points): device word that gets PPO_ERRFLAG_GAE_PROTOCOL when a bounded wait of the time-pipelined scan runs out
+// (the affected strip's outputs are NaN either way)
 hipError_t launch_gae(const float* rewards, const float* values, const float* dones, const float* next_value,
                       const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
-                      hipStream_t s);
+                      int32_t* error_flag, hipStream_t s);
 hipError_t launch_gae_fast(const float* rewards, const float* values, const float* dones, const float* next_value,
                            const int32_t* next_done, int64_t T, int64_t N, float gamma, float gae_lambda, float* adv, float* ret,
                            hipStream_t s);
 hipError_t launch_nstep(const float* rewards, const float* values, const float* dones, const float* next_value,
-                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, hipStream_t s);
+                        const int32_t* next_done, int64_t T, int64_t N, float gamma, float* adv, float* ret, int32_t* error_flag, hipStream_t s);
 
 struct UpdateArgs {
     const float* params;
@@ -578,6 +580,7 @@ struct UpdateArgs {
     int single_wave;         // 1: the one-wave-per-tile matrix-core kernel even for the reference's two shapes (A/B; ppo_config.kernel_flags)
 };
 constexpr int32_t PPO_ERRFLAG_UPDATE_PROTOCOL = 2;
+constexpr int32_t PPO_ERRFLAG_GAE_PROTOCOL = 16;   // gae_pipe_kernel: a bounded wait between its mover waves and its walker ran out (that strip's advantages / returns are NaN)
 constexpr int32_t PPO_ERRFLAG_UPDATE_RANGE = 8;    // a matrix-core update kernel met an observation that does not fit its fp16 operand (|obs| >= 65 504)
 constexpr int32_t PPO_ERRFLAG_ROLLOUT_RANGE = 4;   // rollout16_kernel: |W3| does not fit the fp16 operand (pre-scaled by 2^8)
 int update_blocks_per_net(int M);

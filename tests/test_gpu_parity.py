@@ -111,8 +111,15 @@ def test_gae_kernel_bit_exact_vs_reference(P, util_ctx, name):
         assert np.array_equal(bits(ret), bits(g[U + "gae_returns"]))
 
 
+# The last rows drive every path of the launch selection (csrc/kernels_gae.hip, launch_scan).  gae_pipe_kernel (4096 < N <= 8192, N % 32 == 0, T % 128 == 0):
+# more than one time tile (256, 384: the hand-back wait of `tile > 0`, the cumulative ready counts, the carry across tiles), no done / every step done,
+# 129 strips (just above the switch), N % 128 != 0, and N % 32 != 0 (back to the three-phase kernel); both `nstep` values loop below, so the n-step
+# instantiation runs on each.  The wide-strip kernel of HBM-resident sizes (N >= 65 536: 64 columns x 64-row time tiles): whole tiles, a ragged first tile
+# (T = 200), and a width that is not a multiple of 64 (back to 32-column strips).
 @pytest.mark.parametrize("T,N,p_done", [(128, 4096, 0.05), (128, 4096, 0.002), (300, 1024, 0.02), (5, 100, 0.3), (1, 4, 0.5),
-                                        (129, 64, 0.0), (2048, 32, 0.01), (128, 32768, 0.05), (7, 1, 0.0), (130, 20, 1.0)])
+                                        (129, 64, 0.0), (2048, 32, 0.01), (128, 32768, 0.05), (7, 1, 0.0), (130, 20, 1.0),
+                                        (256, 8192, 0.05), (384, 6144, 0.002), (128, 8192, 0.0), (128, 8192, 1.0), (256, 4128, 0.3),
+                                        (128, 8160, 0.05), (128, 8200, 0.05), (128, 131072, 0.05), (200, 65536, 0.01), (64, 65568, 0.05)])
 def test_gae_kernel_bit_exact_vs_oracle(P, util_ctx, T, N, p_done):
     rng = np.random.default_rng(T * 1000003 + N)
     rewards = np.where(rng.random((T, N)) < 0.05, -1.0, 1.0).astype(np.float32)

@@ -10,7 +10,8 @@ for i in $(seq 1 $R); do
         export PPO_HIP_LIBRARY="$(realpath "$src")"   # binding.py loads this build; the shipped library is never overwritten
         D=/tmp/gae_ab_${i}_$(basename $src)
         rm -rf $D
-        rocprofv3 --kernel-trace -f csv -d $D -o run -- python3 tools/gae_sweep.py ${GAE_SIZES:-4096 8192 32768} > /dev/null 2>&1
+        rocprofv3 --kernel-trace -f csv -d $D -o run -- python3 tools/gae_sweep.py ${GAE_SIZES:-4096 8192 32768} > $D.out 2>&1
+        if grep -q '"bit_exact_vs_oracle": false' $D.out || ! grep -q bit_exact $D.out; then echo "$src: WRONG RESULTS or no run"; tail -n 3 $D.out; fi
         echo "$src: $(python3 tools/gae_by_size.py "$(find $D -name '*kernel_trace.csv' | head -n 1)" /tmp/gae_ab.json | tr '\n' ';')"
     done
 done
