@@ -26,6 +26,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
   gae_roofline  the GAE scan (the kernel BASELINE.json's HBM-roofline target names), algorithmic bytes / launch time: 200 launches in a row
                 on this workload's buffers (live; the duration the committed rocprofv3 trace agrees with), the in-iteration HIP-event
                 reading beside it, the same at 4096 / 8192 / 32768 envs, and the floor probe
+  value_runs    the headline's K-step region timed R more times (same bracket each): median / min / max -- `value` itself stays the FIRST region, the one
+                the round contract defines
+  other_workloads  BASELINE configs[3] (MountainCar, 8192 envs) and one GPU's share of configs[4] (2048 envs, bf16) timed live in this same run, >= 0.5 s each:
+                value, ms_per_step and the dominant kernel's roofline fraction (N = 1, default workload only; --no-other-workloads skips them)
   cpu_baseline  the reference's own CPU ThreadPool path (oracle/_ref/ref_harness = the unmodified reference compiled against
                 LibTorch CPU) timed on this host, or the C port when that binary is absent -- a reported baseline
 """
@@ -100,7 +104,7 @@ def newest_profile(suffix):
     return f if os.path.exists(f) else None
 
 
-GAE_EXACT_4096 = "gae_kernel<16, 0, true, false>"   # the exact scan configs[1] launches (kernels_gae.hip: launch_scan; the last flag is ppo_gae_fast)
+GAE_EXACT_4096 = "gae_kernel<16, 0, true, false, 128"   # the exact scan configs[1] launches (kernels_gae.hip: launch_scan; <strip columns, GAE, 16-byte accesses, not ppo_gae_fast, 128-row tile, ...>)
 
 
 def pmc_traffic(prefix):
@@ -295,6 +299,8 @@ def parse_args(argv=None):
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--num-steps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N = 1, default workload: do not time configs[3] / configs[4] after the headline")
+    ap.add_argument("--repeats", type=int, default=5, help="N = 1: further timed repetitions of the K-step region after the headline one (value_runs); 0 = none")
     ap.add_argument("--comm-selftest", action="store_true", help="N = 1 only: drive the multi-rank code path (RCCL all-reduces over a one-rank communicator, "
                     "three-kernel optimizer step) to see its per-step cost on one GPU; not a valid headline number")
     ap.add_argument("--transport", choices=("auto", "rccl", "exchange", "both"), default="auto", help="N > 1: the gradient all-reduce. rccl = ncclAllReduce over xGMI; "
@@ -496,19 +502,24 @@ def main():
     obs, heads = W["obs"], W["heads"]
     act = sum(heads)
     N, T = args.envs or W["envs"], args.num_steps
-    total_updates = args.steps + args.warmup
-    kind = dict(cartpole=(P.ENV_CARTPOLE, P.DIST_CATEGORICAL), mountaincar=(P.ENV_MOUNTAINCAR, P.DIST_MASKED), config4=(P.ENV_SYNTHETIC, P.DIST_MASKED))[args.workload]
-    cfg = P.dist.shard_config(P.make_config, rank, world, N * world, env_kind=kind[0], dist_kind=kind[1], obs_size=obs,
-                              head_dims=heads, hidden=W["hidden"], n_hidden=W["n_hidden"], num_steps=T, num_minibatches=4, update_epochs=10,
-                              max_episode_steps=W["max_steps"], seed=2, total_timesteps=total_updates * N * T * world, learning_rate=1e-3, gamma=0.98,
-                              gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True,
-                              device=0 if args.same_device else local_rank,
-                              compute_dtype=P.DTYPE_BF16 if args.workload == "config4" else P.DTYPE_F32,
-                              # ppo_config.kernel_flags: which kernel runs a stage (A/B runs); --same-device with more than two ranks: the vector update
-                              # kernel (ranks waiting in the exchange sit on every CU, and a matrix-core update workgroup needs a CU's whole register
-                              # file: tests/test_gpu_exchange.py); --comm-selftest: a real one-rank RCCL communicator
-                              kernel_flags=args.kernel_flags | (P.KERNEL_UPDATE_VECTOR if args.same_device and world > 2 else 0)
-                                           | (P.KERNEL_COMM_SELFTEST if args.comm_selftest and world == 1 else 0))
+    total_updates = args.steps + args.warmup + max(args.repeats, 0) * args.steps   # the learning-rate schedule covers every iteration this run makes
+
+    def make_cfg(workload, n_envs, updates):
+        w = WORKLOADS[workload]
+        kind = dict(cartpole=(P.ENV_CARTPOLE, P.DIST_CATEGORICAL), mountaincar=(P.ENV_MOUNTAINCAR, P.DIST_MASKED), config4=(P.ENV_SYNTHETIC, P.DIST_MASKED))[workload]
+        return P.dist.shard_config(P.make_config, rank, world, n_envs * world, env_kind=kind[0], dist_kind=kind[1], obs_size=w["obs"],
+                                   head_dims=w["heads"], hidden=w["hidden"], n_hidden=w["n_hidden"], num_steps=T, num_minibatches=4, update_epochs=10,
+                                   max_episode_steps=w["max_steps"], seed=2, total_timesteps=updates * n_envs * T * world, learning_rate=1e-3, gamma=0.98,
+                                   gae_lambda=0.95, clip_coef=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, anneal_lr=True,
+                                   device=0 if args.same_device else local_rank,
+                                   compute_dtype=P.DTYPE_BF16 if workload == "config4" else P.DTYPE_F32,
+                                   # ppo_config.kernel_flags: which kernel runs a stage (A/B runs); --same-device with more than two ranks: the vector update
+                                   # kernel (ranks waiting in the exchange sit on every CU, and a matrix-core update workgroup needs a CU's whole register
+                                   # file: tests/test_gpu_exchange.py); --comm-selftest: a real one-rank RCCL communicator
+                                   kernel_flags=args.kernel_flags | (P.KERNEL_UPDATE_VECTOR if args.same_device and world > 2 else 0)
+                                                | (P.KERNEL_COMM_SELFTEST if args.comm_selftest and world == 1 else 0))
+    cfg = make_cfg(args.workload, N, total_updates)
+
     def warm(c):
         try:
             c.init_orthogonal(2)   # same seed on every rank: replicated weights
@@ -570,7 +581,7 @@ def main():
         # brought up in checked stages (dist.start_exchange_checked): None = some rank failed a stage, nothing is left open
         return P.dist.start_exchange_checked(lambda: P.Context(cfg), warm, dist, rank, world)
 
-    def timed(c):
+    def timed(c, steps=None):
         """K steps bracketed by barrier + synchronize on both sides; max over ranks.  A direct-exchange wait that ran out makes ctx.sync() raise
         (PPO_ERR_COMM) and the count is agreed over the ranks besides: a run whose replicas diverged prints no number."""
         def barrier():
@@ -580,7 +591,7 @@ def main():
             c.sync()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps or args.steps):
             c.train_iteration()
         c.sync()
         dt_own = time.perf_counter() - t0      # this rank's own K steps, before it waits for the others
@@ -628,6 +639,15 @@ def main():
     ctx.profile_enable(args.profile)
     dt = timed(ctx)
     prof = ctx.profile_read()
+    # the same K-step region R more times, bracketed the same way, with the same event sampling running: how far one 41-ms region is from the next on this box
+    value_runs = None
+    if world == 1 and args.repeats > 0:
+        reps = [timed(ctx) for _ in range(args.repeats)]
+        vals = sorted(args.steps * N * T / d for d in [dt] + reps)
+        value_runs = {"runs": len(vals), "values": [args.steps * N * T / d for d in [dt] + reps], "median": vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2]),
+                      "min": vals[0], "max": vals[-1], "unit": "env-steps/s",
+                      "note": "the first entry is `value` (the contract's K steps after W warm-up steps); the others are the same K-step region again, each between its own "
+                              "synchronisations"}
     ctx.profile_enable(0)
     st = ctx.stats()
     # N > 1: what every rank measured by itself, so that a scaling record can be read in one pass -- its own time for the K steps (min / max show a
@@ -689,8 +709,64 @@ def main():
     if rank == 0:
         own = [_Ptr(ctx.buffer_ptr(n)[0]) for n in ("REWARDS", "VALUES", "DONES", "NEXT_VALUE", "NEXT_DONE", "ADVANTAGES", "RETURNS")]
         gae_own = gae_b2b(N, own)
-        gae_rows = [gae_b2b(n) for n in (4096, 8192, 32768)]
+        gae_rows = [gae_b2b(n) for n in (4096, 8192, 32768, 131072)]
         gae_fast_rows = [gae_b2b(n, fast=True) for n in (4096, 8192, 32768)]   # the associative scan (ppo_gae_fast): NOT what training runs
+
+    # BASELINE configs[3] and one GPU's share of configs[4], live in this run (N = 1, the default command): a context each, 5 warm-up iterations, then whole
+    # iterations for >= 0.5 s between two synchronisations; the dominant kernel by HIP events on the context's stream as for the headline
+    def measure_other(name):
+        w = WORKLOADS[name]
+        n_envs = w["envs"]
+        probe_iters, min_seconds, warm_iters = 3, 0.5, 5
+        budget = 400   # iterations the learning-rate schedule covers (far more than run)
+        c = P.Context(make_cfg(name, n_envs, budget))
+        try:
+            c.init_orthogonal(2)
+            c.env_reset()
+            for _ in range(warm_iters):
+                c.train_iteration()
+            c.sync()
+            t0 = time.perf_counter()
+            for _ in range(probe_iters):
+                c.train_iteration()
+            c.sync()
+            per_iter = (time.perf_counter() - t0) / probe_iters
+            steps = max(10, min(budget - warm_iters - probe_iters - 1, int(min_seconds / per_iter) + 1))
+            c.profile_enable(4)
+            c.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                c.train_iteration()
+            c.sync()
+            dt_o = time.perf_counter() - t0
+            pr = c.profile_read()
+            c.profile_enable(0)
+            st_o = c.stats()
+        finally:
+            c.close()
+        m_rows = (n_envs * T) // 4
+        fl_o = flops_per_sample(w["obs"], sum(w["heads"]), w["hidden"], w["n_hidden"]) * m_rows
+        fb = pr["fwd_bwd_ms"] / pr["fwd_bwd_launches"] if pr["fwd_bwd_launches"] > 0 else None
+        return {"config": {"workload": (w["label"] % (n_envs, T)) + " (BASELINE.json configs[%d]%s)" % (w["cfg1"], ", one GPU's share" if name == "config4" else ""),
+                           "num_envs_per_gpu": n_envs, "num_steps": T, "minibatch_per_gpu": m_rows, "optimizer_steps_per_step": 40},
+                "value": steps * n_envs * T / dt_o, "unit": "env-steps/s", "steps": steps, "warmup": warm_iters + probe_iters, "ms_per_step": 1e3 * dt_o / steps, "timed_seconds": dt_o,
+                "dtype": "bf16" if name == "config4" else "f32 (update GEMMs: two-term f16 split on f16 MFMA, fp32 accumulate)",
+                "roofline": {"kernel": ("one minibatch step of the generic path (forward, heads + loss, backward per layer, slab sums; both nets in every launch; the optimizer launch is outside the bracket)"
+                                        if name == "config4" else "fwd_bwd_mfma_ws_kernel (gather+forward+PPO loss+backward)"),
+                             "bound": "mfma", "flops_per_launch": fl_o, "avg_launch_ms": fb, "launches": pr["fwd_bwd_launches"],
+                             "achieved": fl_o / (fb * 1e-3) / 1e12 if fb else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": fl_o / (fb * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb else None,
+                             "sampling": "HIP events on the context's stream around 1 launch in 41"},
+                "train_stats": {k: st_o[k] for k in ("loss", "ep_len_mean", "explained_variance", "global_step")}}
+
+    other_workloads = None
+    if rank == 0 and world == 1 and args.workload == "cartpole" and not args.no_other_workloads and not args.comm_selftest and args.kernel_flags == 0:
+        other_workloads = {}
+        for name in ("mountaincar", "config4"):
+            try:
+                other_workloads[name] = measure_other(name)
+            except Exception as ex:   # the headline line is printed whatever happens here
+                other_workloads[name] = {"failed": repr(ex)}
 
     if rank == 0:
         env_steps = args.steps * N * T * world
@@ -740,7 +816,7 @@ def main():
         out = {
             "metric": "env-steps/sec (rollout+update)", "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "weak", "vs_baseline": None, "value_runs": value_runs, "other_workloads": other_workloads,
             "dtype": "bf16" if generic else "f32 (update GEMMs: two-term f16 split on f16 MFMA, fp32 accumulate; everything else IEEE f32)",
             # the gradient all-reduce that ran (N > 1), what was asked for, and why they differ if they do
             "transport": transport, "transport_requested": requested if world > 1 else None, "transport_fallback_reason": fallback_reason,
@@ -755,7 +831,7 @@ def main():
             "profiles": profile_tie(),
             # primary numbers: the launch by itself (200 in a row on this workload's own buffers, live, after the timed region) -- the duration
             # the rocprofv3 kernel trace agrees with; the in-iteration HIP-event reading (an event pair adds ~3 us to a ~5 us launch) is kept beside it
-            "gae_roofline": {"kernel": "gae_kernel (exact mode; 4096 < envs <= 8192 take gae_pipe_kernel, the same scan pipelined in time)", "bound": "hbm", "achieved": gae_own["achieved"], "peak": HBM_PEAK_GBS,
+            "gae_roofline": {"kernel": "gae_kernel (exact mode; 4096 < envs <= 8192 take gae_pipe_kernel, the same scan pipelined in time; from 16384 envs 64-column strips x 32-row time tiles)", "bound": "hbm", "achieved": gae_own["achieved"], "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_own["frac"],
                              "traffic": (gae_tr or {}).get("bytes"), "traffic_detail": gae_tr, "bytes_per_launch": gae_bytes,
                              "avg_launch_ms": gae_own["avg_launch_ms"], "launches": 200,

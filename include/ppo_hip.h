@@ -28,7 +28,7 @@ extern "C" {
 
 #define PPO_MAX_HEADS 8
 #define PPO_API __attribute__((visibility("default")))
-#define PPO_ABI_VERSION 4
+#define PPO_ABI_VERSION 5
 
 typedef int32_t ppo_status;
 enum { PPO_OK = 0, PPO_ERR_INVALID = 1, PPO_ERR_HIP = 2, PPO_ERR_STATE = 3, PPO_ERR_COMM = 4, PPO_ERR_UNSUPPORTED = 5 };
@@ -81,11 +81,13 @@ typedef struct ppo_config {
  *                               once per update (and after every host write of the parameters), the host reads a pinned mirror of them without synchronising (thresholds at half the
  *                               limits: max |W3| >= 128, max |W2| >= 4, anything else >= 8192), and a launch whose weights do not fit takes the vector
  *                               kernel (plain fp32, the same function) -- for that launch only, with the default flags.  An OBSERVATION beyond fp16 written
- *                               into PPO_BUF_OBS cannot be foreseen: the update's record packing raises the context's error word and ppo_read_stats /
- *                               ppo_stats_snapshot_read fail with PPO_ERR_STATE; the parameters are UNDEFINED from that update on (its gradient is not
- *                               finite); PPO_KERNEL_UPDATE_VECTOR has no such limit.  The same holds for a hand-over wait of the update kernel that runs
- *                               out (a protocol error, never observed in 1.6 M launches): reported, parameters undefined.  A host that saves checkpoints
- *                               reads the statistics first (host/PPO/PPOAlgorithm.cpp does).
+ *                               into PPO_BUF_OBS cannot be foreseen: the update's record packing raises the context's error word (only when the matrix-core
+ *                               kernel will read the records) and ppo_read_stats / ppo_stats_snapshot_read fail with PPO_ERR_STATE; PPO_KERNEL_UPDATE_VECTOR
+ *                               has no such limit.  The same holds for a hand-over wait of the update kernel, or of the time-pipelined advantage scan, that
+ *                               runs out (protocol errors, never observed in 1.6 M launches).  ABI 5: the optimizer kernels read the error word and do NOT
+ *                               APPLY a step behind any of these: parameters and AdamW moments keep the values they had before the error (the
+ *                               learning-rate schedule and the step counters run on), the error is sticky.  A gradient that is merely not finite (the
+ *                               reference's 1-row minibatch) is applied as the reference applies it.
  *   PPO_KERNEL_UPDATE_VECTOR    the update's forward / backward on the vector ALU (fwd_bwd_kernel) for every shape: plain fp32 arithmetic; also for
  *                               rehearsals of more than two ranks on ONE GPU (tests/test_gpu_exchange.py).
  *   PPO_KERNEL_UPDATE_ONE_WAVE  the one-wave-per-tile matrix-core kernel (fwd_bwd_mfma_kernel) instead of the wave-specialised one
@@ -295,7 +297,7 @@ PPO_API ppo_status ppo_train_iteration(ppo_ctx* ctx);
  * ep_len_mean / ep_count are what ONE context over all envs would report.  They describe the state at the last ppo_update: episodes that end in
  * a rollout taken AFTER it are not in them yet -- unlike a single context (one rank), whose episode ring is read as it stands.  ppo_comm_init
  * refuses more than 8 ranks (the block holds 8 slots: one node).  While a snapshot is pending (ppo_stats_snapshot) ppo_read_stats fails: read it first.
- * Device-side error words (reset table exhausted, fp16 range of the matrix-core rollout, a bounded wait of the update kernel) surface here and in
+ * Device-side error words (reset table exhausted, fp16 range of the matrix-core rollout, a bounded wait of the update kernel or of the scan) surface here and in
  * ppo_stats_snapshot_read as PPO_ERR_STATE; a host that runs an iteration ahead of its snapshots (the facade's train()) learns of them one
  * iteration late and must check the snapshot before it writes a checkpoint (it does). */
 PPO_API ppo_status ppo_read_stats(ppo_ctx* ctx, ppo_stats* out);
@@ -319,6 +321,8 @@ typedef struct ppo_profile {
     double phase_cycles[24];  /* mode 3: [critic, actor][12 phases] shader cycles of one wave of the dominant kernel */
     int64_t allreduce_launches;   /* N > 1: gradient / statistics all-reduces bracketed (every one in mode 1; in modes 2 and 4 the one behind a bracketed */
     double allreduce_ms;          /* dominant-kernel launch): the collective's device time on THIS rank, waiting for the slowest peer included */
+    int64_t vector_fallback_launches;   /* ABI 5: launches since ppo_ctx_create (NOT reset by a read) that took a vector kernel because a weight did not fit the fp16
+                                         * operands of the matrix-core kernel of the same function (kernel_flags, "fp16 ranges") */
 } ppo_profile;
 /* on: 0 = off, 1 = every instrumented launch, 2 = only the dominant kernel (fused forward/backward; ONE launch in 8 is bracketed: an
  * event pair costs the stream ~3 us, 40 pairs per update were 8 % of the run) and the GAE scan,

@@ -21,7 +21,7 @@ MM_F32X3, MM_BF16 = 0, 1
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
 KERNEL_ROLLOUT_VECTOR, KERNEL_UPDATE_VECTOR, KERNEL_UPDATE_ONE_WAVE, KERNEL_COMM_SELFTEST, KERNEL_GENERIC_CLASSIC = 1, 2, 4, 8, 16   # ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*)
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 COMM_HANDLE_BYTES = 64
 
@@ -76,7 +76,7 @@ class Profile(C.Structure):
     _fields_ = [("fwd_bwd_launches", C.c_int64), ("gae_launches", C.c_int64), ("rollout_launches", C.c_int64),
                 ("optimizer_launches", C.c_int64), ("reduce_launches", C.c_int64), ("fwd_bwd_ms", C.c_double), ("gae_ms", C.c_double),
                 ("rollout_ms", C.c_double), ("optimizer_ms", C.c_double), ("reduce_ms", C.c_double), ("phase_cycles", C.c_double * 24),
-                ("allreduce_launches", C.c_int64), ("allreduce_ms", C.c_double)]
+                ("allreduce_launches", C.c_int64), ("allreduce_ms", C.c_double), ("vector_fallback_launches", C.c_int64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "phase_cycles"}

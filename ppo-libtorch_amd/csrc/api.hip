@@ -180,7 +180,7 @@ struct ppo_ctx {
     bool gen_opt_fused_ok = false;             // generic bf16 path: the last backward pass left the sums of squares gen_opt_fused needs, and nothing touched the gradient since
     bool gen_obs_bf_valid = false;             // generic bf16 path: GenericCtx::obs_bf holds THIS update's observations (set by the update's first step)
     bool wr_in_update = false;                 // rollout / update / stand-alone step, not per launch (an update moves a weight by less than 40 lr: the thresholds' margin)
-    int64_t vector_fallback_launches = 0;   // launches that took a vector kernel because a weight did not fit fp16
+    int64_t vector_fallback_launches = 0;   // launches that took a vector kernel because a weight did not fit fp16 (ppo_profile.vector_fallback_launches)
     unsigned long long* stamps = nullptr;  // [2][12] phase cycles of the diagnostic kernel variant
     GenericCtx* gen = nullptr;       // non-null: synthetic env / network other than 2 x 64 (generic.hpp); every L-dependent entry point dispatches on it
     uint8_t* cur_mask = nullptr;     // generic path: action mask of the observation in NEXT_OBS, [N, A]
@@ -1358,10 +1358,13 @@ static ppo_status gen_rollout(ppo_ctx* c, const int64_t* forced) {
 // (PPO_Discrete.cpp:557-562).  Also leaves the explained-variance partial sums (:647-648), which read the same returns / values.
 static ppo_status pack_records(ppo_ctx* c) {
     if (!c->use_mfma || c->gen) return PPO_OK;
+    // the observation's fp16 range is an error only where the wave-specialised matrix-core kernel will read the records: not with the one-wave kernel, and
+    // not in an update whose weights send every launch to the vector kernel (the caller has refreshed the range snapshot: ppo_update, stand-alone step)
+    const bool ws_will_run = !c->update_single_wave && weights_fit_update_mfma(c);
     HIPCHK(c, launch_pack_records(c->L, B_<float>(c, PPO_BUF_OBS), B_<int32_t>(c, PPO_BUF_ACTIONS),
                                   c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
                                   B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES), c->B, c->rec_critic,
-                                  c->rec_actor, c->ev_sums, c->update_single_wave ? nullptr : c->error_flag, c->stream));
+                                  c->rec_actor, c->ev_sums, ws_will_run ? c->error_flag : nullptr, c->stream));
     return PPO_OK;
 }
 
@@ -1420,7 +1423,7 @@ static hipError_t clip_adamw_any(ppo_ctx* c, int slot, double global_M, int worl
     if (c->gen && c->gen_opt_fused_ok) {
         if (do_step) c->gen_opt_fused_ok = false;   // its partial sums belong to the gradient the step consumes
         return gen_opt_fused(*c->gen, B_<float>(c, PPO_BUF_PARAMS), B_<float>(c, PPO_BUF_GRADS), B_<float>(c, PPO_BUF_EXP_AVG), B_<float>(c, PPO_BUF_EXP_AVG_SQ),
-                             c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, do_step, c->step_stats + slot, clipfrac_accum, c->stream);
+                             c->cfg.max_grad_norm, c->adam_coefs + slot, c->loss_sums, global_M, c->hp, do_step, c->step_stats + slot, clipfrac_accum, c->error_flag, c->stream);
     }
     if (c->gen) {
         if (do_step) c->gen->planes_dirty = true;
@@ -1439,6 +1442,11 @@ extern "C" ppo_status ppo_minibatch_forward_backward(ppo_ctx* c, const int32_t* 
     NEED(c, M >= 1 && M <= c->B, "minibatch size out of range");
     const int slot = c->steps_per_update;  // scratch slot
     {   // stand-alone call: the caller may have rewritten any rollout buffer since the last pack
+        if (c->use_mfma && !c->gen) {
+            const ppo_status rs = refresh_weight_range(c);
+            if (rs != PPO_OK) return rs;
+            if (!c->wr_in_update) wr_snapshot(c);
+        }
         const ppo_status ps = pack_records(c);
         if (ps != PPO_OK) return ps;
     }
@@ -1503,14 +1511,14 @@ extern "C" ppo_status ppo_update(ppo_ctx* c) {
     const int32_t* perm = B_<int32_t>(c, PPO_BUF_PERM);
     // returns, values and advantages are fixed for the whole update: the sample records and the explained-variance sums (:647-648) are formed first,
     // so that a sharded run can send its statistics along with the advantage sums
-    s = pack_records(c);
-    if (s != PPO_OK) return s;
-    if (!c->gen) {
+    if (!c->gen) {   // the fp16-range snapshot of this update first: pack_records asks it whether the matrix-core kernel will read the records
         s = refresh_weight_range(c);
         if (s == PPO_OK) s = sweep_weight_range(c, c->wr_stream);
         if (s != PPO_OK) return s;
         wr_snapshot(c);
     }
+    s = pack_records(c);
+    if (s != PPO_OK) return s;
     struct InUpdate {
         ppo_ctx* c;
         explicit InUpdate(ppo_ctx* x) : c(x) { c->wr_in_update = true; c->gen_obs_bf_valid = false; }
@@ -1809,6 +1817,7 @@ extern "C" ppo_status ppo_profile_read(ppo_ctx* c, ppo_profile* out) {
     unsigned long long st[24];
     HIPCHK(c, hipMemcpy(st, c->stamps, sizeof st, hipMemcpyDeviceToHost));
     for (int i = 0; i < 24; i++) out->phase_cycles[i] = (double)st[i];
+    out->vector_fallback_launches = c->vector_fallback_launches;
     return PPO_OK;
 }
 

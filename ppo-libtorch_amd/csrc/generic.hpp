@@ -182,7 +182,8 @@ hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const
 hipError_t gen_backward_both(const GenericCtx& g, const float* params, int64_t rows, float* grads, hipStream_t s);
 // the optimizer step behind gen_backward_both on a single rank, one launch: loss sums, gradient norm (from the slab sums' partials), clip + AdamW, bf16 weight planes
 hipError_t gen_opt_fused(const GenericCtx& g, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
-                         double* sums_out, double global_M, LossParams hp, bool do_step, StepStats* stats_out, double* clipfrac_accum, hipStream_t s);
+                         double* sums_out, double global_M, LossParams hp, bool do_step, StepStats* stats_out, double* clipfrac_accum, const int32_t* error_flag,
+                         hipStream_t s);
 hipError_t gen_loss_sums(const GenericCtx& g, double* sums_out, float* grads_tail, hipStream_t s);
 hipError_t gen_fill(float* p, int64_t n, float v, hipStream_t s);
 hipError_t gen_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const GenLayout& L, float max_grad_norm, const AdamCoef* coef,

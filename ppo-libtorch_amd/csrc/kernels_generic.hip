@@ -987,6 +987,7 @@ struct GenOptArgs {
     const AdamCoef* coef; const double* loss_part; int loss_blocks; double* sums_out; float* grads_tail;
     double global_M; LossParams hp; int do_step; StepStats* stats_out; double* clipfrac_accum;
     uint16_t* planes; uint16_t* frags; int64_t wp_off[2][GEN_MAX_LAYERS]; int wp_kpad[GEN_MAX_LAYERS];
+    const int32_t* error_flag;   // the context's error word (OptGuard, ppo_internal.hpp): a step behind PPO_ERRFLAG_SKIP_STEP is not applied
 };
 __global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) {
     __shared__ double s_t[4 * GEN_MAX_LAYERS];
@@ -995,6 +996,7 @@ __global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) 
     const GenLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_jobs = 2 * L.n_layers;
+    const int32_t err = opt_guard_word(a.error_flag);
     for (int j = wave; j < n_jobs; j += 4) {
         const int net = j / L.n_layers, l = j % L.n_layers;
         const int64_t n_el = (int64_t)L.out_dim[net][l] * L.in_dim[l] + L.out_dim[net][l];
@@ -1050,7 +1052,7 @@ __global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) 
     if (c > 1.0f) c = 1.0f;
     const AdamCoef k = *a.coef;
     const float b1 = 0.9f, b2 = 0.999f, omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999), eps = 1e-5f;
-    if (a.do_step) {
+    if (a.do_step && !(err & PPO_ERRFLAG_SKIP_STEP)) {
         const int stride = gridDim.x * 256;
         for (int p0 = blockIdx.x * 256 + tid; p0 < L.P; p0 += OPT_EPT * stride) {
             float g[OPT_EPT], pv[OPT_EPT], mv[OPT_EPT], vv[OPT_EPT];
@@ -1417,14 +1419,15 @@ hipError_t gen_backward_both(const GenericCtx& g, const float* params, int64_t r
 // The optimizer step behind the fused backward passes of both nets (gen_backward_both, or gen_backward per net) on a single rank: ONE launch (gen_opt_fused_kernel) for the loss sums, the gradient norm out of the slab sums'
 // partials, clip + AdamW and the refreshed bf16 weight planes.  do_step false: loss scalars and the norm only.
 hipError_t gen_opt_fused(const GenericCtx& g, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
-                         double* sums_out, double global_M, LossParams hp, bool do_step, StepStats* stats_out, double* clipfrac_accum, hipStream_t s) {
+                         double* sums_out, double global_M, LossParams hp, bool do_step, StepStats* stats_out, double* clipfrac_accum, const int32_t* error_flag,
+                         hipStream_t s) {
     const GenLayout& L = g.L;
-    if (!g.sq_part || g.sq_cap <= 0) return hipErrorInvalidValue;
+    if (!g.sq_part || g.sq_cap <= 0 || (PPO_OPT_GUARD && !error_flag)) return hipErrorInvalidValue;
     GenOptArgs a{};
     a.params = params; a.grads = grads; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.L = L; a.max_norm = max_grad_norm;
     a.sq_part = g.sq_part; a.xb = g.sq_cap;
     a.coef = coef; a.loss_part = g.loss_part; a.loss_blocks = GEN_LOSS_BLOCKS; a.sums_out = sums_out; a.grads_tail = grads + L.P;
-    a.global_M = global_M; a.hp = hp; a.do_step = do_step ? 1 : 0; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum;
+    a.global_M = global_M; a.hp = hp; a.do_step = do_step ? 1 : 0; a.stats_out = stats_out; a.clipfrac_accum = clipfrac_accum; a.error_flag = error_flag;
     const bool planes = do_step && g.gemm_prec == PPO_MM_BF16 && g.wfrags != nullptr && !g.planes_dirty;   // dirty planes are rebuilt whole by their next user
     a.planes = planes ? g.wplanes : nullptr; a.frags = planes ? g.wfrags : nullptr;
     for (int net = 0; net < 2; net++) for (int l = 0; l < L.n_layers; l++) a.wp_off[net][l] = g.wp_off[net][l];

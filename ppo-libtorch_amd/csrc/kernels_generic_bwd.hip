@@ -106,6 +106,16 @@ __device__ __forceinline__ void bw_glds16_s(const uint16_t* sbase, uint32_t voff
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(d) : "memory");
 }
 
+// 64 lanes x 4 bytes -> 256 bytes at lds_wave_base, lane-linear: the index list's entries of a tile's rows (layer 0, rows read in place).  A DMA, not a load into a
+// register: a register that an asm load has in flight is, for the compiler, a value it may copy at any time -- hipcc (ROCm 7.2) placed such a copy IN FRONT of the
+// counted wait in one instantiation (harmless there by luck: tests/test_asm_hazards.py found it) -- whereas nothing can touch the LDS words before the ds_read that
+// follows the wait.
+__device__ __forceinline__ void bw_glds4(const int32_t* src, uint32_t dst) {
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
+}
+
 // MFMA operand fragment by TRANSPOSING reads out of an image [k rows][W columns]: lane (i = lane & 31, kg = lane >> 5) receives column x0 + i of the
 // eight rows 16 ks + 8 kg .. + 7.  Lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 (see kernels_gemm.hip: frag).
 template <int W, bool DZ>
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     uint16_t* const sH = sD + BW_RING * DSZ;              // [3][64][64]
     uint16_t* const sO = sH + BW_RING * HSZ;              // [2][64][64] result tile of P1
     float* const sRed = reinterpret_cast<float*>(sO + (P1 ? 2 : 0) * BW_ROWS * BW_KC);   // [2][64]
+    int32_t* const sIdx = reinterpret_cast<int32_t*>(sRed + 2 * BW_KC) + BW_WAVES * 256;  // layer 0: [2][8 waves][64] index-list entries, behind the waves' spare KiBs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware order: workgroup ids go round-robin over the 8 XCDs; the CB column blocks of a row range take consecutive slots of ONE XCD
     const int xcd = bid & 7, slot = bid >> 3;
@@ -219,16 +230,14 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     // ---- LDS-DMA of tile t into buffer t % 3: the image is lane-linear, so lane j of piece p fetches the chunk whose SWIZZLED place is 64 p + j.
     //      EVERY wave issues DPW + 1 instructions per tile (a wave without a piece of a narrow dZ tile fetches zeros into a spare KiB): the counted
     //      s_waitcnt vmcnt in the loop relies on it ----
-    // Gathered h rows: the source row of this lane's row of a tile comes from a.idx.  The load is inline asm like the DMA (a load the compiler can see would get
-    // its own s_waitcnt, and the compiler counts only what it sees: vmcnt(0) in front of the first use, which drains the ring); it is issued one iteration
-    // before the DMA that needs it and IN FRONT of that iteration's DMAs, so the counted wait at the end of the iteration -- all but the last VM_TILE
-    // operations -- covers it; the wait statements carry the register as an operand, which keeps the address arithmetic behind them.
-    auto load_index = [&](int t) -> int {
+    // Gathered h rows (layer 0): the source row of this lane's row of a tile comes from a.idx.  The entries of tile t + 3 travel by DMA into the wave's own 256 bytes
+    // of sIdx[(t + 3) & 1] at the TOP of iteration t, IN FRONT of that iteration's tile DMAs, so the counted wait at the end of the iteration -- all but the last
+    // VM_TILE operations -- covers them; iteration t + 1 reads them back with a ds_read the compiler can see (its own lgkmcnt wait) and issues tile t + 3.  EVERY
+    // wave of a layer-0 instantiation issues the instruction, gathered or not (from the zeros when there is no index list): the counted waits rely on it.
+    // Tiles 0 .. 2: plain loads in the prologue, where nothing is in flight yet.
+    auto index_row = [&](int t) -> int64_t {
         int64_t r = row_begin + (int64_t)t * BW_ROWS + ((64 * wave + lane) >> 3);
-        if (r >= a.rows) r = a.rows - 1;
-        int v;
-        asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(a.idx + r) : "memory");
-        return v;
+        return r >= a.rows ? a.rows - 1 : r;
     };
     const bool gathered = !P1 && a.idx != nullptr;
     // this lane's share of a tile's DMA, fixed for the launch: piece p = wave + 8 i of the dZ tile (lane j of piece p fetches the chunk whose swizzled place is 64 p + j)
@@ -247,7 +256,10 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #pragma unroll
         for (int k = 0; k < KCB; k++) h_off[k] = (uint32_t)(h_row * (int)a.ldh + BW_KC * (KCB * c + k) + 8 * ((q & 7) ^ swz_h(h_row))) * 2u;
     }
-    const uint32_t lds0 = bw_lds_addr(bw_lds), spare0 = bw_lds_addr(sRed + 2 * BW_KC);
+    const uint32_t lds0 = bw_lds_addr(bw_lds), spare0 = bw_lds_addr(sRed + 2 * BW_KC), idx0 = bw_lds_addr(sIdx) + 256u * wave;
+    auto index_dma = [&](int t) {   // layer 0 only
+        bw_glds4(gathered ? a.idx + index_row(t) : reinterpret_cast<const int32_t*>(a.zeros), idx0 + (uint32_t)(t & 1) * (BW_WAVES * 256u));
+    };
     auto issue = [&](int t, int b, int hsrc) {   // tile t into ring buffer b = t % BW_RING
         const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
         const uint32_t dD = lds0 + (uint32_t)(b * DSZ) * 2u;                          // byte addresses in LDS (wave-uniform)
@@ -289,13 +301,10 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #pragma unroll
     for (int r = 0; r < 16; r++) csum[r] = 0.0f;
 
-    int hs_next = 0;   // gathered: this lane's source row in tile t + 2 at the top of iteration t
+    int hs_next = 0;   // gathered: this lane's source row in tile t + 2 when iteration t issues that tile
     {
         int h0 = 0, h1 = 0;
-        if (gathered && n_tiles > 0) {
-            h0 = load_index(0); h1 = load_index(1); hs_next = load_index(2);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(hs_next) :: "memory");
-        }
+        if (gathered && n_tiles > 0) { h0 = a.idx[index_row(0)]; h1 = a.idx[index_row(1)]; hs_next = a.idx[index_row(2)]; }
         if (n_tiles > 0) issue(0, 0, h0);
         if (n_tiles > 1) issue(1, 1, h1);
     }
@@ -320,9 +329,12 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         const uint16_t* const tD = sD + rb * DSZ;
         const uint16_t* const tH = sH + rb * HSZ;
         const int rb2 = rb == 0 ? BW_RING - 1 : rb - 1;   // (t + 2) % 3
-        int hs_load = 0;
         if (t + 2 < n_tiles) {                      // into the buffer every wave finished reading before the barrier that ended iteration t - 1
-            if (gathered) hs_load = load_index(t + 3);
+            if constexpr (!P1) {
+                // tile t + 2's entries landed under the wait that ended iteration t - 1 (tile 2's came with the prologue's loads)
+                if (t > 0) hs_next = gathered ? sIdx[((t + 2) & 1) * (BW_WAVES * 64) + 64 * wave + lane] : 0;
+                index_dma(t + 3);
+            }
             issue(t + 2, rb2, hs_next);
         }
         if constexpr (P1) { if (t > 0) store_out(t - 1); }
@@ -370,17 +382,16 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         // tile t + 2 and the store of tile t - 1) -- counted, so that tile t + 2 stays in flight across the barrier (a plain __syncthreads() would drain
         // it: the compiler's fence waits for vmcnt(0)).  The last iterations issue less: they wait for everything.
 #ifdef BW_FULL_WAIT
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hs_load) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (false) {
 #else
         if (t + 2 < n_tiles) {
 #endif
-            if (t > 0) asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(hs_load) : "n"(VM_PER_ITER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(hs_load) : "n"(VM_TILE) : "memory");   // the first iteration has no result tile to store yet
+            if (t > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_PER_ITER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(VM_TILE) : "memory");   // the first iteration has no result tile to store yet
         } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hs_load) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
-        hs_next = hs_load;
         rb = rb == BW_RING - 1 ? 0 : rb + 1;
         bw_barrier();
     }
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 template <int NB, bool P1, int KCB>
 constexpr size_t bwd_lds_bytes() {   // ring of dZ and h tiles, (P1) two result tiles, the column-sum hand-over, a spare KiB per wave for DMA pieces a narrow tile does not have
     return (BW_RING * ((size_t)BW_ROWS * (32 * NB < 64 ? 64 : 32 * NB) + (size_t)KCB * BW_ROWS * BW_KC) + (P1 ? 2 : 0) * (size_t)BW_ROWS * BW_KC) * sizeof(uint16_t) +
-           2 * BW_KC * sizeof(float) + (size_t)BW_WAVES * 1024;
+           2 * BW_KC * sizeof(float) + (size_t)BW_WAVES * 1024 + (P1 ? 0 : 2 * (size_t)BW_WAVES * 256);   // layer 0: + the ring of index-list entries
 }
 
 template <int NB, bool P1, int KCB>

@@ -558,9 +558,11 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_kernel(float* __restr
     const int tid = threadIdx.x;
     // this thread's element, the norms and the statistics scalars are all requested before anything is consumed
     const int pu = blockIdx.x * ADAM_THREADS + tid;
-    const bool upd = do_step && pu < L.P;
+    bool upd = do_step && pu < L.P;
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
     if (upd) { u_g = grads[pu]; u_p = params[pu]; u_m = exp_avg[pu]; u_v = exp_avg_sq[pu]; }
+    const int32_t err = opt_guard_word(guard.error_flag);   // requested with the step's other loads
+    upd = upd && !(err & PPO_ERRFLAG_SKIP_STEP);   // a step the device knows is garbage is not applied (OptGuard, ppo_internal.hpp)
     double n2[12];
 #pragma unroll
     for (int t = 0; t < 12; t++) n2[t] = t < L.n_tensors ? norm2[t] : 0.0;
@@ -836,6 +838,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
     const bool own = p < L.P;
     float u_g = 0.0f, u_p = 0.0f, u_m = 0.0f, u_v = 0.0f;
     if (own) { u_g = a.grads[p]; u_p = a.p_src[p]; u_m = a.m_src[p]; u_v = a.v_src[p]; }
+    const int32_t err = opt_guard_word(a.guard.error_flag);   // requested with the step's other loads
     const AdamCoef k = *a.coef;
     double ls[5] = { 0, 0, 0, 0, 0 }, cf0 = 0.0, cf1 = 0.0;
     const bool stat_thread = tid == 0 && blockIdx.x == 0;
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adamw_sumsq_kernel(FusedOpt
     }
     const float total = opt_total_norm(L, a.partial, n2s, tid);
     const float c = opt_clip_coef(total, a.max_norm);
-    if (own) {
+    if (own && !(err & PPO_ERRFLAG_SKIP_STEP)) {   // a step the device knows is garbage is not applied (OptGuard, ppo_internal.hpp)
         adamw_apply(u_g, c, k, u_p, u_m, u_v);
         a.params[p] = u_p;
         a.exp_avg[p] = u_m;
@@ -1120,6 +1123,7 @@ hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
                              StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s, OptGuard guard) {
+    if (PPO_OPT_GUARD && !guard.error_flag) return hipErrorInvalidValue;   // the kernel reads the word without a null check
     hipLaunchKernelGGL(grad_norm_kernel, dim3(L.n_tensors), dim3(NORM_THREADS), 0, s, grads, L, norm2_scratch);
     const int blocks = do_step ? (L.P + ADAM_THREADS - 1) / ADAM_THREADS : 1;
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(blocks), dim3(ADAM_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, L, max_grad_norm, norm2_scratch,
@@ -1136,6 +1140,7 @@ hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, 
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
                                     double* partial, hipStream_t s, OptGuard guard) {
+    if (PPO_OPT_GUARD && !guard.error_flag) return hipErrorInvalidValue;   // the kernel reads the word without a null check
     FusedOptArgs a{};
     a.guard = guard;
     a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;
@@ -1154,6 +1159,7 @@ hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* st
                                              void* const* peers, int rank, int n_ranks, size_t slot_bytes, uint64_t seq, int32_t* timeout_flag,
                                              hipStream_t s, OptGuard guard) {
     if (n_ranks < 1 || n_ranks > 8 || (size_t)(L.P + 8) * sizeof(float) > slot_bytes) return hipErrorInvalidValue;
+    if (PPO_OPT_GUARD && !guard.error_flag) return hipErrorInvalidValue;   // the kernel reads the word without a null check
     FusedOptArgs a{};
     a.guard = guard;
     a.slab = slab; a.stat_slab = stat_slab; a.nb0 = n_blocks[0]; a.nb1 = n_blocks[1]; a.L = L; a.grads = grads; a.sums_out = sums_out;

@@ -417,22 +417,47 @@ __device__ __forceinline__ double wave_sum_d_dpp(double v) {
 // w + 8 in a fixed order (all three loads in flight together, sums on the DPP network).  Every thread of the workgroup must call it
 // (one barrier inside); n2s: 12 doubles of shared memory.
 __device__ __forceinline__ float opt_total_norm(const NetLayout& L, const double* __restrict__ partial, double* n2s, int tid) {
-    const int lane = tid & 63, w = tid >> 6;
+    // The wave index as a SCALAR (it is wave-uniform; the compiler cannot know): L.tensor_off[w + 4 j] is then a scalar load out of the kernel arguments.  Indexed
+    // by the per-lane value it was a VECTOR load from the argument segment with a wait behind it, and the partials' loads depended on it: three such pairs in a
+    // row, six dependent memory round trips in a 5 us kernel (round 6, found in the assembly).  Now: the three tensors' block ranges first, then EVERY load of the
+    // wave's three tensors (two per lane and tensor cover 128 workgroups of the slab reduction: more than any tensor of the reference's shapes spans) in one
+    // batch, then the sums -- in the same order as before (a lane's blocks in index order), so the same bits.
+    // Loads are UNCONDITIONAL with clamped addresses and the values selected afterwards: a load inside a divergent branch makes the compiler wait for it at
+    // the join.  The thirteen offsets come as one batch of scalar loads and are picked by selects over a fixed bound, not by a dependent indexed load each.
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (w < 4) {
-        double v[3];
+        int off[13];
+#pragma unroll
+        for (int t = 0; t < 13; t++) off[t] = L.tensor_off[t];
+        int blo[3], bhi[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int t = w + 4 * j;
-            v[j] = 0.0;
-            if (t < L.n_tensors) {
-                const int blo = L.tensor_off[t] / 64, bhi = (L.tensor_off[t + 1] - 1) / 64;
-                for (int b = blo + lane; b <= bhi; b += 64) v[j] += partial[(size_t)b * 12 + t];
-            }
+            int lo = 0, hi = 0;
+#pragma unroll
+            for (int tt = 0; tt < 12; tt++) { lo = tt == t ? off[tt] : lo; hi = tt == t ? off[tt + 1] : hi; }
+            const bool have = t < L.n_tensors;
+            blo[j] = have ? lo / 64 : 1;
+            bhi[j] = have ? (hi - 1) / 64 : 0;
+        }
+        double v0[3], v1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int t = w + 4 * j, b = blo[j] + lane;
+            const int b0 = b <= bhi[j] ? b : 0, b1 = b + 64 <= bhi[j] ? b + 64 : 0;
+            v0[j] = partial[(size_t)b0 * 12 + t];
+            v1[j] = partial[(size_t)b1 * 12 + t];
         }
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const double r = wave_sum_d_dpp(v[j]);
-            if (lane == 0) n2s[w + 4 * j] = r;
+            const int t = w + 4 * j, b = blo[j] + lane;
+            double v = 0.0;
+            v += b <= bhi[j] ? v0[j] : 0.0;
+            v += b + 64 <= bhi[j] ? v1[j] : 0.0;
+            if (bhi[j] - blo[j] >= 128)   // wave-uniform; no tensor of the reference's shapes gets here
+                for (int bb = b + 128; bb <= bhi[j]; bb += 64) v += partial[(size_t)bb * 12 + t];
+            const double r = wave_sum_d_dpp(v);
+            if (lane == 0) n2s[t] = r;
         }
     }
     __syncthreads();
@@ -583,6 +608,7 @@ constexpr int32_t PPO_ERRFLAG_UPDATE_PROTOCOL = 2;
 constexpr int32_t PPO_ERRFLAG_GAE_PROTOCOL = 16;   // gae_pipe_kernel: a bounded wait between its mover waves and its walker ran out (that strip's advantages / returns are NaN)
 constexpr int32_t PPO_ERRFLAG_UPDATE_RANGE = 8;    // a matrix-core update kernel met an observation that does not fit its fp16 operand (|obs| >= 65 504)
 constexpr int32_t PPO_ERRFLAG_ROLLOUT_RANGE = 4;   // rollout16_kernel: |W3| does not fit the fp16 operand (pre-scaled by 2^8)
+constexpr int32_t PPO_ERRFLAG_SKIP_STEP = PPO_ERRFLAG_UPDATE_PROTOCOL | PPO_ERRFLAG_UPDATE_RANGE | PPO_ERRFLAG_GAE_PROTOCOL;   // the optimizer does not apply a step behind these
 int update_blocks_per_net(int M);
 hipError_t launch_minibatch_fwd_bwd(const UpdateArgs& a, hipStream_t s);
 // matrix-core version of the same kernel; sum(head_dims) <= 4, obs in {2, 4}: fp32 carried as two fp16 terms, three
@@ -602,12 +628,29 @@ hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32
 //   (refresh_weight_range); wr_dev[4..6] mirrors what the pinned host words hold.  The HOST reads the mirror without synchronising, an update or two late --
 //   AdamW moves a weight by about lr per step, hence thresholds at half the kernels' limits -- and takes the vector kernels for a launch whose weights do
 //   not fit fp16 instead of failing.
-// The optimizer kernels themselves carry no guard: a load of the error word cost the latency-bound AdamW kernel 0.4 us per step, and skipping a step whose
-// gradient norm is not finite would break parity (the reference applies it: a 1-row minibatch gives NaN parameters there too, tests/test_gpu_parity.py).
-// After PPO_ERRFLAG_UPDATE_PROTOCOL / _RANGE the parameters are undefined; the error is sticky and ppo_read_stats reports it (the facade checks before saving).
+// The optimizer kernels read the context's error word (OptGuard: one load that is in flight with the step's other loads) and do NOT apply a step the
+// device already knows is garbage -- a bounded wait of the update kernel or of the scan ran out, or an observation left the fp16 range of the matrix-core
+// update kernel (PPO_ERRFLAG_SKIP_STEP): parameters and moments stay as they were, the statistics are still written, the error stays sticky and
+// ppo_read_stats reports it.  A gradient that is merely not finite is applied as the reference applies it (a 1-row minibatch gives NaN parameters there
+// too, tests/test_gpu_parity.py): that is parity, not an error.
 struct OptGuard {
     int32_t* error_flag = nullptr;
 };
+#ifndef PPO_OPT_GUARD
+#define PPO_OPT_GUARD 1   /* -DPPO_OPT_GUARD=0: the optimizer kernels without the error-word load (A/B of its cost) */
+#endif
+#ifdef __HIPCC__
+// The error word as a VECTOR load: the address passes through a vector register the compiler cannot see through, so the load is issued in the same batch as
+// the step's other vector loads and waited for with them.  Left to itself hipcc made it two DEPENDENT scalar loads (the pointer out of the kernel arguments,
+// then the word) with a wait behind each at the very top of the kernel, in front of everything else: + 0.15 us on a 5 us launch (trace A/B, NOTES).
+// error_flag is never null here: the launchers refuse a null word (no branch in the kernel: a branch made the compiler wait for the word on the spot).
+__device__ __forceinline__ int32_t opt_guard_word(const int32_t* error_flag) {
+    if (!PPO_OPT_GUARD) return 0;
+    uintptr_t p = reinterpret_cast<uintptr_t>(error_flag);
+    asm volatile("" : "+v"(p));
+    return *reinterpret_cast<const __attribute__((address_space(1))) int32_t*>(p);
+}
+#endif
 __device__ __forceinline__ int wr_class(const NetLayout& L, int p) {
     const bool w3 = (p >= L.w3[0] && p < L.b3[0]) || (p >= L.w3[1] && p < L.b3[1]);
     const bool w2 = (p >= L.w2[0] && p < L.b2[0]) || (p >= L.w2[1] && p < L.b2[1]);
@@ -619,7 +662,7 @@ hipError_t launch_reduce_grads(const float* slab, const double* stat_slab, const
                                double* sums_out, hipStream_t s);
 hipError_t launch_clip_adamw(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const NetLayout& L, float max_grad_norm,
                              const AdamCoef* coef, const double* loss_sums, double global_M, LossParams hp, int world, bool do_step,
-                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s, OptGuard guard = OptGuard());
+                             StepStats* stats_out, double* clipfrac_accum, double* norm2_scratch, hipStream_t s, OptGuard guard);
 // recomputes the three maxima of OptGuard from the parameters (after the host wrote them): wr_dev and wr_host both
 hipError_t launch_weight_range(const float* params, const NetLayout& L, uint32_t* wr_dev, uint32_t* wr_host, hipStream_t s);
 // batched critic on the matrix cores (obs in {2, 4}); same contract as launch_values
@@ -630,12 +673,12 @@ int fused_opt_blocks(const NetLayout& L);
 hipError_t launch_reduce_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                     double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm,
                                     const AdamCoef* coef, double global_M, LossParams hp, StepStats* stats_out, double* clipfrac_accum,
-                                    double* partial, hipStream_t s, OptGuard guard = OptGuard());
+                                    double* partial, hipStream_t s, OptGuard guard);
 hipError_t launch_reduce_exchange_clip_adamw(const float* slab, const double* stat_slab, const int n_blocks[2], const NetLayout& L, float* grads,
                                              double* sums_out, float* params, float* exp_avg, float* exp_avg_sq, float max_grad_norm, const AdamCoef* coef,
                                              double global_M, const LossParams& hp, StepStats* stats_out, double* clipfrac_accum, double* partial,
                                              void* const* peers, int rank, int n_ranks, size_t slot_bytes, uint64_t seq, int32_t* timeout_flag,
-                                             hipStream_t s, OptGuard guard = OptGuard());
+                                             hipStream_t s, OptGuard guard);
 // Device-resident CircularBuffer(100) of finished episodes (reference Utils/Utils.h:30-79).
 struct EpisodeRing {
     float rew[100];

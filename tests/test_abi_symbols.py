@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(P):
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
     assert [e for e in exported if e.startswith("ppo_")] == decl
     assert all(e.startswith("ppo_") or e.startswith("_") for e in exported)  # nothing else leaks from the C-ABI
-    assert lib.ppo_abi_version() == P.binding.ABI_VERSION == 4
+    assert lib.ppo_abi_version() == P.binding.ABI_VERSION == 5
 
 
 def test_struct_mirrors_match_header(P):
@@ -45,16 +45,17 @@ def test_struct_mirrors_match_header(P):
 #include <stddef.h>
 #include "ppo_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ppo_config), offsetof(ppo_config, head_dims), offsetof(ppo_config, seed),
-         offsetof(ppo_config, learning_rate), offsetof(ppo_config, max_grad_norm), sizeof(ppo_stats), offsetof(ppo_stats, ep_count));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ppo_config), offsetof(ppo_config, head_dims), offsetof(ppo_config, seed),
+         offsetof(ppo_config, learning_rate), offsetof(ppo_config, max_grad_norm), sizeof(ppo_stats), offsetof(ppo_stats, ep_count),
+         sizeof(ppo_profile), offsetof(ppo_profile, allreduce_ms), offsetof(ppo_profile, vector_fallback_launches));
   return 0;
 }'''
     exe = "/tmp/ppo_abi_probe"
     subprocess.run(["gcc", "-x", "c", "-I", os.path.join(ROOT, "include"), "-o", exe, "-"], input=probe.encode(), check=True)
     got = [int(x) for x in subprocess.check_output([exe]).split()]
-    Cfg, St = P.binding.Config, P.binding.Stats
+    Cfg, St, Pr = P.binding.Config, P.binding.Stats, P.binding.Profile
     assert got == [C.sizeof(Cfg), Cfg.head_dims.offset, Cfg.seed.offset, Cfg.learning_rate.offset, Cfg.max_grad_norm.offset,
-                   C.sizeof(St), St.ep_count.offset]
+                   C.sizeof(St), St.ep_count.offset, C.sizeof(Pr), Pr.allreduce_ms.offset, Pr.vector_fallback_launches.offset]
 
 
 def test_header_cites_reference_lines():

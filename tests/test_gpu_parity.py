@@ -749,23 +749,52 @@ def test_weights_beyond_fp16_take_the_vector_kernels_for_that_launch(P):
 def test_observation_beyond_fp16_is_reported(P):
     """The wave-specialised update kernel cuts the observation into fp16 terms: |obs| >= 65504 written through the C-ABI's OBS buffer does not fit.  The record
     packing checks it (PPO_ERRFLAG_UPDATE_RANGE) and the next statistics read fails with PPO_ERR_STATE naming PPO_KERNEL_UPDATE_VECTOR -- no silent NaN.
-    (The parameters are undefined after it, as ppo_hip.h says; with PPO_KERNEL_UPDATE_VECTOR the same batch trains.)"""
+    The optimizer kernels read the same error word and do NOT apply a step the device knows is garbage (ppo_hip.h, ABI 5): parameters and AdamW moments after
+    the update are the ones before it, bit for bit.  With PPO_KERNEL_UPDATE_VECTOR the same batch trains."""
     for flags, ok in ((0, False), (P.KERNEL_UPDATE_VECTOR, True)):
-        ctx = P.Context(P.make_config(num_envs=32, num_steps=8, num_minibatches=1, update_epochs=1, seed=2, kernel_flags=flags))
+        ctx = P.Context(P.make_config(num_envs=32, num_steps=8, num_minibatches=2, update_epochs=2, seed=2, kernel_flags=flags))
         ctx.init_orthogonal(1)
         ctx.env_reset()
+        ctx.train_iteration()                 # one clean iteration first: the moments are not all zero
         ctx.rollout()
         ctx.calc_advantage()
+        before = [ctx.get_params(), ctx.read("EXP_AVG"), ctx.read("EXP_AVG_SQ")]
         obs = ctx.read("OBS", (8, 32, 4))
         obs[3, 5, 1] = 1.0e5
         ctx.write("OBS", obs)
         ctx.update()
+        after = [ctx.get_params(), ctx.read("EXP_AVG"), ctx.read("EXP_AVG_SQ")]
         if ok:
-            assert np.isfinite(ctx.stats()["loss"]) and np.isfinite(ctx.get_params()).all()
+            assert np.isfinite(ctx.stats()["loss"]) and np.isfinite(after[0]).all()
+            assert not np.array_equal(before[0], after[0])
         else:
+            for b, a in zip(before, after):
+                assert np.array_equal(b.view(np.uint32), a.view(np.uint32))      # four optimizer steps ran, none was applied
             with pytest.raises(P.binding.PPOError, match="PPO_KERNEL_UPDATE_VECTOR"):
                 ctx.stats()
         ctx.close()
+
+
+def test_observation_beyond_fp16_is_no_error_where_the_vector_kernel_runs(P):
+    """The observation's fp16 range is a limit of the wave-specialised matrix-core kernel only.  In an update whose WEIGHTS already send every launch to the vector
+    kernel (default flags, a hidden-to-hidden weight of 6: test_weights_beyond_fp16_take_the_vector_kernels_for_that_launch) an observation of 1e5 is not an error:
+    the update trains, the statistics read reports nothing, and the launches are counted in ppo_profile.vector_fallback_launches."""
+    ctx = P.Context(P.make_config(num_envs=32, num_steps=8, num_minibatches=2, update_epochs=2, seed=2))
+    ctx.init_orthogonal(1)
+    params = ctx.get_params()
+    params[4 * 64 + 64 + 7] = 6.0
+    ctx.set_params(params)
+    ctx.env_reset()
+    ctx.rollout()
+    ctx.calc_advantage()
+    obs = ctx.read("OBS", (8, 32, 4))
+    obs[3, 5, 1] = 1.0e5
+    ctx.write("OBS", obs)
+    ctx.update()
+    st = ctx.stats()
+    assert np.isfinite(st["loss"]) and np.isfinite(ctx.get_params()).all() and not np.array_equal(ctx.get_params(), params)
+    assert ctx.profile_read()["vector_fallback_launches"] == 4
+    ctx.close()
 
 
 @pytest.mark.parametrize("T,limit", [(1, 500), (2, 1), (5, 1), (7, 2), (64, 3), (33, 500)])

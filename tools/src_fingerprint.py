@@ -46,7 +46,15 @@ def main():
         try:
             head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=20).stdout.strip() or None
         except Exception:
-            head = None   # the GPU box's snapshot carries no .git
+            head = None
+        if not head:
+            # the GPU box's snapshot carries no .git: tools/stamp_head.sh (run in the container before gpurun) leaves `git rev-parse HEAD` (+ "-dirty"
+            # when the tree had uncommitted changes) in .build_head, which travels with the snapshot
+            try:
+                with open(os.path.join(ROOT, ".build_head")) as fh:
+                    head = fh.read().strip() or None
+            except OSError:
+                head = None
         meta = {"tag": tag, "src_sha16": source_fingerprint(), "lib_sha16": file_sha16(os.path.join(ROOT, "ppo-libtorch_amd", "libppo_hip.so")), "git_head": head,
                 "collected_unix": int(time.time()), "files": sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", tag + "_*")))}
         with open(os.path.join(ROOT, "profiles", tag + "_meta.json"), "w") as fh:
