@@ -100,8 +100,14 @@ typedef struct ppo_config {
  *                               norm / AdamW / weight planes as four launches -- instead of rows read in place through the index list, both nets in every
  *                               launch on one stream and one optimizer launch.  Same kernels for the products, same partial-sum partitions: the two forms
  *                               agree to the last bits of a float (only the order in which the gradient norm's partial sums are added differs).  For A/B
- *                               runs and tests. */
-enum { PPO_KERNEL_ROLLOUT_VECTOR = 1, PPO_KERNEL_UPDATE_VECTOR = 2, PPO_KERNEL_UPDATE_ONE_WAVE = 4, PPO_KERNEL_COMM_SELFTEST = 8, PPO_KERNEL_GENERIC_CLASSIC = 16 };
+ *                               runs and tests.
+ *   PPO_KERNEL_GENERIC_SPLIT_HEAD  generic networks with bf16 storage: heads, masked categorical, PPO loss and the head layers' backward as launches of their own
+ *                               (loss_lanes_kernel, bwd_layer_kernel<1, ...>) behind a forward launch that writes logits, values and the top hidden activation
+ *                               to memory -- round 5's step -- instead of in the forward launch's epilogue, on the tile still in LDS (ABI 5 default where the
+ *                               shape allows: <= 4 heads of <= 4 logits).  Same arithmetic (the same bf16 roundings, f32 sums); partial sums are formed per
+ *                               forward workgroup instead of per row range, so the two agree to f32 summation order.  For A/B runs and tests. */
+enum { PPO_KERNEL_ROLLOUT_VECTOR = 1, PPO_KERNEL_UPDATE_VECTOR = 2, PPO_KERNEL_UPDATE_ONE_WAVE = 4, PPO_KERNEL_COMM_SELFTEST = 8, PPO_KERNEL_GENERIC_CLASSIC = 16,
+       PPO_KERNEL_GENERIC_SPLIT_HEAD = 32 };
 
 /* Scalars the reference prints per update (PPO_Discrete.cpp:700-774) plus per-step diagnostics. */
 typedef struct ppo_stats {

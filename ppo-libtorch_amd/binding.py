@@ -20,7 +20,7 @@ MM_EPI_NONE, MM_EPI_BIAS, MM_EPI_BIAS_TANH, MM_EPI_DTANH = 0, 1, 2, 3
 MM_F32X3, MM_BF16 = 0, 1
 DIST_CATEGORICAL, DIST_MASKED = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
-KERNEL_ROLLOUT_VECTOR, KERNEL_UPDATE_VECTOR, KERNEL_UPDATE_ONE_WAVE, KERNEL_COMM_SELFTEST, KERNEL_GENERIC_CLASSIC = 1, 2, 4, 8, 16   # ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*)
+KERNEL_ROLLOUT_VECTOR, KERNEL_UPDATE_VECTOR, KERNEL_UPDATE_ONE_WAVE, KERNEL_COMM_SELFTEST, KERNEL_GENERIC_CLASSIC, KERNEL_GENERIC_SPLIT_HEAD = 1, 2, 4, 8, 16, 32   # ppo_config.kernel_flags (include/ppo_hip.h PPO_KERNEL_*)
 ABI_VERSION = 5
 COMM_ID_BYTES = 128
 COMM_HANDLE_BYTES = 64

@@ -424,7 +424,7 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
         return fail(nullptr, PPO_ERR_INVALID, "unknown env_kind %d", cfg->env_kind);
     if (cfg->dist_kind != PPO_DIST_CATEGORICAL && cfg->dist_kind != PPO_DIST_MASKED) return fail(nullptr, PPO_ERR_INVALID, "unknown dist_kind %d", cfg->dist_kind);
     if (cfg->compute_dtype != PPO_DTYPE_F32 && cfg->compute_dtype != PPO_DTYPE_BF16) return fail(nullptr, PPO_ERR_INVALID, "unknown compute_dtype %d", cfg->compute_dtype);
-    if (cfg->kernel_flags & ~(PPO_KERNEL_ROLLOUT_VECTOR | PPO_KERNEL_UPDATE_VECTOR | PPO_KERNEL_UPDATE_ONE_WAVE | PPO_KERNEL_COMM_SELFTEST | PPO_KERNEL_GENERIC_CLASSIC)) return fail(nullptr, PPO_ERR_INVALID, "unknown bits in kernel_flags 0x%x", cfg->kernel_flags);
+    if (cfg->kernel_flags & ~(PPO_KERNEL_ROLLOUT_VECTOR | PPO_KERNEL_UPDATE_VECTOR | PPO_KERNEL_UPDATE_ONE_WAVE | PPO_KERNEL_COMM_SELFTEST | PPO_KERNEL_GENERIC_CLASSIC | PPO_KERNEL_GENERIC_SPLIT_HEAD)) return fail(nullptr, PPO_ERR_INVALID, "unknown bits in kernel_flags 0x%x", cfg->kernel_flags);
     if (cfg->compute_dtype == PPO_DTYPE_BF16 && !generic)
         return fail(nullptr, PPO_ERR_UNSUPPORTED, "compute_dtype = PPO_DTYPE_BF16 applies to networks whose layers are GEMMs (env_kind = PPO_ENV_SYNTHETIC); the reference's "
                     "2 x 64 networks always compute in f32");
@@ -1267,7 +1267,13 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
         if (two && g.planes_dirty) { HIPCHK(c, gen_weight_planes(g, params, c->stream)); g.planes_dirty = false; }   // shared by both nets: before the fork
         if (two) HIPCHK(c, fork());
         const uint16_t* x0 = in_place ? g.obs_bf : g.xin_bf;
-        if (paired) {
+        // heads + loss + the head layers' backward in the forward launch's epilogue (kernels_generic_fused.hip: FusedLossArgs) where the shape allows
+        g.head_fused = 0;
+        const bool head_fused = paired && in_place && g.rows_rec != nullptr && !(c->cfg.kernel_flags & PPO_KERNEL_GENERIC_SPLIT_HEAD) && gen_fused_loss_ok(g, M);
+        if (head_fused) {
+            HIPCHK(c, gen_fused_forward_loss(g, params, x0, g.ld_in0, M, c->hp, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr,
+                                             g.rows_idx, c->stream));
+        } else if (paired) {
             HIPCHK(c, gen_fused_forward_both(g, params, x0, g.ld_in0, M, g.logits, g.val, c->stream, g.rows_idx));
         } else if (gen_fused_forward_ok(g) && M <= GEN_FUSED_MAX_ROWS) {   // bf16 storage: each net's forward pass is one launch that also leaves its hidden activations
             HIPCHK(c, gen_fused_forward(g, params, 1, nullptr, x0, g.ld_in0, M, true, g.logits, c->stream, g.rows_idx));
@@ -1277,7 +1283,7 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
             HIPCHK(c, gen_forward(g, params, 0, g.xin, M, g.acts[0], nullptr, nullptr, g.val, s0));
         }
         if (two) HIPCHK(c, join());   // the loss reads the logits and the values
-        HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
+        if (!head_fused) HIPCHK(c, gen_loss(GL, c->hp, g, M, 1.0 / global_M, global_M, c->cfg.norm_adv ? c->adv_stats + (size_t)slot * PPO_ADV_PARTS : nullptr, c->stream));
         // backward: paired too (A/B in one call, configs[4] share: 0.621 ms per optimizer step paired, 0.644 with the backward passes on two streams, 0.683 for
         // round 5's first form -- two streams throughout, gathered copies, four optimizer launches)
         if (two_bwd) HIPCHK(c, fork());

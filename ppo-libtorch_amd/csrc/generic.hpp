@@ -104,6 +104,8 @@ struct GenericCtx {
     int sq_cap = 0;                // slab-sum workgroups of the largest layer
     mutable bool sq_valid[2] = {}; // [net]: the net's last backward pass left its part of sq_part
     float* head_db_part = nullptr; // [GEN_LOSS_BLOCKS][act + 1] block sums of d(loss)/d(logits) | d(value) (the head layers' bias gradients)
+    mutable int head_fused = 0;    // > 0: this step's forward launch also ran the loss and the head layers' backward (gen_fused_forward_loss) and left that many
+                                   // per-workgroup partials (dW_head slabs, column sums of dZ_top in cs_part's top block, dZ_top in dz_bf[net][(n_layers - 1) & 1])
     int64_t* act64 = nullptr;      // [N, n_heads] actions of the current rollout step (int64, the stand-alone API's type)
     float* step_lp = nullptr;      // [N] log-prob / entropy of the current rollout step
     float* step_en = nullptr;
@@ -142,6 +144,10 @@ hipError_t gen_fused_forward(const GenericCtx& g, const float* params, int net, 
 // both nets' passes over the same rows (activations kept) in one launch
 hipError_t gen_fused_forward_both(const GenericCtx& g, const float* params, const uint16_t* x_bf, int64_t ld_x, int64_t rows, float* logits, float* val,
                                   hipStream_t s, const int32_t* idx = nullptr);
+// both nets' passes + heads + PPO loss + the head layers' backward in one launch (rows read in place through idx, records g.rows_rec); sets g.head_fused
+bool gen_fused_loss_ok(const GenericCtx& g, int64_t rows);
+hipError_t gen_fused_forward_loss(const GenericCtx& g, const float* params, const uint16_t* x_bf, int64_t ld_x, int64_t rows, const LossParams& hp, double inv_global_M,
+                                  double global_M, const AdvStat* adv_stat, const int32_t* idx, hipStream_t s);
 hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,
                              int64_t step_base, int32_t* ep_len, float* ep_rew, float* obs, uint8_t* masks, int32_t* actions, float* logprobs, float* rewards,
                              float* dones, int32_t* fin_len, float* fin_rew, float* next_obs, int32_t* next_done, uint8_t* cur_mask, const int64_t* forced,

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 }
 
 // The same sums for every layer of a net in ONE launch (bf16 storage: each layer has its own slab block): blockIdx.y = layer.
-struct SlabJob { const float* slab; const float* db_part; float* gw; float* gb; int64_t n_w, n_b, db_stride; int S, db_chunks; };
+struct SlabJob { const float* slab; const float* db_part; float* gw; float* gb; int64_t n_w, n_b, db_stride; int S, db_chunks; int64_t stride; };   // stride: floats between this job's slabs (0: jobs.slab_stride)
 struct SlabJobs { SlabJob j[2 * GEN_MAX_LAYERS]; int64_t slab_stride; double* sq_part; int sq_stride, sq_job0; };   // blockIdx.y = job: a net's layers, or both nets'
 // sq_part != nullptr: the workgroup also leaves the sums of squares of its SLAB_EPB gradient elements, weights and bias apart, as
 // sq_part[((sq_job0 + job) * sq_stride + blockIdx.x) * 2 + {0, 1}] (job slots in the parameter order: net * n_layers + layer) -- the gradient norm then needs no
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(4 * SLAB_EPB) void slab_sum_layers_kernel(SlabJobs 
     if (i < J.n_w + J.n_b) {
         const bool w = i < J.n_w;
         const float* src = w ? J.slab + i : J.db_part + (i - J.n_w);
-        const int64_t stride = w ? jobs.slab_stride : J.db_stride;
+        const int64_t stride = w ? (J.stride ? J.stride : jobs.slab_stride) : J.db_stride;
         const int n = w ? J.S : J.db_chunks;
         const int per = (n + 3) / 4, k0 = q * per, k1 = k0 + per < n ? k0 + per : n;
         int k = k0;
@@ -1296,6 +1296,16 @@ hipError_t fused_backward(const GenericCtx& g, int net_a, int net_b, int64_t row
             most = std::max<int64_t>(most, J.n_w + N);
             S_above[i] = S;
             d[i] = nd;
+        }
+        if (head && g.head_fused > 0) {
+            // the forward launch already ran this layer's backward (gen_fused_forward_loss): its per-workgroup partials stand where a row range's would
+            for (int i = 0; i < n_nets; i++) {
+                SlabJob& J = jobs.j[(n_nets == 2 ? nets[i] : 0) * L.n_layers + l];
+                J.S = g.head_fused; J.stride = (int64_t)L.act * L.hidden;
+                S_above[i] = g.head_fused;
+            }
+            ldd = g.ld_h;
+            continue;
         }
         const hipError_t e = gen_fused_backward_layer(head ? 32 : g.ld_h, q[0], n_nets == 2 ? &q[1] : nullptr, rows, cbk, g.dout_bf[nets[0]] + 64, s);
         if (e != hipSuccess) return e;

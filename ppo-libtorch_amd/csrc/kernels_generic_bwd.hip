@@ -89,7 +89,11 @@ __device__ __forceinline__ void bw_barrier() {
 // stores are never waited for).  M0 = the destination's LDS byte address, saved and restored around the instruction (the compiler reserves M0).
 // The destination is the LDS BYTE ADDRESS as an integer (bw_lds_addr of the array's start + offsets): handed over as a generic pointer, every instruction paid a
 // generic -> local conversion (null check, aperture base) and two v_readfirstlane on top of its address arithmetic.
+#ifndef BW_NT   /* exploration builds: bit 0 = non-temporal DMA of the h tile (read by ONE workgroup), bit 1 = of the dZ tile (read by the CB workgroups of a row range), bit 2 = non-temporal stores of dZ_{l-1} */
+#define BW_NT 0
+#endif
 __device__ __forceinline__ uint32_t bw_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+template <bool NT = false>
 __device__ __forceinline__ void bw_glds16(const uint16_t* src, uint32_t dst) {
 #ifdef BW_GLDS_BUILTIN
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
@@ -97,13 +101,16 @@ __device__ __forceinline__ void bw_glds16(const uint16_t* src, uint32_t dst) {
 #endif
     const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);   // wave-uniform by construction (it depends on the wave's index): the compiler has to be told
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
+    if (NT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
 }
 // The same with the source as a wave-uniform base (SGPR pair) + a 32-bit byte offset per lane: no 64-bit address arithmetic on the vector ALU per instruction.
+template <bool NT = false>
 __device__ __forceinline__ void bw_glds16_s(const uint16_t* sbase, uint32_t voff_bytes, uint32_t dst) {
     const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst);
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(d) : "memory");
+    if (NT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(d) : "memory");
+    else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(d) : "memory");
 }
 
 // 64 lanes x 4 bytes -> 256 bytes at lds_wave_base, lane-linear: the index list's entries of a tile's rows (layer 0, rows read in place).  A DMA, not a load into a
@@ -272,17 +279,17 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             const int p = wave + BW_WAVES * i;
             const bool have = p < CPR;
             const uint32_t dst = have ? dD + 1024u * p : spare0 + 1024u * wave;
-            if (whole && have) bw_glds16_s(dbase, d_off[i], dst);
-            else bw_glds16(have && r0 + d_row[i] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i]) : a.zeros, dst);
+            if (whole && have) bw_glds16_s<(BW_NT & 2) != 0>(dbase, d_off[i], dst);
+            else bw_glds16<(BW_NT & 2) != 0>(have && r0 + d_row[i] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i]) : a.zeros, dst);
         }
 #pragma unroll
         for (int k = 0; k < KCB; k++) {   // image k: columns 64 (KCB c + k) ..
             const uint32_t dst = dH + (uint32_t)(k * BW_ROWS * BW_KC) * 2u + 1024u * wave;
-            if (whole && !gathered) bw_glds16_s(hbase, h_off[k], dst);
+            if (whole && !gathered) bw_glds16_s<(BW_NT & 1) != 0>(hbase, h_off[k], dst);
             else {
                 const uint16_t* src = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k] - (uint32_t)(h_row * (int)a.ldh) * 2u))
                                                : reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(hbase) + h_off[k]);
-                bw_glds16(r0 + h_row < a.rows ? src : a.zeros, dst);
+                bw_glds16<(BW_NT & 1) != 0>(r0 + h_row < a.rows ? src : a.zeros, dst);
             }
         }
     };
@@ -290,8 +297,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     auto store_out = [&](int t) {
         const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
         const int row = tid >> 3, ch = tid & 7;
-        *reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch) =
-            *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
+        const u32x4 piece = *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
+        if (BW_NT & 4) __builtin_nontemporal_store(piece, reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch));
+        else *reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch) = piece;
     };
     // vector-memory operations a wave issues per iteration of the steady state: the DMA pieces of one tile, and (P1) one store of the result tile
     constexpr int VM_TILE = DPW + KCB;           // DMA instructions of one tile

@@ -357,6 +357,49 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_rollout_kernel(const Fu
     if (env_lane) { a.ep_len[e0 + tid] = len; a.ep_rew[e0 + tid] = rew; a.next_done[e0 + tid] = prev_done; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Heads + PPO loss + the HEAD LAYER'S BACKWARD inside the forward kernel (round 6; PPO_MultiDiscrete.cpp:593-668 on a 64-row tile).  When a pass of a tile
+// ends, the tile's logits (or values) sit in s_out and the top hidden activation h sits in an LDS tile -- everything the loss and the head layer's backward
+// need.  Instead of writing logits and h to HBM, reading them back in loss_lanes_kernel (heads, masked categorical, loss, d logits) and again in
+// bwd_layer_kernel<1, true, 1> (dW_head, dZ_top) -- 12.5 + 35.8 us and 168 MB per 65 536-row step -- the workgroup does it on the spot:
+//   E1  threads 0 .. 255, four lanes per row (lane = head, loss_lanes_kernel's arithmetic): d logits / d value as bf16 into two small LDS images, [row][n]
+//       and [n][row]; the loss sums, the head's bias gradient (column sums of the unrounded gradient) reduced per wave and added to per-wave LDS accumulators;
+//   E3  dZ_top[row][k] = (dL[row][:] . W_head[:][k]) (1 - h[row][k]^2): ONE k step (logits padded to 16) per 32 x 32 block, wave w the columns 32 w ..;
+//       bf16 into the free LDS tile, f32 column sums (the top hidden layer's bias gradient) into an LDS accumulator;
+//   E4  dW_head[n][k] += sum_rows dL[row][n] h[row][k]: four k steps (rows), h by transposing reads, accumulated in LDS by the wave that owns the columns;
+//   E5  the dZ_top tile leaves in 16-byte row pieces for the next backward launch.
+// Per WORKGROUP (not per row range): one partial dW_head, one column-sum row, one row of loss sums and of head bias sums -- slab_sum_layers_kernel and
+// gen_opt_fused_kernel add them in workgroup order as they add the other layers' partials.  Every accumulator has ONE writer and a fixed order: same inputs,
+// same bits.  The per-row records (32 bytes through the step's index list) are requested when the tile's first pass starts and are used two passes later.
+// Arithmetic is the unfused path's: the same bf16 roundings of d logits, h and W_head, f32 accumulation, tanh' and every sum in f32.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct FusedLossArgs {
+    LossParams hp; float invM; double global_M;
+    const AdvStat* adv_stat;              // null: advantages are not normalised
+    const int32_t* idx; const float4* rec;
+    uint16_t* dz_top[2]; int64_t ld_dz;   // [net] d(pre-activation) of the top hidden layer, [rows + pad][ld_dz] bf16
+    const uint16_t* whead[2]; int64_t ldw;// [net] bf16 plane of the head layer's weights [n_pad][ldw]
+    float* head_slab[2]; int64_t head_slab_stride;   // [net] per-workgroup partial dW_head [n_real][hidden]
+    float* cs_top[2]; int64_t ld_cs;      // [net] per-workgroup column sums of dZ_top
+    float* head_db_part;                  // [GEN_LOSS_BLOCKS][act + 1]
+    double* loss_part;                    // [GEN_LOSS_BLOCKS][8]
+};
+#ifndef FL_ABL
+#define FL_ABL 0   /* timing-only ablation builds (wrong results): 1 no E1, 2 no E3, 4 no E4, 8 no E5, 16 no record prefetch */
+#endif
+constexpr int FL_NP = 16;                 // logits as staged: one k step of the matrix cores (the slot-wise loss serves <= 4 heads of <= 4 logits)
+constexpr int FL_DLT_PITCH = 72;          // [n][row] image: 64 rows + 8
+constexpr int FL_DW_ROWS = FL_NP + 4;     // LDS rows of the dW_head accumulator: the actor's 16, the critic's (1, padded to 4)
+constexpr size_t fused_loss_lds_bytes(int ld_h) {
+    return (size_t)64 * FL_NP * 2 + (size_t)32 * FL_DLT_PITCH * 2 + (size_t)2 * FU_WAVES * 64 * 16 + (size_t)FL_DW_ROWS * ld_h * 4 + (size_t)4 * ld_h * 4 +
+           16 * 8 * sizeof(double) + 16 * 20 * sizeof(float) + 64 + (size_t)64 * 32;
+}
+__device__ __forceinline__ uint2 fu_read_tr16(const uint16_t* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
 struct FusedForwardArgs {
     FusedNet f;
     const float* x_f32;             // [rows][obs] f32 (rounded to bf16 on the way into LDS), or
@@ -378,8 +421,9 @@ typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 // Two passes in one launch (the two nets over the same rows): workgroups [0, split) run a[0], the rest a[1] -- the second pass's workgroups take the CUs
 // the first pass's leave, with no kernel boundary and no second stream between them.  split == gridDim.x: one pass.
 // dual: every workgroup runs BOTH passes on each of its tiles -- the input tile is fetched and staged from the same registers twice, read from memory once.
-struct FusedForwardPair { FusedForwardArgs a[2]; int split; int dual; };
-template <bool BF>
+struct FusedForwardPair { FusedForwardArgs a[2]; int split; int dual; FusedLossArgs loss; };
+// LOSS: 0 = forward only; PPO_DIST_CATEGORICAL + 1 / PPO_DIST_MASKED + 1 = the loss and the head layer's backward in the epilogue of every pass (dual launches only)
+template <bool BF, int LOSS = 0>
 __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardPair pp) {
     const int second = (int)blockIdx.x >= pp.split ? 1 : 0;
     const FusedForwardArgs& a = pp.a[second];
@@ -396,6 +440,53 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
     const int64_t n_tiles = (a.rows + RB - 1) / RB;
     BFrags pre;
     load_bfrags(pre, a.f, 0, tid >> 6, 0, tid & 63);   // layer 0's first weight fragments travel while the input tile is loaded
+    // ---- LOSS: the LDS behind s_out (and the rollout kernel's mask area): images of d logits, the head weights' fragments, the workgroup's accumulators ----
+    const FusedLossArgs& fl = pp.loss;
+    const int ld_h = (int)fl.ld_dz;
+    uint16_t* const s_dl = reinterpret_cast<uint16_t*>(s_out + RB * 32) + 32 * PPO_MAX_ACT;   // [64][FL_NP]   d logits (d value in column 0), row-major
+    uint16_t* const s_dlt = s_dl + 64 * FL_NP;                                                  // [32][FL_DLT_PITCH] the same, transposed; rows 16 .. 31 stay zero
+    u32x4* const s_wh = reinterpret_cast<u32x4*>(s_dlt + 32 * FL_DLT_PITCH);                    // [2 nets][8 waves][64 lanes] A fragments of W_head^T
+    float* const s_dw = reinterpret_cast<float*>(s_wh + 2 * FU_WAVES * 64);                     // [FL_DW_ROWS][ld_h]: actor rows 0 .. 15, critic row 16
+    // Sums over rows are formed on the DPP network inside each 16-lane row of a wave and added to an accumulator of that (wave, row of 16 lanes) alone: one writer
+    // per word, no cross-row shuffle (80 ds_bpermute per pass in the first version: 29 us of the launch), and the flush adds the partials in a fixed order.
+    float* const s_cs = s_dw + FL_DW_ROWS * ld_h;                                               // [2 nets][2 row halves][ld_h] column sums of dZ_top
+    double* const s_ls = reinterpret_cast<double*>(s_cs + 4 * ld_h);                            // [4 waves x 4 rows of 16 lanes][8] loss sums
+    float* const s_db = reinterpret_cast<float*>(s_ls + 16 * 8);                                // [16][20] head bias sums: [0 .. 15] d logits, [16] d value
+    float* const s_misc = s_db + 16 * 20;                                                       // advantage mean, 1 / (std + eps)
+    float4* const s_rec = reinterpret_cast<float4*>(s_misc + 16);                               // [64 rows][2] the tile's row records
+    if constexpr (LOSS != 0) {
+        const int lane = tid & 63, wave = tid >> 6, li = lane & 31, kg = lane >> 5;
+        for (int e = tid; e < (int)((fused_loss_lds_bytes(ld_h) - 64 - 64 * 32) / 4); e += FU_THREADS) reinterpret_cast<uint32_t*>(s_dl)[e] = 0u;   // accumulators, the padding of the images
+        if (tid == 0) {
+            float mean_f = 0.0f, std_f = 0.0f;
+            if (fl.adv_stat) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int i = 0; i < PPO_ADV_PARTS; i++) { t1 += fl.adv_stat[i].s1; t2 += fl.adv_stat[i].s2; }
+                const double mean = t1 / fl.global_M;
+                const double var = (t2 - t1 * mean) / (fl.global_M - 1.0);
+                mean_f = (float)mean;
+                std_f = (float)sqrt(var < 0.0 ? 0.0 : var);
+            }
+            s_misc[0] = mean_f; s_misc[1] = 1.0f / (std_f + 1e-8f);
+        }
+        __syncthreads();   // (the zeros above are in place before the fragments below are written over them)
+        // W_head^T as the A operand of D[k][row] = sum_n W_head[n][k] dL[row][n]: lane (i = column 32 wave + i, kg) holds n = 8 kg .. 8 kg + 7
+#pragma unroll
+        for (int net = 0; net < 2; net++) {
+            if (32 * wave >= ld_h) break;
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t lo = fl.whead[net][(int64_t)(8 * kg + 2 * e) * fl.ldw + 32 * wave + li], hi = fl.whead[net][(int64_t)(8 * kg + 2 * e + 1) * fl.ldw + 32 * wave + li];
+                w[e] = lo | (hi << 16);
+            }
+            const u32x4 v = { w[0], w[1], w[2], w[3] };
+            s_wh[(net * FU_WAVES + wave) * 64 + lane] = v;
+        }
+    }
+    // The row records (32 bytes through the index list) ride with the input rows: the thread that fetches pieces sub = 0 / 1 of a row also fetches the two halves
+    // of the row's record, a tile ahead, and parks them in s_rec when it stages the tile -- no load whose address or value an epilogue has to wait for.
+    u32x4 prec = { 0u, 0u, 0u, 0u };
     // eight threads per row: thread (row = tid >> 3, sub = tid & 7) owns the row's 16-byte pieces sub, sub + 8, ... (8 bf16 or 4 floats each)
     constexpr bool bf = BF;
     const int ppr = bf ? opad / 8 : (O + 3) / 4;   // pieces per row (f32: O is a multiple of 4, host-checked)
@@ -418,9 +509,13 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
             if (bf) pf[p] = *reinterpret_cast<const u32x4*>(a.x_bf + (ok ? row * a.ld_x + 8 * piece : 0));
             else pf[p] = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4a4*>(a.x_f32 + (ok ? row * O + 4 * piece : 0)));
         }
+        if constexpr (LOSS != 0) {
+            if (!(FL_ABL & 16)) prec = *reinterpret_cast<const u32x4*>(fl.rec + 2 * (rok ? row : 0) + (sub & 1));   // (every thread loads: no divergent branch around a load)
+        }
     };
     auto stage = [&](int64_t tile) {
         const bool rok = tile * RB + prow < a.rows;
+        if constexpr (LOSS != 0) { if (sub < 2) s_rec[2 * prow + sub] = __builtin_bit_cast(float4, prec); }
 #pragma unroll
         for (int p = 0; p < FU_NP; p++) {
             const int piece = sub + 8 * p;
@@ -466,8 +561,266 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
             FU_STAMP(3);
             fused_layers<FM>(x.f, next_off0, tile0, tile1, s_out, x.keep, x.ld_keep, row0, n_rows, pre, dbg);
             const int N = L.out_dim[x.f.net][L.n_layers - 1];
-            for (int e = tid; e < n_rows * N; e += FU_THREADS) x.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];   // (s_out is written again four barriers from here)
+            if constexpr (LOSS == 0) {
+                for (int e = tid; e < n_rows * N; e += FU_THREADS) x.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];   // (s_out is written again four barriers from here)
+            } else {
+                constexpr int DIST = LOSS - 1;
+                const int net = x.f.net;
+                // the thread index through a register the compiler cannot see through: everything the epilogue derives from it (rows, LDS addresses, head offsets) is
+                // then formed HERE, per pass, instead of being hoisted out of the tile loop and kept alive across the layers (the kernel sat at 256 registers and spilled)
+                int te = tid;
+                asm volatile("" : "+v"(te));
+                const int lane = te & 63, wave = __builtin_amdgcn_readfirstlane(te >> 6), li = lane & 31, kg = lane >> 5;
+                // the top hidden activation sits in the tile the head layer read; the other tile is free
+                uint16_t* const hT = (L.n_hidden & 1) ? tile1 : tile0;
+                uint16_t* const oT = (L.n_hidden & 1) ? tile0 : tile1;
+                const int ldA = x.f.ldA;
+                // ---- E1: four lanes per row (lane = head): masked categorical, PPO loss, d logits -- or, in the critic's pass, the value loss and d value ----
+                if (te < 256 && !(FL_ABL & 1)) {
+                    const int row = te >> 2, h = te & 3;
+                    const bool live = row < n_rows;
+                    const float4 lr0 = s_rec[2 * row], lr1 = s_rec[2 * row + 1];   // { old log-prob, advantage, return, old value }, { action bytes, mask bits, -, - }
+                    const int n_heads = L.n_heads, act = L.act;
+                    int A = 0, off = 0;
+#pragma unroll
+                    for (int hh = 0; hh < 4; hh++) { const int w = hh < n_heads ? L.head_dims[hh] : 0; if (hh < h) off += w; if (hh == h) A = w; }
+                    const float clip = fl.hp.clip_coef, lo = 1 - clip, hi_c = 1 + clip, invM = fl.invM;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    float dbs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                    if (net == 1) {
+                        const uint32_t ab = __builtin_bit_cast(uint32_t, lr1.x), mask_bits = DIST == PPO_DIST_MASKED ? __builtin_bit_cast(uint32_t, lr1.y) : 0xffffffffu;
+                        float z[4], p[4];
+                        bool ok[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int k = off + j;
+                            const bool in = j < A;
+                            z[j] = s_out[row * 32 + (k < 32 ? k : 31)];
+                            ok[j] = in && ((mask_bits >> k) & 1u) != 0;
+                            z[j] = in ? ((DIST == PPO_DIST_MASKED && !ok[j]) ? -1e8f : z[j]) : -INFINITY;   // a slot that does not exist: exp -> 0, never the maximum
+                            p[j] = 0.0f;
+                        }
+                        float lp = 0.0f, hH = 0.0f;
+                        const int aidx = (int)((ab >> (8 * h)) & 0xffu);
+                        if (A > 0) {
+                            float mx = -INFINITY;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) if (j < A) mx = z[j] > mx ? z[j] : mx;
+                            float se = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) if (j < A) { p[j] = fast_exp(z[j] - mx); se += p[j]; }
+                            const float lse = fast_log(se) + mx;
+                            const float rse = __builtin_amdgcn_rcpf(se);
+                            float e = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) if (j < A) {
+                                z[j] = z[j] - lse;
+                                p[j] = p[j] * rse;
+                                if (DIST == PPO_DIST_CATEGORICAL) {
+                                    const float l = z[j] > 1.17549435e-38f ? z[j] : 1.17549435e-38f;   // the reference's clamp (Categorical.cpp:112-119)
+                                    e += l * p[j];
+                                } else {
+                                    const float plp = z[j] * p[j];
+                                    e += ok[j] ? plp : 0.0f;
+                                }
+                                if (j == aidx) lp = z[j];
+                            }
+                            hH = -e;
+                        }
+                        // the row's sums in head order on every lane of the row: ((h0 + h1) + h2) + h3 over the heads that exist
+                        // (the row's four lanes are one DPP quad: quad_perm broadcasts, no LDS round trips)
+#define FL_QUAD(v, K) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v)), (K) * 0x55, 0xf, 0xf, false))
+                        float nlp = FL_QUAD(lp, 0), ent = FL_QUAD(hH, 0);
+                        { const float l2 = FL_QUAD(lp, 1), e2 = FL_QUAD(hH, 1); if (1 < n_heads) { nlp += l2; ent += e2; } }
+                        { const float l2 = FL_QUAD(lp, 2), e2 = FL_QUAD(hH, 2); if (2 < n_heads) { nlp += l2; ent += e2; } }
+                        { const float l2 = FL_QUAD(lp, 3), e2 = FL_QUAD(hH, 3); if (3 < n_heads) { nlp += l2; ent += e2; } }
+#undef FL_QUAD
+                        const float logratio = nlp - lr0.x;
+                        const float ratio = fast_exp(logratio);
+                        float adv = lr0.y;
+                        if (fl.hp.norm_adv) adv = (adv - s_misc[0]) * s_misc[1];
+                        const float rc = ratio < lo ? lo : (ratio > hi_c ? hi_c : ratio);
+                        const float l1 = -adv * ratio, l2 = -adv * rc;
+                        const bool inside = (ratio >= lo && ratio <= hi_c);
+                        float d_ratio;
+                        if (l1 > l2) d_ratio = -adv;
+                        else if (l1 < l2) d_ratio = inside ? -adv : 0.0f;
+                        else d_ratio = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);   // torch::max splits ties half / half
+                        const float g_nlp = invM * d_ratio * ratio;
+                        const float g_ent = -fl.hp.ent_coef * invM;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) if (j < A) {
+                            float d = g_nlp * ((j == aidx ? 1.0f : 0.0f) - p[j]);
+                            if (DIST == PPO_DIST_MASKED) d += g_ent * (-p[j] * (z[j] + hH));
+                            d = (live && (DIST != PPO_DIST_MASKED || ok[j])) ? d : 0.0f;
+                            const uint16_t b = fu_bf16(d);
+                            s_dl[row * FL_NP + off + j] = b;
+                            s_dlt[(off + j) * FL_DLT_PITCH + row] = b;
+                            dbs[j] = d;
+                        }
+                        if (h == 3) for (int k = act; k < FL_NP; k++) { s_dl[row * FL_NP + k] = 0; s_dlt[k * FL_DLT_PITCH + row] = 0; }   // (the critic's pass wrote column 0 .. of these images)
+                        if (h == 0 && live) {
+                            s0 = (double)(l1 > l2 ? l1 : l2);
+                            s1 = (double)ent;
+                            s2 = (double)((ratio - 1.0f) - logratio);
+                            s3 = (fabsf(ratio - 1.0f) > clip) ? 1.0 : 0.0;
+                        }
+                        // head bias gradient: the lanes of one head are 4 apart; two rotations inside the 16-lane row leave on every lane the sum over the row's four
+                        // samples; lanes 0 .. 3 of the row add head 0 .. 3's sums to the row's own accumulator
+                        const int acc16 = (4 * wave + (lane >> 4));
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            float v = dbs[j];
+                            v = PPO_DPP_ADD(v, 0x128);   // row_ror:8
+                            v = PPO_DPP_ADD(v, 0x124);   // row_ror:4
+                            if ((lane & 15) < 4 && j < A) s_db[acc16 * 20 + off + j] += v;
+                        }
+                        PPO_DPP_ADD_D(s0, 0xB1); PPO_DPP_ADD_D(s1, 0xB1); PPO_DPP_ADD_D(s2, 0xB1); PPO_DPP_ADD_D(s3, 0xB1);
+                        PPO_DPP_ADD_D(s0, 0x4E); PPO_DPP_ADD_D(s1, 0x4E); PPO_DPP_ADD_D(s2, 0x4E); PPO_DPP_ADD_D(s3, 0x4E);
+                        PPO_DPP_ADD_D(s0, 0x141); PPO_DPP_ADD_D(s1, 0x141); PPO_DPP_ADD_D(s2, 0x141); PPO_DPP_ADD_D(s3, 0x141);
+                        PPO_DPP_ADD_D(s0, 0x140); PPO_DPP_ADD_D(s1, 0x140); PPO_DPP_ADD_D(s2, 0x140); PPO_DPP_ADD_D(s3, 0x140);
+                        if ((lane & 15) == 0) { s_ls[acc16 * 8 + 0] += s0; s_ls[acc16 * 8 + 1] += s1; s_ls[acc16 * 8 + 2] += s2; s_ls[acc16 * 8 + 3] += s3; }
+                    } else {
+                        // the value loss (:603-625), once per row on the row's first lane
+                        float g_v = 0.0f, lossv = 0.0f;
+                        if (h == 0 && live) {
+                            const float v = s_out[row * 32], R = lr0.z, vold = lr0.w;
+                            const float un = (v - R) * (v - R);
+                            if (fl.hp.clip_vloss) {
+                                const float dv = v - vold;
+                                const float dvc = dv < -clip ? -clip : (dv > clip ? clip : dv);
+                                const float vc = vold + dvc;
+                                const float cl = (vc - R) * (vc - R);
+                                lossv = un > cl ? un : cl;
+                                const bool vin = (dv >= -clip && dv <= clip);
+                                const float d_un = 2.0f * (v - R), d_cl = vin ? 2.0f * (vc - R) : 0.0f;
+                                const float d = un > cl ? d_un : (un < cl ? d_cl : 0.5f * d_un + 0.5f * d_cl);
+                                g_v = fl.hp.vf_coef * 0.5f * invM * d;
+                            } else {
+                                lossv = un;
+                                g_v = fl.hp.vf_coef * 0.5f * invM * 2.0f * (v - R);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {   // lane h clears columns 4 h .. 4 h + 3 of the row (column 0: d value)
+                            const uint16_t b = (h == 0 && j == 0) ? fu_bf16(g_v) : (uint16_t)0;
+                            s_dl[row * FL_NP + 4 * h + j] = b;
+                            s_dlt[(4 * h + j) * FL_DLT_PITCH + row] = b;
+                        }
+                        const int acc16 = (4 * wave + (lane >> 4));
+                        float tv = g_v;
+                        tv = PPO_DPP_ADD(tv, 0xB1); tv = PPO_DPP_ADD(tv, 0x4E); tv = PPO_DPP_ADD(tv, 0x141); tv = PPO_DPP_ADD(tv, 0x140);
+                        double t4 = (double)lossv;
+                        PPO_DPP_ADD_D(t4, 0xB1); PPO_DPP_ADD_D(t4, 0x4E); PPO_DPP_ADD_D(t4, 0x141); PPO_DPP_ADD_D(t4, 0x140);
+                        if ((lane & 15) == 0) { s_db[acc16 * 20 + 16] += tv; s_ls[acc16 * 8 + 4] += t4; }
+                    }
+                }
+                __syncthreads();
+                // ---- E3: dZ_top block of wave w: rows 32 i + li, columns 32 w + (r & 3) + 8 (r >> 2) + 4 kg; tanh' from the h tile; column sums in f32 ----
+                const bool own_cols = 32 * wave < ld_h;   // a hidden vector of 128 columns: waves 0 .. 3 (wave-uniform)
+                if (own_cols && !(FL_ABL & 2)) {
+                    const u32x4 wf = s_wh[(net * FU_WAVES + wave) * 64 + lane];
+                    float cs[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) cs[r] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < FM; i++) {
+                        const int row = 32 * i + li;
+                        const u32x4 bfr = *reinterpret_cast<const u32x4*>(s_dl + row * FL_NP + 8 * kg);
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int at = row * ldA + 32 * wave + 8 * q + 4 * kg;
+                            const uint2 hv = *reinterpret_cast<const uint2*>(hT + at);
+                            const float h0 = fu_u2f(hv.x << 16), h1 = fu_u2f(hv.x & 0xffff0000u), h2 = fu_u2f(hv.y << 16), h3 = fu_u2f(hv.y & 0xffff0000u);
+                            const float v0 = acc[4 * q] * (1.0f - h0 * h0), v1 = acc[4 * q + 1] * (1.0f - h1 * h1);
+                            const float v2 = acc[4 * q + 2] * (1.0f - h2 * h2), v3 = acc[4 * q + 3] * (1.0f - h3 * h3);
+                            cs[4 * q] += v0; cs[4 * q + 1] += v1; cs[4 * q + 2] += v2; cs[4 * q + 3] += v3;
+                            *reinterpret_cast<uint2*>(oT + at) = make_uint2(fu_pack(v0, v1), fu_pack(v2, v3));
+                        }
+                    }
+                    // column sums over the tile's 64 rows: the 16 lanes (rows) of a DPP row, then lane 0 of the row adds them to the accumulator of its row half
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float v = cs[r];
+                        v = PPO_DPP_ADD(v, 0xB1); v = PPO_DPP_ADD(v, 0x4E); v = PPO_DPP_ADD(v, 0x141); v = PPO_DPP_ADD(v, 0x140);
+                        if ((lane & 15) == 0) s_cs[(2 * net + ((lane >> 4) & 1)) * ld_h + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg] += v;
+                    }
+                }
+                // ---- E4: dW_head[n][32 w + i] += sum over the tile's rows of dL[row][n] h[row][32 w + i]: four k steps, h by transposing reads ----
+                if (own_cols && !(FL_ABL & 4)) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const u32x4 af = *reinterpret_cast<const u32x4*>(s_dlt + li * FL_DLT_PITCH + 16 * ks + 8 * kg);
+                        const int r = 16 * ks + 8 * kg + ((lane & 15) >> 2);
+                        const int col = 32 * wave + 16 * ((lane & 31) >> 4) + 4 * (lane & 3);
+                        const uint2 blo = fu_read_tr16(hT + r * ldA + col), bhi = fu_read_tr16(hT + (r + 4) * ldA + col);
+                        const u32x4 bfr = { blo.x, blo.y, bhi.x, bhi.y };
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
+                    }
+                    // register r of lane (i, kg) <-> n = (r & 3) + 8 (r >> 2) + 4 kg (< 16: registers 0 .. 7), column 32 w + i
+                    const int n_real = N;
+                    float* const dw = s_dw + (net == 1 ? 0 : FL_NP) * ld_h + 32 * wave + li;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const int n = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (n < n_real) dw[n * ld_h] += acc[r];
+                    }
+                }
+                __syncthreads();
+                // ---- E5: the dZ_top tile leaves in 16-byte row pieces ----
+                if (!(FL_ABL & 8)) {
+                    const int p8 = ld_h / 8, total = RB * p8;
+                    for (int e0 = te; e0 < total; e0 += 4 * FU_THREADS) {
+                        u32x4 v[4];
+                        int row[4], c8[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int e = e0 + j * FU_THREADS, ee = e < total ? e : 0;
+                            row[j] = ee / p8; c8[j] = ee % p8;
+                            v[j] = *reinterpret_cast<const u32x4*>(oT + row[j] * ldA + 8 * c8[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (e0 + j * FU_THREADS < total && row[j] < n_rows)
+                                *reinterpret_cast<u32x4*>(fl.dz_top[net] + (row0 + row[j]) * fl.ld_dz + 8 * c8[j]) = v[j];
+                    }
+                }
+                // the next pass stages its input into tile0: with the dZ tile in tile0 (odd depth) the copy above must have read it first; with the h tile there (even
+                // depth) the barrier in front of E5 already covers the reads (uniform branch)
+                if (L.n_hidden & 1) __syncthreads();
+            }
             FU_STAMP(30);
+        }
+    }
+    if constexpr (LOSS != 0) {
+        // ---- the workgroup's partials: loss sums, head bias sums, dW_head of both nets, the column sums of dZ_top (every accumulator's last add is behind the barrier above) ----
+        const int wg = (int)blockIdx.x, nwg = (int)gridDim.x, act = L.act;
+        if (tid < 8) {
+            double t = 0.0;
+            if (tid < 5) for (int w = 0; w < 16; w++) t += s_ls[w * 8 + tid];
+            fl.loss_part[wg * 8 + tid] = t;
+            for (int b = wg + nwg; b < GEN_LOSS_BLOCKS; b += nwg) fl.loss_part[b * 8 + tid] = 0.0;   // (a launch of fewer workgroups than partial rows: the consumers add all of them)
+        }
+        if (tid >= 64 && tid - 64 <= act) {
+            const int k = tid - 64, kk = k < act ? k : 16;
+            float t = 0.0f;
+            for (int w = 0; w < 16; w++) t += s_db[w * 20 + kk];
+            fl.head_db_part[wg * (act + 1) + k] = t;
+            for (int b = wg + nwg; b < GEN_LOSS_BLOCKS; b += nwg) fl.head_db_part[b * (act + 1) + k] = 0.0f;
+        }
+        const int hid = L.hidden;
+        for (int e = tid; e < act * hid; e += FU_THREADS) fl.head_slab[1][(int64_t)wg * fl.head_slab_stride + e] = s_dw[(e / hid) * ld_h + e % hid];
+        for (int e = tid; e < hid; e += FU_THREADS) fl.head_slab[0][(int64_t)wg * fl.head_slab_stride + e] = s_dw[FL_NP * ld_h + e];
+        for (int e = tid; e < 2 * (int)fl.ld_cs; e += FU_THREADS) {
+            const int net = e / (int)fl.ld_cs, k = e % (int)fl.ld_cs;
+            fl.cs_top[net][(int64_t)wg * fl.ld_cs + k] = k < ld_h ? s_cs[2 * net * ld_h + k] + s_cs[(2 * net + 1) * ld_h + k] : 0.0f;
         }
     }
 }
@@ -507,6 +860,14 @@ static FusedForwardArgs fused_forward_args(const GenericCtx& g, const float* par
     for (int l = 0; l < g.L.n_hidden; l++) a.keep[l] = keep ? g.acts_bf[net][l] : nullptr;
     a.ld_keep = g.ld_h;
     return a;
+}
+template <int LOSS>
+static hipError_t fused_forward_loss_launch(const FusedForwardPair& pp, unsigned blocks, size_t lds, hipStream_t s) {
+    static std::atomic<unsigned long long> lds_ok{0};
+    const hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void*>(&generic_forward_kernel<true, LOSS>), (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((generic_forward_kernel<true, LOSS>), dim3(blocks), dim3(FU_THREADS), lds, s, pp);
+    return hipGetLastError();
 }
 static hipError_t fused_forward_launch(const FusedForwardPair& pp, unsigned blocks, bool bf, hipStream_t s) {
     const size_t lds = fused_lds_bytes(pp.a[0].f, 64);
@@ -550,6 +911,48 @@ hipError_t gen_fused_forward_both(const GenericCtx& g, const float* params, cons
     pp.split = (int)per; pp.dual = 1;   // every workgroup runs both nets on each of its tiles: the rows are fetched once
     return fused_forward_launch(pp, per, true, s);
 #endif
+}
+
+// Heads, loss and the head layers' backward inside the forward launch (FusedLossArgs above).  Shapes: the slot-wise loss's (<= 4 heads of <= 4 logits, packed row
+// records through the index list), hidden widths the backward kernels serve, and room for one partial per workgroup in the head layer's slab and column-sum blocks.
+bool gen_fused_loss_ok(const GenericCtx& g, int64_t rows) {
+    const GenLayout& L = g.L;
+    if (!gen_fused_forward_ok(g) || !gen_fused_backward_ok(g) || !g.obs_bf || !g.row_rec || L.n_heads > 4 || L.act > FL_NP || L.hidden > g.ld_h) return false;
+    for (int h = 0; h < L.n_heads; h++) if (L.head_dims[h] > 4) return false;
+    const FusedNet f = make_fused_net(g, nullptr, 0);
+    if (fused_lds_bytes(f, 64) + fused_loss_lds_bytes(g.ld_h) > 160 * 1024) return false;
+    const int64_t n_tiles = (rows + 63) / 64, blocks = n_tiles < 256 ? n_tiles : 256;
+    return blocks * (int64_t)L.act * L.hidden <= g.wslab_layer_stride && blocks * g.ld_h <= g.cs_layer_stride && blocks <= GEN_LOSS_BLOCKS;
+}
+hipError_t gen_fused_forward_loss(const GenericCtx& g, const float* params, const uint16_t* x_bf, int64_t ld_x, int64_t rows, const LossParams& hp, double inv_global_M,
+                                  double global_M, const AdvStat* adv_stat, const int32_t* idx, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (!gen_fused_loss_ok(g, rows) || !idx || !g.rows_rec) return hipErrorInvalidValue;
+    if (g.planes_dirty) { const hipError_t pe = gen_weight_planes(g, params, s); if (pe != hipSuccess) return pe; g.planes_dirty = false; }
+    const GenLayout& L = g.L;
+    const int top = L.n_layers - 1;
+    FusedForwardPair pp{};
+    pp.a[0] = fused_forward_args(g, params, 1, nullptr, x_bf, ld_x, rows, true, nullptr, idx);
+    pp.a[1] = fused_forward_args(g, params, 0, nullptr, x_bf, ld_x, rows, true, nullptr, idx);
+    pp.a[0].keep[L.n_hidden - 1] = nullptr;   // the top hidden activation is consumed in LDS: it never reaches HBM
+    pp.a[1].keep[L.n_hidden - 1] = nullptr;
+    const int64_t n_tiles = (rows + 63) / 64;
+    const unsigned blocks = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+    pp.split = (int)blocks; pp.dual = 1;
+    FusedLossArgs& fl = pp.loss;
+    fl.hp = hp; fl.invM = (float)inv_global_M; fl.global_M = global_M; fl.adv_stat = (adv_stat && hp.norm_adv) ? adv_stat : nullptr;
+    fl.idx = idx; fl.rec = g.rows_rec;
+    fl.ld_dz = g.ld_h; fl.ldw = g.wp_kpad[top]; fl.head_slab_stride = (int64_t)L.act * L.hidden; fl.ld_cs = g.ld_h;
+    for (int net = 0; net < 2; net++) {
+        fl.dz_top[net] = g.dz_bf[net][top & 1];
+        fl.whead[net] = g.wplanes + g.wp_off[net][top];
+        fl.head_slab[net] = (net == 1 ? g.wslab1 : g.wslab) + (size_t)top * g.wslab_layer_stride;
+        fl.cs_top[net] = g.cs_part[net] + (size_t)top * g.cs_layer_stride;
+    }
+    fl.head_db_part = g.head_db_part; fl.loss_part = g.loss_part;
+    const size_t lds = fused_lds_bytes(pp.a[0].f, 64) + fused_loss_lds_bytes(g.ld_h);
+    g.head_fused = (int)blocks;
+    return hp.dist_kind == PPO_DIST_MASKED ? fused_forward_loss_launch<PPO_DIST_MASKED + 1>(pp, blocks, lds, s) : fused_forward_loss_launch<PPO_DIST_CATEGORICAL + 1>(pp, blocks, lds, s);
 }
 
 hipError_t gen_fused_rollout(const GenericCtx& g, const float* params, int dist_kind, int N, int T, int max_episode_steps, int64_t seed, int64_t env_offset,

@@ -425,7 +425,8 @@ def test_generic_forward_kernels_on_the_reference_multihead_agent(P):
 def test_generic_bf16_step_forms_agree(P, envs, steps):
     """The bf16-storage minibatch step exists in three forms that must compute the same update: the default (rows read in place through the permutation, both
     nets in every launch on one stream, ONE optimizer launch that takes the gradient norm from the slab sums' partial sums of squares and refreshes the bf16
-    weight planes itself), PPO_KERNEL_GENERIC_CLASSIC (gathered copies, one net per launch on two streams, loss sums / norm / AdamW / planes as four launches)
+    weight planes itself; heads, loss and the head layers' backward in the forward launch's epilogue), PPO_KERNEL_GENERIC_SPLIT_HEAD (the same with the loss and the
+    head layers' backward as launches of their own), PPO_KERNEL_GENERIC_CLASSIC (gathered copies, one net per launch on two streams, loss sums / norm / AdamW / planes as four launches)
     and the multi-rank form driven on one GPU by PPO_KERNEL_COMM_SELFTEST (paired launches, the loss sums riding the gradient's all-reduce, norm kernel).
     Same product kernels and the same partition of every partial sum: after a whole iteration (eight optimizer steps) at a shape the fused kernels take (hidden 256, obs padded
     to 128-column blocks) the parameters agree to float rounding -- the one thing that differs is the ORDER in which the norm's partial sums are added."""
@@ -433,7 +434,8 @@ def test_generic_bf16_step_forms_agree(P, envs, steps):
               num_minibatches=4, update_epochs=2, max_episode_steps=50, seed=21, total_timesteps=envs * steps * 4, learning_rate=3e-4, ent_coef=0.01,
               compute_dtype=P.DTYPE_BF16)
     got = {}
-    for name, flags, comm in (("default", 0, False), ("classic", P.KERNEL_GENERIC_CLASSIC, False), ("multi-rank path", P.KERNEL_COMM_SELFTEST, True)):
+    for name, flags, comm in (("default", 0, False), ("classic", P.KERNEL_GENERIC_CLASSIC, False), ("multi-rank path", P.KERNEL_COMM_SELFTEST, True),
+                              ("split head", P.KERNEL_GENERIC_SPLIT_HEAD, False)):
         ctx = P.Context(P.make_config(kernel_flags=flags, **kw))
         if comm:
             ctx.comm_init(P.comm_unique_id(), 0, 1)
@@ -446,8 +448,45 @@ def test_generic_bf16_step_forms_agree(P, envs, steps):
         ctx.close()
     p0 = got["default"][0]
     scale = np.abs(p0).max()
-    for name in ("classic", "multi-rank path"):
+    for name in ("classic", "multi-rank path", "split head"):
         p1 = got[name][0]
         assert np.abs(p1 - p0).max() <= 2e-6 * scale, (name, np.abs(p1 - p0).max(), scale)
         assert abs(got[name][1] - got["default"][1]) <= 1e-5 * max(1.0, abs(got["default"][1])), name
         assert np.array_equal(bits(got[name][3]), bits(got["default"][3])), name   # the rollout's log-probs: the same launch
+
+
+
+@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("heads,hidden,n_hidden", [((3, 3, 3, 2), 256, 4), ((4,), 128, 1), ((2, 4, 1), 256, 3)])
+def test_fused_head_epilogue_equals_the_split_launches(P, masked, heads, hidden, n_hidden):
+    """Heads + masked categorical + PPO loss + the head layers' backward run in the forward launch's epilogue on the tile still in LDS (kernels_generic_fused.hip:
+    FusedLossArgs; the default where the shape allows) or as launches of their own behind a forward pass that writes logits, values and the top activation to memory
+    (PPO_KERNEL_GENERIC_SPLIT_HEAD: loss_lanes_kernel + bwd_layer_kernel<1, ...>).  Same arithmetic -- the same bf16 roundings of d logits, h and W_head, f32
+    accumulation -- and different partitions of the partial sums (per forward workgroup / per row range): on the SAME batch and parameters the whole gradient, the loss
+    scalars and the gradient norm agree to f32 summation order.  Index lists: whole tiles, a ragged last tile, fewer rows than one tile, two rows; depths with the top
+    activation in either LDS tile (n_hidden odd / even)."""
+    kw = dict(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED if masked else P.DIST_CATEGORICAL, obs_size=120, head_dims=heads, hidden=hidden, n_hidden=n_hidden,
+              num_envs=48, num_steps=24, num_minibatches=2, update_epochs=1, max_episode_steps=30, seed=13, learning_rate=3e-4, ent_coef=0.01, compute_dtype=P.DTYPE_BF16)
+    ctxs = [P.Context(P.make_config(kernel_flags=f, **kw)) for f in (0, P.KERNEL_GENERIC_SPLIT_HEAD)]
+    ctxs[0].init_orthogonal(4)
+    params = ctxs[0].get_params()
+    rng = np.random.default_rng(3)
+    params = (params + 0.02 * rng.standard_normal(params.shape)).astype(np.float32)   # biases away from zero
+    for c in ctxs:
+        c.set_params(params)
+        c.env_reset()
+        c.rollout()
+        c.calc_advantage()
+    B = 48 * 24
+    assert np.array_equal(bits(ctxs[0].read("ADVANTAGES")), bits(ctxs[1].read("ADVANTAGES")))
+    for M in (576, 512, 225, 40, 2):   # (the workspace holds one minibatch: B / 2 rows)
+        idx = rng.permutation(B)[:M].astype(np.int32)
+        g = [c.minibatch_forward_backward(idx) for c in ctxs]
+        st = [c.stats() for c in ctxs]
+        scale = np.abs(g[1]).max()
+        assert scale > 0 and np.isfinite(g[0]).all()
+        assert np.abs(g[0] - g[1]).max() <= 2e-5 * scale, (M, float(np.abs(g[0] - g[1]).max()), float(scale))
+        for key in ("pg_loss", "v_loss", "entropy_loss", "approx_kl", "clipfrac_last", "total_norm"):
+            assert abs(st[0][key] - st[1][key]) <= 2e-6 * max(1.0, abs(st[1][key])), (M, key, st[0][key], st[1][key])
+    for c in ctxs:
+        c.close()
