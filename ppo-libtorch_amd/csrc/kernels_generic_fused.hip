@@ -719,36 +719,36 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
                 // ---- E3: dZ_top block of wave w: rows 32 i + li, columns 32 w + (r & 3) + 8 (r >> 2) + 4 kg; tanh' from the h tile; column sums in f32 ----
                 const bool own_cols = 32 * wave < ld_h;   // a hidden vector of 128 columns: waves 0 .. 3 (wave-uniform)
                 if (own_cols && !(FL_ABL & 2)) {
+                    // D[row][column] (the rows' d logits as the A operand, W_head^T as the B operand): lane (i, kg) then holds ONE column, 32 w + i, and register r
+                    // the row 32 blk + (r & 3) + 8 (r >> 2) + 4 kg -- the column sum is an in-lane sum of registers (the other orientation, lane = row, needed
+                    // four DPP steps per register and a read-modify-write per value: two thirds of this phase).  h comes by transposing reads: one ds_read_b64_tr_b16
+                    // hands a lane four consecutive rows of its column -- a 16-lane group addresses rows R .. R + 3 (lane 4 q + p: row R + q, columns 4 p ..).
                     const u32x4 wf = s_wh[(net * FU_WAVES + wave) * 64 + lane];
-                    float cs[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) cs[r] = 0.0f;
+                    const int col = 32 * wave + li;
+                    const int tr_at = ((lane & 15) >> 2) * ldA + 32 * wave + 16 * ((lane & 31) >> 4) + 4 * (lane & 3);   // element offset of this lane's share of a group's read
+                    float csum = 0.0f;
 #pragma unroll
                     for (int i = 0; i < FM; i++) {
-                        const int row = 32 * i + li;
-                        const u32x4 bfr = *reinterpret_cast<const u32x4*>(s_dl + row * FL_NP + 8 * kg);
+                        const u32x4 afr = *reinterpret_cast<const u32x4*>(s_dl + (32 * i + li) * FL_NP + 8 * kg);
                         f32x16 acc;
 #pragma unroll
                         for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr), __builtin_bit_cast(bf16x8, wf), acc, 0, 0, 0);
+                        uint2 hv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) hv[q] = fu_read_tr16(hT + (32 * i + 8 * q + 4 * kg) * ldA + tr_at);
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const int at = row * ldA + 32 * wave + 8 * q + 4 * kg;
-                            const uint2 hv = *reinterpret_cast<const uint2*>(hT + at);
-                            const float h0 = fu_u2f(hv.x << 16), h1 = fu_u2f(hv.x & 0xffff0000u), h2 = fu_u2f(hv.y << 16), h3 = fu_u2f(hv.y & 0xffff0000u);
+                            const int row = 32 * i + 8 * q + 4 * kg;
+                            const float h0 = fu_u2f(hv[q].x << 16), h1 = fu_u2f(hv[q].x & 0xffff0000u), h2 = fu_u2f(hv[q].y << 16), h3 = fu_u2f(hv[q].y & 0xffff0000u);
                             const float v0 = acc[4 * q] * (1.0f - h0 * h0), v1 = acc[4 * q + 1] * (1.0f - h1 * h1);
                             const float v2 = acc[4 * q + 2] * (1.0f - h2 * h2), v3 = acc[4 * q + 3] * (1.0f - h3 * h3);
-                            cs[4 * q] += v0; cs[4 * q + 1] += v1; cs[4 * q + 2] += v2; cs[4 * q + 3] += v3;
-                            *reinterpret_cast<uint2*>(oT + at) = make_uint2(fu_pack(v0, v1), fu_pack(v2, v3));
+                            csum += v0; csum += v1; csum += v2; csum += v3;
+                            oT[(row + 0) * ldA + col] = fu_bf16(v0); oT[(row + 1) * ldA + col] = fu_bf16(v1);
+                            oT[(row + 2) * ldA + col] = fu_bf16(v2); oT[(row + 3) * ldA + col] = fu_bf16(v3);
                         }
                     }
-                    // column sums over the tile's 64 rows: the 16 lanes (rows) of a DPP row, then lane 0 of the row adds them to the accumulator of its row half
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        float v = cs[r];
-                        v = PPO_DPP_ADD(v, 0xB1); v = PPO_DPP_ADD(v, 0x4E); v = PPO_DPP_ADD(v, 0x141); v = PPO_DPP_ADD(v, 0x140);
-                        if ((lane & 15) == 0) s_cs[(2 * net + ((lane >> 4) & 1)) * ld_h + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg] += v;
-                    }
+                    s_cs[(2 * net + kg) * ld_h + col] += csum;   // one accumulator per (net, kg half, column): this lane's alone
                 }
                 // ---- E4: dW_head[n][32 w + i] += sum over the tile's rows of dL[row][n] h[row][32 w + i]: four k steps, h by transposing reads ----
                 if (own_cols && !(FL_ABL & 4)) {
@@ -788,8 +788,13 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
                         }
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            if (e0 + j * FU_THREADS < total && row[j] < n_rows)
+                            if (e0 + j * FU_THREADS < total && row[j] < n_rows) {
+#ifdef FL_E5_NT
+                                __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(fl.dz_top[net] + (row0 + row[j]) * fl.ld_dz + 8 * c8[j]));
+#else
                                 *reinterpret_cast<u32x4*>(fl.dz_top[net] + (row0 + row[j]) * fl.ld_dz + 8 * c8[j]) = v[j];
+#endif
+                            }
                     }
                 }
                 // the next pass stages its input into tile0: with the dZ tile in tile0 (odd depth) the copy above must have read it first; with the h tile there (even
