@@ -169,7 +169,7 @@ struct ppo_ctx {
     bool use_mfma = true;
     bool update_single_wave = false;   // PPO_KERNEL_UPDATE_ONE_WAVE
     bool rollout_vector = false;       // PPO_KERNEL_ROLLOUT_VECTOR
-    // fp16 range of the matrix-core kernels (OptGuard, ppo_internal.hpp): running maxima of |parameter| by class, on the device and mirrored into pinned
+    // fp16 range of the matrix-core kernels (ppo_internal.hpp: weight_range_kernel): maxima of |parameter| by class, taken once per update, on the device and mirrored into pinned
     // host memory that the dispatch reads WITHOUT synchronising; wrange_dirty = the host wrote parameters since they were last computed from scratch
     uint32_t* wr_dev = nullptr;
     uint32_t* wr_host = nullptr;       // hipHostMalloc'ed, mapped: wr_host_dev is the device's address of the same words
@@ -1003,10 +1003,11 @@ static ppo_status consume_finished_episodes(ppo_ctx* c) {
 }
 
 // The matrix-core kernels of the reference's two shapes carry some operands as fp16 (kernels_rollout.hip: 2^8 W3; kernels_update_mfma.hip: c W2 and the
-// products through its columns); the reference has no such limits.  A drop-in user never sees them: the optimizer kernels keep the running maximum of
-// |parameter| per class (OptGuard), the host reads the pinned mirror -- no synchronisation; it lags the device by the launches in flight, during which
-// AdamW moves a weight by about lr per step, hence thresholds at HALF the kernels' limits -- and a launch whose weights are out of range takes the vector
-// kernel (plain fp32, same function).  After the host wrote parameters the maxima are recomputed from scratch (one tiny launch + a synchronisation).
+// products through its columns); the reference has no such limits.  A drop-in user never sees them: weight_range_kernel takes the maxima of |parameter| per
+// class once per update on a stream of its own (sweep_weight_range below; ppo_internal.hpp has the cost bisect), the host reads the pinned mirror -- no
+// synchronisation; it lags the device by the launches in flight, during which AdamW moves a weight by about lr per step, hence thresholds at HALF the
+// kernels' limits -- and a launch whose weights are out of range takes the vector kernel (plain fp32, same function; counted in
+// ppo_profile.vector_fallback_launches).  After the host wrote parameters the maxima are recomputed from scratch (one tiny launch + a synchronisation).
 constexpr float WR_LIMIT_W3 = 128.0f;    // rollout16_kernel: |W3| < 255
 constexpr float WR_LIMIT_W2 = 4.0f;      // update kernels: a column of c W2 with absolute sum ~2^10 overflows the fp16 terms of dz1: 64 x 4 x 2.885 = 739
 constexpr float WR_LIMIT_REST = 8192.0f; // c W1, c b1, c b2: < 65 504 / 2.885
@@ -1249,9 +1250,12 @@ static ppo_status gen_fwd_bwd(ppo_ctx* c, const int32_t* idx, int64_t M, int slo
             g.rows_src = GenRowSrc{ B_<int32_t>(c, PPO_BUF_ACTIONS), c->cfg.dist_kind == PPO_DIST_MASKED ? B_<uint8_t>(c, PPO_BUF_MASKS) : nullptr, B_<float>(c, PPO_BUF_LOGPROBS),
                                     B_<float>(c, PPO_BUF_ADVANTAGES), B_<float>(c, PPO_BUF_RETURNS), B_<float>(c, PPO_BUF_VALUES) };
             if (!c->gen_obs_bf_valid) {
-                HIPCHK(c, launch_to_bf16_pad(B_<float>(c, PPO_BUF_OBS), c->B, GL.obs, g.obs_bf, g.ld_in0, c->stream));
-                if (g.row_rec) HIPCHK(c, gen_pack_rows(GL, g.rows_src, c->B, g.row_rec, c->stream));
-                c->gen_obs_bf_valid = c->wr_in_update;
+                // inside ppo_update: the whole batch once, valid for all of the update's steps.  A stand-alone step (its caller may have rewritten any buffer
+                // since the last one): only the step's own M rows, in place -- not all B of them for a step that reads a few
+                const bool whole = c->wr_in_update;
+                HIPCHK(c, launch_to_bf16_pad(B_<float>(c, PPO_BUF_OBS), whole ? c->B : M, GL.obs, g.obs_bf, g.ld_in0, c->stream, whole ? nullptr : idx));
+                if (g.row_rec) HIPCHK(c, gen_pack_rows(GL, g.rows_src, whole ? c->B : M, g.row_rec, c->stream, whole ? nullptr : idx));
+                c->gen_obs_bf_valid = whole;
             }
             g.rows_idx = idx;
             g.rows_rec = reinterpret_cast<const float4*>(g.row_rec);

@@ -126,7 +126,7 @@ hipError_t gen_weight_planes(const GenericCtx& g, const float* params, hipStream
 hipError_t launch_matmul_bf16(bool trans_a, bool trans_b, int64_t M, int64_t N, int64_t K, const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb,
                               void* c, int64_t ldc, bool c_bf16, int epilogue, const void* aux, int64_t ld_aux, int splits, int64_t c_zstride,
                               float* colsum, int64_t colsum_stride, hipStream_t s);
-hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s);
+hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s, const int32_t* idx = nullptr);   // idx: those rows only, in place
 
 // kernels_generic_fused.hip: bf16-storage networks whose layer inputs fit LDS -- a net's whole forward pass, or the whole T-step rollout of
 // the synthetic env, in one launch
@@ -180,7 +180,7 @@ hipError_t gen_loss(const GenLayout& L, const LossParams& hp, const GenericCtx& 
                     const AdvStat* adv_stat, hipStream_t s);
 // the per-row scalars of all T N samples as one 32-byte record each (the loss kernel of an in-place step reads one record per row)
 bool gen_rows_packable(const GenLayout& L);
-hipError_t gen_pack_rows(const GenLayout& L, const GenRowSrc& src, int64_t B, float* rec, hipStream_t s);
+hipError_t gen_pack_rows(const GenLayout& L, const GenRowSrc& src, int64_t B, float* rec, hipStream_t s, const int32_t* idx = nullptr);   // idx: those B rows only
 // beside_other_net: the other net's backward pass runs at the same time on another stream (the fused launches then size themselves for half the chip)
 hipError_t gen_backward(const GenericCtx& g, const float* params, int net, const float* x, int64_t rows, const float* dout, float* grads,
                         hipStream_t s, bool beside_other_net = false);

@@ -706,20 +706,22 @@ hipError_t launch_matmul_bf16(bool trans_a, bool trans_b, int64_t M, int64_t N, 
 }
 
 // f32 [rows, K] -> bf16 [rows, ld] (round to nearest even), columns K .. ld - 1 zero: the layer input of a bf16 network
-__global__ __launch_bounds__(256) void to_bf16_pad_kernel(const float* __restrict__ src, int64_t rows, int K, uint16_t* __restrict__ dst, int ld) {
+// idx != nullptr: only rows idx[0 .. rows - 1] are converted, each IN PLACE (row idx[j] of src -> row idx[j] of dst): what a stand-alone step of M rows needs of a
+// batch of B (duplicate indices write the same values twice)
+__global__ __launch_bounds__(256) void to_bf16_pad_kernel(const float* __restrict__ src, int64_t rows, int K, uint16_t* __restrict__ dst, int ld, const int32_t* __restrict__ idx) {
     const int64_t total = rows * (ld / 2);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / (ld / 2);
+        const int64_t j = i / (ld / 2), r = idx ? (int64_t)idx[j] : j;
         const int k = 2 * (int)(i % (ld / 2));
         const float x0 = k < K ? src[r * K + k] : 0.0f, x1 = k + 1 < K ? src[r * K + k + 1] : 0.0f;
-        reinterpret_cast<uint32_t*>(dst)[i] = pack_rne(x0, x1);
+        reinterpret_cast<uint32_t*>(dst)[r * (ld / 2) + k / 2] = pack_rne(x0, x1);
     }
 }
-hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s) {
+hipError_t launch_to_bf16_pad(const float* src, int64_t rows, int K, uint16_t* dst, int ld, hipStream_t s, const int32_t* idx) {
     if (rows <= 0) return hipSuccess;
     const int64_t total = rows * (ld / 2);
     const int64_t gb = (total + 255) / 256;
-    hipLaunchKernelGGL(to_bf16_pad_kernel, dim3((unsigned)(gb < 4096 ? gb : 4096)), dim3(256), 0, s, src, rows, K, dst, ld);
+    hipLaunchKernelGGL(to_bf16_pad_kernel, dim3((unsigned)(gb < 4096 ? gb : 4096)), dim3(256), 0, s, src, rows, K, dst, ld, idx);
     return hipGetLastError();
 }
 

@@ -207,9 +207,10 @@ __global__ __launch_bounds__(256) void loss_kernel(GenLayout L, LossParams hp, c
 // and <= 32 logits (gen_rows_packable).
 __global__ __launch_bounds__(256) void pack_rows_kernel(GenLayout L, const int32_t* __restrict__ actions, const uint8_t* __restrict__ masks,
                                                        const float* __restrict__ logprobs, const float* __restrict__ adv, const float* __restrict__ ret,
-                                                       const float* __restrict__ values, int64_t B, float4* __restrict__ rec) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= B) return;
+                                                       const float* __restrict__ values, int64_t B, float4* __restrict__ rec, const int32_t* __restrict__ idx) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= B) return;
+    const int64_t i = idx ? (int64_t)idx[j] : j;   // idx: the records of those B rows only, each in its own place
     uint32_t ab = 0u, mb = 0xffffffffu;
     for (int h = 0; h < L.n_heads; h++) ab |= ((uint32_t)actions[i * L.n_heads + h] & 0xffu) << (8 * h);
     if (masks) { mb = 0u; for (int k = 0; k < L.act; k++) mb |= (masks[i * L.act + k] ? 1u : 0u) << k; }
@@ -1191,10 +1192,10 @@ bool gen_rows_packable(const GenLayout& L) {
     for (int h = 0; h < L.n_heads; h++) if (L.head_dims[h] > 256) return false;
     return true;
 }
-hipError_t gen_pack_rows(const GenLayout& L, const GenRowSrc& src, int64_t B, float* rec, hipStream_t s) {
+hipError_t gen_pack_rows(const GenLayout& L, const GenRowSrc& src, int64_t B, float* rec, hipStream_t s, const int32_t* idx) {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, L, src.actions, src.masks, src.logprobs, src.adv, src.ret, src.values, B,
-                       reinterpret_cast<float4*>(rec));
+                       reinterpret_cast<float4*>(rec), idx);
     return hipGetLastError();
 }
 
@@ -1277,6 +1278,9 @@ hipError_t fused_backward(const GenericCtx& g, int net_a, int net_b, int64_t row
         const int cbk = gen_bwd_col_blocks((int)ldi, l > 0);
         int tpr = 1;
         const int S = gen_bwd_ranges(rows, cbk, half_chip || n_nets == 2, &tpr);
+        // a layer's block holds GEN_SPLIT_MFMA + 1 slabs and cs_layer_stride / ld_h rows of column sums: more ranges than that would run into the next layer's
+        // block (a whole-chip launch of a 128-column layer 0 asks for 256: refused here rather than summed wrong)
+        if ((int64_t)S * g.wslab_stride > g.wslab_layer_stride || (int64_t)S * g.ld_h > g.cs_layer_stride) return hipErrorInvalidValue;
         GenBwdLayer q[2];
         for (int i = 0; i < n_nets; i++) {
             const int net = nets[i];

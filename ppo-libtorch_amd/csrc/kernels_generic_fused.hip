@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_btail(BFrags& b, const FusedNet& f, int l, 
     for (int j = 0; j < FU_KTAIL; j++) b.q[j] = *reinterpret_cast<const u32x4*>(wblk + (int64_t)(k0 + j) * 512);
 }
 
-template <int FM>
+template <int FM, int NW = FU_WAVES>
 __device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off0, uint16_t* tile0, uint16_t* tile1, float* s_out, uint16_t* const* keep, int64_t ld_keep,
                                              int64_t row0, int n_rows, BFrags& pre, unsigned int* dbg = nullptr) {
     // `pre` holds, on entry, the fragments of (layer 0, column block = wave, k steps 0 ..) -- requested by the caller, e.g. while the input tile
@@ -93,7 +93,7 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off
         const int nblk = (N + 31) / 32;
         const float* bias = f.params + L.b_off[f.net][l];
         const int ln = last ? 0 : l + 1;   // the layer whose first fragments are requested during this one
-        for (int cb = wave; cb < nblk || cb == wave; cb += FU_WAVES) {   // every wave passes once (it may own no column block): it still prefetches
+        for (int cb = wave; cb < nblk || cb == wave; cb += NW) {   // every wave passes once (it may own no column block): it still prefetches
             const bool own = cb < nblk;
             f32x16 acc[FM];
 #pragma unroll
@@ -147,7 +147,7 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off
             FU_STAMP(33 + 4 * l);
             // the wave's last pass of this layer: the next layer's first fragments are requested now -- by a wave with an epilogue to do in four
             // pieces spread over it (sixteen loads in a row from all eight waves fill the CU's load queue: ~1 200 cycles of issue stall each)
-            const bool pf_next = cb + FU_WAVES >= nblk;
+            const bool pf_next = cb + NW >= nblk;
             const uint16_t* nblkp = f.wfrags + (last ? next_off0 : f.wp_off[ln]) + ((int64_t)wave * (f.wp_kpad[ln] / 16) * 64 + lane) * 8;   // (layer widths are the same in both nets)
             auto next_piece = [&](int pc) {
 #pragma unroll
@@ -193,18 +193,18 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off
             const int p8 = (N + 7) / 8, total = 32 * FM * p8;
             const bool pow2 = (p8 & (p8 - 1)) == 0;
             const int sh = __builtin_ctz((unsigned)p8);
-            for (int e0 = tid; e0 < total; e0 += 4 * FU_THREADS) {
+            for (int e0 = tid; e0 < total; e0 += 4 * 64 * NW) {
                 u32x4 v[4];
                 int row[4], c8[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int e = e0 + j * FU_THREADS, ee = e < total ? e : 0;
+                    const int e = e0 + j * 64 * NW, ee = e < total ? e : 0;
                     row[j] = pow2 ? ee >> sh : ee / p8; c8[j] = pow2 ? ee & (p8 - 1) : ee % p8;
                     v[j] = *reinterpret_cast<const u32x4*>(dst + row[j] * f.ldA + 8 * c8[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (e0 + j * FU_THREADS < total && row[j] < n_rows) {
+                    if (e0 + j * 64 * NW < total && row[j] < n_rows) {
                         // streamed past the L2 (nt): 268 MB per step that this kernel never reads again (forward launch 172 -> 168 us, A/B in one call)
                         __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(keep[l] + (row0 + row[j]) * ld_keep + 8 * c8[j]));
                     }
@@ -423,14 +423,18 @@ typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 // dual: every workgroup runs BOTH passes on each of its tiles -- the input tile is fetched and staged from the same registers twice, read from memory once.
 struct FusedForwardPair { FusedForwardArgs a[2]; int split; int dual; FusedLossArgs loss; };
 // LOSS: 0 = forward only; PPO_DIST_CATEGORICAL + 1 / PPO_DIST_MASKED + 1 = the loss and the head layer's backward in the epilogue of every pass (dual launches only)
-template <bool BF, int LOSS = 0>
-__global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const FusedForwardPair pp) {
+// NW / FMT: waves per workgroup and 32-row blocks per tile.  8 / 2 = one workgroup of 64-row tiles per CU; 4 / 1 (LOSS == 0 only, exploration: -DFU_HALF) = TWO
+// workgroups of 32-row tiles per CU, whose phases (weights from L2, LDS + matrix cores, tanh epilogue) can overlap each other's instead of running in lockstep.
+template <bool BF, int LOSS = 0, int NW = FU_WAVES, int FMT = 2>
+__global__ __launch_bounds__(64 * NW, NW == FU_WAVES ? 1 : 2) void generic_forward_kernel(const FusedForwardPair pp) {
+    static_assert(LOSS == 0 || (NW == FU_WAVES && FMT == 2), "the loss epilogue is written for eight waves and 64-row tiles");
+    constexpr int FU_THREADS = 64 * NW;   // (shadows the file's constant inside this kernel)
     const int second = (int)blockIdx.x >= pp.split ? 1 : 0;
     const FusedForwardArgs& a = pp.a[second];
     const int bid = (int)blockIdx.x - (second ? pp.split : 0), nblk = second ? (int)gridDim.x - pp.split : pp.split;
     constexpr int FU_NP = fu_np<BF>();
     extern __shared__ __attribute__((aligned(16))) uint16_t fu_lds[];
-    constexpr int FM = 2, RB = 32 * FM;
+    constexpr int FM = FMT, RB = 32 * FM;
     const GenLayout& L = a.f.L;
     const int tid = threadIdx.x;
     uint16_t* tile0 = fu_lds;
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(FU_THREADS, 1) void generic_forward_kernel(const Fu
             FU_STAMP(2);
             __syncthreads();
             FU_STAMP(3);
-            fused_layers<FM>(x.f, next_off0, tile0, tile1, s_out, x.keep, x.ld_keep, row0, n_rows, pre, dbg);
+            fused_layers<FM, NW>(x.f, next_off0, tile0, tile1, s_out, x.keep, x.ld_keep, row0, n_rows, pre, dbg);
             const int N = L.out_dim[x.f.net][L.n_layers - 1];
             if constexpr (LOSS == 0) {
                 for (int e = tid; e < n_rows * N; e += FU_THREADS) x.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];   // (s_out is written again four barriers from here)
@@ -882,6 +886,16 @@ static hipError_t fused_forward_launch(const FusedForwardPair& pp, unsigned bloc
                                 : allow_dynamic_lds(lds_ok[1], reinterpret_cast<const void*>(&generic_forward_kernel<false>));
         if (e != hipSuccess) return e;
     }
+#ifdef FU_HALF
+    if (bf && pp.dual) {   // exploration: two workgroups of four waves and 32-row tiles per CU
+        const int64_t t32 = (pp.a[0].rows + 31) / 32;
+        const unsigned hb = (unsigned)(t32 < 512 ? t32 : 512);
+        FusedForwardPair q = pp;
+        q.split = (int)hb;
+        hipLaunchKernelGGL((generic_forward_kernel<true, 0, 4, 1>), dim3(hb), dim3(256), fused_lds_bytes(pp.a[0].f, 32), s, q);
+        return hipGetLastError();
+    }
+#endif
     if (bf) hipLaunchKernelGGL(generic_forward_kernel<true>, dim3(blocks), dim3(FU_THREADS), lds, s, pp);
     else hipLaunchKernelGGL(generic_forward_kernel<false>, dim3(blocks), dim3(FU_THREADS), lds, s, pp);
     return hipGetLastError();

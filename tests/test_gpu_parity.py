@@ -718,7 +718,7 @@ def test_vector_rollout_flag_is_bit_exact_with_policy_act(P, N):
 
 def test_weights_beyond_fp16_take_the_vector_kernels_for_that_launch(P):
     """The matrix-core kernels carry some operands as fp16 (rollout16_kernel: 2^8 W3, |W3| < 255; the update kernels: c W2 and the products through its
-    columns).  The reference has no such limits, and a drop-in user must not meet them: the optimizer kernels keep the running maximum of |parameter| per class,
+    columns).  The reference has no such limits, and a drop-in user must not meet them: a small kernel takes the maximum of |parameter| per class once per update (and after every host write),
     the host reads its pinned mirror, and a launch whose weights do not fit takes the vector kernel (plain fp32) -- with DEFAULT flags.  Here: an actor
     output-layer weight of 300, and a hidden-to-hidden weight of 6, each set through ppo_params_set_h: the rollout equals the PPO_KERNEL_ROLLOUT_VECTOR context's
     bit for bit (it IS that kernel), the update equals the PPO_KERNEL_UPDATE_VECTOR context's, training goes on and the statistics read reports nothing."""

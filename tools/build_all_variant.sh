@@ -1,7 +1,7 @@
 #!/bin/bash
 # build_all_variant.sh NAME "-DFLAGS": every object rebuilt with the flags -> build_ab/libppo_hip_NAME.so
 set -e
-cd /root/repo
+cd "$(dirname "$0")/.."
 NAME=$1; EXTRA=$2; C=ppo-libtorch_amd/csrc
 OBJS=""
 for f in api kernels_rollout kernels_gae kernels_update kernels_update_mfma kernels_generic kernels_generic_fused kernels_generic_bwd kernels_gemm; do

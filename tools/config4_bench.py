@@ -11,7 +11,7 @@ N, T, K, W = int(os.environ.get("ENVS", 2048)), 128, 5, 2
 ctx = P.Context(P.make_config(env_kind=P.ENV_SYNTHETIC, dist_kind=P.DIST_MASKED, obs_size=376, head_dims=(3, 3, 3, 2), hidden=256, n_hidden=4, num_envs=N,
                               num_steps=T, num_minibatches=4, update_epochs=10, max_episode_steps=200, seed=1, total_timesteps=(K + W) * N * T,
                               learning_rate=3e-4, gamma=0.99, gae_lambda=0.95, ent_coef=0.01,
-                              compute_dtype=P.DTYPE_F32 if os.environ.get("DTYPE", "bf16") == "f32" else P.DTYPE_BF16))
+                              compute_dtype=P.DTYPE_F32 if os.environ.get("DTYPE", "bf16") == "f32" else P.DTYPE_BF16, kernel_flags=int(os.environ.get("KFLAGS", 0))))
 ctx.init_orthogonal(1); ctx.env_reset()
 for _ in range(W):
     ctx.train_iteration()
