@@ -104,6 +104,7 @@ def newest_profile(suffix):
     return f if os.path.exists(f) else None
 
 
+UPDATE_KERNEL_C1 = "fwd_bwd_mfma_ws_kernel<0, 4, 2>"   # configs[1]'s instantiation (plain Categorical, obs 4, two logits); MountainCar's is <1, 2, 3>
 GAE_EXACT_4096 = "gae_kernel<16, 0, true, false, 128"   # the exact scan configs[1] launches (kernels_gae.hip: launch_scan; <strip columns, GAE, 16-byte accesses, not ppo_gae_fast, 128-row tile, ...>)
 
 
@@ -751,7 +752,7 @@ def main():
                            "num_envs_per_gpu": n_envs, "num_steps": T, "minibatch_per_gpu": m_rows, "optimizer_steps_per_step": 40},
                 "value": steps * n_envs * T / dt_o, "unit": "env-steps/s", "steps": steps, "warmup": warm_iters + probe_iters, "ms_per_step": 1e3 * dt_o / steps, "timed_seconds": dt_o,
                 "dtype": "bf16" if name == "config4" else "f32 (update GEMMs: two-term f16 split on f16 MFMA, fp32 accumulate)",
-                "roofline": {"kernel": ("one minibatch step of the generic path (forward, heads + loss, backward per layer, slab sums; both nets in every launch; the optimizer launch is outside the bracket)"
+                "roofline": {"kernel": ("one minibatch step of the generic path (forward with heads + loss + head backward in its epilogue, backward per layer, slab sums; both nets in every launch; the optimizer launch is outside the bracket)"
                                         if name == "config4" else "fwd_bwd_mfma_ws_kernel (gather+forward+PPO loss+backward)"),
                              "bound": "mfma", "flops_per_launch": fl_o, "avg_launch_ms": fb, "launches": pr["fwd_bwd_launches"],
                              "achieved": fl_o / (fb * 1e-3) / 1e12 if fb else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -779,12 +780,13 @@ def main():
         fb_ms, gae_ms = per_launch("fwd_bwd"), per_launch("gae")
         gae_bytes = 20 * N * T + 8 * N
         generic = args.workload == "config4"
-        fb_name = "gemm_kernel" if generic else "fwd_bwd_mfma"
+        fb_name = "gemm_kernel" if generic else UPDATE_KERNEL_C1
         fb_tr, gae_tr = pmc_traffic(fb_name) if args.workload == "cartpole" else None, pmc_traffic(GAE_EXACT_4096) if args.workload == "cartpole" else None
         if generic:
             roof = {"kernel": "one minibatch step of the generic path, both nets in every launch: ONE fused forward launch (generic_forward_kernel, rows read in place through the "
-                              "index list), heads + PPO loss, one fused backward launch per layer (bwd_layer_kernel: weight gradient + the gradient handed down from one LDS-DMA'd "
-                              "tile), slab sums; the optimizer launch is outside the bracket: bf16 operands and activations, f32 accumulation", "bound": "mfma",
+                              "index list; heads, masked categorical, PPO loss and the head layers' backward in its epilogue on the tile still in LDS), one fused backward launch per "
+                              "hidden layer and for layer 0 (bwd_layer_kernel: weight gradient + the gradient handed down from one LDS-DMA'd tile), slab sums; the optimizer launch is "
+                              "outside the bracket: bf16 operands and activations, f32 accumulation", "bound": "mfma",
                     "achieved": fl / (fb_ms * 1e-3) / 1e12 if fb_ms else None, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / (fb_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS if fb_ms else None,
                     # HBM bytes of one minibatch step: the committed --pmc measurement of this workload (tools/collect_profiles.sh, tools/c4_traffic.py)
@@ -809,7 +811,7 @@ def main():
                     # yardstick only: 157.3 TFLOP/s is the peak of the fp32 matrix instruction, which this kernel does not issue
                     "fp32_mfma_peak": F32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": fl / (fb_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if fb_ms else None,
                     "traffic": (fb_tr or {}).get("bytes"), "traffic_detail": fb_tr,
-                    "rocprof": rocprof_kernel_us("fwd_bwd_mfma") if args.workload == "cartpole" else None}
+                    "rocprof": rocprof_kernel_us(UPDATE_KERNEL_C1) if args.workload == "cartpole" else None}
         roof.update({"flops_per_launch": fl, "avg_launch_ms": fb_ms, "launches": prof["fwd_bwd_launches"],
                      "sampling": "HIP events on the context's stream around 1 launch in %s (--profile %d)" % ({1: "1", 2: "8", 4: "41"}.get(args.profile, "?"), args.profile)})
         phases = {"rollout": "rollout", "gae": "gae", "grad_reduce": "reduce", "clip_adamw": "optimizer"}

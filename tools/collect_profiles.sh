@@ -7,9 +7,12 @@ TAG=${1:-r01}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ROOT=$(pwd)
 export TMPDIR=/tmp
-OUT=$ROOT/gpurun_out/$TAG
-mkdir -p "$OUT" "$ROOT/profiles"
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+# raw rocprofv3 output goes to /tmp on the box (a set's traces pass the 64 MiB gpurun merges back, and then NOTHING comes back); the summaries and logs to gpurun_out/<tag>/
+OUT=/tmp/collect_$TAG
+KEEP=$ROOT/gpurun_out/$TAG
+rm -rf "$OUT"
+mkdir -p "$OUT" "$KEEP" "$ROOT/profiles"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-workloads --repeats 0"   # the headline workload alone under the tracer / the counters
 
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o run -- $BENCH > "$OUT/trace.log" 2>&1
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -n 1)" "$ROOT/profiles/${TAG}_kernel_stats.csv"
@@ -63,5 +66,6 @@ python3 $ROOT/bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.
 tail -n 1 "$OUT/bench.json" > "$ROOT/profiles/${TAG}_bench.json"
 python3 $ROOT/bench.py --workload config4 --no-cpu-baseline > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err" && tail -n 1 "$OUT/bench_c4.json" > "$ROOT/profiles/${TAG}_bench_default_config4.json" || echo "config4 bench FAILED"
 python3 $ROOT/bench.py --workload mountaincar --no-cpu-baseline > "$OUT/bench_mc.json" 2> "$OUT/bench_mc.err" && tail -n 1 "$OUT/bench_mc.json" > "$ROOT/profiles/${TAG}_bench_default_mountaincar.json" || echo "mountaincar bench FAILED"
-cp "$ROOT"/profiles/${TAG}_* "$OUT/"
+cp "$ROOT"/profiles/${TAG}_* "$KEEP/"
+cp "$OUT"/*.log "$OUT"/*.txt "$OUT"/*.err "$OUT"/*.json "$KEEP/" 2>/dev/null || true
 echo done
