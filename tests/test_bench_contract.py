@@ -51,3 +51,39 @@ def test_committed_bench_line_keeps_the_contract(path):
 
 def test_there_are_committed_lines():
     assert len(LINES) >= 3
+
+
+R06 = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r06_v*_bench.json")) if "config4" not in os.path.basename(p))
+
+
+@pytest.mark.parametrize("path", R06, ids=[os.path.basename(p) for p in R06])
+def test_round6_default_line_carries_the_other_workloads_and_the_repeats(path):
+    """The driver's default command (`python bench.py --gpus 1 --steps K --warmup W`) times configs[1] as `value` -- and, in the same run, repeats that K-step region
+    (`value_runs`: median / min / max) and times BASELINE configs[3] and one GPU's share of configs[4] live for >= 0.5 s each (`other_workloads`), so that those numbers
+    are driver-observed and not only builder-run lines under profiles/."""
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    assert d["config"]["workload"].endswith("(BASELINE.json configs[1])") and d["n_gpus"] == 1
+    vr = d["value_runs"]
+    assert vr["runs"] == len(vr["values"]) >= 6 and vr["values"][0] == d["value"] and vr["min"] <= vr["median"] <= vr["max"] and vr["unit"] == "env-steps/s"
+    assert vr["min"] == min(vr["values"]) and vr["max"] == max(vr["values"])
+    ow = d["other_workloads"]
+    assert set(ow) == {"mountaincar", "config4"}
+    for name, idx in (("mountaincar", 3), ("config4", 4)):
+        w = ow[name]
+        assert "failed" not in w, w
+        assert "BASELINE.json configs[%d]" % idx in w["config"]["workload"] and "model" not in w["config"]
+        assert w["unit"] == "env-steps/s" and w["timed_seconds"] >= 0.45 and w["steps"] >= 10
+        env_steps = w["steps"] * w["config"]["num_envs_per_gpu"] * w["config"]["num_steps"]
+        assert abs(w["value"] - env_steps / w["timed_seconds"]) <= 1e-6 * w["value"]
+        assert abs(w["ms_per_step"] - 1e3 * w["timed_seconds"] / w["steps"]) <= 1e-9 * w["ms_per_step"] + 1e-9
+        r = w["roofline"]
+        assert r["bound"] == "mfma" and r["peak"] == 2500.0 and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    assert ow["config4"]["dtype"] == "bf16" and ow["mountaincar"]["config"]["num_envs_per_gpu"] == 8192 and ow["config4"]["config"]["num_envs_per_gpu"] == 2048
+    # the profile set the line quotes is tied to the sources it ran on, and names the commit it was collected at
+    p = d["profiles"]
+    assert p["tied"] is True and p["git_head_at_collection"] and d["roofline"]["traffic"] > 0 and d["roofline"]["rocprof"]["avg_us"] > 0
+    assert abs(d["roofline"]["rocprof"]["avg_us"] - 1e3 * d["roofline"]["avg_launch_ms"]) <= 0.15 * d["roofline"]["rocprof"]["avg_us"]   # trace and HIP events agree
+
+
+def test_there_is_a_round6_line():
+    assert len(R06) >= 1
