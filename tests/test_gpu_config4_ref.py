@@ -181,7 +181,8 @@ def test_f32_path_at_config4_share_against_the_compiled_reference(P, share_batch
 
 def test_bf16_path_at_config4_share_distance_from_the_compiled_reference(P, share_batch):
     """The arithmetic BASELINE configs[4] names (bf16 operands and activations, f32 accumulation and master weights) on the same batch: how far it sits from
-    the reference's fp32 numbers over the 40 steps.  A measured distance with bars at ~3x of it; the parity claim is the f32 test above."""
+    the reference's fp32 numbers over the 40 steps.  A measured distance with regression FENCES at ~3x of it -- no parity claim; the parity claim is the f32 test above, and past the
+    first ~29 steps that one is itself relaxed from 1e-5 to 4x the reference's own one-ulp-twin distance."""
     d, m = _drive(P, "config4_share_2048x128", share_batch, 1)
     _report("config4_share_2048x128", 1, d)
     assert all(np.isfinite(x) for x in d.values() if not isinstance(x, dict))

@@ -33,7 +33,8 @@ def P():
 # reference's own 2 x 64 shape AND at configs[4]'s shape (obs 376, 4 x 256, heads [3, 3, 3, 2]: tests/test_oracle_vs_golden.py against tests/golden/config4_*.pgld), and the
 # build's f32 generic path is held to the same fixtures directly (tests/test_gpu_config4_ref.py; the tests at the end of this file for 2 x 64).  bf16 arithmetic has no
 # counterpart in the reference: its bars are distances (measured, x 3), not parity.
-# bf16 bars = ~3x the measured values above (log-prob 6e-4 -> 2e-3, value 2e-3 -> 4e-3 (2x), losses 2e-6 -> 6e-6, gradient 2e-4 -> 6e-4 of max).
+# bf16 bars = REGRESSION FENCES at ~3x the measured values above (log-prob 6e-4 -> 2e-3, value 2e-3 -> 4e-3 (2x), losses 2e-6 -> 6e-6, gradient 2e-4 -> 6e-4 of max): they
+# say "the bf16 kernels have not moved away from the bf16 oracle", not "the bf16 kernels are within a derived bound of the reference" (DESIGN.md section 0, row x1).
 TOL = {0: dict(fwd=5e-6, fwd_v=5e-6, agree=0.995, loss=1e-5, grad=1e-4, same=1e-6), 1: dict(fwd=2e-3, fwd_v=4e-3, agree=0.98, loss=6e-6, grad=6e-4, same=1e-6)}
 
 
@@ -160,7 +161,8 @@ def test_config4_shape_obs376_4x256_heads_3332(P):
 def test_config4_shape_in_bf16(P):
     """BASELINE configs[4] in the arithmetic it names -- "4x256 MLP bf16 with MFMA GEMMs" (compute_dtype = PPO_DTYPE_BF16: bf16 operands and
     stored activations, f32 accumulation, f32 master weights) -- end to end against the oracle's bf16 mode (oracle/ppo_oracle.h: ORC_DTYPE_BF16),
-    which rounds at the same points: rollout log-probs / values, the sampler, one minibatch step's losses and gradient, the optimizer step."""
+    which rounds at the same points: rollout log-probs / values, the sampler, one minibatch step's losses and gradient, the optimizer step.  The bars are regression fences
+    (TOL above), not parity with the reference: the f32 path carries that (tests/test_gpu_config4_ref.py)."""
     _check_shape(P, obs_dim=376, hidden=256, n_hidden=4, heads=(3, 3, 3, 2), N=256, T=32, nmb=4, masked=True, seed=3, max_steps=25, dtype=1)
 
 
