@@ -89,6 +89,16 @@ __device__ __forceinline__ void bw_barrier() {
 // stores are never waited for).  M0 = the destination's LDS byte address, saved and restored around the instruction (the compiler reserves M0).
 // The destination is the LDS BYTE ADDRESS as an integer (bw_lds_addr of the array's start + offsets): handed over as a generic pointer, every instruction paid a
 // generic -> local conversion (null check, aperture base) and two v_readfirstlane on top of its address arithmetic.
+// How a tile reaches LDS.  BW_FETCH_REGS = 0 (shipped): the LDS-DMA ring (global_load_lds_dwordx4 by inline asm, counted waits).  1 (exploration, round 6): plain 16-byte
+// global loads into registers two tiles ahead, parked in LDS by ds_write_b128 one tile ahead -- every load the compiler's own, two register sets of VM_TILE quads
+// alternating (named, the tile loop unrolled by two: indexed by t & 1 hipcc keeps them in scratch memory: 185 us per launch).  Why it was tried: the fetch, not HBM and
+// not the products, is what the launch waits for -- a timing-only build without any fetch runs the hidden layers' launch in 35 us instead of 53 and layer 0's in 30
+// instead of 54, with every source cache-resident it is still 53, and the in-kernel stamps show 800 - 2000 cycles per tile in front of the first product: the CU takes a
+// tile's 40 KB at ~26 B/clk and the issuing waves are blocked meanwhile.  Plain loads are no faster through that path (62.8 / 55.5 us against 51.8 / 53.0 for the DMA in
+// one call) and cost 40 registers: not taken.  NOTES "bwd_layer_kernel: where a tile's cycles go".
+#ifndef BW_FETCH_REGS
+#define BW_FETCH_REGS 0
+#endif
 #ifndef BW_NT   /* exploration builds: bit 0 = non-temporal DMA of the h tile (read by ONE workgroup), bit 1 = of the dZ tile (read by the CB workgroups of a row range), bit 2 = non-temporal stores of dZ_{l-1} */
 #define BW_NT 0
 #endif
@@ -186,6 +196,12 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     const int xcd = bid & 7, slot = bid >> 3;
     const int z = (slot / a.CB) * 8 + xcd, c = slot % a.CB;   // c counts blocks of 64 KCB columns
     if (z >= a.S) return;
+#ifdef BW_INTERLEAVE   /* exploration: range z takes tiles z, z + S, z + 2 S, ...: at any moment the workgroups of a launch read ONE contiguous band of rows */
+    const int64_t all_tiles = (a.rows + BW_ROWS - 1) / BW_ROWS;
+    int n_tiles = z < all_tiles ? (int)((all_tiles - z + a.S - 1) / a.S) : 0;
+    if (n_tiles > a.tiles_per_range) n_tiles = a.tiles_per_range;
+    auto tile_row = [&](int t) -> int64_t { return ((int64_t)t * a.S + z) * BW_ROWS; };
+#else
     const int64_t row_begin = (int64_t)z * a.tiles_per_range * BW_ROWS;
     int n_tiles = a.tiles_per_range;
     {
@@ -193,6 +209,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         const int64_t have = left <= 0 ? 0 : (left + BW_ROWS - 1) / BW_ROWS;
         if (have < n_tiles) n_tiles = (int)have;
     }
+    auto tile_row = [&](int t) -> int64_t { return row_begin + (int64_t)t * BW_ROWS; };
+#endif
     const int li = lane & 31, kg = lane >> 5;
     const bool p1_wave = P1 && wave < 4;
     const int cb1 = wave & 1, rb1 = (wave >> 1) & 1;   // P1: the wave's 32 columns (of the block's 64) and 32 rows (of the tile's 64)
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     // wave of a layer-0 instantiation issues the instruction, gathered or not (from the zeros when there is no index list): the counted waits rely on it.
     // Tiles 0 .. 2: plain loads in the prologue, where nothing is in flight yet.
     auto index_row = [&](int t) -> int64_t {
-        int64_t r = row_begin + (int64_t)t * BW_ROWS + ((64 * wave + lane) >> 3);
+        int64_t r = tile_row(t) + ((64 * wave + lane) >> 3);
         return r >= a.rows ? a.rows - 1 : r;
     };
     const bool gathered = !P1 && a.idx != nullptr;
@@ -267,23 +285,32 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     auto index_dma = [&](int t) {   // layer 0 only
         bw_glds4(gathered ? a.idx + index_row(t) : reinterpret_cast<const int32_t*>(a.zeros), idx0 + (uint32_t)(t & 1) * (BW_WAVES * 256u));
     };
-    auto issue = [&](int t, int b, int hsrc) {   // tile t into ring buffer b = t % BW_RING
-        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
-        const uint32_t dD = lds0 + (uint32_t)(b * DSZ) * 2u;                          // byte addresses in LDS (wave-uniform)
-        const uint32_t dH = lds0 + (uint32_t)(BW_RING * DSZ + b * HSZ) * 2u;
+    // One of the VM_TILE = DPW + KCB LDS-DMA instructions a wave issues for tile t (into ring buffer b = t % BW_RING): p < DPW = a KiB of the dZ tile, else an h image's.
+    // They are issued ONE AT A TIME between the products of the tile loop (round 6): eight waves issuing their five at the top of the iteration queued on the CU's one
+    // address path -- 40 KB at 64 B/clk -- and every wave sat 800 - 930 cycles of a 3 400-cycle iteration in front of its first product (in-kernel stamps, NOTES).
+    auto issue_piece = [&](int t, int b, int hsrc, int p) {
+#ifdef BW_ABL_NODMA   /* timing-only: no tile ever arrives */
+        return;
+#endif
+        const int64_t r0 = tile_row(t);
         const bool whole = r0 + BW_ROWS <= a.rows;   // wave-uniform: every row of the tile exists (all tiles but the minibatch's last)
-        const uint16_t* const dbase = a.d + r0 * a.ldd;   // wave-uniform bases: SGPR pair + the lane's 32-bit offset
-        const uint16_t* const hbase = a.h + r0 * a.ldh;
-#pragma unroll
-        for (int i = 0; i < DPW; i++) {
-            const int p = wave + BW_WAVES * i;
-            const bool have = p < CPR;
-            const uint32_t dst = have ? dD + 1024u * p : spare0 + 1024u * wave;
-            if (whole && have) bw_glds16_s<(BW_NT & 2) != 0>(dbase, d_off[i], dst);
-            else bw_glds16<(BW_NT & 2) != 0>(have && r0 + d_row[i] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i]) : a.zeros, dst);
-        }
-#pragma unroll
-        for (int k = 0; k < KCB; k++) {   // image k: columns 64 (KCB c + k) ..
+#ifndef BW_ABL
+#define BW_ABL 0   /* timing-only ablations (wrong results): 1 = every tile's DMA reads the first rows (cache-resident), 2 = every result tile is stored over the first rows */
+#endif
+        const int64_t r0s = (BW_ABL & 1) ? (int64_t)(t & 1) * BW_ROWS : r0;
+        if (p < DPW) {
+            const int i = p;
+            const uint32_t dD = lds0 + (uint32_t)(b * DSZ) * 2u;                          // byte addresses in LDS (wave-uniform)
+            const uint16_t* const dbase = a.d + r0s * a.ldd;   // wave-uniform base: SGPR pair + the lane's 32-bit offset
+            const int pc = wave + BW_WAVES * i;
+            const bool have = pc < CPR;
+            const uint32_t dst = have ? dD + 1024u * pc : spare0 + 1024u * wave;
+            if (whole && have) bw_glds16_s<(BW_NT & 2) != 0>(dbase, d_off[i < DPW ? i : 0], dst);
+            else bw_glds16<(BW_NT & 2) != 0>(have && r0 + d_row[i < DPW ? i : 0] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i < DPW ? i : 0]) : a.zeros, dst);
+        } else {
+            const int k = p - DPW < KCB ? p - DPW : 0;   // image k: columns 64 (KCB c + k) ..
+            const uint32_t dH = lds0 + (uint32_t)(BW_RING * DSZ + b * HSZ) * 2u;
+            const uint16_t* const hbase = a.h + r0s * a.ldh;
             const uint32_t dst = dH + (uint32_t)(k * BW_ROWS * BW_KC) * 2u + 1024u * wave;
             if (whole && !gathered) bw_glds16_s<(BW_NT & 1) != 0>(hbase, h_off[k], dst);
             else {
@@ -293,9 +320,41 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             }
         }
     };
+    auto issue = [&](int t, int b, int hsrc) {   // all of tile t's pieces (the prologue)
+#pragma unroll
+        for (int p = 0; p < DPW + KCB; p++) issue_piece(t, b, hsrc, p);
+    };
+    // BW_FETCH_REGS: the same pieces as plain loads (same source addresses: the swizzle sits on the source) and their ds_write to the same lane-linear places
+    auto fetch_piece = [&](int t, int hsrc, int p) -> u32x4 {
+        const int64_t r0 = tile_row(t);
+        const int64_t r0s = (BW_ABL & 1) ? (int64_t)(t & 1) * BW_ROWS : r0;
+        const uint16_t* src;
+        if (p < DPW) {
+            const int i = p < DPW ? p : 0;
+            const bool have = wave + BW_WAVES * i < CPR && r0 + d_row[i] < a.rows;
+            src = have ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.d + r0s * a.ldd) + d_off[i]) : a.zeros;
+        } else {
+            const int k = p - DPW < KCB ? p - DPW : 0;
+            const uint16_t* rowp = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k] - (uint32_t)(h_row * (int)a.ldh) * 2u))
+                                            : reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + r0s * a.ldh) + h_off[k]);
+            src = r0 + h_row < a.rows ? rowp : a.zeros;
+        }
+        return *reinterpret_cast<const u32x4*>(src);   // (a select between addresses, not a branch around the load)
+    };
+    auto park_piece = [&](int b, int p, const u32x4 v) {
+        uint16_t* dst;
+        if (p < DPW) {
+            const int pc = wave + BW_WAVES * (p < DPW ? p : 0);
+            if (pc >= CPR) return;   // (wave-uniform) a narrow dZ tile has no such piece
+            dst = sD + b * DSZ + 512 * pc;
+        } else {
+            dst = sH + b * HSZ + (p - DPW) * BW_ROWS * BW_KC + 512 * wave;
+        }
+        *reinterpret_cast<u32x4*>(dst + 8 * lane) = v;
+    };
     // the result tile of tile t leaves in 16-byte row pieces (rows past the minibatch are zeros: they keep the destination's padding zero)
     auto store_out = [&](int t) {
-        const int64_t r0 = row_begin + (int64_t)t * BW_ROWS;
+        const int64_t r0 = (BW_ABL & 2) ? (int64_t)(t & 1) * BW_ROWS : tile_row(t);
         const int row = tid >> 3, ch = tid & 7;
         const u32x4 piece = *reinterpret_cast<const u32x4*>(sO + (t & 1) * BW_ROWS * BW_KC + row * BW_KC + ((ch ^ swz_h(row)) << 3));
         if (BW_NT & 4) __builtin_nontemporal_store(piece, reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch));
@@ -313,9 +372,18 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     {
         int h0 = 0, h1 = 0;
         if (gathered && n_tiles > 0) { h0 = a.idx[index_row(0)]; h1 = a.idx[index_row(1)]; hs_next = a.idx[index_row(2)]; }
-        if (n_tiles > 0) issue(0, 0, h0);
-        if (n_tiles > 1) issue(1, 1, h1);
+        if (!BW_FETCH_REGS) {
+            if (n_tiles > 0) issue(0, 0, h0);
+            if (n_tiles > 1) issue(1, 1, h1);
+        } else {
+            // tiles 0 and 1 go through the registers into their buffers here; tile 2 is requested at the top of iteration 0 like every tile t + 2
+#pragma unroll
+            for (int p = 0; p < DPW + KCB; p++) { if (n_tiles > 0) park_piece(0, p, fetch_piece(0, h0, p)); }
+#pragma unroll
+            for (int p = 0; p < DPW + KCB; p++) { if (n_tiles > 1) park_piece(1, p, fetch_piece(1, h1, p)); }
+        }
     }
+    u32x4 rt0[BW_FETCH_REGS ? DPW + KCB : 1], rt1[BW_FETCH_REGS ? DPW + KCB : 1];   // BW_FETCH_REGS: the pieces of tile k wait in set k & 1 from iteration k - 2 (requested) to the end of iteration k - 1 (parked)
     // lane-constant LDS offsets of everything the tile loop reads (elements; see frag_off)
     int p1_rd[KS1], ep_at[4];          // P1: the row's 16-byte B fragments of dZ; the epilogue's 8-byte places in the h / result images
     int a_lo[NBW], a_hi[NBW], h_lo[2 * KCB], h_hi[2 * KCB];   // P2: transposing reads of dZ (A) and h (B) at k step 0
@@ -330,31 +398,78 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #pragma unroll
         for (int h = 0; h < 2 * KCB; h++) { frag_off<BW_KC, false>(32 * (h & 1), lane, h_lo[h], h_hi[h]); h_lo[h] += (h >> 1) * BW_ROWS * BW_KC; h_hi[h] += (h >> 1) * BW_ROWS * BW_KC; }
     }
-    if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_TILE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
+    if (BW_FETCH_REGS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the parking writes of tiles 0 and 1 are in LDS)
+    else if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_TILE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
     bw_barrier();
+#ifdef BW_STAMP   /* diagnostic build: cycle sums of the tile loop's phases for one P1 and one P2 wave of workgroup 0, printed by the device */
+    unsigned long long st_sum[5] = { 0, 0, 0, 0, 0 }, st_t0 = 0, st_begin = __builtin_amdgcn_s_memtime();
+#define BW_ST(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_sum[i] += now_ - st_t0; st_t0 = now_; } while (0)
+#else
+#define BW_ST(i) do { } while (0)
+#endif
     int rb = 0;   // ring buffer of tile t (t % BW_RING, kept by rotation: no division in the loop)
-    for (int t = 0; t < n_tiles; t++) {
+    // The body of one iteration, with the two register sets of BW_FETCH_REGS named by the CALLER: indexed by t & 1 the sets were an array with a run-time index, which
+    // hipcc keeps in scratch memory (every piece: load, wait, scratch store ... scratch load, wait, ds_write: 185 us per launch).  The loop below runs the body twice
+    // per trip with the sets swapped.
+    constexpr int NRT = BW_FETCH_REGS ? DPW + KCB : 1;
+    auto body = [&](const int t, u32x4 (&rt_fetch)[NRT], u32x4 (&rt_park)[NRT]) {
+#ifdef BW_STAMP
+        st_t0 = __builtin_amdgcn_s_memtime();
+#endif
         const uint16_t* const tD = sD + rb * DSZ;
         const uint16_t* const tH = sH + rb * HSZ;
         const int rb2 = rb == 0 ? BW_RING - 1 : rb - 1;   // (t + 2) % 3
+        int hs_load = 0;   // BW_FETCH_REGS, gathered: the index-list entry of this lane's row in tile t + 3 (a plain load: used at the top of the next iteration)
         if (t + 2 < n_tiles) {                      // into the buffer every wave finished reading before the barrier that ended iteration t - 1
             if constexpr (!P1) {
-                // tile t + 2's entries landed under the wait that ended iteration t - 1 (tile 2's came with the prologue's loads)
-                if (t > 0) hs_next = gathered ? sIdx[((t + 2) & 1) * (BW_WAVES * 64) + 64 * wave + lane] : 0;
-                index_dma(t + 3);
+                if (BW_FETCH_REGS) {
+                    if (gathered) hs_load = a.idx[index_row(t + 3)];
+                } else {
+                    // tile t + 2's entries landed under the wait that ended iteration t - 1 (tile 2's came with the prologue's loads)
+                    if (t > 0) hs_next = gathered ? sIdx[((t + 2) & 1) * (BW_WAVES * 64) + 64 * wave + lane] : 0;
+                    index_dma(t + 3);
+                }
             }
-            issue(t + 2, rb2, hs_next);
+            if (BW_FETCH_REGS) {
+#pragma unroll
+                for (int p = 0; p < VM_TILE; p++) rt_fetch[p] = fetch_piece(t + 2, hs_next, p);
+            }
         }
+        const bool pf = t + 2 < n_tiles;   // (uniform) this iteration issues tile t + 2's pieces, between its products: `pieces(lo, hi)` below
+#ifndef BW_DMA_SPREAD
+#define BW_DMA_SPREAD 0   /* 1: a tile's DMA instructions one at a time between the products (measured: the stall moves into the products, layer 0 gets slower); 0: all at the top */
+#endif
+        if (!BW_FETCH_REGS && !BW_DMA_SPREAD && pf) issue(t + 2, rb2, hs_next);
+        auto pieces = [&](int lo, int hi) {
+            if (!BW_FETCH_REGS && BW_DMA_SPREAD && pf) {
+#pragma unroll
+                for (int p = 0; p < VM_TILE; p++) if (p >= lo && p < hi) issue_piece(t + 2, rb2, hs_next, p);
+            }
+        };
+        BW_ST(0);   // (index entries of tile t + 3 requested)
         if constexpr (P1) { if (t > 0) store_out(t - 1); }
+        BW_ST(1);   // result tile of t - 1 stored
         if (p1_wave) {
             // ---- P1: D[kcol][row] = sum_n W[n][kcol] dZ[row][n]; lane = row, registers = columns ----
+            // The rows' fragments come from LDS a batch of k steps AHEAD of their products (read one by one in front of its MFMA, as the compiler laid the plain loop
+            // out with a single register quad, every product waited out an LDS round trip: 2 100 cycles for 16 products; stamps, NOTES)
+            constexpr int BT = KS1 >= 4 ? 4 : KS1, NBT = KS1 / BT;
             f32x16 acc1;
 #pragma unroll
             for (int r = 0; r < 16; r++) acc1[r] = 0.0f;
+            u32x4 bq[2][BT];
 #pragma unroll
-            for (int ks = 0; ks < KS1; ks++) {
-                const u32x4 bfr = *reinterpret_cast<const u32x4*>(tD + p1_rd[ks]);
-                acc1 = bw_mfma(wfrag(ks), bfr, acc1);
+            for (int j = 0; j < BT; j++) bq[0][j] = *reinterpret_cast<const u32x4*>(tD + p1_rd[j]);
+#pragma unroll
+            for (int b = 0; b < NBT; b++) {
+                if (b + 1 < NBT) {
+#pragma unroll
+                    for (int j = 0; j < BT; j++) bq[(b + 1) & 1][j] = *reinterpret_cast<const u32x4*>(tD + p1_rd[(b + 1) * BT + j]);
+                }
+                asm volatile("" ::: "memory");   // the next batch's reads are issued in front of this batch's products
+#pragma unroll
+                for (int j = 0; j < BT; j++) acc1 = bw_mfma(wfrag(b * BT + j), bq[b & 1][j], acc1);
+                pieces(b * VM_TILE / NBT, (b + 1) * VM_TILE / NBT);
             }
             // epilogue: register r <-> column 32 cb1 + (r & 3) + 8 (r >> 2) + 4 kg of the block; tanh' from the staged h, result to its own image
             uint16_t* const tO = sO + (t & 1) * BW_ROWS * BW_KC;
@@ -369,8 +484,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             }
         } else if (pj >= 0 && pj * NBW < NB) {
             // ---- P2: dW[n][kcol] += dZ^T h over the tile's 64 rows (4 k steps): the wave's n blocks against every 32-column half of the workgroup's columns ----
+            // (the fragments of k step ks + 1 requested before the products of k step ks -- the same double buffering as P1's -- was measured and is not taken:
+            // the hidden layers' launch did not move, layer 0's got 4 us slower)
+            constexpr int KS2 = BW_ROWS / 16;
 #pragma unroll
-            for (int ks = 0; ks < BW_ROWS / 16; ks++) {
+            for (int ks = 0; ks < KS2; ks++) {
                 u32x4 bf[2 * KCB];
 #pragma unroll
                 for (int h = 0; h < 2 * KCB; h++) bf[h] = frag_at(tH + 16 * ks * BW_KC, h_lo[h], h_hi[h]);
@@ -384,11 +502,26 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
                             st[2 * KCB * i + h] = __builtin_bit_cast(u32x16, bw_mfma(af, bf[h], __builtin_bit_cast(f32x16, st[2 * KCB * i + h])));
                     }
                 }
+                pieces(ks * VM_TILE / KS2, (ks + 1) * VM_TILE / KS2);
             }
+        } else {
+            pieces(0, VM_TILE);   // a wave without products (narrow layers) still issues its share of the DMA
         }
+        BW_ST(2);   // products (+ P1's epilogue) with tile t + 2's DMA between them
         // this wave's pieces of tile t + 1 have landed: everything it issued up to them is done, i.e. all but what this iteration issued (the pieces of
         // tile t + 2 and the store of tile t - 1) -- counted, so that tile t + 2 stays in flight across the barrier (a plain __syncthreads() would drain
         // it: the compiler's fence waits for vmcnt(0)).  The last iterations issue less: they wait for everything.
+        if (BW_FETCH_REGS) {
+            // tile t + 1 (requested a whole iteration ago, at the top of iteration t - 1) goes from its registers into ring buffer (t + 1) % 3, which nobody has read since
+            // iteration t - 2; the compiler's own wait in front of these writes counts the younger loads of tile t + 2 and lets them fly on
+            if (t >= 1 && t + 1 < n_tiles) {
+                const int rb1n = rb == BW_RING - 1 ? 0 : rb + 1;
+#pragma unroll
+                for (int p = 0; p < VM_TILE; p++) park_piece(rb1n, p, rt_park[p]);
+            }
+            hs_next = hs_load;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else
 #ifdef BW_FULL_WAIT
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (false) {
@@ -401,8 +534,19 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         rb = rb == BW_RING - 1 ? 0 : rb + 1;
+        BW_ST(3);   // counted wait for tile t + 1
         bw_barrier();
+        BW_ST(4);   // barrier
+    };
+    for (int t = 0; t < n_tiles; t += 2) {   // even tiles are requested into rt0 and parked from rt1, odd tiles the other way round
+        body(t, rt0, rt1);
+        if (t + 1 < n_tiles) body(t + 1, rt1, rt0);
     }
+#ifdef BW_STAMP
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && NB == 8)
+        printf("BWST P1=%d wave %d tiles %d total %llu | issue %llu store %llu compute %llu wait %llu barrier %llu\n", (int)P1, wave, n_tiles,
+               (unsigned long long)(__builtin_amdgcn_s_memtime() - st_begin), st_sum[0], st_sum[1], st_sum[2], st_sum[3], st_sum[4]);
+#endif
     if constexpr (P1) { if (n_tiles > 0) store_out(n_tiles - 1); }
 
     // ---- the workgroup's slice of the weight gradient: register r of lane (i, kg) <-> n = 32 nb + (r & 3) + 8 (r >> 2) + 4 kg, column = block's 32 half + i ----
