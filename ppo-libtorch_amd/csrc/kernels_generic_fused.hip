@@ -74,7 +74,8 @@ __device__ __forceinline__ void load_btail(BFrags& b, const FusedNet& f, int l, 
     for (int j = 0; j < FU_KTAIL; j++) b.q[j] = *reinterpret_cast<const u32x4*>(wblk + (int64_t)(k0 + j) * 512);
 }
 
-template <int FM, int NW = FU_WAVES>
+// XB: k steps whose row fragments are read from LDS together, in front of their products (4; 2 where registers are short: the f32-input kernel holds 48 of them for the next tile)
+template <int FM, int NW = FU_WAVES, int XB = 4>
 __device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off0, uint16_t* tile0, uint16_t* tile1, float* s_out, uint16_t* const* keep, int64_t ld_keep,
                                              int64_t row0, int n_rows, BFrags& pre, unsigned int* dbg = nullptr) {
     // `pre` holds, on entry, the fragments of (layer 0, column block = wave, k steps 0 ..) -- requested by the caller, e.g. while the input tile
@@ -123,17 +124,25 @@ __device__ __forceinline__ void fused_layers(const FusedNet& f, int64_t next_off
                 const uint16_t* xr[FM];
 #pragma unroll
                 for (int i = 0; i < FM; i++) xr[i] = src + (32 * i + li) * f.ldA + 8 * kg;
-                auto batch = [&](int kx, int jq) {   // k steps kx .. kx + 3 of the tile against fragments q[jq .. jq + 3]
-                    u32x4 x[FM][4];
+                auto batch = [&](int kx0, int jq0) {   // k steps kx0 .. kx0 + 3 of the tile against fragments q[jq0 .. jq0 + 3], XB at a time
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int h = 0; h < 4 / XB; h++) {
+                        const int kx = kx0 + XB * h, jq = jq0 + XB * h;
+                        u32x4 x[FM][XB];
 #pragma unroll
-                        for (int i = 0; i < FM; i++) x[i][j] = *reinterpret_cast<const u32x4*>(xr[i] + 16 * (kx + j));
+                        for (int j = 0; j < XB; j++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                            for (int i = 0; i < FM; i++) x[i][j] = *reinterpret_cast<const u32x4*>(xr[i] + 16 * (kx + j));
+                        // ... and a scheduling barrier keeps them there: without it hipcc sinks every read to its product and reuses ONE register quad -- ds_read, s_waitcnt
+                        // lgkmcnt(0), v_mfma, 32 times per layer and tile, an LDS round trip in front of every product (found in the assembly in round 6; a memory
+                        // fence is not enough: the products have no memory semantics and climb up between the reads)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int i = 0; i < FM; i++)   // D[n][row]: weights are the A operand, the rows the B operand
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pre.q[jq + j]), __builtin_bit_cast(bf16x8, x[i][j]), acc[i], 0, 0, 0);
+                        for (int j = 0; j < XB; j++)
+#pragma unroll
+                            for (int i = 0; i < FM; i++)   // D[n][row]: weights are the A operand, the rows the B operand
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pre.q[jq + j]), __builtin_bit_cast(bf16x8, x[i][j]), acc[i], 0, 0, 0);
+                    }
                 };
                 FU_STAMP(32 + 4 * l);
                 batch(0, 0); batch(4, 4);
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, NW == FU_WAVES ? 1 : 2) void generic_forwa
             FU_STAMP(2);
             __syncthreads();
             FU_STAMP(3);
-            fused_layers<FM, NW>(x.f, next_off0, tile0, tile1, s_out, x.keep, x.ld_keep, row0, n_rows, pre, dbg);
+            fused_layers<FM, NW, BF ? 4 : 1>(x.f, next_off0, tile0, tile1, s_out, x.keep, x.ld_keep, row0, n_rows, pre, dbg);
             const int N = L.out_dim[x.f.net][L.n_layers - 1];
             if constexpr (LOSS == 0) {
                 for (int e = tid; e < n_rows * N; e += FU_THREADS) x.out[(row0 + e / N) * N + e % N] = s_out[(e / N) * 32 + e % N];   // (s_out is written again four barriers from here)
