@@ -466,7 +466,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #pragma unroll
                     for (int j = 0; j < BT; j++) bq[(b + 1) & 1][j] = *reinterpret_cast<const u32x4*>(tD + p1_rd[(b + 1) * BT + j]);
                 }
-                asm volatile("" ::: "memory");   // the next batch's reads are issued in front of this batch's products
+                __builtin_amdgcn_sched_barrier(0);   // the next batch's reads are issued in front of this batch's products
 #pragma unroll
                 for (int j = 0; j < BT; j++) acc1 = bw_mfma(wfrag(b * BT + j), bq[b & 1][j], acc1);
                 pieces(b * VM_TILE / NBT, (b + 1) * VM_TILE / NBT);
@@ -489,17 +489,21 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
             constexpr int KS2 = BW_ROWS / 16;
 #pragma unroll
             for (int ks = 0; ks < KS2; ks++) {
-                u32x4 bf[2 * KCB];
+                u32x4 bf[2 * KCB], af[NBW];
 #pragma unroll
                 for (int h = 0; h < 2 * KCB; h++) bf[h] = frag_at(tH + 16 * ks * BW_KC, h_lo[h], h_hi[h]);
+#pragma unroll
+                for (int i = 0; i < NBW; i++) af[i] = frag_at(tD + 16 * ks * N, a_lo[i], a_hi[i]);   // (a block past NB reads inside the tile and is not used)
+#ifndef BW_P2_NOBARRIER
+                __builtin_amdgcn_sched_barrier(0);   // every transposing read of the k step in front of its products (hipcc sinks each read to its product otherwise)
+#endif
 #pragma unroll
                 for (int i = 0; i < NBW; i++) {
                     const int nb = pj * NBW + i;
                     if (nb < NB) {
-                        const u32x4 af = frag_at(tD + 16 * ks * N, a_lo[i], a_hi[i]);
 #pragma unroll
                         for (int h = 0; h < 2 * KCB; h++)
-                            st[2 * KCB * i + h] = __builtin_bit_cast(u32x16, bw_mfma(af, bf[h], __builtin_bit_cast(f32x16, st[2 * KCB * i + h])));
+                            st[2 * KCB * i + h] = __builtin_bit_cast(u32x16, bw_mfma(af[i], bf[h], __builtin_bit_cast(f32x16, st[2 * KCB * i + h])));
                     }
                 }
                 pieces(ks * VM_TILE / KS2, (ks + 1) * VM_TILE / KS2);
