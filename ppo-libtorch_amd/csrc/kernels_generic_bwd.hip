@@ -89,16 +89,12 @@ __device__ __forceinline__ void bw_barrier() {
 // stores are never waited for).  M0 = the destination's LDS byte address, saved and restored around the instruction (the compiler reserves M0).
 // The destination is the LDS BYTE ADDRESS as an integer (bw_lds_addr of the array's start + offsets): handed over as a generic pointer, every instruction paid a
 // generic -> local conversion (null check, aperture base) and two v_readfirstlane on top of its address arithmetic.
-// How a tile reaches LDS.  BW_FETCH_REGS = 0 (shipped): the LDS-DMA ring (global_load_lds_dwordx4 by inline asm, counted waits).  1 (exploration, round 6): plain 16-byte
-// global loads into registers two tiles ahead, parked in LDS by ds_write_b128 one tile ahead -- every load the compiler's own, two register sets of VM_TILE quads
-// alternating (named, the tile loop unrolled by two: indexed by t & 1 hipcc keeps them in scratch memory: 185 us per launch).  Why it was tried: the fetch, not HBM and
-// not the products, is what the launch waits for -- a timing-only build without any fetch runs the hidden layers' launch in 35 us instead of 53 and layer 0's in 30
-// instead of 54, with every source cache-resident it is still 53, and the in-kernel stamps show 800 - 2000 cycles per tile in front of the first product: the CU takes a
-// tile's 40 KB at ~26 B/clk and the issuing waves are blocked meanwhile.  Plain loads are no faster through that path (62.8 / 55.5 us against 51.8 / 53.0 for the DMA in
-// one call) and cost 40 registers: not taken.  NOTES "bwd_layer_kernel: where a tile's cycles go".
-#ifndef BW_FETCH_REGS
-#define BW_FETCH_REGS 0
-#endif
+// How a tile reaches LDS: the LDS-DMA ring (global_load_lds_dwordx4 by inline asm, counted waits).  The fetch, not HBM and not the products, is what the launch waits
+// for: a timing-only build without any fetch runs the hidden layers' launch in 35 us instead of 53 and layer 0's in 30 instead of 54; with every source cache-resident it
+// is still 53; a CU's address path moves a tile's 40 KB in ~900 cycles (tools/probes/l2_stream: 45 - 59 B/clk per CU by LDS-DMA, ~30 by plain loads, whatever the number
+// of CUs) and the waves that issue the instructions are blocked meanwhile (in-kernel stamps: 800 - 2000 cycles per tile).  Plain loads into registers + ds_write (two
+// register sets, the tile loop unrolled by two) were built: 62.8 / 55.5 us against 51.8 / 53.0; so was issuing the pieces one at a time between the products
+// (BW_DMA_SPREAD: the stall moves into the products) and leaving the fetch to the P2 waves alone (BW_ALL_MOVERS = 0: below).
 #ifndef BW_NT   /* exploration builds: bit 0 = non-temporal DMA of the h tile (read by ONE workgroup), bit 1 = of the dZ tile (read by the CB workgroups of a row range), bit 2 = non-temporal stores of dZ_{l-1} */
 #define BW_NT 0
 #endif
@@ -183,7 +179,15 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     constexpr int DSZ = BW_ROWS * (N < 64 ? 64 : N);      // elements of one dZ buffer (>= the weight block [N][64])
     constexpr int P2W = P1 ? 4 : 8;            // waves that run P2
     constexpr int NBW = (NB + P2W - 1) / P2W;  // n blocks of a P2 wave (each against both 32-column halves of the block)
-    constexpr int DPW = (CPR + BW_WAVES - 1) / BW_WAVES;   // 1-KiB DMA pieces of the dZ tile per wave (the tile has CPR of them)
+    // Movers: the waves that issue a tile's DMA.  Every wave fetches its eighth of the tile (BW_ALL_MOVERS = 1, shipped).  0: beside P1 only the four P2 waves do -- they
+    // have the slack (the P1 waves carry the epilogue and are the longer path of an iteration), and a wave is blocked while the CU's address path moves what it issued
+    // (~900 cycles for the tile's 40 KB: stamps, NOTES) -- measured in one call: 53.5 against 52.6 us for the hidden layers' launch: the blocked time only moves.
+#ifndef BW_ALL_MOVERS
+#define BW_ALL_MOVERS 1
+#endif
+    constexpr int MW = (P1 && !BW_ALL_MOVERS) ? 4 : BW_WAVES;      // movers
+    constexpr int DPW = (CPR + MW - 1) / MW;   // 1-KiB DMA pieces of the dZ tile per mover (the tile has CPR of them)
+    constexpr int HPW = BW_WAVES / MW;         // 1-KiB pieces of an h image per mover (an image has eight)
     static_assert(NB == 1 || NB == 4 || NB == 8, "dZ widths of 32 (a head), 128 and 256");
     extern __shared__ __attribute__((aligned(16))) uint16_t bw_lds[];
     uint16_t* const sD = bw_lds;                          // [3][64][N]  (buffer 2 first holds the weight block [N][64], once)
@@ -215,6 +219,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     const bool p1_wave = P1 && wave < 4;
     const int cb1 = wave & 1, rb1 = (wave >> 1) & 1;   // P1: the wave's 32 columns (of the block's 64) and 32 rows (of the tile's 64)
     const int pj = P1 ? wave - 4 : wave;               // P2: the wave's index among the P2 waves (< 0: not one)
+    const bool mover = MW == BW_WAVES || pj >= 0;      // (wave-uniform) this wave issues DMA
+    const int mv = MW == BW_WAVES ? wave : (pj >= 0 ? pj : 0);   // its index among the movers
 
     // What a wave keeps for the whole launch lives in ONE register block `st`: a P1 wave's weight fragments (4 registers per k step) or a P2 wave's
     // accumulators (16 per n block and column half).  The two kinds of waves never need both, but two arrays would both be live through the tile loop for the
@@ -267,19 +273,20 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     const bool gathered = !P1 && a.idx != nullptr;
     // this lane's share of a tile's DMA, fixed for the launch: piece p = wave + 8 i of the dZ tile (lane j of piece p fetches the chunk whose swizzled place is 64 p + j)
     // and one piece of each h image -- row within the tile, and the byte offset from the tile's first row
-    int d_row[DPW], h_row;
-    uint32_t d_off[DPW], h_off[KCB];
+    int d_row[DPW], h_row[HPW];
+    uint32_t d_off[DPW], h_off[KCB][HPW];
 #pragma unroll
     for (int i = 0; i < DPW; i++) {
-        const int q = 64 * (wave + BW_WAVES * i) + lane;
+        const int q = 64 * (mv + MW * i) + lane;
         d_row[i] = q / CPR;
         d_off[i] = (uint32_t)(d_row[i] * (int)a.ldd + 8 * ((q % CPR) ^ swz_d<CPR>(d_row[i]))) * 2u;
     }
-    {
-        const int q = 64 * wave + lane;
-        h_row = q >> 3;
 #pragma unroll
-        for (int k = 0; k < KCB; k++) h_off[k] = (uint32_t)(h_row * (int)a.ldh + BW_KC * (KCB * c + k) + 8 * ((q & 7) ^ swz_h(h_row))) * 2u;
+    for (int j = 0; j < HPW; j++) {
+        const int q = 64 * (mv + MW * j) + lane;
+        h_row[j] = q >> 3;
+#pragma unroll
+        for (int k = 0; k < KCB; k++) h_off[k][j] = (uint32_t)(h_row[j] * (int)a.ldh + BW_KC * (KCB * c + k) + 8 * ((q & 7) ^ swz_h(h_row[j]))) * 2u;
     }
     const uint32_t lds0 = bw_lds_addr(bw_lds), spare0 = bw_lds_addr(sRed + 2 * BW_KC), idx0 = bw_lds_addr(sIdx) + 256u * wave;
     auto index_dma = [&](int t) {   // layer 0 only
@@ -299,58 +306,32 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #endif
         const int64_t r0s = (BW_ABL & 1) ? (int64_t)(t & 1) * BW_ROWS : r0;
         if (p < DPW) {
-            const int i = p;
+            const int i = p < DPW ? p : 0;
             const uint32_t dD = lds0 + (uint32_t)(b * DSZ) * 2u;                          // byte addresses in LDS (wave-uniform)
             const uint16_t* const dbase = a.d + r0s * a.ldd;   // wave-uniform base: SGPR pair + the lane's 32-bit offset
-            const int pc = wave + BW_WAVES * i;
+            const int pc = mv + MW * i;
             const bool have = pc < CPR;
             const uint32_t dst = have ? dD + 1024u * pc : spare0 + 1024u * wave;
-            if (whole && have) bw_glds16_s<(BW_NT & 2) != 0>(dbase, d_off[i < DPW ? i : 0], dst);
-            else bw_glds16<(BW_NT & 2) != 0>(have && r0 + d_row[i < DPW ? i : 0] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i < DPW ? i : 0]) : a.zeros, dst);
+            if (whole && have) bw_glds16_s<(BW_NT & 2) != 0>(dbase, d_off[i], dst);
+            else bw_glds16<(BW_NT & 2) != 0>(have && r0 + d_row[i] < a.rows ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(dbase) + d_off[i]) : a.zeros, dst);
         } else {
-            const int k = p - DPW < KCB ? p - DPW : 0;   // image k: columns 64 (KCB c + k) ..
+            const int hp = p - DPW;
+            const int k = hp / HPW < KCB ? hp / HPW : 0, j = hp % HPW;   // image k (columns 64 (KCB c + k) ..), its piece mv + MW j
             const uint32_t dH = lds0 + (uint32_t)(BW_RING * DSZ + b * HSZ) * 2u;
             const uint16_t* const hbase = a.h + r0s * a.ldh;
-            const uint32_t dst = dH + (uint32_t)(k * BW_ROWS * BW_KC) * 2u + 1024u * wave;
-            if (whole && !gathered) bw_glds16_s<(BW_NT & 1) != 0>(hbase, h_off[k], dst);
+            const uint32_t dst = dH + (uint32_t)(k * BW_ROWS * BW_KC) * 2u + 1024u * (mv + MW * j);
+            if (whole && !gathered) bw_glds16_s<(BW_NT & 1) != 0>(hbase, h_off[k][j], dst);
             else {
-                const uint16_t* src = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k] - (uint32_t)(h_row * (int)a.ldh) * 2u))
-                                               : reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(hbase) + h_off[k]);
-                bw_glds16<(BW_NT & 1) != 0>(r0 + h_row < a.rows ? src : a.zeros, dst);
+                const uint16_t* src = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k][j] - (uint32_t)(h_row[j] * (int)a.ldh) * 2u))
+                                               : reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(hbase) + h_off[k][j]);
+                bw_glds16<(BW_NT & 1) != 0>(r0 + h_row[j] < a.rows ? src : a.zeros, dst);
             }
         }
     };
-    auto issue = [&](int t, int b, int hsrc) {   // all of tile t's pieces (the prologue)
+    auto issue = [&](int t, int b, int hsrc) {   // all of this mover's pieces of tile t
+        if (!mover) return;
 #pragma unroll
-        for (int p = 0; p < DPW + KCB; p++) issue_piece(t, b, hsrc, p);
-    };
-    // BW_FETCH_REGS: the same pieces as plain loads (same source addresses: the swizzle sits on the source) and their ds_write to the same lane-linear places
-    auto fetch_piece = [&](int t, int hsrc, int p) -> u32x4 {
-        const int64_t r0 = tile_row(t);
-        const int64_t r0s = (BW_ABL & 1) ? (int64_t)(t & 1) * BW_ROWS : r0;
-        const uint16_t* src;
-        if (p < DPW) {
-            const int i = p < DPW ? p : 0;
-            const bool have = wave + BW_WAVES * i < CPR && r0 + d_row[i] < a.rows;
-            src = have ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.d + r0s * a.ldd) + d_off[i]) : a.zeros;
-        } else {
-            const int k = p - DPW < KCB ? p - DPW : 0;
-            const uint16_t* rowp = gathered ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + (int64_t)hsrc * a.ldh) + (h_off[k] - (uint32_t)(h_row * (int)a.ldh) * 2u))
-                                            : reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(a.h + r0s * a.ldh) + h_off[k]);
-            src = r0 + h_row < a.rows ? rowp : a.zeros;
-        }
-        return *reinterpret_cast<const u32x4*>(src);   // (a select between addresses, not a branch around the load)
-    };
-    auto park_piece = [&](int b, int p, const u32x4 v) {
-        uint16_t* dst;
-        if (p < DPW) {
-            const int pc = wave + BW_WAVES * (p < DPW ? p : 0);
-            if (pc >= CPR) return;   // (wave-uniform) a narrow dZ tile has no such piece
-            dst = sD + b * DSZ + 512 * pc;
-        } else {
-            dst = sH + b * HSZ + (p - DPW) * BW_ROWS * BW_KC + 512 * wave;
-        }
-        *reinterpret_cast<u32x4*>(dst + 8 * lane) = v;
+        for (int p = 0; p < DPW + KCB * HPW; p++) issue_piece(t, b, hsrc, p);
     };
     // the result tile of tile t leaves in 16-byte row pieces (rows past the minibatch are zeros: they keep the destination's padding zero)
     auto store_out = [&](int t) {
@@ -361,7 +342,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         else *reinterpret_cast<u32x4*>(a.dz_out + (r0 + row) * a.ld_out + BW_KC * c + 8 * ch) = piece;
     };
     // vector-memory operations a wave issues per iteration of the steady state: the DMA pieces of one tile, and (P1) one store of the result tile
-    constexpr int VM_TILE = DPW + KCB;           // DMA instructions of one tile
+    constexpr int VM_TILE = DPW + KCB * HPW;     // DMA instructions of one tile (per mover)
     constexpr int VM_PER_ITER = VM_TILE + (P1 ? 1 : 0);
 
     float csum[16];
@@ -372,18 +353,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
     {
         int h0 = 0, h1 = 0;
         if (gathered && n_tiles > 0) { h0 = a.idx[index_row(0)]; h1 = a.idx[index_row(1)]; hs_next = a.idx[index_row(2)]; }
-        if (!BW_FETCH_REGS) {
-            if (n_tiles > 0) issue(0, 0, h0);
-            if (n_tiles > 1) issue(1, 1, h1);
-        } else {
-            // tiles 0 and 1 go through the registers into their buffers here; tile 2 is requested at the top of iteration 0 like every tile t + 2
-#pragma unroll
-            for (int p = 0; p < DPW + KCB; p++) { if (n_tiles > 0) park_piece(0, p, fetch_piece(0, h0, p)); }
-#pragma unroll
-            for (int p = 0; p < DPW + KCB; p++) { if (n_tiles > 1) park_piece(1, p, fetch_piece(1, h1, p)); }
-        }
+        if (n_tiles > 0) issue(0, 0, h0);
+        if (n_tiles > 1) issue(1, 1, h1);
     }
-    u32x4 rt0[BW_FETCH_REGS ? DPW + KCB : 1], rt1[BW_FETCH_REGS ? DPW + KCB : 1];   // BW_FETCH_REGS: the pieces of tile k wait in set k & 1 from iteration k - 2 (requested) to the end of iteration k - 1 (parked)
     // lane-constant LDS offsets of everything the tile loop reads (elements; see frag_off)
     int p1_rd[KS1], ep_at[4];          // P1: the row's 16-byte B fragments of dZ; the epilogue's 8-byte places in the h / result images
     int a_lo[NBW], a_hi[NBW], h_lo[2 * KCB], h_hi[2 * KCB];   // P2: transposing reads of dZ (A) and h (B) at k step 0
@@ -398,7 +370,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #pragma unroll
         for (int h = 0; h < 2 * KCB; h++) { frag_off<BW_KC, false>(32 * (h & 1), lane, h_lo[h], h_hi[h]); h_lo[h] += (h >> 1) * BW_ROWS * BW_KC; h_hi[h] += (h >> 1) * BW_ROWS * BW_KC; }
     }
-    if (BW_FETCH_REGS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the parking writes of tiles 0 and 1 are in LDS)
+    if (!mover) { }   // (a wave that fetches nothing waits for nothing: the movers' waits and the barrier cover the tile)
     else if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM_TILE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0 has landed
     bw_barrier();
 #ifdef BW_STAMP   /* diagnostic build: cycle sums of the tile loop's phases for one P1 and one P2 wave of workgroup 0, printed by the device */
@@ -408,42 +380,31 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #define BW_ST(i) do { } while (0)
 #endif
     int rb = 0;   // ring buffer of tile t (t % BW_RING, kept by rotation: no division in the loop)
-    // The body of one iteration, with the two register sets of BW_FETCH_REGS named by the CALLER: indexed by t & 1 the sets were an array with a run-time index, which
-    // hipcc keeps in scratch memory (every piece: load, wait, scratch store ... scratch load, wait, ds_write: 185 us per launch).  The loop below runs the body twice
-    // per trip with the sets swapped.
-    constexpr int NRT = BW_FETCH_REGS ? DPW + KCB : 1;
-    auto body = [&](const int t, u32x4 (&rt_fetch)[NRT], u32x4 (&rt_park)[NRT]) {
+    // The body of one iteration as a lambda, run TWICE per trip of the loop below: unrolled by two the layer-0 launch is 6 - 8 us faster (46.7 against 53 - 55 us: found
+    // by accident when an exploration build needed two named register sets; the ring index and the parities become compile-time facts of each copy)
+    auto body = [&](const int t) {
 #ifdef BW_STAMP
         st_t0 = __builtin_amdgcn_s_memtime();
 #endif
         const uint16_t* const tD = sD + rb * DSZ;
         const uint16_t* const tH = sH + rb * HSZ;
         const int rb2 = rb == 0 ? BW_RING - 1 : rb - 1;   // (t + 2) % 3
-        int hs_load = 0;   // BW_FETCH_REGS, gathered: the index-list entry of this lane's row in tile t + 3 (a plain load: used at the top of the next iteration)
         if (t + 2 < n_tiles) {                      // into the buffer every wave finished reading before the barrier that ended iteration t - 1
             if constexpr (!P1) {
-                if (BW_FETCH_REGS) {
-                    if (gathered) hs_load = a.idx[index_row(t + 3)];
-                } else {
-                    // tile t + 2's entries landed under the wait that ended iteration t - 1 (tile 2's came with the prologue's loads)
-                    if (t > 0) hs_next = gathered ? sIdx[((t + 2) & 1) * (BW_WAVES * 64) + 64 * wave + lane] : 0;
-                    index_dma(t + 3);
-                }
-            }
-            if (BW_FETCH_REGS) {
-#pragma unroll
-                for (int p = 0; p < VM_TILE; p++) rt_fetch[p] = fetch_piece(t + 2, hs_next, p);
+                // tile t + 2's entries landed under the wait that ended iteration t - 1 (tile 2's came with the prologue's loads)
+                if (t > 0) hs_next = gathered ? sIdx[((t + 2) & 1) * (BW_WAVES * 64) + 64 * wave + lane] : 0;
+                index_dma(t + 3);
             }
         }
         const bool pf = t + 2 < n_tiles;   // (uniform) this iteration issues tile t + 2's pieces, between its products: `pieces(lo, hi)` below
 #ifndef BW_DMA_SPREAD
 #define BW_DMA_SPREAD 0   /* 1: a tile's DMA instructions one at a time between the products (measured: the stall moves into the products, layer 0 gets slower); 0: all at the top */
 #endif
-        if (!BW_FETCH_REGS && !BW_DMA_SPREAD && pf) issue(t + 2, rb2, hs_next);
+        if (!BW_DMA_SPREAD && pf) issue(t + 2, rb2, hs_next);
         auto pieces = [&](int lo, int hi) {
-            if (!BW_FETCH_REGS && BW_DMA_SPREAD && pf) {
+            if (BW_DMA_SPREAD && pf) {
 #pragma unroll
-                for (int p = 0; p < VM_TILE; p++) if (p >= lo && p < hi) issue_piece(t + 2, rb2, hs_next, p);
+                for (int p = 0; p < VM_TILE; p++) if (mover && p >= lo && p < hi) issue_piece(t + 2, rb2, hs_next, p);
             }
         };
         BW_ST(0);   // (index entries of tile t + 3 requested)
@@ -515,16 +476,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         // this wave's pieces of tile t + 1 have landed: everything it issued up to them is done, i.e. all but what this iteration issued (the pieces of
         // tile t + 2 and the store of tile t - 1) -- counted, so that tile t + 2 stays in flight across the barrier (a plain __syncthreads() would drain
         // it: the compiler's fence waits for vmcnt(0)).  The last iterations issue less: they wait for everything.
-        if (BW_FETCH_REGS) {
-            // tile t + 1 (requested a whole iteration ago, at the top of iteration t - 1) goes from its registers into ring buffer (t + 1) % 3, which nobody has read since
-            // iteration t - 2; the compiler's own wait in front of these writes counts the younger loads of tile t + 2 and lets them fly on
-            if (t >= 1 && t + 1 < n_tiles) {
-                const int rb1n = rb == BW_RING - 1 ? 0 : rb + 1;
-#pragma unroll
-                for (int p = 0; p < VM_TILE; p++) park_piece(rb1n, p, rt_park[p]);
-            }
-            hs_next = hs_load;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!mover) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave that fetches nothing: its result tile is in LDS; the movers' waits + the barrier cover the tiles
         } else
 #ifdef BW_FULL_WAIT
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -542,9 +495,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         bw_barrier();
         BW_ST(4);   // barrier
     };
-    for (int t = 0; t < n_tiles; t += 2) {   // even tiles are requested into rt0 and parked from rt1, odd tiles the other way round
-        body(t, rt0, rt1);
-        if (t + 1 < n_tiles) body(t + 1, rt1, rt0);
+    for (int t = 0; t < n_tiles; t += 2) {
+        body(t);
+        if (t + 1 < n_tiles) body(t + 1);
     }
 #ifdef BW_STAMP
     if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && NB == 8)
