@@ -400,7 +400,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
 #ifndef BW_DMA_SPREAD
 #define BW_DMA_SPREAD 0   /* 1: a tile's DMA instructions one at a time between the products (measured: the stall moves into the products, layer 0 gets slower); 0: all at the top */
 #endif
-        if (!BW_DMA_SPREAD && pf) issue(t + 2, rb2, hs_next);
+#ifndef BW_STAGGER
+#define BW_STAGGER 0   /* 1: beside P1 the P2 waves issue their pieces BEHIND their products, the P1 waves in front of theirs, so that a SIMD's two waves are blocked in the address path at different times -- measured 55.9 against 53.1 us: not taken */
+#endif
+        const bool late = BW_STAGGER && P1 && !p1_wave;   // (wave-uniform)
+        if (!BW_DMA_SPREAD && pf && !late) issue(t + 2, rb2, hs_next);
         auto pieces = [&](int lo, int hi) {
             if (BW_DMA_SPREAD && pf) {
 #pragma unroll
@@ -472,7 +476,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwd_layer_kernel(const BwdPair 
         } else {
             pieces(0, VM_TILE);   // a wave without products (narrow layers) still issues its share of the DMA
         }
-        BW_ST(2);   // products (+ P1's epilogue) with tile t + 2's DMA between them
+        if (!BW_DMA_SPREAD && pf && late) issue(t + 2, rb2, hs_next);
+        BW_ST(2);   // products (+ P1's epilogue; the P2 waves' share of tile t + 2's DMA behind them)
         // this wave's pieces of tile t + 1 have landed: everything it issued up to them is done, i.e. all but what this iteration issued (the pieces of
         // tile t + 2 and the store of tile t - 1) -- counted, so that tile t + 2 stays in flight across the barrier (a plain __syncthreads() would drain
         // it: the compiler's fence waits for vmcnt(0)).  The last iterations issue less: they wait for everything.
