@@ -746,6 +746,26 @@ def test_weights_beyond_fp16_take_the_vector_kernels_for_that_launch(P):
         assert abs(outs[0][3][where] - value) < 0.1
 
 
+def test_weights_that_grow_past_the_thresholds_by_optimizer_steps_alone(P):
+    """The other way into the fp16-range fallback: nobody writes the parameters -- AdamW itself moves them past the thresholds (learning rate 1.0: a weight moves by up to
+    the parameters pass the hidden-to-hidden threshold of 4 within a few updates).  The maxima are swept once per update on a stream of their own into a pinned mirror the host reads
+    without synchronising, so the dispatch sees them an update late; the thresholds sit at half the kernels' limits for exactly that lag.  What must hold: no range error is ever raised, the
+    run stays finite, and from some update on the launches are counted as vector fallbacks (`ppo_profile.vector_fallback_launches`)."""
+    ctx = P.Context(P.make_config(num_envs=64, num_steps=16, num_minibatches=2, update_epochs=4, seed=11, total_timesteps=64 * 16 * 12, learning_rate=1.0, anneal_lr=False))
+    ctx.init_orthogonal(2)
+    ctx.env_reset()
+    seen = []
+    for it in range(10):
+        ctx.train_iteration()
+        st = ctx.stats()                       # raises PPO_ERR_STATE if any kernel flagged a range error
+        p = ctx.get_params()
+        assert np.isfinite(p).all() and np.isfinite(st["loss"]), it
+        seen.append((float(np.abs(p).max()), ctx.profile_read()["vector_fallback_launches"]))
+    assert seen[-1][0] > 4.0, seen            # the weights did grow past the hidden-to-hidden threshold
+    assert seen[-1][1] > 0 and seen[0][1] <= seen[-1][1], seen   # ... and the launches took the vector kernels from some update on
+    ctx.close()
+
+
 def test_observation_beyond_fp16_is_reported(P):
     """The wave-specialised update kernel cuts the observation into fp16 terms: |obs| >= 65504 written through the C-ABI's OBS buffer does not fit.  The record
     packing checks it (PPO_ERRFLAG_UPDATE_RANGE) and the next statistics read fails with PPO_ERR_STATE naming PPO_KERNEL_UPDATE_VECTOR -- no silent NaN.
