@@ -159,8 +159,8 @@ struct ppo_ctx {
     double* clipfrac_accum = nullptr;   // {sum, count}
     double* norm2 = nullptr;            // [12] per-tensor squared gradient norms of the current step
     double* ev_sums = nullptr;          // [PPO_EV_BLOCKS][4]
-    float* rec_critic = nullptr;        // [B][8] packed sample records the matrix-core update kernel gathers from (launch_pack_records)
-    float* rec_actor = nullptr;         // [B][8]
+    float* rec_critic = nullptr;        // [B][16] packed sample records the matrix-core update kernel gathers from (launch_pack_records): critic | actor per sample
+    float* rec_actor = nullptr;         // = rec_critic + 8 (not an allocation of its own)
     int32_t* row_counts = nullptr;      // [T]
     uint64_t* group_bits = nullptr;     // [T, ceil(N/64)] ballots of finished episodes
     EpisodeRing* ring = nullptr;
@@ -546,8 +546,8 @@ extern "C" ppo_status ppo_ctx_create(const ppo_config* cfg, ppo_ctx** out) {
     CK(dalloc(c, &c->fused_partial, (size_t)fused_opt_blocks(c->L) * 12));
     CK(dalloc(c, &c->ev_sums, PPO_EV_BLOCKS * 4));
     if (c->use_mfma && !generic) {
-        CK(dalloc(c, &c->rec_critic, (size_t)B * 8));
-        CK(dalloc(c, &c->rec_actor, (size_t)B * 8));
+        CK(dalloc(c, &c->rec_critic, (size_t)B * 16));   // both nets' records of a sample side by side: one 64-byte sector (kernels_update_mfma.hip: pack_records_kernel)
+        c->rec_actor = c->rec_critic + 8;
     }
     CK(dalloc(c, &c->row_counts, (size_t)c->T));
     CK(dalloc(c, &c->group_bits, (size_t)c->T * ((N + 63) / 64)));

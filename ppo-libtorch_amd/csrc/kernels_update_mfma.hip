@@ -276,7 +276,7 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
     float wv[NS_];
 #pragma unroll
     for (int i = 0; i < NS_; i++) wv[i] = P[se[i] < 0 ? 0 : se[i]];
-    float4 x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];   // behind the weight loads: its wait for the index overlaps theirs.  Row 0 stands in for a missing row; zeroed at the point of use
+    float4 x_n = rec[4 * (size_t)(row_n < 0 ? 0 : row_n)];   // behind the weight loads: its wait for the index overlaps theirs.  Row 0 stands in for a missing row; zeroed at the point of use
     {
         // 4096 weights, 8 per thread: each is scaled, cut into its two fp16 terms once per launch and stored at its natural [n][k] place
         uint16_t* wn = reinterpret_cast<uint16_t*>(smem + m.w2);
@@ -371,12 +371,12 @@ __device__ __forceinline__ void mf_body(const UpdateArgs& a, float* smem, const 
         float x[4] = { valid ? x_n.x : 0.0f, valid ? x_n.y : 0.0f, valid ? x_n.z : 0.0f, valid ? x_n.w : 0.0f };
         // per-sample scalars of this tile: issued now, consumed at the loss.  critic: {return, old value, -, -}; actor: {old log-prob,
         // advantage, actions (8 bits per head), mask bits}
-        const float4 sc = rec[2 * (size_t)row + 1];
+        const float4 sc = rec[4 * (size_t)row + 1];
         float s_f0 = sc.x, s_f1 = sc.y;
         uint32_t s_actbits = f2u(sc.z), s_maskbits = f2u(sc.w);
         {   // next tile's observation (its index arrived a tile ago); the index after that
             row_n = row_nn;
-            x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];
+            x_n = rec[4 * (size_t)(row_n < 0 ? 0 : row_n)];
             row_nn = fetch_row(tile + 2 * tile_step);
         }
         if (hi == 0) {
@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
         if (tid < MG_FLAG_WORDS) flags[tid] = tid == MG_ONE ? 0x3c00u : 0u;   // MG_ONE: the fp16 cell {1, 0, 0, 0}
     }
     float4 x_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (wave < MG_FW) x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];
+    if (wave < MG_FW) x_n = rec[4 * (size_t)(row_n < 0 ? 0 : row_n)];
     __syncthreads();
 #ifdef MG_STAMP
     const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
@@ -1222,12 +1222,12 @@ __device__ __forceinline__ void mg_body(const UpdateArgs& a, float* smem, const 
             const int row = valid ? row_n : 0;
             // four scalars, not an array: a select between array elements by `hi` (layer 1's B operand) sends an array to scratch memory
             const float x0 = valid ? x_n.x : 0.0f, x1 = valid ? x_n.y : 0.0f, x2 = valid ? x_n.z : 0.0f, x3 = valid ? x_n.w : 0.0f;
-            const float4 sc = rec[2 * (size_t)row + 1];
+            const float4 sc = rec[4 * (size_t)row + 1];
             float s_f0 = sc.x, s_f1 = sc.y;
             uint32_t s_actbits = f2u(sc.z), s_maskbits = f2u(sc.w);
             {
                 row_n = row_nn;
-                x_n = rec[2 * (size_t)(row_n < 0 ? 0 : row_n)];
+                x_n = rec[4 * (size_t)(row_n < 0 ? 0 : row_n)];
                 row_nn = fetch_row(tile + 2 * tile_step);
             }
             // ---------------- layer 1 (f16 MFMA on terms, K = 16: observation + the constant 1 that carries the bias) ----------------
@@ -1845,10 +1845,13 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float* __restri
         if (masks) { mb = 0u; for (int k = 0; k < A; k++) mb |= (masks[i * A + k] ? 1u : 0u) << k; }
         x_absmax = fmaxf(fmaxf(x_absmax, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
         const float R = returns[i], V = values[i];
-        rec_critic[2 * i] = x;
-        rec_critic[2 * i + 1] = make_float4(R, V, 0.0f, 0.0f);
-        rec_actor[2 * i] = x;
-        rec_actor[2 * i + 1] = make_float4(logprobs[i], advantages[i], u2f(ab), u2f(mb));
+        // the two nets' records of a sample are the two halves of ONE 64-byte sector (rec_actor = rec_critic + 2 float4; a sample is 4 float4 apart in both): the
+        // critic's and the actor's workgroups that gather the same sample run in the same launch on the same XCD, so the second of them finds the sector in L2 --
+        // as two separate arrays every 32-byte gather fetched a 64-byte sector of its own (21.5 MB per launch against 13.6 algorithmic)
+        rec_critic[4 * i] = x;
+        rec_critic[4 * i + 1] = make_float4(R, V, 0.0f, 0.0f);
+        rec_actor[4 * i] = x;
+        rec_actor[4 * i + 1] = make_float4(logprobs[i], advantages[i], u2f(ab), u2f(mb));
         const double y = R, d = (double)(R - V);
         sy += y; sy2 += y * y; sd += d; sd2 += d * d;
     }
@@ -2063,7 +2066,7 @@ hipError_t launch_minibatch_fwd_bwd_mfma(const UpdateArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// rec_critic / rec_actor: [B][8] floats each; ev_sums: [PPO_EV_BLOCKS][4] partial sums of the explained variance
+// rec_critic / rec_actor: ONE array [B][16] floats, the critic's record in floats 0 .. 7 of a sample and the actor's in 8 .. 15 (rec_actor = rec_critic + 8); ev_sums: [PPO_EV_BLOCKS][4] partial sums of the explained variance
 hipError_t launch_pack_records(const NetLayout& L, const float* obs, const int32_t* actions, const uint8_t* masks, const float* logprobs,
                                const float* advantages, const float* returns, const float* values, int64_t B, float* rec_critic, float* rec_actor,
                                double* ev_sums, int32_t* error_flag, hipStream_t s) {
