@@ -996,7 +996,12 @@ struct XchgPtrs8 { void* p[8]; };
 // waits for flags that a peer stamps only when ITS last workgroup has arrived, so all workgroups of a rank must be resident at once --
 // a grid sized by the element count (1 800 workgroups for configs[4]'s 460 k gradient floats) can exceed what the chip holds and then
 // waits for workgroups that cannot start.
-constexpr int XCHG_MAX_BLOCKS = 256;
+// ... and bounded well BELOW the number of CUs (round 6: 64, it was 256): a waiting exchange workgroup holds a slot of its CU, and the matrix-core kernels of the generic
+// path need a CU's whole register file (two waves of 250 registers per SIMD) and all but ~1 KB of its LDS -- beside a resident exchange wave they cannot start.  One
+// rank per GPU never meets that; ranks REHEARSED on one GPU do: with the exchange on all 256 CUs, the rank that arrives first waits for a peer whose forward launch can
+// find no CU (seen once in this round's runs as a 30 s wait that ran out in tests/test_gpu_exchange.py, after the forward kernel's registers grew from 216 to 253).  With 64
+// workgroups even three waiting ranks leave a quarter of the chip to the one that still computes.  The payload of a step (37 KB; 2.4 MB at configs[4]) does not need more.
+constexpr int XCHG_MAX_BLOCKS = 64;
 template <class Tp>
 __global__ __launch_bounds__(256) void exchange_allreduce_kernel(Tp* __restrict__ buf, size_t count, XchgPtrs8 peers, int rank, int n, size_t slot_bytes,
                                                                  unsigned long long seq, int32_t* timeout_flag) {
