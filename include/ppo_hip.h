@@ -71,10 +71,15 @@ typedef struct ppo_config {
 } ppo_config;
 
 /* ppo_config.kernel_flags.  The defaults put the reference's two shapes on the matrix cores; every alternative computes the same function.
- *   PPO_KERNEL_ROLLOUT_VECTOR   the fused rollout on the vector ALU (rollout2_kernel): logits formed by the same fp32 multiply-adds, in the same order, as
- *                               ppo_policy_act.  The default rollout16_kernel forms layer 2 and the logits as two-term fp16 products on the matrix cores:
- *                               its logits agree with ppo_policy_act's to fp32 noise (~1e-7), NOT bit for bit, so an action sampled where the uniform
- *                               sits within ~1e-6 of a bin edge can differ (measured: <= 2 of 8 192).  Use this flag for golden / bit-exact replays.
+ *   PPO_KERNEL_ROLLOUT_VECTOR   the fused rollout AND the stand-alone policy (ppo_policy_act) on the vector ALU (rollout2_kernel, policy_act_kernel): logits
+ *                               formed by plain fp32 multiply-adds.  The default rollout16_kernel forms layer 2 and the logits as two-term fp16 products on
+ *                               the matrix cores, ~1e-7 away.  ppo_policy_act ALWAYS runs the arithmetic the context's rollout runs (default:
+ *                               policy_act16_kernel, the same products in the same order; under this flag, or for a launch whose output-layer weights do
+ *                               not fit fp16, the vector form), so a free-running rollout and the stand-alone policy on the same observations, weights and
+ *                               step index agree in every log-prob bit and every sampled action (tests/test_gpu_parity.py:
+ *                               test_fused_rollout_equals_stepwise_api).  Between the two arithmetics an action sampled where the uniform sits within ~1e-6
+ *                               of a bin edge can differ (measured: <= 2 of 8 192): use this flag to replay recordings made with it, or with round <= 5
+ *                               builds' stand-alone policy.
  *   fp16 ranges                 The matrix-core kernels carry some operands as fp16 terms: rollout16_kernel 2^8 W3 (|W3| < 255), the update kernels c W2 and
  *                               the products through its columns (sum |W2[:, k]| < ~350), c W1 / c b1 / c b2 (< 22 700) and the observation (< 65 504).  The
  *                               reference has none of these limits and a caller never meets the weight limits: the maxima of |parameter| per class are taken
@@ -193,7 +198,8 @@ PPO_API ppo_status ppo_get_value(ppo_ctx* ctx, const float* obs, int64_t n, floa
  *   obs [n,O]; mask u8 [n,A] or NULL; forced_action i64 [n,H] or NULL (NULL -> sample, Categorical.cpp:73-79, with the
  *   context's counter-based generator keyed by (seed, env_offset+row, step_index, head));
  *   outputs action i64 [n,H] (the transposed layout the reference returns, Agent.cpp:168), logprob/entropy/value f32 [n]
- *   (log-probs and entropies summed over heads, :165-168).  Any output may be NULL. */
+ *   (log-probs and entropies summed over heads, :165-168).  Any output may be NULL.
+ *   Arithmetic: that of the kernel ppo_rollout would run in this context now (PPO_KERNEL_ROLLOUT_VECTOR above): bit for bit the rollout's log-probs / actions. */
 PPO_API ppo_status ppo_policy_act(ppo_ctx* ctx, const float* obs, const uint8_t* mask, const int64_t* forced_action, int64_t n,
                           int64_t step_index, int64_t* action, float* logprob, float* entropy, float* value);
 

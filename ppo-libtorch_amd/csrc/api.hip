@@ -890,6 +890,10 @@ extern "C" ppo_status ppo_get_value(ppo_ctx* c, const float* obs, int64_t n, flo
     return PPO_OK;
 }
 
+static ppo_status refresh_weight_range(ppo_ctx* c);          // (the fp16 range of the matrix-core kernels' operands: defined with ppo_rollout below)
+static inline void wr_snapshot(ppo_ctx* c);
+static inline bool weights_fit_rollout16(const ppo_ctx* c);
+
 extern "C" ppo_status ppo_policy_act(ppo_ctx* c, const float* obs, const uint8_t* mask, const int64_t* forced_action, int64_t n,
                                      int64_t step_index, int64_t* action, float* logprob, float* entropy, float* value) {
     NEED(c, c && obs, "null argument");
@@ -900,8 +904,18 @@ extern "C" ppo_status ppo_policy_act(ppo_ctx* c, const float* obs, const uint8_t
         if (s == PPO_OK && value) s = gen_values(c, obs, n, value);
         return s;
     }
+    // The stand-alone policy runs the arithmetic of the kernel this context's ROLLOUT would run now (round 6): rollout16_kernel's two-term fp16 products
+    // on the matrix cores by default, the vector ALU's fp32 multiply-adds under PPO_KERNEL_ROLLOUT_VECTOR or while the output layer's weights do not fit
+    // (the same range snapshot, the same decision as ppo_rollout) -- so a caller comparing the two on the same observations sees the same bits.
+    bool as16 = !c->rollout_vector && policy_act16_serves(c->L);
+    if (as16) {
+        const ppo_status rs = refresh_weight_range(c);
+        if (rs != PPO_OK) return rs;
+        wr_snapshot(c);
+        if (!weights_fit_rollout16(c)) { as16 = false; c->vector_fallback_launches += 1; }
+    }
     HIPCHK(c, launch_policy_act(B_<float>(c, PPO_BUF_PARAMS), c->L, c->cfg.dist_kind, obs, mask, forced_action, n, c->cfg.seed, c->cfg.env_offset,
-                                step_index, action, logprob, entropy, value, false, c->stream));
+                                step_index, action, logprob, entropy, value, false, c->stream, as16, c->error_flag));
     return PPO_OK;
 }
 

@@ -1019,7 +1019,6 @@ __global__ __launch_bounds__(256) void gen_opt_fused_kernel(const GenOptArgs a) 
             s_t[2 * j] = (double)nw * nw; s_t[2 * j + 1] = (double)nb * nb;
         }
     }
-    double lsum[5] = { 0, 0, 0, 0, 0 };
     if (blockIdx.x == 0) {   // the loss kernel's block sums (uniform branch): the five columns requested together
         double v5[5] = { 0, 0, 0, 0, 0 };
         for (int b = tid; b < a.loss_blocks; b += 256) {

@@ -559,7 +559,9 @@ hipError_t launch_aos_to_soa(const float* aos, float* soa, int N, int O, bool to
 
 hipError_t launch_policy_act(const float* params, const NetLayout& L, int dist_kind, const float* obs, const uint8_t* mask,
                              const int64_t* forced_action, int64_t n, int64_t seed, int64_t env_offset, int64_t step_index,
-                             int64_t* action, float* logprob, float* entropy, float* value, bool value_only, hipStream_t s);
+                             int64_t* action, float* logprob, float* entropy, float* value, bool value_only, hipStream_t s, bool as_rollout16 = false,
+                             int32_t* error_flag = nullptr);   // as_rollout16: rollout16_kernel's arithmetic where that kernel serves the shape (policy_act16_serves)
+bool policy_act16_serves(const NetLayout& L);
 hipError_t launch_categorical(int dist_kind, const float* logits, const uint8_t* mask, const int64_t* value, int64_t n, int A,
                               float* m_logits, float* m_probs, float* log_prob, float* entropy, int64_t* mode, hipStream_t s);
 

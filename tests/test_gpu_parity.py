@@ -649,14 +649,16 @@ def test_ragged_minibatches(P):
 
 
 # ------------------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("vector", [False, True])
 @pytest.mark.parametrize("N", [96, 7, 33])   # 7, 33: the last 16-env tile of the fused rollout is ragged
-def test_fused_rollout_equals_stepwise_api(P, N):
-    """ppo_rollout (one launch) against T x { policy_act, env_step } through the stand-alone entry points.  The env side -- observations, rewards,
-    done flags, auto-resets, truncation -- must agree BIT FOR BIT when the stepwise loop is driven with the rollout's own actions, and so must the
-    values (same critic kernel arithmetic).  The rollout's actor runs on the matrix cores (16 envs per tile, fp32 carried as two fp16 terms), the
-    stand-alone policy_act on the vector ALU: their log-probs agree to fp32 noise (3e-6 is the bar against the reference; 1 - 2 ULP measured), and
-    the actions each samples from the SAME Philox word may differ only where the uniform draw falls within that noise of a CDF edge."""
-    cfg = dict(num_envs=N, num_steps=40, num_minibatches=1, update_epochs=1, seed=5, max_episode_steps=30)
+def test_fused_rollout_equals_stepwise_api(P, N, vector):
+    """ppo_rollout (one launch) against T x { policy_act, env_step } through the stand-alone entry points, FREE-RUNNING: the stepwise loop samples its own
+    actions.  Everything must agree BIT FOR BIT -- observations, rewards, done flags, auto-resets, truncation, values, log-probs, and every sampled action.
+    The stand-alone policy runs the arithmetic of the kernel the context's rollout runs (round 6; include/ppo_hip.h): by default rollout16_kernel's
+    (matrix cores, 16 rows per tile, fp32 carried as two fp16 terms: policy_act16_kernel), under PPO_KERNEL_ROLLOUT_VECTOR the vector ALU's fp32
+    multiply-adds (rollout2_kernel / policy_act_kernel) -- the rollout for golden replays against earlier rounds' recordings.  Until round 6 the stand-alone
+    policy was always the vector form and a default context's free-running rollout could differ from it in <= 2 of 8 192 actions."""
+    cfg = dict(num_envs=N, num_steps=40, num_minibatches=1, update_epochs=1, seed=5, max_episode_steps=30, kernel_flags=P.KERNEL_ROLLOUT_VECTOR if vector else 0)
     a = P.Context(P.make_config(**cfg))
     b = P.Context(P.make_config(**cfg))
     a.init_orthogonal(11)
@@ -671,47 +673,71 @@ def test_fused_rollout_equals_stepwise_api(P, N):
     r_obs, r_act, r_lp, r_v, r_rew, r_done = (a.read("OBS", (T, N, 4)), a.read("ACTIONS", (T, N)), a.read("LOGPROBS", (T, N)),
                                               a.read("VALUES", (T, N)), a.read("REWARDS", (T, N)), a.read("DONES", (T, N)))
     done = np.zeros(N, np.float32)
-    flips = 0
     for t in range(T):
         assert np.array_equal(bits(obs), bits(r_obs[t])) and np.array_equal(done, r_done[t])
-        sampled, _, _, _ = b.policy_act(obs, step_index=t)                      # the stand-alone sampler on the same Philox word
-        flips += int((sampled.ravel() != r_act[t]).sum())
-        act, lp, en, v = b.policy_act(obs, action=r_act[t].reshape(N, 1).astype(np.int64), step_index=t)
-        np.testing.assert_allclose(lp, r_lp[t], rtol=0, atol=1e-6)
-        assert np.array_equal(bits(v), bits(r_v[t]))
-        obs, rew, d = b.env_step(r_act[t].reshape(N, 1).astype(np.int64))
+        act, lp, en, v = b.policy_act(obs, step_index=t)                        # the stand-alone sampler on the same Philox word
+        assert np.array_equal(act.ravel(), r_act[t]), (t, int((act.ravel() != r_act[t]).sum()))
+        assert np.array_equal(bits(lp), bits(r_lp[t])) and np.array_equal(bits(v), bits(r_v[t]))
+        f_act, f_lp, _, _ = b.policy_act(obs, action=act, step_index=t)        # teacher-forced with the same actions: the same log-prob bits
+        assert np.array_equal(f_act, act) and np.array_equal(bits(f_lp), bits(lp))
+        obs, rew, d = b.env_step(act)
         assert np.array_equal(rew, r_rew[t])
         done = d.astype(np.float32)
     assert np.array_equal(bits(obs), bits(a.read("NEXT_OBS", (N, 4))))
-    assert flips <= 2, flips
     assert r_done.sum() > 0  # truncation at 30 steps exercised
     a.close()
     b.close()
 
 
-@pytest.mark.parametrize("N", [96, 33])
-def test_vector_rollout_flag_is_bit_exact_with_policy_act(P, N):
-    """ppo_config.kernel_flags & PPO_KERNEL_ROLLOUT_VECTOR (include/ppo_hip.h): the fused rollout on the vector ALU forms its logits with ppo_policy_act's
-    own multiply-adds -- log-probs BIT FOR BIT, and every action the stand-alone sampler draws from the same Philox word is the rollout's (no flips).
-    This is the rollout for golden / bit-exact replays; the default matrix-core rollout agrees to fp32 noise (the test above)."""
-    cfg = dict(num_envs=N, num_steps=40, num_minibatches=1, update_epochs=1, seed=5, max_episode_steps=30)
-    a = P.Context(P.make_config(kernel_flags=P.KERNEL_ROLLOUT_VECTOR, **cfg))
-    b = P.Context(P.make_config(**cfg))
-    a.init_orthogonal(11)
-    params = a.get_params()
+def test_the_two_rollout_arithmetics_agree_to_fp32_noise(P):
+    """The matrix-core form (default) and the vector-ALU form (PPO_KERNEL_ROLLOUT_VECTOR) of the policy compute the same function: on the same observations and
+    teacher-forced actions their log-probs agree to 1e-6 (3e-6 is the bar against the reference; 1 - 2 ULP measured), and of the actions each samples from the
+    SAME Philox word at most a handful fall on different sides of a CDF edge.  The values come from one critic kernel in both: bit for bit."""
+    N = 4096
+    cfg = dict(num_envs=N, num_steps=4, num_minibatches=1, update_epochs=1, seed=5)
+    m = P.Context(P.make_config(**cfg))
+    v = P.Context(P.make_config(kernel_flags=P.KERNEL_ROLLOUT_VECTOR, **cfg))
+    m.init_orthogonal(11)
+    params = m.get_params()
     params[-130:] *= 30.0
+    m.set_params(params)
+    v.set_params(params)
+    obs = np.random.default_rng(3).uniform(-0.3, 0.3, (2 * N + 5, 4)).astype(np.float32)
+    am, lpm, enm, vm = m.policy_act(obs, step_index=9)
+    av, lpv, env_, vv = v.policy_act(obs, step_index=9)
+    assert int((am != av).sum()) <= 3
+    _, lpm_f, enm_f, _ = m.policy_act(obs, action=av, step_index=9)
+    np.testing.assert_allclose(lpm_f, lpv, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(enm_f, env_, rtol=0, atol=1e-6)
+    assert np.array_equal(bits(vm), bits(vv))
+    assert not np.array_equal(bits(lpm_f), bits(lpv))   # (they ARE two arithmetics: if this ever fails the flag has stopped selecting anything)
+    m.close()
+    v.close()
+
+
+def test_policy_act_follows_the_rollout_into_the_vector_kernel_when_weights_leave_fp16(P):
+    """An actor output-layer weight of 300 does not fit rollout16_kernel's fp16 operand: the rollout of a DEFAULT context takes the vector kernel for that
+    launch (the test below), and so must the stand-alone policy -- same range snapshot, same decision -- or the two would disagree exactly where a drop-in
+    user cannot see why.  Free-running, bit for bit, and counted in ppo_profile.vector_fallback_launches."""
+    N, T = 48, 12
+    cfg = dict(num_envs=N, num_steps=T, num_minibatches=1, update_epochs=1, seed=5)
+    a = P.Context(P.make_config(**cfg))
+    b = P.Context(P.make_config(**cfg))
+    a.init_orthogonal(3)
+    params = a.get_params()
+    params[-130] = 300.0
     a.set_params(params)
     b.set_params(params)
     a.env_reset()
     obs = b.env_reset()
     a.rollout()
-    T = 40
-    r_obs, r_act, r_lp, r_v = a.read("OBS", (T, N, 4)), a.read("ACTIONS", (T, N)), a.read("LOGPROBS", (T, N)), a.read("VALUES", (T, N))
+    r_act, r_lp = a.read("ACTIONS", (T, N)), a.read("LOGPROBS", (T, N))
     for t in range(T):
-        assert np.array_equal(bits(obs), bits(r_obs[t]))
-        act, lp, en, v = b.policy_act(obs, step_index=t)
-        assert np.array_equal(act.ravel(), r_act[t]) and np.array_equal(bits(lp), bits(r_lp[t])) and np.array_equal(bits(v), bits(r_v[t]))
+        act, lp, _, _ = b.policy_act(obs, step_index=t)
+        assert np.array_equal(act.ravel(), r_act[t]) and np.array_equal(bits(lp), bits(r_lp[t]))
         obs, _, _ = b.env_step(act)
+    assert a.profile_read()["vector_fallback_launches"] >= 1 and b.profile_read()["vector_fallback_launches"] >= T
+    b.stats()   # no range error was raised
     a.close()
     b.close()
 
