@@ -31,9 +31,11 @@ if os.environ.get("STAMPS"):   # diagnostic build (-DFU_DBG_STAMPS): cycle stamp
     sub = {}
     for l in range(5):
         sub[32 + 4 * l] = "L%d bias issued" % l; sub[33 + 4 * l] = "L%d products done" % l; sub[34 + 4 * l] = "L%d next frags issued" % l
+        if os.environ.get("STAMPS") == "2":   # a scratch build with two more stamps per layer (top of the layer; its scalars have arrived)
+            sub[52 + 2 * l] = "L%d top" % l; sub[53 + 2 * l] = "L%d scalars in" % l
     prev = st[0]
     for i in sorted(names):
         print("  %-16s +%6d cycles (%6d since top)" % (names[i], (st[i] - prev) & 0xffffffff, (st[i] - st[0]) & 0xffffffff))
         prev = st[i]
-    for i in sorted(sub):
+    for i in sorted(sub, key=lambda i: (st[i] - st[0]) & 0xffffffff):
         print("  %-22s %6d since top" % (sub[i], (st[i] - st[0]) & 0xffffffff))
