@@ -27,8 +27,11 @@ if args.transport in args.fail_on.split(","):
 if rank == 0:
     print(json.dumps({"metric": "env-steps/sec (rollout+update)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "transport": args.transport,
                       "transport_fallback_reason": args.fallback_reason}), flush=True)
-dist.barrier()
-dist.destroy_process_group()
+try:                      # (as bench.py: a peer that has already left is not a failed run)
+    dist.barrier()
+    dist.destroy_process_group()
+except Exception as e:
+    sys.stderr.write("teardown: %s\n" % e)
 """
 
 
@@ -56,7 +59,7 @@ def test_failed_run_is_retried_once_in_fresh_processes_on_the_other_transport(tm
     r = _run(tmp_path, ["--fail-on", "auto"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
     d = json.loads(lines[0])
     assert d["transport"] == "exchange" and "exited with rc" in d["transport_fallback_reason"]
 
